@@ -1,0 +1,81 @@
+"""Enumerations shared by the aviaries, the controllers and the C-ABI.
+
+Member names and string values are kept value-compatible with the reference
+(`gym_pybullet_drones/utils/enums.py:3-48`) so that user code written against it
+(`Physics.DYN`, `ActionType("one_d_rpm")`, ...) keeps working.  What is new here is
+the integer side: every enum that reaches the HIP kernel carries the code the
+C-ABI in `include/gpd.h` expects (`GPD_MODEL_*`, `GPD_ACT_*`, `GPD_PHYS_*`).
+"""
+from enum import Enum
+
+
+class DroneModel(Enum):
+    CF2X = "cf2x"    # Crazyflie 2.x, X configuration
+    CF2P = "cf2p"    # Crazyflie 2.x, + configuration
+    RACE = "racer"   # racing quad, X configuration
+
+    @property
+    def code(self) -> int:
+        """`GPD_MODEL_*` value of include/gpd.h."""
+        return {"cf2x": 0, "cf2p": 1, "racer": 2}[self.value]
+
+
+class Physics(Enum):
+    PYB = "pyb"
+    DYN = "dyn"
+    PYB_GND = "pyb_gnd"
+    PYB_DRAG = "pyb_drag"
+    PYB_DW = "pyb_dw"
+    PYB_GND_DRAG_DW = "pyb_gnd_drag_dw"
+
+    @property
+    def flags(self) -> int:
+        """Bit mask of the aerodynamic add-on terms (`GPD_PHYS_GND|DRAG|DW`).
+
+        The explicit integrator is the only engine in this package: the `PYB_*`
+        members select which of the reference's add-on force models
+        (`BaseAviary.py:354-367`) are evaluated *inside* the explicit integrator
+        (SURVEY.md App. A.4).  Plain `PYB` maps to no add-on, i.e. to `DYN`.
+        """
+        return {"pyb": 0, "dyn": 0, "pyb_gnd": 1, "pyb_drag": 2, "pyb_dw": 4,
+                "pyb_gnd_drag_dw": 7}[self.value]
+
+
+class ImageType(Enum):
+    RGB = 0
+    DEP = 1
+    SEG = 2
+    BW = 3
+
+
+class ActionType(Enum):
+    RPM = "rpm"
+    PID = "pid"
+    VEL = "vel"
+    ONE_D_RPM = "one_d_rpm"
+    ONE_D_PID = "one_d_pid"
+
+    @property
+    def code(self) -> int:
+        """`GPD_ACT_*` value of include/gpd.h."""
+        return {"rpm": 0, "pid": 1, "vel": 2, "one_d_rpm": 3, "one_d_pid": 4}[self.value]
+
+    @property
+    def dim(self) -> int:
+        """Per-drone action width (`BaseRLAviary.py:141-146`)."""
+        return {"rpm": 4, "pid": 3, "vel": 4, "one_d_rpm": 1, "one_d_pid": 1}[self.value]
+
+    @property
+    def uses_pid(self) -> bool:
+        return self in (ActionType.PID, ActionType.VEL, ActionType.ONE_D_PID)
+
+
+class ObservationType(Enum):
+    KIN = "kin"
+    RGB = "rgb"
+
+
+#: physics add-on bits, mirrored in include/gpd.h
+PHYS_GND, PHYS_DRAG, PHYS_DW = 1, 2, 4
+#: raw-RPM action clipped to [0, MAX_RPM] (CtrlAviary, `CtrlAviary.py:140`); kernel-only code
+ACT_RAW_RPM = 5

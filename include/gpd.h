@@ -1,0 +1,204 @@
+/*
+ * gpd.h — C-ABI of libgpd.so, the MI355X (gfx950) native hot path of the vectorised
+ * quadrotor simulator: BaseAviary's per-drone physics step (explicit integrator + drag,
+ * ground effect, downwash), DSLPIDControl, the RL action mapping, the 12-float kinematic
+ * observation and the Hover / MultiHover reward, termination and truncation tests, fused
+ * into one HIP kernel over a structure-of-arrays drone state.
+ *
+ * The reference (utiasDSL/gym-pybullet-drones, pure Python) has no FFI layer; its boundary is
+ * the Python class surface.  Each entry point below names the reference code it replaces
+ * (paths relative to the reference checkout, gym_pybullet_drones/...).  INTEGRATION.md shows
+ * the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory (PyTorch-ROCm tensors on the
+ *     Python side); the library never allocates, frees or retains tensor memory;
+ *   - every call is asynchronous on the hipStream_t passed as `void* stream` (NULL = default
+ *     stream), takes no locks and keeps no mutable global state except the thread-local
+ *     last-error string, so it is re-entrant per stream and capturable in a hipGraph;
+ *   - return value: 0 on success, a negative GPD_E* code for argument errors, a positive
+ *     hipError_t for runtime errors; gpd_last_error() describes the last failure of the
+ *     calling thread.  No C++ exception crosses the boundary;
+ *   - drone n = env * drones_per_env + d (the D drones of one aviary are adjacent);
+ *   - quaternions are (x, y, z, w), as in the reference's state vector
+ *     (envs/BaseAviary.py:559);
+ *   - all arithmetic is IEEE fp32 with correctly-rounded sqrt/div and OCML sin/cos/atan2/asin
+ *     (no fast-math), FMA contraction allowed.
+ */
+#ifndef GPD_H
+#define GPD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPD_ABI_VERSION 1
+
+/* DroneModel (utils/enums.py:3-8) */
+enum { GPD_MODEL_CF2X = 0, GPD_MODEL_CF2P = 1, GPD_MODEL_RACE = 2 };
+
+/* ActionType (utils/enums.py:35-41) + the raw, clipped RPM action of CtrlAviary
+ * (envs/CtrlAviary.py:121-140) */
+enum {
+    GPD_ACT_RPM = 0,       /* rpm = HOVER_RPM*(1+0.05*a[0:4])      envs/BaseRLAviary.py:191-192 */
+    GPD_ACT_PID = 1,       /* a[0:3] = waypoint, DSLPID            envs/BaseRLAviary.py:193-207 */
+    GPD_ACT_VEL = 2,       /* a[0:4] = direction+speed, DSLPID     envs/BaseRLAviary.py:208-223 */
+    GPD_ACT_ONE_D_RPM = 3, /* rpm = HOVER_RPM*(1+0.05*a[0]) x4     envs/BaseRLAviary.py:224-225 */
+    GPD_ACT_ONE_D_PID = 4, /* target = pos + 0.1*[0,0,a[0]], DSLPID envs/BaseRLAviary.py:226-235 */
+    GPD_ACT_RAW_RPM = 5    /* rpm = clip(a[0:4], 0, MAX_RPM)       envs/CtrlAviary.py:140 */
+};
+
+/* Aerodynamic add-on terms evaluated inside the explicit integrator
+ * (envs/BaseAviary.py:354-367 dispatch; formulas :715-811) */
+enum { GPD_PHYS_GND = 1, GPD_PHYS_DRAG = 2, GPD_PHYS_DW = 4 };
+
+/* Which task's reward / termination / truncation is evaluated in the step kernel */
+enum {
+    GPD_TASK_NONE = 0,       /* reward -1, never terminated/truncated (envs/CtrlAviary.py:144-190) */
+    GPD_TASK_HOVER = 1,      /* envs/HoverAviary.py:68-117 */
+    GPD_TASK_MULTIHOVER = 2  /* envs/MultiHoverAviary.py:75-130 */
+};
+
+enum {
+    GPD_EINVAL = -1,   /* bad argument (NULL pointer, non-positive size, unknown enum) */
+    GPD_ERANGE = -2,   /* size outside what the kernel supports (e.g. drones_per_env > 256) */
+    GPD_ENOTSUP = -3   /* combination not supported (e.g. PID action on the RACE model) */
+};
+
+/*
+ * Per-airframe constants.  Replaces the attributes BaseAviary.__init__ derives from the URDF
+ * (envs/BaseAviary.py:97-128, _parseURDFParameters :985-1017) and the DSLPIDControl gains
+ * (control/DSLPIDControl.py:37-60, control/BaseControl.py:35-39).  Passed BY VALUE in the
+ * kernel argument segment, i.e. it lives in scalar registers: every field is wave-uniform.
+ */
+typedef struct GpdParams {
+    int32_t drone_model;       /* GPD_MODEL_* */
+    float M;                   /* mass [kg] */
+    float L;                   /* arm length [m] */
+    float KF, KM;              /* thrust / torque coefficients */
+    float GRAVITY;             /* G*M with G = 9.8            envs/BaseAviary.py:117 */
+    float J[3], J_INV[3];      /* diagonal inertia and its inverse */
+    float prop_x[4], prop_y[4];/* rotor offsets in the body frame (URDF prop links) */
+    float gnd_eff_coeff, prop_radius, gnd_eff_h_clip;   /* envs/BaseAviary.py:128 */
+    float drag_coeff[3];
+    float dw_coeff[3];
+    float hover_rpm, max_rpm;  /* envs/BaseAviary.py:118-119 */
+    /* DSLPID (the RL aviaries always build CF2X controllers, envs/BaseRLAviary.py:75-76) */
+    float pid_gravity, pid_kf; /* control/BaseControl.py:35-37 */
+    float p_for[3], i_for[3], d_for[3];
+    float p_tor[3], i_tor[3], d_tor[3];
+    float mixer[12];           /* row-major 4x3, control/DSLPIDControl.py:47-60 */
+    float pwm2rpm_scale, pwm2rpm_const, min_pwm, max_pwm;
+    float speed_limit;         /* ActionType.VEL, envs/BaseRLAviary.py:94-95 */
+} GpdParams;
+
+/*
+ * Structure-of-arrays drone state; every row is a contiguous float[N] inside a [rows][ld]
+ * block (ld >= N).  Replaces BaseAviary's pos/quat/vel/rpy_rates/last_clipped_action arrays and
+ * the PyBullet state store (envs/BaseAviary.py:468-477, 509-519, 865-877) and the per-drone
+ * DSLPIDControl members (control/DSLPIDControl.py:65-78).
+ */
+typedef struct GpdState {
+    float* kin;            /* [13][ld]: pos xyz | quat xyzw | vel xyz | rpy_rates (body rates) xyz */
+    float* last_rpm;       /* [4][ld] last applied RPMs (last_clipped_action); NULL = not tracked
+                              (required with GPD_PHYS_DRAG) */
+    float* pid;            /* [9][ld]: integral_pos_e | last_rpy | integral_rpy_e; NULL unless a
+                              PID action type is used */
+    int32_t* step_counter; /* [num_envs] physics steps since reset (envs/BaseAviary.py:460,382) */
+    int64_t ld;            /* row pitch in floats */
+} GpdState;
+
+/* Per-call configuration of gpd_step */
+typedef struct GpdStepCfg {
+    int32_t num_envs;        /* E */
+    int32_t drones_per_env;  /* D, 1..256 */
+    int32_t act_type;        /* GPD_ACT_* */
+    int32_t substeps;        /* PYB_STEPS_PER_CTRL = pyb_freq/ctrl_freq  envs/BaseAviary.py:81 */
+    uint32_t physics_flags;  /* GPD_PHYS_* mask */
+    float pyb_dt;            /* PYB_TIMESTEP   envs/BaseAviary.py:83 */
+    float ctrl_dt;           /* CTRL_TIMESTEP  envs/BaseAviary.py:82 */
+    int32_t task;            /* GPD_TASK_* */
+    float xy_bound, z_bound, tilt_bound;  /* truncation box  envs/HoverAviary.py:110-111 */
+    float term_dist;         /* 1e-4            envs/HoverAviary.py:93 */
+    int32_t trunc_counter;   /* truncated iff step_counter > trunc_counter, i.e.
+                                step_counter/PYB_FREQ > EPISODE_LEN_SEC  envs/HoverAviary.py:114 */
+    int32_t target_per_env;  /* 0: target_pos is [D][3] shared by all envs; 1: [E*D][3] */
+    int32_t init_per_env;    /* 0: init_pose is [D][7] shared by all envs; 1: [E*D][7] */
+    int32_t auto_reset;      /* 1: envs that end (terminated|truncated) are reset in the same call,
+                                the SB3 DummyVecEnv convention (examples/learn.py:54-58) */
+} GpdStepCfg;
+
+/* ABI version of the loaded library (== GPD_ABI_VERSION of the header it was built from). */
+int gpd_abi_version(void);
+
+/* Description of the last error on the calling thread ("" if none). */
+const char* gpd_last_error(void);
+
+/* sizeof(GpdParams), sizeof(GpdState), sizeof(GpdStepCfg): lets a binding verify its struct
+ * mirrors before the first call. */
+void gpd_struct_sizes(int32_t out[3]);
+
+/*
+ * One env.step() for E aviaries of D drones.  Replaces BaseAviary.step's hot body
+ * (envs/BaseAviary.py:341-382): _preprocessAction (envs/BaseRLAviary.py:160-239, incl.
+ * DSLPIDControl.computeControl, control/DSLPIDControl.py:82-259), `substeps` x { _dynamics +
+ * _integrateQ (:815-892) with the _groundEffect/_drag/_downwash terms (:715-811) },
+ * _updateAndStoreKinematicInformation (:509-519), the kinematic part of _computeObs
+ * (envs/BaseRLAviary.py:307-315), _computeReward/_computeTerminated/_computeTruncated
+ * (envs/HoverAviary.py:68-117, envs/MultiHoverAviary.py:75-130) and the step-counter update.
+ *
+ *   action      [E*D][A] row-major, A = 4 (RPM, VEL, RAW_RPM), 3 (PID), 1 (ONE_D_*)
+ *   target_pos  [D][3] or [E*D][3]: TARGET_POS of the task (ignored for GPD_TASK_NONE, may be NULL)
+ *   init_pose   [D][7] or [E*D][7]: INIT_XYZS xyz + quaternion of INIT_RPYS; used by auto_reset
+ *               only (may be NULL when auto_reset == 0)
+ *   obs12       [E*D][12] out: pos | rpy | vel | ang_v   (envs/BaseRLAviary.py:314); with
+ *               auto_reset it holds the post-reset observation of the envs that ended
+ *   reward      [E] out
+ *   terminated  [E] out (0/1), truncated [E] out (0/1)
+ *   term_obs12  [E*D][12] out or NULL: with auto_reset, rows of envs that ended receive the last
+ *               observation of the finished episode (SB3's info["terminal_observation"]); other
+ *               rows are left untouched
+ */
+int gpd_step(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg,
+             const float* action, const float* target_pos, const float* init_pose,
+             float* obs12, float* reward, uint8_t* terminated, uint8_t* truncated,
+             float* term_obs12, void* stream);
+
+/*
+ * Masked reset.  Replaces BaseAviary.reset/_housekeeping (envs/BaseAviary.py:220-255, 451-477)
+ * for the envs whose mask byte is non-zero (mask == NULL: all).  Sets pos/quat to init_pose,
+ * vel, rpy_rates, last_rpm and step_counter to zero and writes the initial obs12 rows.  As in
+ * the reference, the DSLPID state is NOT reset unless reset_pid != 0.
+ */
+int gpd_reset(const GpdState* state, const float* init_pose, int32_t init_per_env,
+              const uint8_t* mask, int32_t num_envs, int32_t drones_per_env, int32_t reset_pid,
+              float* obs12, void* stream);
+
+/*
+ * Batched DSLPIDControl.computeControl (control/DSLPIDControl.py:82-145) for n independent
+ * controllers.  Inputs are row-major [n][3] / [n][4] arrays; `pid` is the [9][ld] controller
+ * state (updated in place).  target_rpy / target_vel / target_rpy_rates may be NULL (= zeros,
+ * the reference's defaults).  Outputs: rpm [n][4], pos_e [n][3] (may be NULL), yaw_e [n]
+ * (may be NULL; computed_target_rpy[2] - cur_rpy[2]).
+ */
+int gpd_pid(const GpdParams* params, float* pid, int64_t ld, float ctrl_dt,
+            const float* cur_pos, const float* cur_quat, const float* cur_vel,
+            const float* target_pos, const float* target_rpy, const float* target_vel,
+            const float* target_rpy_rates, float* rpm, float* pos_e, float* yaw_e,
+            int32_t n, void* stream);
+
+/*
+ * Gather the 20-float state vectors of BaseAviary._getDroneStateVector
+ * (envs/BaseAviary.py:541-561): pos3 | quat4 | rpy3 | vel3 | ang_v3 | last_clipped_action4,
+ * from the SoA state and the obs12 rows of the latest step.  state20 is [n][20].
+ */
+int gpd_state_vectors(const GpdState* state, const float* obs12, float* state20, int32_t n,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPD_H */
