@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the fused HIP step on synthetic hover batches.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--mode graph|eager]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one `env.step()` of EVERY aviary on this rank = one launch of the fused kernel.
+Default workload `hover65536_240hz` (BASELINE.json's metric): 65 536 HoverAviaries per GPU (1 drone
+each), Physics.DYN, ActionType.RPM, pyb_freq = ctrl_freq = 240 Hz (one physics step per env step,
+so env-steps == drone-steps), same-step auto-reset on, actions pre-generated on the device and
+changed every step.  Weak scaling: every rank owns its own 65 536 aviaries; no data-path collective
+unless `--allgather` asks for the optional RCCL all-gather of the observation shards.
+
+Rank 0 prints ONE JSON line (metric/value/unit + roofline + cpu_baseline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+WORKLOADS = {
+    # name: (envs/GPU, drones/env, physics flags, ctrl_freq, act, task)
+    "hover65536_240hz": dict(E=65536, D=1, phys=0, ctrl=240, act="rpm", task="hover"),
+    "hover65536_30hz": dict(E=65536, D=1, phys=0, ctrl=30, act="rpm", task="hover"),
+    "hover4096_240hz": dict(E=4096, D=1, phys=0, ctrl=240, act="rpm", task="hover"),
+    "hover65536_ext_240hz": dict(E=65536, D=1, phys=7, ctrl=240, act="rpm", task="hover"),
+    "stack8x8192_ext_240hz": dict(E=8192, D=8, phys=7, ctrl=240, act="rpm", task="multihover"),
+    "multihover2x16384_240hz": dict(E=16384, D=2, phys=4, ctrl=240, act="rpm", task="multihover"),
+    "hover65536_pid_240hz": dict(E=65536, D=1, phys=0, ctrl=240, act="pid", task="hover"),
+    "hover4m_240hz": dict(E=4194304, D=1, phys=0, ctrl=240, act="rpm", task="hover"),
+    "hover16m_240hz": dict(E=16777216, D=1, phys=0, ctrl=240, act="rpm", task="hover"),
+}
+
+
+def make_env(w, device, seed):
+    from gym_pybullet_drones_amd.envs import VectorAviary
+    from gym_pybullet_drones_amd.utils.enums import ActionType
+    E, D = w["E"], w["D"]
+    rng = np.random.default_rng(seed)
+    if D == 1:
+        xyz = np.array([0, 0, 0.1125]) + rng.uniform(-0.5, 0.5, size=(E, D, 3)) * np.array([1, 1, 0])
+    else:   # drones stacked 0.3 m apart so downwash / ground effect are active
+        xyz = rng.uniform(-0.05, 0.05, size=(E, D, 3)) + np.arange(D)[None, :, None] * np.array([0.05, 0, 0.3]) + \
+            np.array([0, 0, 0.1])
+    rpy = rng.uniform(-0.1, 0.1, size=(E, D, 3))
+    env = VectorAviary(E, D, initial_xyzs=xyz, initial_rpys=rpy, physics=w["phys"], pyb_freq=240,
+                       ctrl_freq=w["ctrl"], act=ActionType(w["act"]), task=w["task"], auto_reset=True,
+                       track_rpm=bool(w["phys"] & 2), device=device)
+    return env
+
+
+def make_actions(w, env, device, seed, pool):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    a = torch.rand((pool, env.NUM_ENVS, env.NUM_DRONES, env.ACT_DIM), generator=g, device=device) * 2 - 1
+    if w["act"] == "pid":
+        a = a * 0.5
+        a[..., 2] += 1.0
+    return a.contiguous()
+
+
+def cpu_baseline(w, budget_s=12.0):
+    """Time the loop-structured float64 oracle (the CPU 'port' of the reference's per-drone Python/numpy
+    path; PyBullet itself is not installable here) on ONE host core, on a bounded sample of the workload."""
+    from oracle.aviary_oracle import OracleAviary
+    urdf = os.path.join(REPO, "gym-pybullet-drones_amd", "assets", "cf2x.urdf")
+    D = w["D"]
+    env = OracleAviary(urdf, "cf2x", num_drones=D, physics_flags=w["phys"], pyb_freq=240, ctrl_freq=w["ctrl"],
+                       act=w["act"], task=w["task"] if w["task"] != "hover" or D == 1 else "multihover")
+    rng = np.random.default_rng(0)
+    A = env.action_buffer[0].shape[1]
+    acts = rng.uniform(-1, 1, size=(64, D, A))
+    env.step(acts[0])
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        for k in range(16):
+            _, _, term, trunc = env.step(acts[(n + k) % 64])
+            if term or trunc:
+                env.reset()
+        n += 16
+    dt = time.perf_counter() - t0
+    S = 240 // w["ctrl"]
+    return {"value": n * D * S / dt, "unit": "drone-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n} env.step() of ONE aviary ({D} drone(s), S={S}) through oracle/aviary_oracle.py "
+                      f"(float64 per-drone numpy loop restating BaseAviary._dynamics + BaseRLAviary + task) in {dt:.1f}s "
+                      f"on 1 host core; PyBullet (Physics.PYB) is not installable in this image"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--warmup", type=int, default=400)
+    ap.add_argument("--workload", default="hover65536_240hz", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
+                    help="graph: replay a hipGraph of 16 consecutive steps; eager: one host launch per step")
+    ap.add_argument("--allgather", action="store_true", help="all-gather the obs shards over RCCL every step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from gym_pybullet_drones_amd import dist as gdist
+    rank, world, local = gdist.init_from_env("nccl" if args.gpus > 1 else None)
+    if args.gpus != world:
+        if rank == 0:
+            print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run", file=sys.stderr)
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    device = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(device)
+
+    w = WORKLOADS[args.workload]
+    env = make_env(w, device, seed=1000 + rank)
+    POOL = 16
+    actions = make_actions(w, env, device, seed=2000 + rank, pool=POOL)
+    core = env.core
+    S = core.S
+    gather = gdist.ObsAllGather(core.N, 12, device=device) if args.allgather else None
+
+    def one_step(i):
+        env.step(actions[i % POOL])
+        if gather is not None:
+            gather(core.obs12)
+
+    # warm-up (untimed)
+    for i in range(min(args.warmup, 64)):
+        one_step(i)
+    torch.cuda.synchronize()
+    graph = None
+    if args.mode == "graph":
+        stream = torch.cuda.Stream(device)
+        stream.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(stream):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                for i in range(POOL):
+                    one_step(i)
+        torch.cuda.current_stream(device).wait_stream(stream)
+
+    def run(k):
+        if graph is None:
+            for i in range(k):
+                one_step(i)
+        else:
+            assert k % POOL == 0
+            for _ in range(k // POOL):
+                graph.replay()
+
+    K = (args.steps + POOL - 1) // POOL * POOL if graph is not None else args.steps
+    W = (args.warmup + POOL - 1) // POOL * POOL if graph is not None else args.warmup
+    run(W)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    run(K)
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t1 = time.perf_counter()
+    wall = gdist.max_over_ranks(t1 - t0, device=device)
+    ev_ms = ev0.elapsed_time(ev1)
+
+    if rank == 0:
+        n_total = core.N * world
+        value = n_total * S * K / wall
+        bytes_launch = core.bytes_per_step()
+        launch_us = ev_ms * 1e3 / K
+        achieved = bytes_launch / (launch_us * 1e-6) / 1e9
+        out = {
+            "metric": "env steps/sec (whole node), HoverAviary N=65536 drones @240Hz",
+            "value": value, "unit": "drone-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "envs_per_gpu": core.E, "drones_per_env": core.D,
+                       "total_drones": n_total, "physics": "DYN" + "".join(n for b, n in ((1, "+GND"), (2, "+DRAG"), (4, "+DW")) if w["phys"] & b),
+                       "pyb_freq": 240, "ctrl_freq": w["ctrl"], "substeps_per_step": S, "action": w["act"],
+                       "task": w["task"], "auto_reset": True, "launch": args.mode,
+                       "obs_allgather": bool(args.allgather), "env_steps_per_s": n_total * K / wall},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "gpd_step_kernel", "bytes_per_launch": bytes_launch,
+                         "launch_us_hip_events": launch_us},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

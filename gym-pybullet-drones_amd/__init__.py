@@ -1,0 +1,34 @@
+"""MI355X-native vectorised quadrotor simulator — drop-in for the hot path of gym-pybullet-drones.
+
+Import name: `gym_pybullet_drones_amd` (the directory is `gym-pybullet-drones_amd/`; the sibling
+`gym_pybullet_drones_amd/` only redirects the import here).
+
+    from gym_pybullet_drones_amd.envs import HoverAviary, MultiHoverAviary      # reference-shaped, 1 aviary
+    from gym_pybullet_drones_amd.envs import VectorHoverAviary                  # E aviaries per launch
+    from gym_pybullet_drones_amd.control import DSLPIDControl
+    from gym_pybullet_drones_amd.utils.enums import DroneModel, Physics, ActionType, ObservationType
+
+`install_as("gym_pybullet_drones")` makes the reference's own import paths resolve to this
+package (`from gym_pybullet_drones.envs.HoverAviary import HoverAviary`).
+"""
+import importlib
+import sys
+
+from ._gym_shim import register as _register
+
+__version__ = "0.1.0"
+
+_register(id='ctrl-aviary-v0', entry_point='gym_pybullet_drones_amd.envs:CtrlAviary')
+_register(id='hover-aviary-v0', entry_point='gym_pybullet_drones_amd.envs:HoverAviary')
+_register(id='multihover-aviary-v0', entry_point='gym_pybullet_drones_amd.envs:MultiHoverAviary')
+
+
+def install_as(name: str = "gym_pybullet_drones"):
+    """Alias this package (and its envs/control/utils modules) under another top-level name."""
+    me = sys.modules[__name__]
+    sys.modules[name] = me
+    for sub in ("envs", "envs.BaseAviary", "envs.BaseRLAviary", "envs.HoverAviary", "envs.MultiHoverAviary",
+                "envs.CtrlAviary", "envs.VectorAviary", "control", "control.BaseControl", "control.DSLPIDControl",
+                "utils", "utils.enums"):
+        sys.modules[f"{name}.{sub}"] = importlib.import_module(f"{__name__}.{sub}")
+    return me

@@ -1,0 +1,115 @@
+"""ctypes binding of `csrc/libgpd.so` (the C-ABI declared in include/gpd.h).
+
+There is NO fallback: if the library is missing or does not match the header, importing the
+product path raises.  `build()` compiles it in-tree with hipcc for gfx950 (cross-compiles on a
+machine without a GPU).
+"""
+import ctypes
+import os
+import subprocess
+
+from .params import GpdParams
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+LIB_PATH = os.path.join(CSRC, "libgpd.so")
+ABI_VERSION = 1
+
+HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared"]
+
+
+class GpdError(RuntimeError):
+    pass
+
+
+class GpdState(ctypes.Structure):
+    """mirror of `struct GpdState`"""
+    _fields_ = [("kin", ctypes.c_void_p), ("last_rpm", ctypes.c_void_p), ("pid", ctypes.c_void_p),
+                ("step_counter", ctypes.c_void_p), ("ld", ctypes.c_int64)]
+
+
+class GpdStepCfg(ctypes.Structure):
+    """mirror of `struct GpdStepCfg`"""
+    _fields_ = [("num_envs", ctypes.c_int32), ("drones_per_env", ctypes.c_int32), ("act_type", ctypes.c_int32),
+                ("substeps", ctypes.c_int32), ("physics_flags", ctypes.c_uint32), ("pyb_dt", ctypes.c_float),
+                ("ctrl_dt", ctypes.c_float), ("task", ctypes.c_int32), ("xy_bound", ctypes.c_float),
+                ("z_bound", ctypes.c_float), ("tilt_bound", ctypes.c_float), ("term_dist", ctypes.c_float),
+                ("trunc_counter", ctypes.c_int32), ("target_per_env", ctypes.c_int32),
+                ("init_per_env", ctypes.c_int32), ("auto_reset", ctypes.c_int32)]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/gpd.hip -> csrc/libgpd.so for gfx950.  Returns the library path."""
+    src = os.path.join(CSRC, "gpd.hip")
+    hdr = os.path.join(INCLUDE, "gpd.h")
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(src), os.path.getmtime(hdr))
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, src, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise GpdError("hipcc failed:\n" + res.stdout + res.stderr)
+    return LIB_PATH
+
+
+_lib = None
+
+_P = ctypes.c_void_p
+_SIGNATURES = {
+    "gpd_abi_version": (ctypes.c_int, []),
+    "gpd_last_error": (ctypes.c_char_p, []),
+    "gpd_struct_sizes": (None, [ctypes.POINTER(ctypes.c_int32)]),
+    "gpd_step": (ctypes.c_int, [ctypes.POINTER(GpdParams), ctypes.POINTER(GpdState), ctypes.POINTER(GpdStepCfg),
+                                _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gpd_reset": (ctypes.c_int, [ctypes.POINTER(GpdState), _P, ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_int32,
+                                 ctypes.c_int32, _P, _P]),
+    "gpd_pid": (ctypes.c_int, [ctypes.POINTER(GpdParams), _P, ctypes.c_int64, ctypes.c_float, _P, _P, _P, _P, _P, _P,
+                               _P, _P, _P, _P, ctypes.c_int32, _P]),
+    "gpd_state_vectors": (ctypes.c_int, [ctypes.POINTER(GpdState), _P, _P, ctypes.c_int32, _P]),
+}
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and verify the shared library.  Raises GpdError when it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GpdError(f"{LIB_PATH} not found: the HIP extension has not been built "
+                       "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                       "There is no CPU fallback for the simulator's hot path.")
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise GpdError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError as e:
+            raise GpdError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if L.gpd_abi_version() != ABI_VERSION:
+        raise GpdError(f"libgpd ABI {L.gpd_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
+    sizes = (ctypes.c_int32 * 3)()
+    L.gpd_struct_sizes(sizes)
+    want = (ctypes.sizeof(GpdParams), ctypes.sizeof(GpdState), ctypes.sizeof(GpdStepCfg))
+    if tuple(sizes) != want:
+        raise GpdError(f"struct layout mismatch: library {tuple(sizes)} vs binding {want}")
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().gpd_last_error().decode("utf-8", "replace")
+        raise GpdError(f"{what} failed (code {rc}): {msg}")
+
+
+def exported_symbols():
+    return list(_SIGNATURES)

@@ -1,0 +1,196 @@
+"""Host side of the hot path: owns the structure-of-arrays drone state in HBM (PyTorch-ROCm
+tensors) and launches the HIP kernels of `csrc/libgpd.so` through the C-ABI (`include/gpd.h`).
+
+PyTorch is used for device memory and streams only; every arithmetic step of the simulator runs
+in the hand-written kernels.  Layout (N = num_envs * drones_per_env, drone n = env*D + d):
+
+    kin       float32 [13][ld]   pos xyz | quat xyzw | vel xyz | body rates xyz   (ld = N rounded
+                                 up to 64 so every row starts on a 256-byte boundary)
+    last_rpm  float32 [4][ld]    last applied RPMs (optional)
+    pid       float32 [9][ld]    DSLPID integrators / last rpy (PID action types only)
+    counter   int32   [E]        physics steps since the env's last reset
+    obs12     float32 [N][12]    pos | rpy | vel | ang_v — row-major, ready for a policy / all-gather
+    reward    float32 [E], terminated/truncated uint8 [E]
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _native
+from .params import DroneParams, PIDGains, euler_to_quat, trunc_counter
+from .utils.enums import ACT_RAW_RPM, ActionType, DroneModel, PHYS_DRAG, Physics
+
+TASK_NONE, TASK_HOVER, TASK_MULTIHOVER = 0, 1, 2
+_ACT_DIM = {0: 4, 1: 3, 2: 4, 3: 1, 4: 1, 5: 4, 6: 4}
+_PID_ACTS = (1, 2, 4)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class SimCore:
+    """E aviaries x D drones advanced by one fused kernel launch per `step()`."""
+
+    def __init__(self, drone_model: DroneModel = DroneModel.CF2X, num_envs: int = 1, drones_per_env: int = 1,
+                 physics=Physics.DYN, pyb_freq: int = 240, ctrl_freq: int = 240, act_code: int = 0,
+                 task: int = TASK_NONE, initial_xyzs=None, initial_rpys=None, target_pos=None,
+                 episode_len_sec: float = 8.0, xy_bound: float = 1.5, z_bound: float = 2.0, tilt_bound: float = 0.4,
+                 term_dist: float = 1e-4, auto_reset: bool = False, track_rpm: bool = True,
+                 keep_terminal_obs: bool = False, device=None, gains: PIDGains = None):
+        if pyb_freq % ctrl_freq != 0:
+            raise ValueError("[ERROR] pyb_freq is not divisible by ctrl_freq.")
+        self.lib = _native.lib()                      # raises if the HIP extension is missing
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+        if device is None or torch.device(device).type != "cuda":
+            raise _native.GpdError("the simulator's hot path runs on an MI355X only: no CUDA/HIP device available "
+                                   "(there is no CPU fallback)")
+        self.device = torch.device(device)
+        self.E, self.D = int(num_envs), int(drones_per_env)
+        self.N = self.E * self.D
+        if not (1 <= self.D <= 256):
+            raise ValueError("drones_per_env must be in 1..256")
+        self.ld = (self.N + 63) // 64 * 64
+        self.P = DroneParams(drone_model)
+        self.physics_flags = physics.flags if isinstance(physics, Physics) else int(physics)
+        self.act_code = int(act_code)
+        self.A = _ACT_DIM[self.act_code]
+        self.uses_pid = self.act_code in _PID_ACTS
+        if self.uses_pid and drone_model == DroneModel.RACE:
+            raise ValueError("[ERROR] no controller is available for the specified drone_model")
+        self.S = pyb_freq // ctrl_freq
+        self.pyb_freq, self.ctrl_freq = pyb_freq, ctrl_freq
+        self.task = task
+        self.auto_reset = bool(auto_reset)
+        self._params = self.P.to_struct(pid_model=DroneModel.CF2X, gains=gains)   # BaseRLAviary.py:75-76
+
+        dev, f32 = self.device, torch.float32
+        self.kin = torch.zeros((13, self.ld), dtype=f32, device=dev)
+        need_rpm = track_rpm or bool(self.physics_flags & PHYS_DRAG)
+        self.last_rpm = torch.zeros((4, self.ld), dtype=f32, device=dev) if need_rpm else None
+        self.pid = torch.zeros((9, self.ld), dtype=f32, device=dev) if self.uses_pid else None
+        self.step_counter = torch.zeros((self.E,), dtype=torch.int32, device=dev)
+        self.obs12 = torch.zeros((self.N, 12), dtype=f32, device=dev)
+        self.reward = torch.zeros((self.E,), dtype=f32, device=dev)
+        self.terminated = torch.zeros((self.E,), dtype=torch.uint8, device=dev)
+        self.truncated = torch.zeros((self.E,), dtype=torch.uint8, device=dev)
+        self.term_obs12 = torch.zeros((self.N, 12), dtype=f32, device=dev) if keep_terminal_obs else None
+
+        # initial poses: (D,3) shared by all envs, or (E,D,3) per env
+        if initial_xyzs is None:
+            initial_xyzs = self.P.default_init_xyzs(self.D)
+        xyz = np.asarray(initial_xyzs, dtype=np.float64)
+        rpy = np.zeros((self.D, 3)) if initial_rpys is None else np.asarray(initial_rpys, dtype=np.float64)
+        if xyz.shape not in ((self.D, 3), (self.E, self.D, 3)):
+            raise ValueError(f"initial_xyzs must have shape ({self.D},3) or ({self.E},{self.D},3), got {xyz.shape}")
+        if rpy.shape not in ((self.D, 3), (self.E, self.D, 3)):
+            raise ValueError(f"initial_rpys must have shape ({self.D},3) or ({self.E},{self.D},3), got {rpy.shape}")
+        self.init_per_env = int(xyz.ndim == 3 or rpy.ndim == 3)
+        if self.init_per_env:
+            xyz = np.broadcast_to(xyz, (self.E, self.D, 3))
+            rpy = np.broadcast_to(rpy, (self.E, self.D, 3))
+        self.INIT_XYZS, self.INIT_RPYS = np.array(xyz), np.array(rpy)
+        pose = np.concatenate([xyz, euler_to_quat(rpy)], axis=-1).reshape(-1, 7)
+        self.init_pose = torch.tensor(pose, dtype=f32, device=dev).contiguous()
+        self.set_target(target_pos)
+
+        self._state = _native.GpdState(kin=self.kin.data_ptr(),
+                                       last_rpm=self.last_rpm.data_ptr() if self.last_rpm is not None else None,
+                                       pid=self.pid.data_ptr() if self.pid is not None else None,
+                                       step_counter=self.step_counter.data_ptr(), ld=self.ld)
+        self._cfg = _native.GpdStepCfg(
+            num_envs=self.E, drones_per_env=self.D, act_type=self.act_code, substeps=self.S,
+            physics_flags=self.physics_flags, pyb_dt=1.0 / pyb_freq, ctrl_dt=1.0 / ctrl_freq, task=task,
+            xy_bound=xy_bound, z_bound=z_bound, tilt_bound=tilt_bound, term_dist=term_dist,
+            trunc_counter=trunc_counter(episode_len_sec, pyb_freq), target_per_env=self.target_per_env,
+            init_per_env=self.init_per_env, auto_reset=int(self.auto_reset))
+        self.reset()
+
+    # ------------------------------------------------------------------------------------------
+    def set_target(self, target_pos):
+        """TARGET_POS of the task: (D,3) shared, or (E,D,3) per env; None = zeros."""
+        if target_pos is None:
+            target_pos = np.zeros((self.D, 3))
+        tp = np.asarray(target_pos, dtype=np.float64)
+        if tp.shape not in ((self.D, 3), (self.E, self.D, 3)):
+            raise ValueError(f"target_pos must have shape ({self.D},3) or ({self.E},{self.D},3), got {tp.shape}")
+        self.target_per_env = int(tp.ndim == 3)
+        self.TARGET_POS = tp
+        self.target = torch.tensor(tp.reshape(-1, 3), dtype=torch.float32, device=self.device).contiguous()
+        if hasattr(self, "_cfg"):
+            self._cfg.target_per_env = self.target_per_env
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self, mask=None, reset_pid: bool = False):
+        """Masked reset (mask: uint8/bool tensor [E] on the device, None = all envs)."""
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        with torch.cuda.device(self.device):
+            rc = self.lib.gpd_reset(ctypes.byref(self._state), _ptr(self.init_pose), self.init_per_env, _ptr(mask),
+                                    self.E, self.D, int(reset_pid), _ptr(self.obs12), self._stream())
+        _native.check(rc, "gpd_reset")
+        return self.obs12
+
+    def step(self, action: torch.Tensor):
+        """One env step for every aviary.  `action`: float32 device tensor with E*D*A elements.
+
+        Returns views of the persistent output tensors (obs12 [N,12], reward [E], terminated [E],
+        truncated [E]); they are overwritten by the next call.  Asynchronous on the current stream.
+        """
+        if action.device != self.device or action.dtype != torch.float32 or not action.is_contiguous():
+            action = action.to(device=self.device, dtype=torch.float32).contiguous()
+        if action.numel() != self.N * self.A:
+            raise ValueError(f"action has {action.numel()} elements, expected {self.N}x{self.A}")
+        with torch.cuda.device(self.device):
+            rc = self.lib.gpd_step(ctypes.byref(self._params), ctypes.byref(self._state), ctypes.byref(self._cfg),
+                                   _ptr(action), _ptr(self.target), _ptr(self.init_pose), _ptr(self.obs12),
+                                   _ptr(self.reward), _ptr(self.terminated), _ptr(self.truncated),
+                                   _ptr(self.term_obs12), self._stream())
+        _native.check(rc, "gpd_step")
+        return self.obs12, self.reward, self.terminated, self.truncated
+
+    def state_vectors(self) -> torch.Tensor:
+        """[N,20] state vectors in `_getDroneStateVector` order (BaseAviary.py:559-561)."""
+        out = torch.empty((self.N, 20), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.gpd_state_vectors(ctypes.byref(self._state), _ptr(self.obs12), _ptr(out), self.N,
+                                            self._stream())
+        _native.check(rc, "gpd_state_vectors")
+        return out
+
+    # ---- state access for tests / checkpointing (host <-> device copies, off the hot path) ---------
+    def get_state(self) -> dict:
+        n = self.N
+        out = {"kin": self.kin[:, :n].clone(), "step_counter": self.step_counter.clone()}
+        if self.last_rpm is not None:
+            out["last_rpm"] = self.last_rpm[:, :n].clone()
+        if self.pid is not None:
+            out["pid"] = self.pid[:, :n].clone()
+        return out
+
+    def set_state(self, kin=None, last_rpm=None, pid=None, step_counter=None):
+        n = self.N
+        if kin is not None:
+            self.kin[:, :n].copy_(torch.as_tensor(kin, dtype=torch.float32))
+        if last_rpm is not None and self.last_rpm is not None:
+            self.last_rpm[:, :n].copy_(torch.as_tensor(last_rpm, dtype=torch.float32))
+        if pid is not None and self.pid is not None:
+            self.pid[:, :n].copy_(torch.as_tensor(pid, dtype=torch.float32))
+        if step_counter is not None:
+            self.step_counter.copy_(torch.as_tensor(step_counter, dtype=torch.int32))
+
+    def bytes_per_step(self) -> int:
+        """Algorithmic HBM bytes one `step()` moves (SURVEY.md §8d accounting)."""
+        per_drone = (13 + self.A) * 4 + (13 + 12) * 4            # state+action in, state+obs out
+        if self.uses_pid:
+            per_drone += 2 * 9 * 4
+        if self.physics_flags & PHYS_DRAG:
+            per_drone += 4 * 4
+        if self.last_rpm is not None:
+            per_drone += 4 * 4
+        per_env = 4 + 2 + 2 * 4                                   # reward + 2 flags + counter r/w
+        return per_drone * self.N + per_env * self.E

@@ -1,0 +1,264 @@
+"""`BaseAviary`: the reference's single-aviary `gymnasium.Env` surface on top of the HIP engine.
+
+Mirrors the public interface of the reference class (`envs/BaseAviary.py:25-216` constructor and
+constants, `reset` `:220-255`, `step` `:259-383`, `render`/`close` `:387-421`, the kinematic cache
+`:509-519`, `_getDroneStateVector` `:541-561`, the eight subclass hooks `:1021-1104`,
+`_calculateNextStep` `:1108-1150`) so subclasses written against the reference keep working.  What
+is different underneath: there is no PyBullet — the whole `step()` body (action mapping, PID,
+physics sub-steps, cache refresh, observation, reward, termination, truncation) is one launch of
+the fused gfx950 kernel (`engine.SimCore`, E=1 aviary x NUM_DRONES), and this class only copies the
+handful of resulting floats back to numpy attributes with the reference's names and shapes.
+
+Deviations from the reference, on purpose:
+  * `physics`: only the explicit integrator exists.  `Physics.PYB` behaves as `Physics.DYN`;
+    `PYB_GND/DRAG/DW/GND_DRAG_DW` enable those force models *inside* the explicit integrator.
+  * arithmetic is float32 on the device (the reference is float64 numpy); attributes are float64
+    numpy copies of the float32 results.
+  * GUI, video recording, cameras, obstacles are not available (`gui=True`/`record=True` raise).
+"""
+import time
+
+import numpy as np
+import torch
+
+from .. import engine
+from .._gym_shim import Env
+from ..params import DroneParams
+from ..utils.enums import ACT_DIRECT_RPM, DroneModel, Physics
+
+
+class BaseAviary(Env):
+    """Base class for "drone aviary" Gym environments (MI355X-native)."""
+
+    #: set by subclasses whose action mapping / task is evaluated inside the kernel
+    _TASK = engine.TASK_NONE
+
+    def __init__(self,
+                 drone_model: DroneModel = DroneModel.CF2X,
+                 num_drones: int = 1,
+                 neighbourhood_radius: float = np.inf,
+                 initial_xyzs=None,
+                 initial_rpys=None,
+                 physics: Physics = Physics.PYB,
+                 pyb_freq: int = 240,
+                 ctrl_freq: int = 240,
+                 gui=False,
+                 record=False,
+                 obstacles=False,
+                 user_debug_gui=True,
+                 vision_attributes=False,
+                 output_folder='results',
+                 device=None):
+        if gui or record or vision_attributes:
+            raise NotImplementedError("GUI, video recording and camera observations are outside the MI355X hot path")
+        #### Constants (reference names) ###########################
+        self.G = 9.8
+        self.RAD2DEG = 180 / np.pi
+        self.DEG2RAD = np.pi / 180
+        self.CTRL_FREQ = ctrl_freq
+        self.PYB_FREQ = pyb_freq
+        if self.PYB_FREQ % self.CTRL_FREQ != 0:
+            raise ValueError('[ERROR] in BaseAviary.__init__(), pyb_freq is not divisible by env_freq.')
+        self.PYB_STEPS_PER_CTRL = int(self.PYB_FREQ / self.CTRL_FREQ)
+        self.CTRL_TIMESTEP = 1. / self.CTRL_FREQ
+        self.PYB_TIMESTEP = 1. / self.PYB_FREQ
+        self.NUM_DRONES = num_drones
+        self.NEIGHBOURHOOD_RADIUS = neighbourhood_radius
+        self.DRONE_MODEL = drone_model
+        self.GUI, self.RECORD = False, False
+        self.PHYSICS = physics
+        self.OBSTACLES = obstacles
+        self.USER_DEBUG = user_debug_gui
+        self.URDF = self.DRONE_MODEL.value + ".urdf"
+        self.OUTPUT_FOLDER = output_folder
+        self.CLIENT = -1                      # there is no PyBullet client
+        P = DroneParams(drone_model)
+        for name in ("M", "L", "THRUST2WEIGHT_RATIO", "J", "J_INV", "KF", "KM", "COLLISION_H", "COLLISION_R",
+                     "COLLISION_Z_OFFSET", "MAX_SPEED_KMH", "GND_EFF_COEFF", "PROP_RADIUS", "DRAG_COEFF",
+                     "DW_COEFF_1", "DW_COEFF_2", "DW_COEFF_3", "GRAVITY", "HOVER_RPM", "MAX_RPM", "MAX_THRUST",
+                     "MAX_XY_TORQUE", "MAX_Z_TORQUE", "GND_EFF_H_CLIP"):
+            setattr(self, name, getattr(P, name))
+        self._drone_params = P
+        #### Initial poses ##########################################
+        if initial_xyzs is None:
+            self.INIT_XYZS = P.default_init_xyzs(self.NUM_DRONES)
+        elif np.array(initial_xyzs).shape == (self.NUM_DRONES, 3):
+            self.INIT_XYZS = np.array(initial_xyzs, dtype=np.float64)
+        else:
+            raise ValueError("[ERROR] invalid initial_xyzs in BaseAviary.__init__(), try initial_xyzs.reshape(NUM_DRONES,3)")
+        if initial_rpys is None:
+            self.INIT_RPYS = np.zeros((self.NUM_DRONES, 3))
+        elif np.array(initial_rpys).shape == (self.NUM_DRONES, 3):
+            self.INIT_RPYS = np.array(initial_rpys, dtype=np.float64)
+        else:
+            raise ValueError("[ERROR] invalid initial_rpys in BaseAviary.__init__(), try initial_rpys.reshape(NUM_DRONES,3)")
+        #### Spaces ##################################################
+        self.action_space = self._actionSpace()
+        self.observation_space = self._observationSpace()
+        #### The engine: one aviary of NUM_DRONES drones on the GPU ##
+        fused = self._fusedActionCode()
+        self._fused_action = fused is not None
+        task_kw = self._taskConfig()
+        self._core = engine.SimCore(drone_model=drone_model, num_envs=1, drones_per_env=num_drones,
+                                    physics=physics, pyb_freq=pyb_freq, ctrl_freq=ctrl_freq,
+                                    act_code=fused if self._fused_action else ACT_DIRECT_RPM,
+                                    task=self._TASK, initial_xyzs=self.INIT_XYZS, initial_rpys=self.INIT_RPYS,
+                                    auto_reset=False, track_rpm=True, device=device, **task_kw)
+        self.DRONE_IDS = np.arange(1, self.NUM_DRONES + 1)
+        self._housekeeping()
+        self._updateAndStoreKinematicInformation()
+
+    ################################################################################
+
+    def reset(self, seed: int = None, options: dict = None):
+        """Resets the environment -> (obs, info)."""
+        super().reset(seed=seed, options=options)
+        self._housekeeping()
+        self._updateAndStoreKinematicInformation()
+        return self._computeObs(), self._computeInfo()
+
+    ################################################################################
+
+    def step(self, action):
+        """Advances the environment by one control step -> (obs, reward, terminated, truncated, info)."""
+        action = np.asarray(action)
+        if self._fused_action:
+            self._recordAction(action)
+            dev_action = torch.as_tensor(np.ascontiguousarray(action, dtype=np.float32).reshape(self.NUM_DRONES, -1),
+                                         device=self._core.device)
+        else:
+            rpm = np.reshape(self._preprocessAction(action), (self.NUM_DRONES, 4))
+            dev_action = torch.as_tensor(np.ascontiguousarray(rpm, dtype=np.float32), device=self._core.device)
+        self._core.step(dev_action)
+        self._updateAndStoreKinematicInformation()
+        obs = self._computeObs()
+        reward = self._computeReward()
+        terminated = self._computeTerminated()
+        truncated = self._computeTruncated()
+        info = self._computeInfo()
+        self.step_counter = self.step_counter + (1 * self.PYB_STEPS_PER_CTRL)
+        return obs, reward, terminated, truncated, info
+
+    ################################################################################
+
+    def render(self, mode='human', close=False):
+        """Prints a textual output of the environment."""
+        if self.first_render_call:
+            print("[WARNING] BaseAviary.render() is implemented as text-only")
+            self.first_render_call = False
+        elapsed = max(time.time() - self.RESET_TIME, 1e-9)
+        print("\n[INFO] BaseAviary.render() ——— it {:04d}".format(self.step_counter),
+              "——— wall-clock time {:.1f}s,".format(elapsed),
+              "simulation time {:.1f}s@{:d}Hz ({:.2f}x)".format(self.step_counter * self.PYB_TIMESTEP, self.PYB_FREQ,
+                                                                (self.step_counter * self.PYB_TIMESTEP) / elapsed))
+        for i in range(self.NUM_DRONES):
+            print("[INFO] BaseAviary.render() ——— drone {:d}".format(i),
+                  "——— x {:+06.2f}, y {:+06.2f}, z {:+06.2f}".format(*self.pos[i]),
+                  "——— velocity {:+06.2f}, {:+06.2f}, {:+06.2f}".format(*self.vel[i]),
+                  "——— roll {:+06.2f}, pitch {:+06.2f}, yaw {:+06.2f}".format(*(self.rpy[i] * self.RAD2DEG)),
+                  "——— angular velocity {:+06.4f}, {:+06.4f}, {:+06.4f} ——— ".format(*self.ang_v[i]))
+
+    def close(self):
+        """Terminates the environment (nothing to disconnect from)."""
+
+    def getPyBulletClient(self):
+        return self.CLIENT
+
+    def getDroneIds(self):
+        return self.DRONE_IDS
+
+    ################################################################################
+
+    def _housekeeping(self):
+        """Zero the counters and put every drone back at its initial pose (on the device)."""
+        self.RESET_TIME = time.time()
+        self.step_counter = 0
+        self.first_render_call = True
+        self._core.reset()
+
+    def _updateAndStoreKinematicInformation(self):
+        """Refresh the numpy kinematic cache from the device (one small device-to-host copy)."""
+        n = self.NUM_DRONES
+        core = self._core
+        packed = torch.cat([core.state_vectors(), core.kin[10:13, :n].t(),
+                            core.reward.expand(n, 1), core.terminated.to(torch.float32).expand(n, 1),
+                            core.truncated.to(torch.float32).expand(n, 1)], dim=1).cpu().numpy().astype(np.float64)
+        self.pos = packed[:, 0:3].copy()
+        self.quat = packed[:, 3:7].copy()
+        self.rpy = packed[:, 7:10].copy()
+        self.vel = packed[:, 10:13].copy()
+        self.ang_v = packed[:, 13:16].copy()
+        self.last_clipped_action = packed[:, 16:20].copy()
+        self.rpy_rates = packed[:, 20:23].copy()
+        self._k_reward = float(packed[0, 23])
+        self._k_terminated = bool(packed[0, 24] != 0)
+        self._k_truncated = bool(packed[0, 25] != 0)
+
+    def _getDroneStateVector(self, nth_drone):
+        """(20,) state vector: pos3 | quat4 | rpy3 | vel3 | ang_v3 | last_clipped_action4."""
+        state = np.hstack([self.pos[nth_drone, :], self.quat[nth_drone, :], self.rpy[nth_drone, :],
+                           self.vel[nth_drone, :], self.ang_v[nth_drone, :], self.last_clipped_action[nth_drone, :]])
+        return state.reshape(20,)
+
+    def _getAdjacencyMatrix(self):
+        """(NUM_DRONES, NUM_DRONES) adjacency matrix for NEIGHBOURHOOD_RADIUS (BaseAviary.py:658-675)."""
+        d = np.linalg.norm(self.pos[:, None, :] - self.pos[None, :, :], axis=-1)
+        return (d < self.NEIGHBOURHOOD_RADIUS).astype(np.float64)
+
+    def _normalizedActionToRPM(self, action):
+        """[-1, 1] -> [0, MAX_RPM], non-linear (BaseAviary.py:896-914; unused by the RL aviaries)."""
+        if np.any(np.abs(action) > 1):
+            print("\n[ERROR] it", self.step_counter, "in BaseAviary._normalizedActionToRPM(), out-of-bound action")
+        return np.where(action <= 0, (action + 1) * self.HOVER_RPM, self.HOVER_RPM + (self.MAX_RPM - self.HOVER_RPM) * action)
+
+    ################################################################################
+    # engine configuration hooks (new) -------------------------------------------------------------
+
+    def _fusedActionCode(self):
+        """Kernel action code when the action->RPM mapping runs inside the kernel, else None (the
+        subclass's `_preprocessAction` is then called in Python and its RPMs are fed directly)."""
+        return None
+
+    def _recordAction(self, action):
+        """Called with the raw action when the mapping is fused (BaseRLAviary keeps its action buffer)."""
+
+    def _taskConfig(self) -> dict:
+        """Extra `SimCore` keyword arguments describing the task evaluated in the kernel."""
+        return {}
+
+    ################################################################################
+    # the reference's subclass hooks ---------------------------------------------------------------
+
+    def _actionSpace(self):
+        raise NotImplementedError
+
+    def _observationSpace(self):
+        raise NotImplementedError
+
+    def _computeObs(self):
+        raise NotImplementedError
+
+    def _preprocessAction(self, action):
+        raise NotImplementedError
+
+    def _computeReward(self):
+        raise NotImplementedError
+
+    def _computeTerminated(self):
+        raise NotImplementedError
+
+    def _computeTruncated(self):
+        raise NotImplementedError
+
+    def _computeInfo(self):
+        raise NotImplementedError
+
+    ################################################################################
+
+    def _calculateNextStep(self, current_position, destination, step_size=1):
+        """Waypoint at most `step_size` away from `current_position` towards `destination`."""
+        direction = destination - current_position
+        distance = np.linalg.norm(direction)
+        if distance <= step_size:
+            return destination
+        return current_position + (direction / distance) * step_size

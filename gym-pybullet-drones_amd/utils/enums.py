@@ -79,3 +79,5 @@ class ObservationType(Enum):
 PHYS_GND, PHYS_DRAG, PHYS_DW = 1, 2, 4
 #: raw-RPM action clipped to [0, MAX_RPM] (CtrlAviary, `CtrlAviary.py:140`); kernel-only code
 ACT_RAW_RPM = 5
+#: RPMs taken as they are (output of a user subclass's own `_preprocessAction`); kernel-only code
+ACT_DIRECT_RPM = 6

@@ -48,7 +48,9 @@ enum {
     GPD_ACT_VEL = 2,       /* a[0:4] = direction+speed, DSLPID     envs/BaseRLAviary.py:208-223 */
     GPD_ACT_ONE_D_RPM = 3, /* rpm = HOVER_RPM*(1+0.05*a[0]) x4     envs/BaseRLAviary.py:224-225 */
     GPD_ACT_ONE_D_PID = 4, /* target = pos + 0.1*[0,0,a[0]], DSLPID envs/BaseRLAviary.py:226-235 */
-    GPD_ACT_RAW_RPM = 5    /* rpm = clip(a[0:4], 0, MAX_RPM)       envs/CtrlAviary.py:140 */
+    GPD_ACT_RAW_RPM = 5,   /* rpm = clip(a[0:4], 0, MAX_RPM)       envs/CtrlAviary.py:140 */
+    GPD_ACT_DIRECT_RPM = 6 /* rpm = a[0:4] as is: the output of a user subclass's own
+                              _preprocessAction (envs/BaseAviary.py:341,1051-1064) */
 };
 
 /* Aerodynamic add-on terms evaluated inside the explicit integrator

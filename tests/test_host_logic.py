@@ -1,0 +1,170 @@
+"""CPU-side checks: constants, URDF parsing, the C-ABI library's exports, sharding, gloo all-gather."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ASSETS, REPO, urdf
+
+
+def test_constants_match_survey_appendix_d():
+    from gym_pybullet_drones_amd.params import DroneParams
+    from gym_pybullet_drones_amd.utils.enums import DroneModel
+    x = DroneParams(DroneModel.CF2X)
+    assert x.M == 0.027 and x.L == 0.0397 and x.KF == 3.16e-10 and x.KM == 7.94e-12
+    assert x.GRAVITY == pytest.approx(0.2646, rel=1e-12)
+    assert x.HOVER_RPM == pytest.approx(14468.429183500699, rel=1e-14)
+    assert x.MAX_RPM == pytest.approx(21702.64377525105, rel=1e-14)
+    assert x.MAX_THRUST == pytest.approx(0.59535, rel=1e-12)
+    assert x.MAX_XY_TORQUE == pytest.approx(0.00835637404, rel=1e-8)
+    assert x.MAX_Z_TORQUE == pytest.approx(0.00747955538, rel=1e-8)
+    assert x.GND_EFF_H_CLIP == pytest.approx(0.03776371349, rel=1e-8)
+    assert x.SPEED_LIMIT == pytest.approx(0.25)
+    np.testing.assert_allclose(x.default_init_xyzs(2), [[0, 0, 0.1125], [0.1588, 0.1588, 0.1125]], atol=1e-12)
+    p = DroneParams(DroneModel.CF2P)
+    assert p.MAX_XY_TORQUE == pytest.approx(0.00590884875, rel=1e-8) and p.J[0, 0] == 2.3951e-5
+    r = DroneParams(DroneModel.RACE)
+    assert r.HOVER_RPM == pytest.approx(15494.600499144828, rel=1e-14)
+    assert r.MAX_RPM == pytest.approx(31640.869585066295, rel=1e-14)
+    assert r.GND_EFF_H_CLIP == pytest.approx(0.20730637885, rel=1e-8)
+    np.testing.assert_allclose(r.PROP_OFFSETS[:, :2], [[.085, .0675], [-.085, .0675], [-.085, -.0675], [.085, -.0675]])
+
+
+@pytest.mark.parametrize("model", ["cf2x", "cf2p", "racer"])
+def test_name_based_and_positional_parsers_agree(model):
+    """The product parser (by tag name) and the oracle's positional parser (the reference's way) read the same file."""
+    from gym_pybullet_drones_amd.params import DroneParams
+    from gym_pybullet_drones_amd.utils.enums import DroneModel
+    from oracle.aviary_oracle import UrdfConstants
+    a, b = DroneParams(DroneModel(model)), UrdfConstants(urdf(model), model)
+    for k in ("M", "L", "KF", "KM", "THRUST2WEIGHT_RATIO", "COLLISION_H", "COLLISION_R", "COLLISION_Z_OFFSET", "MAX_SPEED_KMH",
+              "GND_EFF_COEFF", "PROP_RADIUS", "DW_COEFF_1", "DW_COEFF_2", "DW_COEFF_3", "GRAVITY", "HOVER_RPM", "MAX_RPM",
+              "GND_EFF_H_CLIP", "MAX_XY_TORQUE", "MAX_Z_TORQUE", "SPEED_LIMIT"):
+        assert getattr(a, k) == getattr(b, k), k
+    np.testing.assert_array_equal(a.J, b.J)
+    np.testing.assert_array_equal(a.DRAG_COEFF, b.DRAG_COEFF)
+    np.testing.assert_array_equal(a.PROP_OFFSETS, b.PROP_OFFSETS)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference checkout not present")
+@pytest.mark.parametrize("model", ["cf2x", "cf2p", "racer"])
+def test_shipped_assets_carry_the_reference_constants(model):
+    from oracle.aviary_oracle import UrdfConstants
+    mine = UrdfConstants(urdf(model), model)
+    ref = UrdfConstants(f"/root/reference/gym_pybullet_drones/assets/{model}.urdf", model)
+    for k, v in vars(ref).items():
+        np.testing.assert_array_equal(getattr(mine, k), v, err_msg=k)
+
+
+def test_enums_are_value_compatible():
+    from gym_pybullet_drones_amd.utils.enums import ActionType, DroneModel, ObservationType, Physics
+    assert [m.value for m in DroneModel] == ["cf2x", "cf2p", "racer"]
+    assert [m.value for m in Physics] == ["pyb", "dyn", "pyb_gnd", "pyb_drag", "pyb_dw", "pyb_gnd_drag_dw"]
+    assert [m.value for m in ActionType] == ["rpm", "pid", "vel", "one_d_rpm", "one_d_pid"]
+    assert [m.value for m in ObservationType] == ["kin", "rgb"]
+    assert [a.dim for a in ActionType] == [4, 3, 4, 1, 1]
+    assert Physics.PYB_GND_DRAG_DW.flags == 7 and Physics.DYN.flags == 0
+
+
+def test_trunc_counter_is_the_float64_threshold():
+    from gym_pybullet_drones_amd.params import trunc_counter
+    assert trunc_counter(8, 240) == 1920
+    for L, f in ((8, 240), (8, 48), (0.1, 240), (7.3, 1000), (1 / 3, 240)):
+        c = trunc_counter(L, f)
+        assert not (c / f > L) and ((c + 1) / f > L)
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads (no GPU needed) and exports exactly the functions include/gpd.h declares."""
+    from gym_pybullet_drones_amd import _native
+    _native.build()
+    L = _native.lib()
+    hdr = open(os.path.join(REPO, "include", "gpd.h")).read()
+    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(gpd_\w+)\s*\(", hdr, flags=re.M))
+    assert declared == set(_native.exported_symbols())
+    for name in declared:
+        assert hasattr(L, name)
+    assert L.gpd_abi_version() == int(re.search(r"#define GPD_ABI_VERSION (\d+)", hdr).group(1))
+    # argument validation happens before any device work, so it is testable without a GPU
+    assert L.gpd_step(None, None, None, None, None, None, None, None, None, None, None, None) == -1
+    assert b"NULL" in L.gpd_last_error()
+    assert L.gpd_pid(None, None, 0, ctypes.c_float(0.0), None, None, None, None, None, None, None, None, None, None, 0, None) == -1
+
+
+def test_struct_mirrors_match_the_header_layout():
+    from gym_pybullet_drones_amd import _native
+    from gym_pybullet_drones_amd.params import DroneParams, GpdParams
+    from gym_pybullet_drones_amd.utils.enums import DroneModel
+    sizes = (ctypes.c_int32 * 3)()
+    _native.lib().gpd_struct_sizes(sizes)
+    assert tuple(sizes) == (ctypes.sizeof(GpdParams), ctypes.sizeof(_native.GpdState), ctypes.sizeof(_native.GpdStepCfg))
+    s = DroneParams(DroneModel.CF2P).to_struct(pid_model=DroneModel.CF2P)
+    assert s.drone_model == 1 and list(s.mixer)[:3] == [0.0, -1.0, -1.0]
+    assert s.pid_kf == pytest.approx(3.16e-10, rel=1e-6) and s.hover_rpm == pytest.approx(14468.429, rel=1e-6)
+    r = DroneParams(DroneModel.RACE).to_struct(pid_model=DroneModel.RACE)
+    assert r.pid_kf == 0.0        # no controller: the kernel entry points refuse PID action types
+
+
+def test_product_path_refuses_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from gym_pybullet_drones_amd import _native
+    from gym_pybullet_drones_amd.envs import HoverAviary, VectorHoverAviary
+    with pytest.raises(_native.GpdError):
+        HoverAviary()
+    with pytest.raises(_native.GpdError):
+        VectorHoverAviary(16)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "gym-pybullet-drones_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), os.path.join(root, f)
+
+
+def test_env_shard_partitions():
+    from gym_pybullet_drones_amd.dist import env_shard
+    for total, world in ((524288, 8), (10, 3), (7, 8), (131072, 4)):
+        blocks = [env_shard(total, r, world) for r in range(world)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == total
+        assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+        sizes = [b - a for a, b in blocks]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_obs_allgather_world2_gloo(tmp_path):
+    """The N>1 exchange path (all-gather of observation shards) on CPU with gloo, world_size 2."""
+    script = tmp_path / "w.py"
+    script.write_text(f"""
+import sys; sys.path.insert(0, {REPO!r})
+import torch, torch.distributed as dist
+from gym_pybullet_drones_amd import dist as gdist
+rank, world, local = gdist.init_from_env("gloo")
+assert world == 2
+a, b = gdist.env_shard(10, rank, world)
+shard = torch.arange((b - a) * 12, dtype=torch.float32).reshape(b - a, 12) + 1000 * rank
+ag = gdist.ObsAllGather(b - a, 12, device="cpu")
+full = ag(shard)
+assert full.shape == (10, 12)
+assert torch.equal(full[:5], torch.arange(60, dtype=torch.float32).reshape(5, 12))
+assert torch.equal(full[5:], torch.arange(60, dtype=torch.float32).reshape(5, 12) + 1000)
+full2, work = ag(shard, async_op=True); work.wait()
+assert torch.equal(full2, full)
+assert gdist.max_over_ranks(float(rank)) == 1.0
+dist.barrier(); dist.destroy_process_group()
+open({str(tmp_path)!r} + f"/ok{{rank}}", "w").write("ok")
+""")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
