@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--workload", default="hover65536_240hz", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
-                    help="graph: replay a hipGraph of 16 consecutive steps; eager: one host launch per step")
+                    help="graph: replay a hipGraph of 64 consecutive steps; eager: one host launch per step")
     ap.add_argument("--allgather", action="store_true", help="all-gather the obs shards over RCCL every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -120,7 +120,7 @@ def main():
 
     w = WORKLOADS[args.workload]
     env = make_env(w, device, seed=1000 + rank)
-    POOL = 16
+    POOL = 64      # env steps captured per hipGraph (amortises the ~10-16 us replay cost)
     actions = make_actions(w, env, device, seed=2000 + rank, pool=POOL)
     core = env.core
     S = core.S

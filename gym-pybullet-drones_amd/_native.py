@@ -33,7 +33,8 @@ class GpdStepCfg(ctypes.Structure):
     """mirror of `struct GpdStepCfg`"""
     _fields_ = [("num_envs", ctypes.c_int32), ("drones_per_env", ctypes.c_int32), ("act_type", ctypes.c_int32),
                 ("substeps", ctypes.c_int32), ("physics_flags", ctypes.c_uint32), ("pyb_dt", ctypes.c_float),
-                ("ctrl_dt", ctypes.c_float), ("task", ctypes.c_int32), ("xy_bound", ctypes.c_float),
+                ("ctrl_dt", ctypes.c_float), ("inv_ctrl_dt", ctypes.c_float), ("lanes_per_wave", ctypes.c_int32),
+                ("task", ctypes.c_int32), ("xy_bound", ctypes.c_float),
                 ("z_bound", ctypes.c_float), ("tilt_bound", ctypes.c_float), ("term_dist", ctypes.c_float),
                 ("trunc_counter", ctypes.c_int32), ("target_per_env", ctypes.c_int32),
                 ("init_per_env", ctypes.c_int32), ("auto_reset", ctypes.c_int32)]

@@ -18,8 +18,14 @@
 //   reward / terminated / truncated    envs/HoverAviary.py:68-117, envs/MultiHoverAviary.py:75-130
 //   step counter, same-step auto-reset envs/BaseAviary.py:382, 451-477
 //
-// Build: hipcc -O3 --offload-arch=gfx950 -fPIC -shared  (no fast-math: IEEE div/sqrt, OCML
-// sin/cos/atan2/asin/exp; FMA contraction is on, as is hipcc's default).
+// Arithmetic: fp32, FMA contraction on (hipcc default), NO -ffast-math.  The kernel at N = 65 536 is
+// bound by the length of one wave's dependent VALU chain (one wave per SIMD), so the hot functions are
+// written for few instructions at <= 2 ulp instead of calling the branchy IEEE/OCML versions:
+//   1/x, sqrt, 1/sqrt      v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 (1 ulp)
+//   quaternion exponential cos(t) and sin(t)/t as even polynomials in t^2 (no sqrt, no division, no
+//                          range reduction; |t| <= 1 rad per sub-step, exact OCML path beyond)
+//   atan2 / asin           one odd minimax polynomial on [0,1] (abs err 7e-8) + octant fix-up
+// Build: hipcc -O3 --offload-arch=gfx950 -fPIC -shared
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -51,11 +57,43 @@ struct Mat3 {
     float r00, r01, r02, r10, r11, r12, r20, r21, r22;
 };
 
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
+// atan2 with the IEEE sign/quadrant conventions Bullet's Euler extraction relies on; minimax
+// polynomial for atan(t)/t in t^2 on [0,1] (max abs error 7.4e-8 evaluated in fp32)
+__device__ __forceinline__ float atan2_poly(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float t = mn * fast_rcp(mx);
+    t = (mx == 0.0f) ? 0.0f : t;                 // atan2(0, 0) = 0
+    const float u = t * t;
+    float p = 2.766283504e-03f;
+    p = fmaf(p, u, -1.573124913e-02f);
+    p = fmaf(p, u, 4.213762361e-02f);
+    p = fmaf(p, u, -7.456854827e-02f);
+    p = fmaf(p, u, 1.061837064e-01f);
+    p = fmaf(p, u, -1.419779779e-01f);
+    p = fmaf(p, u, 1.999187203e-01f);
+    p = fmaf(p, u, -3.333303671e-01f);
+    p = fmaf(p, u, 9.999999818e-01f);
+    p *= t;
+    p = (ay > ax) ? (1.57079632679489661923f - p) : p;
+    p = (x < 0.0f) ? (3.14159265358979323846f - p) : p;
+    return copysignf(p, y);
+}
+
+// asin(s) = atan2(s, sqrt((1-s)(1+s))); the factored form keeps full relative accuracy near |s| = 1
+__device__ __forceinline__ float asin_poly(float s) {
+    return atan2_poly(s, fast_sqrt(fmaxf((1.0f - s) * (1.0f + s), 0.0f)));
+}
+
 // btMatrix3x3::setRotation (reached via p.getMatrixFromQuaternion, envs/BaseAviary.py:836);
 // insensitive to |q| (DYN never renormalises q)
 __device__ __forceinline__ Mat3 quat_to_mat(float x, float y, float z, float w) {
     const float d = x * x + y * y + z * z + w * w;
-    const float s = 2.0f / d;
+    const float s = 2.0f * fast_rcp(d);
     const float xs = x * s, ys = y * s, zs = z * s;
     const float wx = w * xs, wy = w * ys, wz = w * zs;
     const float xx = x * xs, xy = x * ys, xz = x * zs;
@@ -73,13 +111,13 @@ __device__ __forceinline__ void quat_to_rpy(float x, float y, float z, float w,
     const float sqx = x * x, sqy = y * y, sqz = z * z, squ = w * w;
     const float sarg = -2.0f * (x * z - w * y);
     if (sarg <= -0.99999f) {
-        roll = 0.0f; pitch = -1.57079632679489661923f; yaw = 2.0f * atan2f(x, -y);
+        roll = 0.0f; pitch = -1.57079632679489661923f; yaw = 2.0f * atan2_poly(x, -y);
     } else if (sarg >= 0.99999f) {
-        roll = 0.0f; pitch = 1.57079632679489661923f; yaw = 2.0f * atan2f(-x, y);
+        roll = 0.0f; pitch = 1.57079632679489661923f; yaw = 2.0f * atan2_poly(-x, y);
     } else {
-        roll = atan2f(2.0f * (y * z + w * x), squ - sqx - sqy + sqz);
-        pitch = asinf(sarg);
-        yaw = atan2f(2.0f * (x * y + w * z), squ + sqx - sqy - sqz);
+        roll = atan2_poly(2.0f * (y * z + w * x), squ - sqx - sqy + sqz);
+        pitch = asin_poly(sarg);
+        yaw = atan2_poly(2.0f * (x * y + w * z), squ + sqx - sqy - sqz);
     }
 }
 
@@ -97,7 +135,7 @@ struct Pid {   // DSLPIDControl members, control/DSLPIDControl.py:73-78
 
 // DSLPIDControl.computeControl (control/DSLPIDControl.py:82-145).
 // Returns the four RPMs; optionally the desired-vs-current yaw needed by the standalone entry.
-__device__ __forceinline__ void dslpid(const GpdParams& P, float dt, const Kin& k, float roll, float pitch,
+__device__ __forceinline__ void dslpid(const GpdParams& P, float dt, float inv_dt, const Kin& k, float roll, float pitch,
                                        float yaw, const Mat3& R, float tx, float ty, float tz, float tyaw,
                                        float tvx, float tvy, float tvz, float trr, float trp, float try_,
                                        Pid& s, float rpm[4], float pos_e[3], float* yaw_e) {
@@ -111,16 +149,16 @@ __device__ __forceinline__ void dslpid(const GpdParams& P, float dt, const Kin& 
     const float fy = P.p_for[1] * epy + P.i_for[1] * s.ipy + P.d_for[1] * evy;
     const float fz = P.p_for[2] * epz + P.i_for[2] * s.ipz + P.d_for[2] * evz + P.pid_gravity;
     const float along = fmaxf(0.0f, fx * R.r02 + fy * R.r12 + fz * R.r22);
-    const float base_pwm = (sqrtf(along / (4.0f * P.pid_kf)) - P.pwm2rpm_const) / P.pwm2rpm_scale;
-    const float fn = sqrtf(fx * fx + fy * fy + fz * fz);
-    const float zbx = fx / fn, zby = fy / fn, zbz = fz / fn;
+    const float base_pwm = (fast_sqrt(along * P.pid_inv_4kf) - P.pwm2rpm_const) * P.inv_pwm2rpm_scale;
+    const float fn = fast_rsq(fx * fx + fy * fy + fz * fz);
+    const float zbx = fx * fn, zby = fy * fn, zbz = fz * fn;
     float sy, cy;
     sincosf(tyaw, &sy, &cy);                      // heading = [cos, sin, 0]
     float ybx = zby * 0.0f - zbz * sy;            // zb x heading
     float yby = zbz * cy - zbx * 0.0f;
     float ybz = zbx * sy - zby * cy;
-    const float yn = sqrtf(ybx * ybx + yby * yby + ybz * ybz);
-    ybx /= yn; yby /= yn; ybz /= yn;
+    const float yn = fast_rsq(ybx * ybx + yby * yby + ybz * ybz);
+    ybx *= yn; yby *= yn; ybz *= yn;
     const float xbx = yby * zbz - ybz * zby;      // yb x zb
     const float xby = ybz * zbx - ybx * zbz;
     const float xbz = ybx * zby - yby * zbx;
@@ -131,9 +169,9 @@ __device__ __forceinline__ void dslpid(const GpdParams& P, float dt, const Kin& 
     const float m02 = xbx * R.r02 + xby * R.r12 + xbz * R.r22, m20 = zbx * R.r00 + zby * R.r10 + zbz * R.r20;
     const float m10 = ybx * R.r00 + yby * R.r10 + ybz * R.r20, m01 = xbx * R.r01 + xby * R.r11 + xbz * R.r21;
     const float erx = m21 - m12, ery = m02 - m20, erz = m10 - m01;
-    const float ewx = trr - (roll - s.lr) / dt;   // finite difference of Euler angles, no unwrap (:247)
-    const float ewy = trp - (pitch - s.lp) / dt;
-    const float ewz = try_ - (yaw - s.ly) / dt;
+    const float ewx = trr - (roll - s.lr) * inv_dt;   // finite difference of Euler angles, no unwrap (:247)
+    const float ewy = trp - (pitch - s.lp) * inv_dt;
+    const float ewz = try_ - (yaw - s.ly) * inv_dt;
     s.lr = roll; s.lp = pitch; s.ly = yaw;
     s.irx = clampf(clampf(s.irx - erx * dt, -1500.0f, 1500.0f), -1.0f, 1.0f);
     s.iry = clampf(clampf(s.iry - ery * dt, -1500.0f, 1500.0f), -1.0f, 1.0f);
@@ -150,7 +188,7 @@ __device__ __forceinline__ void dslpid(const GpdParams& P, float dt, const Kin& 
     if (pos_e) { pos_e[0] = epx; pos_e[1] = epy; pos_e[2] = epz; }
     if (yaw_e) {
         // yaw of the intrinsic-XYZ Euler angles of R* (scipy as_euler('XYZ'), :205): atan2(-R01, R00)
-        *yaw_e = atan2f(-ybx, xbx) - yaw;
+        *yaw_e = atan2_poly(-ybx, xbx) - yaw;
     }
 }
 
@@ -173,7 +211,7 @@ __device__ __forceinline__ void substep(const GpdParams& P, float h, uint32_t fl
         for (int i = 0; i < 4; ++i) {
             float hz = k.pz + R.r20 * P.prop_x[i] + R.r21 * P.prop_y[i];
             hz = fmaxf(hz, P.gnd_eff_h_clip);
-            const float ratio = P.prop_radius / (4.0f * hz);
+            const float ratio = (0.25f * P.prop_radius) * fast_rcp(hz);
             g[i] = sq[i] * P.KF * P.gnd_eff_coeff * (ratio * ratio);
         }
         // |roll| < pi/2 and |pitch| < pi/2 on Bullet's Euler extraction (:742), without the atan2/asin:
@@ -214,16 +252,28 @@ __device__ __forceinline__ void substep(const GpdParams& P, float h, uint32_t fl
     ty -= k.wz * jwx - k.wx * jwz;
     const float tzz = tz - (k.wx * jwy - k.wy * jwx);
     // semi-implicit Euler (:860-862): position uses the NEW velocity
-    const float inv_m = 1.0f / P.M;
-    k.vx += h * (Fx * inv_m); k.vy += h * (Fy * inv_m); k.vz += h * (Fz * inv_m);
+    k.vx += h * (Fx * P.inv_M); k.vy += h * (Fy * P.inv_M); k.vz += h * (Fz * P.inv_M);
     k.wx += h * (P.J_INV[0] * tx); k.wy += h * (P.J_INV[1] * ty); k.wz += h * (P.J_INV[2] * tzz);
     k.px += h * k.vx; k.py += h * k.vy; k.pz += h * k.vz;
     // exact exponential quaternion update q <- q (x) exp(w h / 2)  (:879-892)
-    const float n = sqrtf(k.wx * k.wx + k.wy * k.wy + k.wz * k.wz);
-    if (n > 1e-8f) {                                       // !np.isclose(n, 0)
-        float sn, cs;
+    //   q' = cos(t) q + (sin(t)/|w|) (q (x) [w,0]),  t = |w| h / 2.  cos(t) and sin(t)/t are even functions
+    //   of t, evaluated as minimax polynomials in u = t^2 (abs err 7e-8 / 5e-8 for t <= 1 rad, i.e. body
+    //   rates up to 480 rad/s at 240 Hz): no sqrt, no division, no range reduction.
+    const float n2 = k.wx * k.wx + k.wy * k.wy + k.wz * k.wz;
+    const float u = n2 * (0.25f * h * h);
+    float cs, sc;
+    if (__builtin_expect(u <= 1.0f, 1)) {
+        cs = fmaf(fmaf(fmaf(fmaf(2.412107309e-05f, u, -1.388295778e-03f), u, 4.166645522e-02f), u, -4.999999736e-01f),
+                  u, 9.999999995e-01f);
+        sc = fmaf(fmaf(fmaf(fmaf(2.693749890e-06f, u, -1.983586443e-04f), u, 8.333314057e-03f), u, -1.666666643e-01f),
+                  u, 1.0f) * (0.5f * h);
+    } else {   // tumbling faster than 480 rad/s: exact path
+        const float n = sqrtf(n2);
+        float sn;
         sincosf(n * h * 0.5f, &sn, &cs);
-        const float sc = sn / n;
+        sc = sn / n;
+    }
+    if (n2 > 1e-16f) {                                     // !np.isclose(|w|, 0)  (|w| <= 1e-8 keeps q)
         const float lx = k.wz * k.qy - k.wy * k.qz + k.wx * k.qw;
         const float ly = -k.wz * k.qx + k.wx * k.qz + k.wy * k.qw;
         const float lz = k.wy * k.qx - k.wx * k.qy + k.wz * k.qw;
@@ -237,10 +287,20 @@ __device__ __forceinline__ void substep(const GpdParams& P, float h, uint32_t fl
     avz = R.r20 * k.wx + R.r21 * k.wy + R.r22 * k.wz;
 }
 
-__device__ __forceinline__ void store_obs12(float* __restrict__ obs, int64_t n, float px, float py, float pz,
+// SoA row access as  <uniform 64-bit row base in SGPRs> + <32-bit per-lane byte offset>: this is the
+// global_load/store "saddr + voffset" form, one VGPR of address for all rows instead of a 64-bit
+// add per access.  (gpd_step bounds N so that every byte offset fits 32 bits.)
+__device__ __forceinline__ float ld_row(const float* __restrict__ base, int64_t ld, int r, uint32_t off4) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + r * ld) + off4);
+}
+__device__ __forceinline__ void st_row(float* __restrict__ base, int64_t ld, int r, uint32_t off4, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base + r * ld) + off4) = v;
+}
+
+__device__ __forceinline__ void store_obs12(float* __restrict__ obs, uint32_t n, float px, float py, float pz,
                                             float roll, float pitch, float yaw, float vx, float vy, float vz,
                                             float ax, float ay, float az) {
-    float4* o = reinterpret_cast<float4*>(obs + n * 12);
+    float4* o = reinterpret_cast<float4*>(reinterpret_cast<char*>(obs) + n * 48u);
     o[0] = make_float4(px, py, pz, roll);
     o[1] = make_float4(pitch, yaw, vx, vy);
     o[2] = make_float4(vz, ax, ay, az);
@@ -259,14 +319,20 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     float* __restrict__ reward, uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
     float* __restrict__ term_obs12) {
     const int D = MULTI ? C.drones_per_env : 1;
-    const int lanes = MULTI ? (kBlock / D) * D : kBlock;     // whole envs per workgroup
     const int tid = threadIdx.x;
-    const int64_t N = static_cast<int64_t>(C.num_envs) * D;
-    const int64_t n = static_cast<int64_t>(blockIdx.x) * lanes + tid;
-    const bool active = (tid < lanes) && (n < N);
+    const uint32_t N = static_cast<uint32_t>(C.num_envs) * static_cast<uint32_t>(D);
+    // MULTI: whole aviaries per workgroup, one lane per drone.  Single-drone aviaries: L = lanes_per_wave
+    // (16/32/64) active lanes per 64-wide wavefront -- a batch too small to fill the chip is spread over
+    // more wavefronts so that every SIMD has 2-4 waves to interleave (the kernel is bound by the latency of
+    // one wave's dependent instruction chain there, not by issue slots or bandwidth).
+    const int L = MULTI ? 64 : C.lanes_per_wave;
+    const int lanes = MULTI ? (kBlock / D) * D : (kBlock / 64) * L;
+    const uint32_t n = MULTI ? blockIdx.x * lanes + tid : (blockIdx.x * (kBlock / 64) + (tid >> 6)) * L + (tid & 63);
+    const uint32_t off4 = n * 4u;
+    const bool active = (MULTI ? (tid < lanes) : ((tid & 63) < L)) && (n < N);
     const int le = MULTI ? tid / D : tid;                    // env index inside the workgroup
     const int d = MULTI ? tid - le * D : 0;                  // drone index inside the env
-    const int64_t env = MULTI ? static_cast<int64_t>(blockIdx.x) * (lanes / D) + le : n;
+    const uint32_t env = MULTI ? blockIdx.x * (lanes / D) + le : n;
     const int64_t ld = S.ld;
 
     __shared__ float sh_pos[MULTI ? 3 * kBlock : 1];         // downwash: positions of the env's drones
@@ -276,11 +342,11 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     // ---- load state ------------------------------------------------------------------------------
     Kin k;
     if (active) {
-        const float* kin = S.kin + n;
-        k.px = kin[0 * ld]; k.py = kin[1 * ld]; k.pz = kin[2 * ld];
-        k.qx = kin[3 * ld]; k.qy = kin[4 * ld]; k.qz = kin[5 * ld]; k.qw = kin[6 * ld];
-        k.vx = kin[7 * ld]; k.vy = kin[8 * ld]; k.vz = kin[9 * ld];
-        k.wx = kin[10 * ld]; k.wy = kin[11 * ld]; k.wz = kin[12 * ld];
+        k.px = ld_row(S.kin, ld, 0, off4); k.py = ld_row(S.kin, ld, 1, off4); k.pz = ld_row(S.kin, ld, 2, off4);
+        k.qx = ld_row(S.kin, ld, 3, off4); k.qy = ld_row(S.kin, ld, 4, off4); k.qz = ld_row(S.kin, ld, 5, off4);
+        k.qw = ld_row(S.kin, ld, 6, off4);
+        k.vx = ld_row(S.kin, ld, 7, off4); k.vy = ld_row(S.kin, ld, 8, off4); k.vz = ld_row(S.kin, ld, 9, off4);
+        k.wx = ld_row(S.kin, ld, 10, off4); k.wy = ld_row(S.kin, ld, 11, off4); k.wz = ld_row(S.kin, ld, 12, off4);
     } else {
         k = Kin{0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
     }
@@ -290,10 +356,10 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     if (!PID) {
         if (active) {
             if (C.act_type == GPD_ACT_ONE_D_RPM) {
-                const float r = P.hover_rpm * (1.0f + 0.05f * action[n]);
+                const float r = P.hover_rpm * (1.0f + 0.05f * ld_row(action, 0, 0, off4));
                 rpm[0] = rpm[1] = rpm[2] = rpm[3] = r;
             } else {
-                const float4 a = reinterpret_cast<const float4*>(action)[n];
+                const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(action) + n * 16u);
                 if (C.act_type == GPD_ACT_RAW_RPM) {
                     rpm[0] = clampf(a.x, 0.0f, P.max_rpm); rpm[1] = clampf(a.y, 0.0f, P.max_rpm);
                     rpm[2] = clampf(a.z, 0.0f, P.max_rpm); rpm[3] = clampf(a.w, 0.0f, P.max_rpm);
@@ -311,35 +377,34 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
         float roll, pitch, yaw;
         quat_to_rpy(k.qx, k.qy, k.qz, k.qw, roll, pitch, yaw);
         if (active) {
-            float* ps = S.pid + n;
-            s.ipx = ps[0 * ld]; s.ipy = ps[1 * ld]; s.ipz = ps[2 * ld];
-            s.lr = ps[3 * ld]; s.lp = ps[4 * ld]; s.ly = ps[5 * ld];
-            s.irx = ps[6 * ld]; s.iry = ps[7 * ld]; s.irz = ps[8 * ld];
+            s.ipx = ld_row(S.pid, ld, 0, off4); s.ipy = ld_row(S.pid, ld, 1, off4); s.ipz = ld_row(S.pid, ld, 2, off4);
+            s.lr = ld_row(S.pid, ld, 3, off4); s.lp = ld_row(S.pid, ld, 4, off4); s.ly = ld_row(S.pid, ld, 5, off4);
+            s.irx = ld_row(S.pid, ld, 6, off4); s.iry = ld_row(S.pid, ld, 7, off4); s.irz = ld_row(S.pid, ld, 8, off4);
             if (C.act_type == GPD_ACT_PID) {
                 // waypoint limited to a 1 m approach step (_calculateNextStep, BaseAviary.py:1132-1150)
-                const float ax = action[n * 3 + 0], ay = action[n * 3 + 1], az = action[n * 3 + 2];
+                const float* ap = reinterpret_cast<const float*>(reinterpret_cast<const char*>(action) + n * 12u);
+                const float ax = ap[0], ay = ap[1], az = ap[2];
                 const float dx = ax - k.px, dy = ay - k.py, dz = az - k.pz;
-                const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
-                if (dist <= 1.0f) { tx = ax; ty = ay; tz = az; }
-                else { tx = k.px + dx / dist; ty = k.py + dy / dist; tz = k.pz + dz / dist; }
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                if (fast_sqrt(d2) <= 1.0f) { tx = ax; ty = ay; tz = az; }
+                else { const float id = fast_rsq(d2); tx = k.px + dx * id; ty = k.py + dy * id; tz = k.pz + dz * id; }
             } else if (C.act_type == GPD_ACT_VEL) {
-                const float4 a = reinterpret_cast<const float4*>(action)[n];
-                const float nn = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+                const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(action) + n * 16u);
+                const float nn2 = a.x * a.x + a.y * a.y + a.z * a.z;
                 const float sp = P.speed_limit * fabsf(a.w);
-                if (nn != 0.0f) { tvx = sp * (a.x / nn); tvy = sp * (a.y / nn); tvz = sp * (a.z / nn); }
+                if (nn2 != 0.0f) { const float in = fast_rsq(nn2); tvx = sp * (a.x * in); tvy = sp * (a.y * in); tvz = sp * (a.z * in); }
                 tyaw = yaw;                                   // keep the current yaw (:220)
             } else {   // GPD_ACT_ONE_D_PID
-                tz = k.pz + 0.1f * action[n];
+                tz = k.pz + 0.1f * ld_row(action, 0, 0, off4);
             }
         }
         const Mat3 R = quat_to_mat(k.qx, k.qy, k.qz, k.qw);
-        dslpid(P, C.ctrl_dt, k, roll, pitch, yaw, R, tx, ty, tz, tyaw, tvx, tvy, tvz, 0.0f, 0.0f, 0.0f, s, rpm,
-               nullptr, nullptr);
+        dslpid(P, C.ctrl_dt, C.inv_ctrl_dt, k, roll, pitch, yaw, R, tx, ty, tz, tyaw, tvx, tvy, tvz, 0.0f, 0.0f, 0.0f, s,
+               rpm, nullptr, nullptr);
         if (active) {
-            float* ps = S.pid + n;
-            ps[0 * ld] = s.ipx; ps[1 * ld] = s.ipy; ps[2 * ld] = s.ipz;
-            ps[3 * ld] = s.lr; ps[4 * ld] = s.lp; ps[5 * ld] = s.ly;
-            ps[6 * ld] = s.irx; ps[7 * ld] = s.iry; ps[8 * ld] = s.irz;
+            st_row(S.pid, ld, 0, off4, s.ipx); st_row(S.pid, ld, 1, off4, s.ipy); st_row(S.pid, ld, 2, off4, s.ipz);
+            st_row(S.pid, ld, 3, off4, s.lr); st_row(S.pid, ld, 4, off4, s.lp); st_row(S.pid, ld, 5, off4, s.ly);
+            st_row(S.pid, ld, 6, off4, s.irx); st_row(S.pid, ld, 7, off4, s.iry); st_row(S.pid, ld, 8, off4, s.irz);
         }
     }
 
@@ -350,8 +415,8 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     if (EXT && (flags & GPD_PHYS_DRAG)) {
         // the first sub-step sees the PREVIOUS env step's action (BaseAviary.py:359,372)
         if (active) {
-            const float* lr = S.last_rpm + n;
-            drag_sum = ((lr[0 * ld] + lr[1 * ld]) + lr[2 * ld]) + lr[3 * ld];
+            drag_sum = ((ld_row(S.last_rpm, ld, 0, off4) + ld_row(S.last_rpm, ld, 1, off4)) +
+                        ld_row(S.last_rpm, ld, 2, off4)) + ld_row(S.last_rpm, ld, 3, off4);
         }
     }
     float avx = 0.0f, avy = 0.0f, avz = 0.0f;
@@ -366,13 +431,13 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
             for (int j = 0; j < D; ++j) {
                 const float dz = sh_pos[2 * kBlock + base + j] - k.pz;
                 const float ddx = sh_pos[base + j] - k.px, ddy = sh_pos[kBlock + base + j] - k.py;
-                const float dxy = sqrtf(ddx * ddx + ddy * ddy);
-                if (dz > 0.0f && dxy < 10.0f) {
-                    const float ratio = P.prop_radius / (4.0f * dz);
+                const float dxy2 = ddx * ddx + ddy * ddy;
+                if (dz > 0.0f && dxy2 < 100.0f) {            // dz > 0 and dxy < 10 m
+                    const float ratio = (0.25f * P.prop_radius) * fast_rcp(dz);
                     const float alpha = P.dw_coeff[0] * (ratio * ratio);
                     const float beta = P.dw_coeff[1] * dz + P.dw_coeff[2];
-                    const float q = dxy / beta;
-                    dw += -alpha * expf(-0.5f * (q * q));
+                    const float ib = fast_rcp(beta);
+                    dw += -alpha * expf(-0.5f * (dxy2 * (ib * ib)));
                 }
             }
         }
@@ -392,9 +457,10 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
         float my_rew = 0.0f, my_dist = 0.0f;
         bool my_out = false;
         if (active) {
-            const float* tp = target_pos + (C.target_per_env ? n * 3 : static_cast<int64_t>(d) * 3);
+            const float* tp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(target_pos) +
+                                                             (C.target_per_env ? n * 12u : static_cast<uint32_t>(d) * 12u));
             const float ex = tp[0] - k.px, ey = tp[1] - k.py, ez = tp[2] - k.pz;
-            my_dist = sqrtf(ex * ex + ey * ey + ez * ez);
+            my_dist = fast_sqrt(ex * ex + ey * ey + ez * ez);
             const float d2 = my_dist * my_dist;
             my_rew = fmaxf(0.0f, 2.0f - d2 * d2);
             my_out = fabsf(k.px) > C.xy_bound || fabsf(k.py) > C.xy_bound || k.pz > C.z_bound ||
@@ -444,20 +510,21 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     float l0 = rpm[0], l1 = rpm[1], l2 = rpm[2], l3 = rpm[3];
     if (do_reset) {
         if (term_obs12) store_obs12(term_obs12, n, k.px, k.py, k.pz, roll, pitch, yaw, k.vx, k.vy, k.vz, avx, avy, avz);
-        const float* ip = init_pose + (C.init_per_env ? n * 7 : static_cast<int64_t>(d) * 7);
+        const float* ip = reinterpret_cast<const float*>(reinterpret_cast<const char*>(init_pose) +
+                                                         (C.init_per_env ? n * 28u : static_cast<uint32_t>(d) * 28u));
         k = Kin{ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], ip[6], 0, 0, 0, 0, 0, 0};
         quat_to_rpy(k.qx, k.qy, k.qz, k.qw, roll, pitch, yaw);
         avx = avy = avz = 0.0f;
         l0 = l1 = l2 = l3 = 0.0f;                              // last_clipped_action zeroed (BaseAviary.py:468)
     }
-    float* kin = S.kin + n;
-    kin[0 * ld] = k.px; kin[1 * ld] = k.py; kin[2 * ld] = k.pz;
-    kin[3 * ld] = k.qx; kin[4 * ld] = k.qy; kin[5 * ld] = k.qz; kin[6 * ld] = k.qw;
-    kin[7 * ld] = k.vx; kin[8 * ld] = k.vy; kin[9 * ld] = k.vz;
-    kin[10 * ld] = k.wx; kin[11 * ld] = k.wy; kin[12 * ld] = k.wz;
+    st_row(S.kin, ld, 0, off4, k.px); st_row(S.kin, ld, 1, off4, k.py); st_row(S.kin, ld, 2, off4, k.pz);
+    st_row(S.kin, ld, 3, off4, k.qx); st_row(S.kin, ld, 4, off4, k.qy); st_row(S.kin, ld, 5, off4, k.qz);
+    st_row(S.kin, ld, 6, off4, k.qw);
+    st_row(S.kin, ld, 7, off4, k.vx); st_row(S.kin, ld, 8, off4, k.vy); st_row(S.kin, ld, 9, off4, k.vz);
+    st_row(S.kin, ld, 10, off4, k.wx); st_row(S.kin, ld, 11, off4, k.wy); st_row(S.kin, ld, 12, off4, k.wz);
     if (S.last_rpm) {
-        float* lr = S.last_rpm + n;
-        lr[0 * ld] = l0; lr[1 * ld] = l1; lr[2 * ld] = l2; lr[3 * ld] = l3;
+        st_row(S.last_rpm, ld, 0, off4, l0); st_row(S.last_rpm, ld, 1, off4, l1);
+        st_row(S.last_rpm, ld, 2, off4, l2); st_row(S.last_rpm, ld, 3, off4, l3);
     }
     store_obs12(obs12, n, k.px, k.py, k.pz, roll, pitch, yaw, k.vx, k.vy, k.vz, avx, avy, avz);
 }
@@ -528,7 +595,7 @@ __global__ __launch_bounds__(kBlock) void gpd_pid_kernel(
         tr[0] = target_rpy_rates[n * 3]; tr[1] = target_rpy_rates[n * 3 + 1]; tr[2] = target_rpy_rates[n * 3 + 2];
     }
     float rpm[4], pe[3], ye;
-    dslpid(P, dt, k, roll, pitch, yaw, R, target_pos[n * 3], target_pos[n * 3 + 1], target_pos[n * 3 + 2], tyaw,
+    dslpid(P, dt, 1.0f / dt, k, roll, pitch, yaw, R, target_pos[n * 3], target_pos[n * 3 + 1], target_pos[n * 3 + 2], tyaw,
            tv[0], tv[1], tv[2], tr[0], tr[1], tr[2], s, rpm, pe, &ye);
     pid[0 * ld + n] = s.ipx; pid[1 * ld + n] = s.ipy; pid[2 * ld + n] = s.ipz;
     pid[3 * ld + n] = s.lr; pid[4 * ld + n] = s.lp; pid[5 * ld + n] = s.ly;
@@ -605,6 +672,7 @@ int gpd_step(const GpdParams* params, const GpdState* state, const GpdStepCfg* c
     if (cfg->physics_flags & ~7u) return fail(GPD_EINVAL, "gpd_step: unknown physics flag");
     const int64_t N = static_cast<int64_t>(cfg->num_envs) * cfg->drones_per_env;
     if (state->ld < N) return fail(GPD_EINVAL, "gpd_step: state.ld < num_envs*drones_per_env");
+    if (N > (1LL << 26)) return fail(GPD_ERANGE, "gpd_step: more than 2^26 drones per launch (32-bit byte offsets)");
     const bool pid = cfg->act_type == GPD_ACT_PID || cfg->act_type == GPD_ACT_VEL || cfg->act_type == GPD_ACT_ONE_D_PID;
     if (pid && !state->pid) return fail(GPD_EINVAL, "gpd_step: PID action type needs state.pid");
     if (pid && params->pid_kf <= 0.0f)
@@ -614,7 +682,11 @@ int gpd_step(const GpdParams* params, const GpdState* state, const GpdStepCfg* c
     if (cfg->task != GPD_TASK_NONE && !target_pos) return fail(GPD_EINVAL, "gpd_step: task needs target_pos");
     if (cfg->auto_reset && !init_pose) return fail(GPD_EINVAL, "gpd_step: auto_reset needs init_pose");
     const bool multi = cfg->drones_per_env > 1;
-    const int lanes = multi ? (kBlock / cfg->drones_per_env) * cfg->drones_per_env : kBlock;
+    GpdStepCfg c = *cfg;
+    if (c.lanes_per_wave == 0) c.lanes_per_wave = 64;
+    if (c.lanes_per_wave != 16 && c.lanes_per_wave != 32 && c.lanes_per_wave != 64)
+        return fail(GPD_EINVAL, "gpd_step: lanes_per_wave must be 0, 16, 32 or 64");
+    const int lanes = multi ? (kBlock / cfg->drones_per_env) * cfg->drones_per_env : (kBlock / 64) * c.lanes_per_wave;
     const int64_t blocks = (N + lanes - 1) / lanes;
     if (blocks > 0x7fffffffLL) return fail(GPD_ERANGE, "gpd_step: too many drones for one launch");
     const dim3 grid(static_cast<unsigned>(blocks));
@@ -622,14 +694,14 @@ int gpd_step(const GpdParams* params, const GpdState* state, const GpdStepCfg* c
     const bool ext = cfg->physics_flags != 0;
     hipError_t e;
     if (pid) {
-        e = ext ? launch_step<true, true>(multi, grid, st, *params, *state, *cfg, action, target_pos, init_pose, obs12,
+        e = ext ? launch_step<true, true>(multi, grid, st, *params, *state, c, action, target_pos, init_pose, obs12,
                                           reward, terminated, truncated, term_obs12)
-                : launch_step<true, false>(multi, grid, st, *params, *state, *cfg, action, target_pos, init_pose,
+                : launch_step<true, false>(multi, grid, st, *params, *state, c, action, target_pos, init_pose,
                                            obs12, reward, terminated, truncated, term_obs12);
     } else {
-        e = ext ? launch_step<false, true>(multi, grid, st, *params, *state, *cfg, action, target_pos, init_pose,
+        e = ext ? launch_step<false, true>(multi, grid, st, *params, *state, c, action, target_pos, init_pose,
                                            obs12, reward, terminated, truncated, term_obs12)
-                : launch_step<false, false>(multi, grid, st, *params, *state, *cfg, action, target_pos, init_pose,
+                : launch_step<false, false>(multi, grid, st, *params, *state, c, action, target_pos, init_pose,
                                             obs12, reward, terminated, truncated, term_obs12);
     }
     if (e != hipSuccess) return hip_fail(e, "gpd_step launch");

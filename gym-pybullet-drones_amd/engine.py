@@ -10,9 +10,10 @@ in the hand-written kernels.  Layout (N = num_envs * drones_per_env, drone n = e
     pid       float32 [9][ld]    DSLPID integrators / last rpy (PID action types only)
     counter   int32   [E]        physics steps since the env's last reset
     obs12     float32 [N][12]    pos | rpy | vel | ang_v — row-major, ready for a policy / all-gather
-    reward    float32 [E], terminated/truncated uint8 [E]
+    reward    float32 [E], terminated/truncated bool (1 byte) [E]
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -28,6 +29,24 @@ _PID_ACTS = (1, 2, 4)
 
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+#: MI355X: 256 CUs x 4 SIMDs
+_NUM_SIMDS = 1024
+
+
+def lanes_per_wave(num_drones: int, drones_per_env: int) -> int:
+    """Active lanes per 64-wide wavefront for single-drone aviaries (`GpdStepCfg.lanes_per_wave`).
+
+    Measured on MI355X (profiles/r01_lanes_per_wave.txt): at N = 65 536 the full width wins (5.76 us vs
+    6.22 us at 32 and 7.02 us at 16 lanes) -- the launch is bound by the serialised load -> compute ->
+    store phases of waves that all start together, not by per-wave instruction latency, so spreading the
+    batch over more, narrower waves only adds wave launches.  The knob stays in the ABI for tuning;
+    `GPD_LANES_PER_WAVE` overrides."""
+    env = os.environ.get("GPD_LANES_PER_WAVE")
+    if env:
+        return int(env)
+    return 64
 
 
 class SimCore:
@@ -74,8 +93,9 @@ class SimCore:
         self.step_counter = torch.zeros((self.E,), dtype=torch.int32, device=dev)
         self.obs12 = torch.zeros((self.N, 12), dtype=f32, device=dev)
         self.reward = torch.zeros((self.E,), dtype=f32, device=dev)
-        self.terminated = torch.zeros((self.E,), dtype=torch.uint8, device=dev)
-        self.truncated = torch.zeros((self.E,), dtype=torch.uint8, device=dev)
+        # torch.bool is one byte holding 0/1, exactly what the kernel stores: no conversion kernel needed
+        self.terminated = torch.zeros((self.E,), dtype=torch.bool, device=dev)
+        self.truncated = torch.zeros((self.E,), dtype=torch.bool, device=dev)
         self.term_obs12 = torch.zeros((self.N, 12), dtype=f32, device=dev) if keep_terminal_obs else None
 
         # initial poses: (D,3) shared by all envs, or (E,D,3) per env
@@ -102,7 +122,8 @@ class SimCore:
                                        step_counter=self.step_counter.data_ptr(), ld=self.ld)
         self._cfg = _native.GpdStepCfg(
             num_envs=self.E, drones_per_env=self.D, act_type=self.act_code, substeps=self.S,
-            physics_flags=self.physics_flags, pyb_dt=1.0 / pyb_freq, ctrl_dt=1.0 / ctrl_freq, task=task,
+            physics_flags=self.physics_flags, pyb_dt=1.0 / pyb_freq, ctrl_dt=1.0 / ctrl_freq,
+            inv_ctrl_dt=float(ctrl_freq), lanes_per_wave=lanes_per_wave(self.N, self.D), task=task,
             xy_bound=xy_bound, z_bound=z_bound, tilt_bound=tilt_bound, term_dist=term_dist,
             trunc_counter=trunc_counter(episode_len_sec, pyb_freq), target_per_env=self.target_per_env,
             init_per_env=self.init_per_env, auto_reset=int(self.auto_reset))

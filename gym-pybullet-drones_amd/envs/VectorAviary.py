@@ -119,7 +119,7 @@ class VectorAviary:
         info = {}
         if self.core.term_obs12 is not None:
             info["terminal_observation"] = self.core.term_obs12.view(self.NUM_ENVS, self.NUM_DRONES, 12)
-        return self._obs(), reward, terminated.bool(), truncated.bool(), info
+        return self._obs(), reward, terminated, truncated, info
 
     def state_vectors(self) -> torch.Tensor:
         """(E, D, 20) `_getDroneStateVector`-ordered states (needs `track_rpm=True` for the RPM columns)."""

@@ -61,18 +61,19 @@ class GpdParams(ctypes.Structure):
     """ctypes mirror of `struct GpdParams` (include/gpd.h)."""
     _fields_ = [
         ("drone_model", ctypes.c_int32),
-        ("M", ctypes.c_float), ("L", ctypes.c_float), ("KF", ctypes.c_float), ("KM", ctypes.c_float),
+        ("M", ctypes.c_float), ("inv_M", ctypes.c_float), ("L", ctypes.c_float), ("KF", ctypes.c_float),
+        ("KM", ctypes.c_float),
         ("GRAVITY", ctypes.c_float),
         ("J", ctypes.c_float * 3), ("J_INV", ctypes.c_float * 3),
         ("prop_x", ctypes.c_float * 4), ("prop_y", ctypes.c_float * 4),
         ("gnd_eff_coeff", ctypes.c_float), ("prop_radius", ctypes.c_float), ("gnd_eff_h_clip", ctypes.c_float),
         ("drag_coeff", ctypes.c_float * 3), ("dw_coeff", ctypes.c_float * 3),
         ("hover_rpm", ctypes.c_float), ("max_rpm", ctypes.c_float),
-        ("pid_gravity", ctypes.c_float), ("pid_kf", ctypes.c_float),
+        ("pid_gravity", ctypes.c_float), ("pid_kf", ctypes.c_float), ("pid_inv_4kf", ctypes.c_float),
         ("p_for", ctypes.c_float * 3), ("i_for", ctypes.c_float * 3), ("d_for", ctypes.c_float * 3),
         ("p_tor", ctypes.c_float * 3), ("i_tor", ctypes.c_float * 3), ("d_tor", ctypes.c_float * 3),
         ("mixer", ctypes.c_float * 12),
-        ("pwm2rpm_scale", ctypes.c_float), ("pwm2rpm_const", ctypes.c_float),
+        ("pwm2rpm_scale", ctypes.c_float), ("inv_pwm2rpm_scale", ctypes.c_float), ("pwm2rpm_const", ctypes.c_float),
         ("min_pwm", ctypes.c_float), ("max_pwm", ctypes.c_float),
         ("speed_limit", ctypes.c_float),
     ]
@@ -156,6 +157,7 @@ class DroneParams:
         s = GpdParams()
         s.drone_model = self.DRONE_MODEL.code
         s.M, s.L, s.KF, s.KM, s.GRAVITY = self.M, self.L, self.KF, self.KM, self.GRAVITY
+        s.inv_M = 1.0 / self.M
         for k in range(3):
             s.J[k] = self.J[k, k]
             s.J_INV[k] = self.J_INV[k, k]
@@ -170,12 +172,14 @@ class DroneParams:
             cp = pid_params or (self if pid_model == self.DRONE_MODEL else DroneParams(pid_model))
             s.pid_gravity = pid_g * cp.M
             s.pid_kf = cp.KF
+            s.pid_inv_4kf = 1.0 / (4.0 * cp.KF)
             for k in range(3):
                 s.p_for[k], s.i_for[k], s.d_for[k] = gains.P_COEFF_FOR[k], gains.I_COEFF_FOR[k], gains.D_COEFF_FOR[k]
                 s.p_tor[k], s.i_tor[k], s.d_tor[k] = gains.P_COEFF_TOR[k], gains.I_COEFF_TOR[k], gains.D_COEFF_TOR[k]
             for k in range(12):
                 s.mixer[k] = MIXER[pid_model].reshape(-1)[k]
             s.pwm2rpm_scale, s.pwm2rpm_const = gains.PWM2RPM_SCALE, gains.PWM2RPM_CONST
+            s.inv_pwm2rpm_scale = 1.0 / gains.PWM2RPM_SCALE
             s.min_pwm, s.max_pwm = gains.MIN_PWM, gains.MAX_PWM
         s.speed_limit = self.SPEED_LIMIT
         return s

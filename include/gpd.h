@@ -22,8 +22,8 @@
  *   - drone n = env * drones_per_env + d (the D drones of one aviary are adjacent);
  *   - quaternions are (x, y, z, w), as in the reference's state vector
  *     (envs/BaseAviary.py:559);
- *   - all arithmetic is IEEE fp32 with correctly-rounded sqrt/div and OCML sin/cos/atan2/asin
- *     (no fast-math), FMA contraction allowed.
+ *   - all arithmetic is fp32 with FMA contraction, no -ffast-math; reciprocals/square roots are the
+ *     1-ulp hardware instructions and atan2/asin/sin/cos are <= 2-ulp polynomials (csrc/gpd.hip).
  */
 #ifndef GPD_H
 #define GPD_H
@@ -78,7 +78,7 @@ enum {
  */
 typedef struct GpdParams {
     int32_t drone_model;       /* GPD_MODEL_* */
-    float M;                   /* mass [kg] */
+    float M, inv_M;            /* mass [kg] and its reciprocal */
     float L;                   /* arm length [m] */
     float KF, KM;              /* thrust / torque coefficients */
     float GRAVITY;             /* G*M with G = 9.8            envs/BaseAviary.py:117 */
@@ -90,10 +90,11 @@ typedef struct GpdParams {
     float hover_rpm, max_rpm;  /* envs/BaseAviary.py:118-119 */
     /* DSLPID (the RL aviaries always build CF2X controllers, envs/BaseRLAviary.py:75-76) */
     float pid_gravity, pid_kf; /* control/BaseControl.py:35-37 */
+    float pid_inv_4kf;         /* 1/(4*pid_kf), host-computed in float64 */
     float p_for[3], i_for[3], d_for[3];
     float p_tor[3], i_tor[3], d_tor[3];
     float mixer[12];           /* row-major 4x3, control/DSLPIDControl.py:47-60 */
-    float pwm2rpm_scale, pwm2rpm_const, min_pwm, max_pwm;
+    float pwm2rpm_scale, inv_pwm2rpm_scale, pwm2rpm_const, min_pwm, max_pwm;
     float speed_limit;         /* ActionType.VEL, envs/BaseRLAviary.py:94-95 */
 } GpdParams;
 
@@ -122,6 +123,10 @@ typedef struct GpdStepCfg {
     uint32_t physics_flags;  /* GPD_PHYS_* mask */
     float pyb_dt;            /* PYB_TIMESTEP   envs/BaseAviary.py:83 */
     float ctrl_dt;           /* CTRL_TIMESTEP  envs/BaseAviary.py:82 */
+    float inv_ctrl_dt;       /* CTRL_FREQ as a float (exact), multiplies where the reference divides by dt */
+    int32_t lanes_per_wave;  /* 16, 32 or 64 drones per 64-lane wavefront when drones_per_env == 1 (0 = 64):
+                                fewer active lanes = more wavefronts per SIMD = shorter critical path when
+                                the batch is too small to fill the chip (latency-bound regime) */
     int32_t task;            /* GPD_TASK_* */
     float xy_bound, z_bound, tilt_bound;  /* truncation box  envs/HoverAviary.py:110-111 */
     float term_dist;         /* 1e-4            envs/HoverAviary.py:93 */
