@@ -195,6 +195,13 @@ def main():
                          "kernel": "gpd_step_kernel", "bytes_per_launch": bytes_launch,
                          "launch_us_hip_events": launch_us},
         }
+        tfile = os.path.join(REPO, "profiles", "hbm_traffic.json")
+        if os.path.exists(tfile):   # measured offline in separate --pmc passes (see the file's _comment)
+            rec = json.load(open(tfile)).get(args.workload)
+            if rec:
+                out["roofline"]["traffic"] = rec["traffic_bytes"]
+                out["roofline"]["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                out["roofline"]["rocprof_kernel_avg_us"] = rec["rocprof_kernel_avg_ns"] / 1e3
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))

@@ -350,6 +350,19 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     } else {
         k = Kin{0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
     }
+    // everything the tail of the kernel needs from memory is requested NOW, together with the state, so
+    // that no second round trip sits between the physics and the stores (a load issued inside the task
+    // section costs a full ~1 us memory latency on the critical path of a launch that lasts ~5 us)
+    int counter = 0;
+    float tgx = 0.0f, tgy = 0.0f, tgz = 0.0f;
+    if (active) {
+        if (!MULTI || d == 0) counter = S.step_counter[env];
+        if (C.task != GPD_TASK_NONE) {
+            const float* tp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(target_pos) +
+                                                             (C.target_per_env ? n * 12u : static_cast<uint32_t>(d) * 12u));
+            tgx = tp[0]; tgy = tp[1]; tgz = tp[2];
+        }
+    }
 
     // ---- action -> RPM (computed ONCE per env step from the cached state, BaseAviary.py:341) -----
     float rpm[4] = {0, 0, 0, 0};
@@ -452,14 +465,11 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     // ---- task: reward / terminated / truncated ---------------------------------------------------------
     float rew = -1.0f;
     bool term = false, trunc = false;
-    int counter = 0;
     if (C.task != GPD_TASK_NONE) {
         float my_rew = 0.0f, my_dist = 0.0f;
         bool my_out = false;
         if (active) {
-            const float* tp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(target_pos) +
-                                                             (C.target_per_env ? n * 12u : static_cast<uint32_t>(d) * 12u));
-            const float ex = tp[0] - k.px, ey = tp[1] - k.py, ez = tp[2] - k.pz;
+            const float ex = tgx - k.px, ey = tgy - k.py, ez = tgz - k.pz;
             my_dist = fast_sqrt(ex * ex + ey * ey + ez * ez);
             const float d2 = my_dist * my_dist;
             my_rew = fmaxf(0.0f, 2.0f - d2 * d2);
@@ -467,14 +477,13 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
                      fabsf(roll) > C.tilt_bound || fabsf(pitch) > C.tilt_bound;
         }
         if (!MULTI) {
-            if (active) counter = S.step_counter[env];
             rew = my_rew;
             term = my_dist < C.term_dist;
             trunc = my_out || (counter > C.trunc_counter);   // tested BEFORE the increment (App. B.7)
         } else {
             __syncthreads();
             sh_red[tid] = my_rew; sh_red[kBlock + tid] = my_dist; sh_red[2 * kBlock + tid] = my_out ? 1.0f : 0.0f;
-            if (active && d == 0) sh_flag[tid] = S.step_counter[env];
+            if (active && d == 0) sh_flag[tid] = counter;
             __syncthreads();
             const int base = le * D;
             float r = 0.0f, dsum = 0.0f, o = 0.0f;
@@ -486,14 +495,11 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
             term = dsum < C.term_dist;
             trunc = (o > 0.0f) || (counter > C.trunc_counter);
         }
-    } else {
-        if (!MULTI) { if (active) counter = S.step_counter[env]; }
-        else {
-            __syncthreads();
-            if (active && d == 0) sh_flag[tid] = S.step_counter[env];
-            __syncthreads();
-            counter = sh_flag[le * D];
-        }
+    } else if (MULTI) {
+        __syncthreads();
+        if (active && d == 0) sh_flag[tid] = counter;
+        __syncthreads();
+        counter = sh_flag[le * D];
     }
     if (!active) return;
 

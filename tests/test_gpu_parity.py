@@ -185,24 +185,27 @@ def test_open_loop_trajectory_1920_steps(gpu_device, S):
 
 
 def test_open_loop_with_all_force_terms(gpu_device):
-    """8 drones stacked 0.3 m apart per aviary, GND|DRAG|DW on, 240 physics steps (1 s).
+    """8 drones stacked 0.3 m apart per aviary (lowest at 0.8 m), GND|DRAG|DW on, 120 physics steps (0.5 s).
 
-    Not longer: the lowest drone is held up by the ground effect while the one above it is pushed down by
-    the downwash of six others, so after ~1.5 s their heights cross and alpha ~ 1/dz^2 diverges — the
-    reference's model is singular there and no two precisions agree past that encounter."""
+    Horizon and start height are chosen on purpose: every drone but the top one is pushed down by the
+    downwash of its neighbour above (~half its weight), so the stack sinks; once the lowest drone reaches
+    the ground-effect zone (z < ~0.1 m, after ~0.6 s from 0.8 m) it is held up while the next one keeps
+    falling, their heights cross and alpha ~ 1/dz^2 diverges — the reference's downwash model is singular
+    at dz -> 0+ and no two precisions (nor two float64 runs) agree past such an encounter.  Ground effect at
+    small heights is covered by the one-step tests above."""
     rng = np.random.default_rng(11)
     E, D, S = 512, 8, 2
     # 0.12 m lateral offset per level keeps dxy >> |beta| so the downwash Gaussian stays well-conditioned
     # while the stack stretches through dz = 0.6875 m (beta = 0)
     xyz = rng.uniform(-0.02, 0.02, size=(E, D, 3)) + np.arange(D)[None, :, None] * np.array([0.12, 0.0, 0.3]) + \
-        np.array([0, 0, 0.06])
+        np.array([0, 0, 0.8])
     rpy = rng.uniform(-0.05, 0.05, size=(E, D, 3))
     b = BatchedAviary(urdf("cf2x"), "cf2x", E, D, initial_xyzs=xyz, initial_rpys=rpy, physics_flags=7, pyb_freq=240,
                       ctrl_freq=120, act="rpm", task="multihover")
     core = _core("cf2x", E, D, 7, S, "rpm", "multihover", xyz, rpy, gpu_device, target=b.TARGET_POS)
     _sync_from_oracle(core, b)
-    acts = (0.2 + 0.02 * rng.uniform(-1, 1, size=(120, E, D, 4))).astype(np.float32)
-    errs = _traj_errors(core, b, acts, gpu_device, {2, 60, 120, 240})
+    acts = (0.2 + 0.02 * rng.uniform(-1, 1, size=(60, E, D, 4))).astype(np.float32)
+    errs = _traj_errors(core, b, acts, gpu_device, {2, 60, 120})
     for t, e in sorted(errs.items()):
         print(f"t={t:5d} " + " ".join(f"{g}={v:.2e}" for g, v in e.items()))
         for g, v in e.items():
