@@ -80,19 +80,20 @@ def lib() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise GpdError(f"{LIB_PATH} not found: the HIP extension has not been built "
+    path = os.environ.get("GPD_LIB", LIB_PATH)     # GPD_LIB: A/B-test another build of the same ABI
+    if not os.path.exists(path):
+        raise GpdError(f"{path} not found: the HIP extension has not been built "
                        "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
                        "There is no CPU fallback for the simulator's hot path.")
     try:
-        L = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(path)
     except OSError as e:
-        raise GpdError(f"cannot load {LIB_PATH}: {e}") from e
+        raise GpdError(f"cannot load {path}: {e}") from e
     for name, (res, args) in _SIGNATURES.items():
         try:
             fn = getattr(L, name)
         except AttributeError as e:
-            raise GpdError(f"{LIB_PATH} does not export {name}") from e
+            raise GpdError(f"{path} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
     if L.gpd_abi_version() != ABI_VERSION:

@@ -36,7 +36,10 @@
 
 namespace {
 
-constexpr int kBlock = 256;   // 4 wavefronts; one workgroup per CU fills all 4 SIMDs
+#ifndef GPD_BLOCK
+#define GPD_BLOCK 256
+#endif
+constexpr int kBlock = GPD_BLOCK;   // 256 = 4 wavefronts; one workgroup per CU fills all 4 SIMDs
 
 thread_local std::string g_last_error;
 

@@ -1,0 +1,158 @@
+"""Parity at BASELINE.json's full sizes: against the C oracle where it finishes in seconds, and through
+size-independent properties (analytic known answers, batch-size independence, permutation equivariance,
+norm preservation) at 524 288 drones."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import urdf
+from oracle.c_oracle import CAviary
+from test_gpu_parity import GROUPS, _core, _oracle_kin, _sync_from_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(core, orc, acts, dev, checkpoints):
+    N = orc.E * orc.D
+    maxima = {g: fl for g, (_, fl) in GROUPS.items()}
+    snaps = {}
+    for k in range(acts.shape[0]):
+        orc.step(acts[k].astype(np.float64))
+        core.step(torch.as_tensor(acts[k], device=dev))
+        ref = _oracle_kin(orc)
+        for g, (sl, _) in GROUPS.items():
+            maxima[g] = max(maxima[g], float(np.abs(ref[sl]).max()))
+        t = (k + 1) * orc.S
+        if t in checkpoints:
+            snaps[t] = (core.kin[:, :N].cpu().numpy().astype(np.float64), ref.copy())
+    return {t: {g: float(np.abs(a[sl] - b[sl]).max() / maxima[g]) for g, (sl, _) in GROUPS.items()}
+            for t, (a, b) in snaps.items()}
+
+
+def test_config2_65536_hover_1920_physics_steps(gpu_device):
+    """BASELINE metric config: 65 536 HoverAviaries, DYN, 30 Hz control / 240 Hz physics, 1920 physics steps."""
+    rng = np.random.default_rng(65536)
+    E, D, S = 65536, 1, 8
+    xyz = np.array([0, 0, 0.1125]) + rng.uniform(-0.5, 0.5, size=(E, D, 3)) * np.array([1, 1, 0])
+    rpy = rng.uniform(-0.1, 0.1, size=(E, D, 3))
+    orc = CAviary(urdf("cf2x"), "cf2x", E, D, initial_xyzs=xyz, initial_rpys=rpy, pyb_freq=240, ctrl_freq=30, act="rpm",
+                  task="hover")
+    core = _core("cf2x", E, D, 0, S, "rpm", "hover", xyz, rpy, gpu_device, target=orc.TARGET_POS)
+    _sync_c(core, orc)
+    acts = (0.01 * rng.uniform(-1, 1, size=(1, E, D, 4)) + 0.01 * rng.uniform(-1, 1, size=(240, E, D, 4))).astype(np.float32)
+    errs = _run(core, orc, acts, gpu_device, {8, 240, 1920})
+    for t, e in sorted(errs.items()):
+        print(f"t={t:5d} " + " ".join(f"{g}={v:.2e}" for g, v in e.items()))
+        assert max(e.values()) < 1e-4, (t, e)
+    # task outputs of the last step
+    np.testing.assert_allclose(core.reward.cpu().numpy(), orc.reward, rtol=1e-3, atol=1e-3)
+    assert (core.truncated.cpu().numpy() != orc.truncated.astype(bool)).mean() < 0.002
+
+
+def test_config3_stacks_of_8_all_force_terms(gpu_device):
+    """BASELINE config 3 (ii): 8192 aviaries x 8 stacked drones, GND|DRAG|DW, 0.25 s (60 physics steps).
+
+    Short on purpose: among 65 536 drones with random tilts a few drift under their upper neighbour within
+    half a second, where the downwash Gaussian exp(-(dxy/beta)^2/2) with |beta| ~ 0.06 m has a relative
+    condition number of (dxy/beta)^2 ~ 10-100 and its 1/dz^2 prefactor is ~3x the drone's weight; fp32 and
+    fp64 then separate by 1e-3..1e-2 m although every single step agrees to 1e-6 (one-step tests)."""
+    rng = np.random.default_rng(8192)
+    E, D, S = 8192, 8, 1
+    xyz = rng.uniform(-0.02, 0.02, size=(E, D, 3)) + np.arange(D)[None, :, None] * np.array([0.12, 0.0, 0.3]) + \
+        np.array([0, 0, 0.8])
+    rpy = rng.uniform(-0.05, 0.05, size=(E, D, 3))
+    orc = CAviary(urdf("cf2x"), "cf2x", E, D, initial_xyzs=xyz, initial_rpys=rpy, physics_flags=7, pyb_freq=240,
+                  ctrl_freq=240, act="rpm", task="multihover")
+    core = _core("cf2x", E, D, 7, S, "rpm", "multihover", xyz, rpy, gpu_device, target=orc.TARGET_POS)
+    _sync_c(core, orc)
+    acts = (0.2 + 0.02 * rng.uniform(-1, 1, size=(60, E, D, 4))).astype(np.float32)
+    errs = _run(core, orc, acts, gpu_device, {1, 30, 60})
+    for t, e in sorted(errs.items()):
+        print(f"t={t:5d} " + " ".join(f"{g}={v:.2e}" for g, v in e.items()))
+        assert max(e.values()) < 1e-4, (t, e)
+    np.testing.assert_allclose(core.reward.cpu().numpy(), orc.reward, rtol=1e-3, atol=1e-3)
+
+
+def _sync_c(core, orc):
+    """CAviary has the same state attributes as BatchedAviary (the PID block aside, unused here)."""
+    assert core.pid is None
+    _sync_from_oracle(core, orc)
+
+
+def test_524288_drones_free_fall_and_hover_known_answers(gpu_device):
+    """SURVEY App. A.6 KATs at config-4 size on one GPU: rpm = 0 -> exact semi-implicit free fall;
+    rpm = HOVER_RPM -> equilibrium."""
+    E, k = 524288, 240
+    core = _core("cf2x", E, 1, 0, 1, "raw_rpm", "none", None, None, gpu_device)
+    z0 = 0.1125
+    zero = torch.zeros((E, 4), device=gpu_device)
+    for _ in range(k):
+        core.step(zero)
+    kin = core.kin[:, :E]
+    g, dt = 9.8, 1.0 / 240
+    vz = kin[9].cpu().numpy().astype(np.float64)
+    z = kin[2].cpu().numpy().astype(np.float64)
+    assert np.ptp(vz) == 0 and np.ptp(z) == 0                       # every lane computes the same thing
+    assert vz[0] == pytest.approx(-g * dt * k, rel=2e-6)
+    assert z[0] == pytest.approx(z0 - g * dt * dt * k * (k + 1) / 2, rel=2e-6)
+    assert float(kin[0:2].abs().max()) == 0 and float(kin[10:13].abs().max()) == 0
+    np.testing.assert_array_equal(kin[3:7, 0].cpu().numpy(), [0, 0, 0, 1])
+    # hover: 4*KF*HOVER_RPM^2 = GRAVITY -> |a| at fp32 rounding level
+    core.reset()
+    hov = torch.full((E, 4), float(core.P.HOVER_RPM), device=gpu_device)
+    for _ in range(k):
+        core.step(hov)
+    assert abs(float(core.kin[9, 0])) < 2e-5 and abs(float(core.kin[2, 0]) - z0) < 2e-5
+
+
+def test_batch_size_independence_and_permutation_equivariance(gpu_device):
+    """A drone's trajectory does not depend on how many others share the launch nor on its lane:
+    bitwise identical results for the same drone in a 4096- and a 524 288-drone batch, and under a
+    permutation of the batch."""
+    rng = np.random.default_rng(99)
+    big, small, steps = 524288, 4096, 24
+    xyz = (np.array([0, 0, 0.5]) + rng.uniform(-0.5, 0.5, size=(big, 1, 3))).astype(np.float32).astype(np.float64)
+    rpy = rng.uniform(-0.3, 0.3, size=(big, 1, 3))
+    acts = torch.as_tensor(rng.uniform(-1, 1, size=(steps, big, 1, 3)).astype(np.float32) * 0.5, device=gpu_device)
+    perm = torch.as_tensor(rng.permutation(big), device=gpu_device)
+    a = _core("cf2x", big, 1, 3, 2, "pid", "hover", xyz, rpy, gpu_device)
+    b = _core("cf2x", small, 1, 3, 2, "pid", "hover", xyz[:small], rpy[:small], gpu_device)
+    pc = perm.cpu().numpy()
+    c = _core("cf2x", big, 1, 3, 2, "pid", "hover", xyz[pc], rpy[pc], gpu_device)
+    for k in range(steps):
+        a.step(acts[k])
+        b.step(acts[k, :small].contiguous())
+        c.step(acts[k][perm].contiguous())
+    assert torch.equal(a.kin[:, :small], b.kin[:, :small])
+    assert torch.equal(a.obs12[:small], b.obs12[:small])
+    assert torch.equal(a.pid[:, :small], b.pid[:, :small])
+    assert torch.equal(a.reward[:small], b.reward[:small])
+    assert torch.equal(a.kin[:, :big][:, perm], c.kin[:, :big])
+    assert torch.equal(a.obs12[perm], c.obs12)
+    # quaternion norm is preserved by the exponential update (never renormalised, App. B.6)
+    qn = a.kin[3:7, :big].pow(2).sum(0).sqrt()
+    assert float((qn - 1).abs().max()) < 1e-5
+
+
+def test_multihover_131072x2_reward_is_sum_of_hover_rewards(gpu_device):
+    """BASELINE config 5 size on one GPU: with downwash off, a 2-drone MultiHover aviary is two independent
+    drones; its kinematics are bitwise those of single-drone runs and its reward is the fp32 sum of theirs."""
+    rng = np.random.default_rng(5)
+    E, D, steps = 131072, 2, 16
+    xyz = rng.uniform(-0.3, 0.3, size=(E, D, 3)) + np.array([0, 0, 0.6])
+    rpy = rng.uniform(-0.1, 0.1, size=(E, D, 3))
+    tgt = xyz + np.array([[0, 0, 1.0], [0, 0, 0.5]])
+    acts = torch.as_tensor(rng.uniform(-1, 1, size=(steps, E, D, 4)).astype(np.float32) * 0.3, device=gpu_device)
+    m = _core("cf2x", E, D, 1, 8, "rpm", "multihover", xyz, rpy, gpu_device, target=tgt)
+    s = _core("cf2x", E * D, 1, 1, 8, "rpm", "hover", xyz.reshape(E * D, 1, 3), rpy.reshape(E * D, 1, 3), gpu_device,
+              target=tgt.reshape(E * D, 1, 3))
+    for k in range(steps):
+        m.step(acts[k])
+        s.step(acts[k].reshape(E * D, 1, 4))
+        # two template instantiations of the kernel (MULTI / not): same source expressions, so the results
+        # are expected to be bitwise equal; 1e-6 allows for a different FMA contraction choice
+        assert torch.allclose(m.kin[:, :E * D], s.kin[:, :E * D], rtol=0, atol=1e-6)
+        assert torch.allclose(m.obs12, s.obs12, rtol=0, atol=1e-6)
+        r = s.reward.view(E, D)
+        assert torch.allclose(m.reward, (r[:, 0] + r[:, 1]), rtol=0, atol=2e-6)
+    assert int(m.step_counter[0]) == steps * 8
