@@ -96,16 +96,104 @@ def cpu_baseline(w, budget_s=12.0):
                       f"on 1 host core; PyBullet (Physics.PYB) is not installable in this image"}
 
 
+def measure(mode, args, env, actions, gather, device, world, POOL):
+    """Time K env steps of every aviary on this rank.  mode 'graph': one kernel launch per env step, 64
+    steps captured in a hipGraph; 'eager': one host launch per step; 'rollout': `gpd_rollout`, POOL steps
+    per launch (actions of the POOL steps pre-staged, every step's obs/reward/flags written)."""
+    from gym_pybullet_drones_amd import dist as gdist
+    core = env.core
+
+    def one_step(i):
+        env.step(actions[i % POOL])
+        if gather is not None:
+            gather(core.obs12)
+
+    gather_k = None
+    if mode == "rollout" and gather is not None:
+        gather_k = gdist.ObsAllGather(POOL * core.N, 12, device=device)   # one larger collective per rollout
+
+    def one_rollout():
+        if os.environ.get("GPD_BENCH_HOLD") or os.environ.get("GPD_BENCH_LAST"):   # diagnostics only
+            a = actions[0] if os.environ.get("GPD_BENCH_HOLD") else actions
+            core.rollout(a, num_steps=POOL, last_only=bool(os.environ.get("GPD_BENCH_LAST")), update_latest=False)
+            return
+        obs = core.rollout(actions, update_latest=False)[0]
+        if gather_k is not None:
+            gather_k(obs.view(-1, 12))
+
+    graph = None
+    if mode == "rollout":
+        one_rollout()
+    else:
+        for i in range(min(args.warmup, 64)):
+            one_step(i)
+    torch.cuda.synchronize()
+    if mode == "graph":
+        stream = torch.cuda.Stream(device)
+        stream.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(stream):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                for i in range(POOL):
+                    one_step(i)
+        torch.cuda.current_stream(device).wait_stream(stream)
+
+    def run(k):
+        if mode == "eager":
+            for i in range(k):
+                one_step(i)
+        else:
+            assert k % POOL == 0
+            for _ in range(k // POOL):
+                one_rollout() if mode == "rollout" else graph.replay()
+
+    K = args.steps if mode == "eager" else (args.steps + POOL - 1) // POOL * POOL
+    W = args.warmup if mode == "eager" else (args.warmup + POOL - 1) // POOL * POOL
+    run(W)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()          # on the current stream = the stream every gpd_* launch above goes to
+    run(K)
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t1 = time.perf_counter()
+    wall = gdist.max_over_ranks(t1 - t0, device=device)
+    ev_ms = ev0.elapsed_time(ev1)
+    launches = K // POOL if mode == "rollout" else K
+    bytes_launch = core.bytes_per_rollout(POOL) if mode == "rollout" else core.bytes_per_step()
+    launch_us = ev_ms * 1e3 / launches
+    achieved = bytes_launch / (launch_us * 1e-6) / 1e9
+    n_total = core.N * world
+    steps_per_launch = POOL if mode == "rollout" else 1
+    return {
+        "K": K, "W": W, "wall": wall, "value": n_total * core.S * K / wall, "env_steps_per_s": n_total * K / wall,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "gpd_step_kernel",
+                     "env_steps_per_launch": steps_per_launch, "bytes_per_launch": bytes_launch,
+                     "bytes_per_drone_per_env_step": bytes_launch / (core.N * steps_per_launch),
+                     "launch_us_hip_events": launch_us},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4000)
-    ap.add_argument("--warmup", type=int, default=400)
+    ap.add_argument("--steps", type=int, default=8192)
+    ap.add_argument("--warmup", type=int, default=512)
     ap.add_argument("--workload", default="hover65536_240hz", choices=sorted(WORKLOADS))
-    ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
-                    help="graph: replay a hipGraph of 64 consecutive steps; eager: one host launch per step")
-    ap.add_argument("--allgather", action="store_true", help="all-gather the obs shards over RCCL every step")
+    ap.add_argument("--mode", default="rollout", choices=["rollout", "graph", "eager"],
+                    help="rollout: gpd_rollout, 64 env steps per launch (state in registers, actions pre-staged); "
+                         "graph: one launch per env step, hipGraph of 64 steps; eager: one host launch per step")
+    ap.add_argument("--allgather", action="store_true", help="all-gather the obs shards over RCCL")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-second-leg", action="store_true",
+                    help="skip the extra one-launch-per-step measurement reported next to the rollout headline")
     args = ap.parse_args()
 
     from gym_pybullet_drones_amd import dist as gdist
@@ -120,88 +208,46 @@ def main():
 
     w = WORKLOADS[args.workload]
     env = make_env(w, device, seed=1000 + rank)
-    POOL = 64      # env steps captured per hipGraph (amortises the ~10-16 us replay cost)
+    POOL = 64      # env steps per rollout launch / per captured hipGraph
     actions = make_actions(w, env, device, seed=2000 + rank, pool=POOL)
     core = env.core
-    S = core.S
     gather = gdist.ObsAllGather(core.N, 12, device=device) if args.allgather else None
 
-    def one_step(i):
-        env.step(actions[i % POOL])
-        if gather is not None:
-            gather(core.obs12)
-
-    # warm-up (untimed)
-    for i in range(min(args.warmup, 64)):
-        one_step(i)
-    torch.cuda.synchronize()
-    graph = None
-    if args.mode == "graph":
-        stream = torch.cuda.Stream(device)
-        stream.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(stream):
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
-                for i in range(POOL):
-                    one_step(i)
-        torch.cuda.current_stream(device).wait_stream(stream)
-
-    def run(k):
-        if graph is None:
-            for i in range(k):
-                one_step(i)
-        else:
-            assert k % POOL == 0
-            for _ in range(k // POOL):
-                graph.replay()
-
-    K = (args.steps + POOL - 1) // POOL * POOL if graph is not None else args.steps
-    W = (args.warmup + POOL - 1) // POOL * POOL if graph is not None else args.warmup
-    run(W)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record()
-    run(K)
-    ev1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    t1 = time.perf_counter()
-    wall = gdist.max_over_ranks(t1 - t0, device=device)
-    ev_ms = ev0.elapsed_time(ev1)
+    second = None
+    if args.mode == "rollout" and not args.no_second_leg:
+        second = measure("graph", args, env, actions, gather, device, world, POOL)
+        env.reset()
+    m = measure(args.mode, args, env, actions, gather, device, world, POOL)
 
     if rank == 0:
         n_total = core.N * world
-        value = n_total * S * K / wall
-        bytes_launch = core.bytes_per_step()
-        launch_us = ev_ms * 1e3 / K
-        achieved = bytes_launch / (launch_us * 1e-6) / 1e9
+        launch = {"rollout": f"rollout{POOL}", "graph": "graph", "eager": "eager"}[args.mode]
         out = {
             "metric": "env steps/sec (whole node), HoverAviary N=65536 drones @240Hz",
-            "value": value, "unit": "drone-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": m["value"], "unit": "drone-steps/s", "n_gpus": world, "steps": m["K"], "warmup": m["W"],
+            "ms_per_step": m["wall"] * 1e3 / m["K"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "envs_per_gpu": core.E, "drones_per_env": core.D,
                        "total_drones": n_total, "physics": "DYN" + "".join(n for b, n in ((1, "+GND"), (2, "+DRAG"), (4, "+DW")) if w["phys"] & b),
-                       "pyb_freq": 240, "ctrl_freq": w["ctrl"], "substeps_per_step": S, "action": w["act"],
-                       "task": w["task"], "auto_reset": True, "launch": args.mode,
-                       "obs_allgather": bool(args.allgather), "env_steps_per_s": n_total * K / wall},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "gpd_step_kernel", "bytes_per_launch": bytes_launch,
-                         "launch_us_hip_events": launch_us},
+                       "pyb_freq": 240, "ctrl_freq": w["ctrl"], "substeps_per_step": core.S, "action": w["act"],
+                       "task": w["task"], "auto_reset": True, "launch": launch,
+                       "obs_allgather": bool(args.allgather), "env_steps_per_s": m["env_steps_per_s"]},
+            "roofline": m["roofline"],
         }
+        if second is not None:
+            out["one_launch_per_step"] = {"value": second["value"], "unit": "drone-steps/s", "steps": second["K"],
+                                          "launch": "graph (hipGraph of 64 single-step launches)",
+                                          "roofline": second["roofline"]}
         tfile = os.path.join(REPO, "profiles", "hbm_traffic.json")
         if os.path.exists(tfile):   # measured offline in separate --pmc passes (see the file's _comment)
-            rec = json.load(open(tfile)).get(args.workload)
-            if rec:
-                out["roofline"]["traffic"] = rec["traffic_bytes"]
-                out["roofline"]["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
-                out["roofline"]["rocprof_kernel_avg_us"] = rec["rocprof_kernel_avg_ns"] / 1e3
+            table = json.load(open(tfile))
+            for key, roof in ((f"{args.workload}:{launch}", out["roofline"]),
+                              (f"{args.workload}:graph", second["roofline"] if second else None)):
+                rec = table.get(key)
+                if rec and roof is not None:
+                    roof["traffic"] = rec["traffic_bytes"]
+                    roof["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                    roof["rocprof_kernel_avg_us"] = rec["rocprof_kernel_avg_ns"] / 1e3
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))

@@ -14,9 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(CSRC, "libgpd.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
-HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared"]
+HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared"]
 
 
 class GpdError(RuntimeError):
@@ -67,6 +67,9 @@ _SIGNATURES = {
     "gpd_struct_sizes": (None, [ctypes.POINTER(ctypes.c_int32)]),
     "gpd_step": (ctypes.c_int, [ctypes.POINTER(GpdParams), ctypes.POINTER(GpdState), ctypes.POINTER(GpdStepCfg),
                                 _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gpd_rollout": (ctypes.c_int, [ctypes.POINTER(GpdParams), ctypes.POINTER(GpdState), ctypes.POINTER(GpdStepCfg),
+                                   ctypes.c_int32, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_int64, _P, _P, _P,
+                                   ctypes.c_int64, _P, _P]),
     "gpd_reset": (ctypes.c_int, [ctypes.POINTER(GpdState), _P, ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_int32,
                                  ctypes.c_int32, _P, _P]),
     "gpd_pid": (ctypes.c_int, [ctypes.POINTER(GpdParams), _P, ctypes.c_int64, ctypes.c_float, _P, _P, _P, _P, _P, _P,

@@ -36,6 +36,12 @@
 
 namespace {
 
+// Floating-point contraction is OFF for the whole file and every fused multiply-add is written out as fmaf():
+// which a*b+c pairs get fused would otherwise depend on the code around each inlined copy of a function, and the
+// same drone would round differently in the single-step kernel, the rollout kernel and the multi-drone variants.
+// With explicit FMAs a drone's trajectory is bit-identical in every kernel variant, batch size and lane.
+#pragma clang fp contract(off)
+
 #ifndef GPD_BLOCK
 #define GPD_BLOCK 256
 #endif
@@ -58,15 +64,23 @@ int hip_fail(hipError_t e, const char* where) {
 // ------------------------------------------------------------------------------------------------
 struct Mat3 {
     float r00, r01, r02, r10, r11, r12, r20, r21, r22;
+    float m22;     // 1 - r22, computed directly (no cancellation for a near-level attitude)
 };
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 
+// The three functions below are inlined at several places of the step kernel (rpy at the top of a step for
+// DSLPID, at its tail for the observation, after an auto-reset).  FMA contraction is switched OFF inside them
+// and every fused operation is written out, so that each inlined copy rounds identically: a K-step rollout
+// carries the tail's rpy into the next step where a single-step launch recomputes it at the top, and the two
+// must agree bit for bit.
+
 // atan2 with the IEEE sign/quadrant conventions Bullet's Euler extraction relies on; minimax
 // polynomial for atan(t)/t in t^2 on [0,1] (max abs error 7.4e-8 evaluated in fp32)
 __device__ __forceinline__ float atan2_poly(float y, float x) {
+#pragma clang fp contract(off)
     const float ax = fabsf(x), ay = fabsf(y);
     const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
     float t = mn * fast_rcp(mx);
@@ -89,38 +103,42 @@ __device__ __forceinline__ float atan2_poly(float y, float x) {
 
 // asin(s) = atan2(s, sqrt((1-s)(1+s))); the factored form keeps full relative accuracy near |s| = 1
 __device__ __forceinline__ float asin_poly(float s) {
+#pragma clang fp contract(off)
     return atan2_poly(s, fast_sqrt(fmaxf((1.0f - s) * (1.0f + s), 0.0f)));
 }
 
 // btMatrix3x3::setRotation (reached via p.getMatrixFromQuaternion, envs/BaseAviary.py:836);
 // insensitive to |q| (DYN never renormalises q)
 __device__ __forceinline__ Mat3 quat_to_mat(float x, float y, float z, float w) {
-    const float d = x * x + y * y + z * z + w * w;
+    const float d = fmaf(x, x, fmaf(y, y, fmaf(z, z, w * w)));
     const float s = 2.0f * fast_rcp(d);
     const float xs = x * s, ys = y * s, zs = z * s;
     const float wx = w * xs, wy = w * ys, wz = w * zs;
-    const float xx = x * xs, xy = x * ys, xz = x * zs;
-    const float yy = y * ys, yz = y * zs, zz = z * zs;
     Mat3 R;
-    R.r00 = 1.0f - (yy + zz); R.r01 = xy - wz;          R.r02 = xz + wy;
-    R.r10 = xy + wz;          R.r11 = 1.0f - (xx + zz); R.r12 = yz - wx;
-    R.r20 = xz - wy;          R.r21 = yz + wx;          R.r22 = 1.0f - (xx + yy);
+    R.r00 = 1.0f - fmaf(y, ys, z * zs); R.r01 = fmaf(x, ys, -wz);           R.r02 = fmaf(x, zs, wy);
+    R.r10 = fmaf(x, ys, wz);            R.r11 = 1.0f - fmaf(x, xs, z * zs); R.r12 = fmaf(y, zs, -wx);
+    R.m22 = fmaf(x, xs, y * ys);
+    R.r20 = fmaf(x, zs, -wy);           R.r21 = fmaf(y, zs, wx);            R.r22 = 1.0f - R.m22;
     return R;
 }
 
 // pybullet_getEulerFromQuaternion incl. its gimbal branches (envs/BaseAviary.py:518)
 __device__ __forceinline__ void quat_to_rpy(float x, float y, float z, float w,
                                             float& roll, float& pitch, float& yaw) {
-    const float sqx = x * x, sqy = y * y, sqz = z * z, squ = w * w;
-    const float sarg = -2.0f * (x * z - w * y);
+#pragma clang fp contract(off)
+    const float sarg = -2.0f * fmaf(x, z, -(w * y));
     if (sarg <= -0.99999f) {
         roll = 0.0f; pitch = -1.57079632679489661923f; yaw = 2.0f * atan2_poly(x, -y);
     } else if (sarg >= 0.99999f) {
         roll = 0.0f; pitch = 1.57079632679489661923f; yaw = 2.0f * atan2_poly(-x, y);
     } else {
-        roll = atan2_poly(2.0f * (y * z + w * x), squ - sqx - sqy + sqz);
+        const float ww_zz = fmaf(w, w, z * z);                   // squ + sqz
+        const float xx_yy = fmaf(x, x, y * y);                   // sqx + sqy
+        const float ww_yy = fmaf(w, w, -(y * y));                // squ - sqy
+        const float xx_zz = fmaf(x, x, -(z * z));                // sqx - sqz
+        roll = atan2_poly(2.0f * fmaf(y, z, w * x), ww_zz - xx_yy);     // squ - sqx - sqy + sqz
         pitch = asin_poly(sarg);
-        yaw = atan2_poly(2.0f * (x * y + w * z), squ + sqx - sqy - sqz);
+        yaw = atan2_poly(2.0f * fmaf(x, y, w * z), ww_yy + xx_zz);      // squ + sqx - sqy - sqz
     }
 }
 
@@ -145,48 +163,48 @@ __device__ __forceinline__ void dslpid(const GpdParams& P, float dt, float inv_d
     // ---- position loop, :187-203
     const float epx = tx - k.px, epy = ty - k.py, epz = tz - k.pz;
     const float evx = tvx - k.vx, evy = tvy - k.vy, evz = tvz - k.vz;
-    s.ipx = clampf(s.ipx + epx * dt, -2.0f, 2.0f);
-    s.ipy = clampf(s.ipy + epy * dt, -2.0f, 2.0f);
-    s.ipz = clampf(clampf(s.ipz + epz * dt, -2.0f, 2.0f), -0.15f, 0.15f);
-    const float fx = P.p_for[0] * epx + P.i_for[0] * s.ipx + P.d_for[0] * evx;
-    const float fy = P.p_for[1] * epy + P.i_for[1] * s.ipy + P.d_for[1] * evy;
-    const float fz = P.p_for[2] * epz + P.i_for[2] * s.ipz + P.d_for[2] * evz + P.pid_gravity;
-    const float along = fmaxf(0.0f, fx * R.r02 + fy * R.r12 + fz * R.r22);
+    s.ipx = clampf(fmaf(epx, dt, s.ipx), -2.0f, 2.0f);
+    s.ipy = clampf(fmaf(epy, dt, s.ipy), -2.0f, 2.0f);
+    s.ipz = clampf(clampf(fmaf(epz, dt, s.ipz), -2.0f, 2.0f), -0.15f, 0.15f);
+    const float fx = fmaf(P.d_for[0], evx, fmaf(P.i_for[0], s.ipx, P.p_for[0] * epx));
+    const float fy = fmaf(P.d_for[1], evy, fmaf(P.i_for[1], s.ipy, P.p_for[1] * epy));
+    const float fz = fmaf(P.d_for[2], evz, fmaf(P.i_for[2], s.ipz, P.p_for[2] * epz)) + P.pid_gravity;
+    const float along = fmaxf(0.0f, fmaf(fz, R.r22, fmaf(fy, R.r12, fx * R.r02)));
     const float base_pwm = (fast_sqrt(along * P.pid_inv_4kf) - P.pwm2rpm_const) * P.inv_pwm2rpm_scale;
-    const float fn = fast_rsq(fx * fx + fy * fy + fz * fz);
+    const float fn = fast_rsq(fmaf(fz, fz, fmaf(fy, fy, fx * fx)));
     const float zbx = fx * fn, zby = fy * fn, zbz = fz * fn;
     float sy, cy;
     sincosf(tyaw, &sy, &cy);                      // heading = [cos, sin, 0]
-    float ybx = zby * 0.0f - zbz * sy;            // zb x heading
-    float yby = zbz * cy - zbx * 0.0f;
-    float ybz = zbx * sy - zby * cy;
-    const float yn = fast_rsq(ybx * ybx + yby * yby + ybz * ybz);
+    float ybx = -(zbz * sy);                      // zb x heading
+    float yby = zbz * cy;
+    float ybz = fmaf(zbx, sy, -(zby * cy));
+    const float yn = fast_rsq(fmaf(ybz, ybz, fmaf(yby, yby, ybx * ybx)));
     ybx *= yn; yby *= yn; ybz *= yn;
-    const float xbx = yby * zbz - ybz * zby;      // yb x zb
-    const float xby = ybz * zbx - ybx * zbz;
-    const float xbz = ybx * zby - yby * zbx;
+    const float xbx = fmaf(yby, zbz, -(ybz * zby));   // yb x zb
+    const float xby = fmaf(ybz, zbx, -(ybx * zbz));
+    const float xbz = fmaf(ybx, zby, -(yby * zbx));
     // ---- attitude loop, :240-259.  The reference rebuilds R* from its Euler angles through scipy;
     // that round trip returns the same orthonormal matrix (to 3e-16), so R* = [xb yb zb] is used.
     // e_R = vee(R*^T R - R^T R*): M_ij = col_i(R*) . col_j(R)
-    const float m21 = zbx * R.r01 + zby * R.r11 + zbz * R.r21, m12 = ybx * R.r02 + yby * R.r12 + ybz * R.r22;
-    const float m02 = xbx * R.r02 + xby * R.r12 + xbz * R.r22, m20 = zbx * R.r00 + zby * R.r10 + zbz * R.r20;
-    const float m10 = ybx * R.r00 + yby * R.r10 + ybz * R.r20, m01 = xbx * R.r01 + xby * R.r11 + xbz * R.r21;
+    const float m21 = fmaf(zbz, R.r21, fmaf(zby, R.r11, zbx * R.r01)), m12 = fmaf(ybz, R.r22, fmaf(yby, R.r12, ybx * R.r02));
+    const float m02 = fmaf(xbz, R.r22, fmaf(xby, R.r12, xbx * R.r02)), m20 = fmaf(zbz, R.r20, fmaf(zby, R.r10, zbx * R.r00));
+    const float m10 = fmaf(ybz, R.r20, fmaf(yby, R.r10, ybx * R.r00)), m01 = fmaf(xbz, R.r21, fmaf(xby, R.r11, xbx * R.r01));
     const float erx = m21 - m12, ery = m02 - m20, erz = m10 - m01;
-    const float ewx = trr - (roll - s.lr) * inv_dt;   // finite difference of Euler angles, no unwrap (:247)
-    const float ewy = trp - (pitch - s.lp) * inv_dt;
-    const float ewz = try_ - (yaw - s.ly) * inv_dt;
+    const float ewx = fmaf(-(roll - s.lr), inv_dt, trr);   // finite difference of Euler angles, no unwrap (:247)
+    const float ewy = fmaf(-(pitch - s.lp), inv_dt, trp);
+    const float ewz = fmaf(-(yaw - s.ly), inv_dt, try_);
     s.lr = roll; s.lp = pitch; s.ly = yaw;
-    s.irx = clampf(clampf(s.irx - erx * dt, -1500.0f, 1500.0f), -1.0f, 1.0f);
-    s.iry = clampf(clampf(s.iry - ery * dt, -1500.0f, 1500.0f), -1.0f, 1.0f);
-    s.irz = clampf(s.irz - erz * dt, -1500.0f, 1500.0f);
-    const float t0 = clampf(-P.p_tor[0] * erx + P.d_tor[0] * ewx + P.i_tor[0] * s.irx, -3200.0f, 3200.0f);
-    const float t1 = clampf(-P.p_tor[1] * ery + P.d_tor[1] * ewy + P.i_tor[1] * s.iry, -3200.0f, 3200.0f);
-    const float t2 = clampf(-P.p_tor[2] * erz + P.d_tor[2] * ewz + P.i_tor[2] * s.irz, -3200.0f, 3200.0f);
+    s.irx = clampf(clampf(fmaf(-erx, dt, s.irx), -1500.0f, 1500.0f), -1.0f, 1.0f);
+    s.iry = clampf(clampf(fmaf(-ery, dt, s.iry), -1500.0f, 1500.0f), -1.0f, 1.0f);
+    s.irz = clampf(fmaf(-erz, dt, s.irz), -1500.0f, 1500.0f);
+    const float t0 = clampf(fmaf(P.i_tor[0], s.irx, fmaf(P.d_tor[0], ewx, -(P.p_tor[0] * erx))), -3200.0f, 3200.0f);
+    const float t1 = clampf(fmaf(P.i_tor[1], s.iry, fmaf(P.d_tor[1], ewy, -(P.p_tor[1] * ery))), -3200.0f, 3200.0f);
+    const float t2 = clampf(fmaf(P.i_tor[2], s.irz, fmaf(P.d_tor[2], ewz, -(P.p_tor[2] * erz))), -3200.0f, 3200.0f);
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        const float pwm = clampf(base_pwm + P.mixer[3 * m] * t0 + P.mixer[3 * m + 1] * t1 + P.mixer[3 * m + 2] * t2,
+        const float pwm = clampf(fmaf(P.mixer[3 * m + 2], t2, fmaf(P.mixer[3 * m + 1], t1, fmaf(P.mixer[3 * m], t0, base_pwm))),
                                  P.min_pwm, P.max_pwm);
-        rpm[m] = P.pwm2rpm_scale * pwm + P.pwm2rpm_const;
+        rpm[m] = fmaf(P.pwm2rpm_scale, pwm, P.pwm2rpm_const);
     }
     if (pos_e) { pos_e[0] = epx; pos_e[1] = epy; pos_e[2] = epz; }
     if (yaw_e) {
@@ -195,74 +213,89 @@ __device__ __forceinline__ void dslpid(const GpdParams& P, float dt, float inv_d
     }
 }
 
+// Thrust of one rotor as a deviation from the hover thrust F_h = GRAVITY/4 = KF*HOVER_RPM^2:
+//   g = KF*rpm^2 - F_h = KF*(rpm - h)*(rpm + h) + (KF*h^2 - F_h),   h = float(HOVER_RPM)
+// rpm - h is exact in fp32 (Sterbenz) for any rpm a quadrotor flies at, so g keeps ~1e-7 RELATIVE accuracy where
+// KF*rpm^2 - F_h computed naively keeps 1e-7 of F_h -- 20..1000x coarser near hover.
+__device__ __forceinline__ float thrust_dev(const GpdParams& P, float rpm) {
+    return fmaf(P.KF * (rpm - P.hover_rpm), rpm + P.hover_rpm, P.hover_resid);
+}
+// ... and for the normalised action types, rpm = HOVER_RPM*(1 + e) (envs/BaseRLAviary.py:191-192):
+//   g = F_h*((1 + e)^2 - 1) = F_h * e * (2 + e), with no reference to the rounded rpm at all
+__device__ __forceinline__ float thrust_dev_norm(const GpdParams& P, float e) {
+    return P.hover_thrust * (e * (2.0f + e));
+}
+
 // One physics sub-step (envs/BaseAviary.py:831-877 + :879-892), state in registers.
-//   rpm[4]      current action
+//   g[4]        rotor thrusts minus the hover thrust (KF*rpm_i^2 - GRAVITY/4), constant over the sub-steps
 //   drag_rpm_sum  sum of the rpm the drag term sees (previous action on sub-step 0), only if DRAG
 //   dw_force    body-z downwash force on this drone (already summed over the drones above), only if DW
+// Forces are assembled from the deviations: total thrust T = GRAVITY + sum(g) (+ ground effect, downwash), so
+//   F_z = R22*T - GRAVITY = R22*(T - GRAVITY) - GRAVITY*(1 - R22)      (1 - R22 computed directly)
+// and the torques only see differences of the g_i (F_h cancels analytically: every torque row sums to zero).
 template <bool EXT>
-__device__ __forceinline__ void substep(const GpdParams& P, float h, uint32_t flags, const float rpm[4],
+__device__ __forceinline__ void substep(const GpdParams& P, float h, uint32_t flags, const float g[4],
                                         float drag_rpm_sum, float dw_force, Kin& k,
                                         float& avx, float& avy, float& avz) {
     const Mat3 R = quat_to_mat(k.qx, k.qy, k.qz, k.qw);
-    const float s0 = rpm[0] * rpm[0], s1 = rpm[1] * rpm[1], s2 = rpm[2] * rpm[2], s3 = rpm[3] * rpm[3];
-    float f0 = s0 * P.KF, f1 = s1 * P.KF, f2 = s2 * P.KF, f3 = s3 * P.KF;
+    float f0 = g[0], f1 = g[1], f2 = g[2], f3 = g[3];      // thrust deviations (ground effect adds to them)
     if (EXT && (flags & GPD_PHYS_GND)) {
-        // per-rotor extra thrust (:739-743): h_i = world z of rotor i, clipped from below
-        const float sq[4] = {s0, s1, s2, s3};
-        float g[4];
+        // per-rotor extra thrust (:739-743): KF*rpm_i^2 * coeff * (r/(4 h_i))^2, h_i = world z of rotor i, clipped
+        float e[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float hz = k.pz + R.r20 * P.prop_x[i] + R.r21 * P.prop_y[i];
+            float hz = fmaf(R.r21, P.prop_y[i], fmaf(R.r20, P.prop_x[i], k.pz));
             hz = fmaxf(hz, P.gnd_eff_h_clip);
             const float ratio = (0.25f * P.prop_radius) * fast_rcp(hz);
-            g[i] = sq[i] * P.KF * P.gnd_eff_coeff * (ratio * ratio);
+            e[i] = (P.hover_thrust + g[i]) * P.gnd_eff_coeff * (ratio * ratio);
         }
         // |roll| < pi/2 and |pitch| < pi/2 on Bullet's Euler extraction (:742), without the atan2/asin:
         // pitch = asin(sarg) is inside (-pi/2, pi/2) off the gimbal branches and exactly +-pi/2 on them;
-        // roll = atan2(a, b) has |roll| < pi/2 iff b > 0 (or a == b == 0).
-        const float sarg = -2.0f * (k.qx * k.qz - k.qw * k.qy);
-        const float a = 2.0f * (k.qy * k.qz + k.qw * k.qx);
-        const float b = k.qw * k.qw - k.qx * k.qx - k.qy * k.qy + k.qz * k.qz;
+        // roll = atan2(a, b) has |roll| < pi/2 iff b > 0 (or a == b == 0).  Same expressions as quat_to_rpy.
+        const float sarg = -2.0f * fmaf(k.qx, k.qz, -(k.qw * k.qy));
+        const float a = 2.0f * fmaf(k.qy, k.qz, k.qw * k.qx);
+        const float b = fmaf(k.qw, k.qw, k.qz * k.qz) - fmaf(k.qx, k.qx, k.qy * k.qy);
         const bool on = (sarg > -0.99999f) && (sarg < 0.99999f) && (b > 0.0f || (a == 0.0f && b == 0.0f));
-        if (on) { f0 += g[0]; f1 += g[1]; f2 += g[2]; f3 += g[3]; }
+        if (on) { f0 += e[0]; f1 += e[1]; f2 += e[2]; f3 += e[3]; }
     }
-    float fzb = ((f0 + f1) + f2) + f3;                     // np.sum order
-    if (EXT && (flags & GPD_PHYS_DW)) fzb += dw_force;
-    float Fx = R.r02 * fzb, Fy = R.r12 * fzb, Fz = R.r22 * fzb - P.GRAVITY;
+    float dev = ((f0 + f1) + f2) + f3;                     // total thrust minus GRAVITY
+    if (EXT && (flags & GPD_PHYS_DW)) dev += dw_force;
+    const float T = P.GRAVITY + dev;
+    float Fx = R.r02 * T, Fy = R.r12 * T, Fz = fmaf(R.r22, dev, -(P.GRAVITY * R.m22));
     if (EXT && (flags & GPD_PHYS_DRAG)) {
         // world force -DRAG_COEFF * v * sum(2*pi*rpm/60) (:771-774; R R^T cancels)
         const float wsum = drag_rpm_sum * (6.28318530717958647692f / 60.0f);
-        Fx -= P.drag_coeff[0] * k.vx * wsum;
-        Fy -= P.drag_coeff[1] * k.vy * wsum;
-        Fz -= P.drag_coeff[2] * k.vz * wsum;
+        Fx = fmaf(-(P.drag_coeff[0] * k.vx), wsum, Fx);
+        Fy = fmaf(-(P.drag_coeff[1] * k.vy), wsum, Fy);
+        Fz = fmaf(-(P.drag_coeff[2] * k.vz), wsum, Fz);
     }
-    float z0 = s0 * P.KM, z1 = s1 * P.KM, z2 = s2 * P.KM, z3 = s3 * P.KM;
-    if (P.drone_model == GPD_MODEL_RACE) { z0 = -z0; z1 = -z1; z2 = -z2; z3 = -z3; }
-    const float tz = -z0 + z1 - z2 + z3;
+    // z torque from KM*rpm_i^2 = (KM/KF)*(F_h + g_i): alternating signs, F_h cancels (ground effect not included, :842)
+    float tz = P.km_over_kf * (((-g[0] + g[1]) - g[2]) + g[3]);
+    if (P.drone_model == GPD_MODEL_RACE) tz = -tz;
     float tx, ty;
     if (P.drone_model == GPD_MODEL_CF2P) {
         tx = (f1 - f3) * P.L;
         ty = (-f0 + f2) * P.L;
     } else {
         const float arm = P.L * 0.70710678118654752440f;   // L / sqrt(2)
-        tx = (f0 + f1 - f2 - f3) * arm;
-        ty = (-f0 + f1 + f2 - f3) * arm;
+        tx = (((f0 + f1) - f2) - f3) * arm;
+        ty = (((-f0 + f1) + f2) - f3) * arm;
         if (P.drone_model == GPD_MODEL_CF2X) tx = -tx;
     }
     // Euler's rotation equation with diagonal J
     const float jwx = P.J[0] * k.wx, jwy = P.J[1] * k.wy, jwz = P.J[2] * k.wz;
-    tx -= k.wy * jwz - k.wz * jwy;
-    ty -= k.wz * jwx - k.wx * jwz;
-    const float tzz = tz - (k.wx * jwy - k.wy * jwx);
+    tx -= fmaf(k.wy, jwz, -(k.wz * jwy));
+    ty -= fmaf(k.wz, jwx, -(k.wx * jwz));
+    const float tzz = tz - fmaf(k.wx, jwy, -(k.wy * jwx));
     // semi-implicit Euler (:860-862): position uses the NEW velocity
-    k.vx += h * (Fx * P.inv_M); k.vy += h * (Fy * P.inv_M); k.vz += h * (Fz * P.inv_M);
-    k.wx += h * (P.J_INV[0] * tx); k.wy += h * (P.J_INV[1] * ty); k.wz += h * (P.J_INV[2] * tzz);
-    k.px += h * k.vx; k.py += h * k.vy; k.pz += h * k.vz;
+    k.vx = fmaf(h, Fx * P.inv_M, k.vx); k.vy = fmaf(h, Fy * P.inv_M, k.vy); k.vz = fmaf(h, Fz * P.inv_M, k.vz);
+    k.wx = fmaf(h, P.J_INV[0] * tx, k.wx); k.wy = fmaf(h, P.J_INV[1] * ty, k.wy); k.wz = fmaf(h, P.J_INV[2] * tzz, k.wz);
+    k.px = fmaf(h, k.vx, k.px); k.py = fmaf(h, k.vy, k.py); k.pz = fmaf(h, k.vz, k.pz);
     // exact exponential quaternion update q <- q (x) exp(w h / 2)  (:879-892)
     //   q' = cos(t) q + (sin(t)/|w|) (q (x) [w,0]),  t = |w| h / 2.  cos(t) and sin(t)/t are even functions
     //   of t, evaluated as minimax polynomials in u = t^2 (abs err 7e-8 / 5e-8 for t <= 1 rad, i.e. body
     //   rates up to 480 rad/s at 240 Hz): no sqrt, no division, no range reduction.
-    const float n2 = k.wx * k.wx + k.wy * k.wy + k.wz * k.wz;
+    const float n2 = fmaf(k.wz, k.wz, fmaf(k.wy, k.wy, k.wx * k.wx));
     const float u = n2 * (0.25f * h * h);
     float cs, sc;
     if (__builtin_expect(u <= 1.0f, 1)) {
@@ -277,17 +310,17 @@ __device__ __forceinline__ void substep(const GpdParams& P, float h, uint32_t fl
         sc = sn / n;
     }
     if (n2 > 1e-16f) {                                     // !np.isclose(|w|, 0)  (|w| <= 1e-8 keeps q)
-        const float lx = k.wz * k.qy - k.wy * k.qz + k.wx * k.qw;
-        const float ly = -k.wz * k.qx + k.wx * k.qz + k.wy * k.qw;
-        const float lz = k.wy * k.qx - k.wx * k.qy + k.wz * k.qw;
-        const float lw = -k.wx * k.qx - k.wy * k.qy - k.wz * k.qz;
-        k.qx = cs * k.qx + sc * lx; k.qy = cs * k.qy + sc * ly;
-        k.qz = cs * k.qz + sc * lz; k.qw = cs * k.qw + sc * lw;
+        const float lx = fmaf(k.wx, k.qw, fmaf(k.wz, k.qy, -(k.wy * k.qz)));
+        const float ly = fmaf(k.wy, k.qw, fmaf(k.wx, k.qz, -(k.wz * k.qx)));
+        const float lz = fmaf(k.wz, k.qw, fmaf(k.wy, k.qx, -(k.wx * k.qy)));
+        const float lw = -fmaf(k.wz, k.qz, fmaf(k.wy, k.qy, k.wx * k.qx));
+        k.qx = fmaf(sc, lx, cs * k.qx); k.qy = fmaf(sc, ly, cs * k.qy);
+        k.qz = fmaf(sc, lz, cs * k.qz); k.qw = fmaf(sc, lw, cs * k.qw);
     }
     // world angular velocity handed to the state store: PRE-update rotation, post-update rates (:873)
-    avx = R.r00 * k.wx + R.r01 * k.wy + R.r02 * k.wz;
-    avy = R.r10 * k.wx + R.r11 * k.wy + R.r12 * k.wz;
-    avz = R.r20 * k.wx + R.r21 * k.wy + R.r22 * k.wz;
+    avx = fmaf(R.r02, k.wz, fmaf(R.r01, k.wy, R.r00 * k.wx));
+    avy = fmaf(R.r12, k.wz, fmaf(R.r11, k.wy, R.r10 * k.wx));
+    avz = fmaf(R.r22, k.wz, fmaf(R.r21, k.wy, R.r20 * k.wx));
 }
 
 // SoA row access as  <uniform 64-bit row base in SGPRs> + <32-bit per-lane byte offset>: this is the
@@ -310,12 +343,264 @@ __device__ __forceinline__ void store_obs12(float* __restrict__ obs, uint32_t n,
 }
 
 // ------------------------------------------------------------------------------------------------
-// the fused step kernel
+// One env step of one drone, everything in registers.  Shared by the single-step kernel (gpd_step) and the
+// rollout kernel (gpd_rollout): same statements in the same order, so K rollout steps are bitwise K single
+// steps.
 //   PID   : action types that run DSLPID (PID / VEL / ONE_D_PID)
 //   EXT   : any of the GND/DRAG/DW terms may be enabled (flags tested at run time, uniformly)
-//   MULTI : drones_per_env > 1 (env-level reductions and downwash go through LDS)
+//   MULTI : drones_per_env > 1 (env-level reductions and downwash go through LDS + workgroup barriers)
 // ------------------------------------------------------------------------------------------------
+// Workgroup barrier for LDS hand-offs: waits for this wave's outstanding LDS operations only (lgkmcnt), not for
+// its global stores -- __syncthreads() would add a release fence, and with it a wait for every store in flight.
+__device__ __forceinline__ void wg_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0); vmcnt / expcnt untouched
+    __builtin_amdgcn_s_barrier();
+}
+
+struct Lane {             // which drone a lane works on
+    uint32_t n;           // drone index (0 for a lane without a drone: it computes on drone 0 and stores nothing)
+    uint32_t env;         // aviary index
+    int tid;              // compute-lane index inside the workgroup (0 .. kBlock-1)
+    int le, d;            // aviary / drone-in-aviary inside the workgroup
+    bool active;
+};
+
+struct Carry {            // what a drone carries from one env step to the next
+    Kin k;
+    Pid s;                // DSLPID members
+    float l0, l1, l2, l3; // last_clipped_action
+    int counter;          // the aviary's step counter
+    float roll, pitch, yaw;   // rpy of the cached pose (BaseAviary.py:518), carried from the tail of one step to
+                              // the top of the next (DSLPID reads it there)
+};
+
+struct StepOut {          // what one env step hands to the stores
+    float o[12];          // observation row: pos | rpy | vel | ang_v (of the reset pose if the aviary was reset)
+    float to[12];         // last observation of the finished episode (meaningful only if `reset`)
+    float rew;
+    bool term, trunc, reset;
+};
+
 template <bool PID, bool EXT, bool MULTI>
+__device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C, const uint32_t flags, const int D,
+                                         const Lane& L, const float4 act, const float tgx, const float tgy,
+                                         const float tgz, const bool ip_regs, const float* __restrict__ ipose,
+                                         const float ip0, const float ip1, const float ip2, const float ip3,
+                                         const float ip4, const float ip5, const float ip6, float* sh_pos,
+                                         float* sh_red, Carry& c, StepOut& out) {
+    Kin& k = c.k;
+    // ---- action -> RPM (computed ONCE per env step from the cached state, BaseAviary.py:341) -----
+    float rpm[4] = {0, 0, 0, 0};
+    float g[4];                                              // rotor thrusts minus the hover thrust
+    if (!PID) {
+        if (C.act_type == GPD_ACT_ONE_D_RPM) {
+            const float e = 0.05f * act.x;
+            rpm[0] = rpm[1] = rpm[2] = rpm[3] = fmaf(P.hover_rpm, e, P.hover_rpm);
+            g[0] = g[1] = g[2] = g[3] = thrust_dev_norm(P, e);
+        } else if (C.act_type == GPD_ACT_RAW_RPM) {
+            rpm[0] = clampf(act.x, 0.0f, P.max_rpm); rpm[1] = clampf(act.y, 0.0f, P.max_rpm);
+            rpm[2] = clampf(act.z, 0.0f, P.max_rpm); rpm[3] = clampf(act.w, 0.0f, P.max_rpm);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[i] = thrust_dev(P, rpm[i]);
+        } else if (C.act_type == GPD_ACT_DIRECT_RPM) {
+            rpm[0] = act.x; rpm[1] = act.y; rpm[2] = act.z; rpm[3] = act.w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[i] = thrust_dev(P, rpm[i]);
+        } else {   // GPD_ACT_RPM: NOT clipped
+            const float e0 = 0.05f * act.x, e1 = 0.05f * act.y, e2 = 0.05f * act.z, e3 = 0.05f * act.w;
+            rpm[0] = fmaf(P.hover_rpm, e0, P.hover_rpm); rpm[1] = fmaf(P.hover_rpm, e1, P.hover_rpm);
+            rpm[2] = fmaf(P.hover_rpm, e2, P.hover_rpm); rpm[3] = fmaf(P.hover_rpm, e3, P.hover_rpm);
+            g[0] = thrust_dev_norm(P, e0); g[1] = thrust_dev_norm(P, e1);
+            g[2] = thrust_dev_norm(P, e2); g[3] = thrust_dev_norm(P, e3);
+        }
+    } else {
+        float tx = k.px, ty = k.py, tz = k.pz, tyaw = 0.0f, tvx = 0.0f, tvy = 0.0f, tvz = 0.0f;
+        if (C.act_type == GPD_ACT_PID) {
+            // waypoint limited to a 1 m approach step (_calculateNextStep, BaseAviary.py:1132-1150)
+            const float dx = act.x - k.px, dy = act.y - k.py, dz = act.z - k.pz;
+            const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            if (fast_sqrt(d2) <= 1.0f) { tx = act.x; ty = act.y; tz = act.z; }
+            else { const float id = fast_rsq(d2); tx = fmaf(dx, id, k.px); ty = fmaf(dy, id, k.py); tz = fmaf(dz, id, k.pz); }
+        } else if (C.act_type == GPD_ACT_VEL) {
+            const float nn2 = fmaf(act.z, act.z, fmaf(act.y, act.y, act.x * act.x));
+            const float sp = P.speed_limit * fabsf(act.w);
+            if (nn2 != 0.0f) { const float in = fast_rsq(nn2); tvx = sp * (act.x * in); tvy = sp * (act.y * in); tvz = sp * (act.z * in); }
+            tyaw = c.yaw;                                 // keep the current yaw (:220)
+        } else {   // GPD_ACT_ONE_D_PID
+            tz = fmaf(0.1f, act.x, k.pz);
+        }
+        const Mat3 R = quat_to_mat(k.qx, k.qy, k.qz, k.qw);
+        dslpid(P, C.ctrl_dt, C.inv_ctrl_dt, k, c.roll, c.pitch, c.yaw, R, tx, ty, tz, tyaw, tvx, tvy, tvz, 0.0f, 0.0f, 0.0f,
+               c.s, rpm, nullptr, nullptr);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = thrust_dev(P, rpm[i]);
+    }
+
+    // ---- S physics sub-steps, state in registers -------------------------------------------------
+    const float cur_sum = ((rpm[0] + rpm[1]) + rpm[2]) + rpm[3];
+    // the first sub-step of a step sees the PREVIOUS env step's action (BaseAviary.py:359,372)
+    float drag_sum = (EXT && (flags & GPD_PHYS_DRAG)) ? ((c.l0 + c.l1) + c.l2) + c.l3 : cur_sum;
+    float avx = 0.0f, avy = 0.0f, avz = 0.0f;
+    for (int ss = 0; ss < C.substeps; ++ss) {
+        float dw = 0.0f;
+        if (EXT && MULTI && (flags & GPD_PHYS_DW)) {
+            // every drone sees the same pre-sub-step snapshot of its aviary (BaseAviary.py:346-347,798)
+            wg_barrier();
+            sh_pos[L.tid] = k.px; sh_pos[kBlock + L.tid] = k.py; sh_pos[2 * kBlock + L.tid] = k.pz;
+            wg_barrier();
+            const int base = L.le * D;
+            for (int j = 0; j < D; ++j) {
+                const float dz = sh_pos[2 * kBlock + base + j] - k.pz;
+                const float ddx = sh_pos[base + j] - k.px, ddy = sh_pos[kBlock + base + j] - k.py;
+                const float dxy2 = fmaf(ddy, ddy, ddx * ddx);
+                if (dz > 0.0f && dxy2 < 100.0f) {            // dz > 0 and dxy < 10 m
+                    const float ratio = (0.25f * P.prop_radius) * fast_rcp(dz);
+                    const float alpha = P.dw_coeff[0] * (ratio * ratio);
+                    const float beta = fmaf(P.dw_coeff[1], dz, P.dw_coeff[2]);
+                    const float ib = fast_rcp(beta);
+                    dw -= alpha * expf(-0.5f * (dxy2 * (ib * ib)));
+                }
+            }
+        }
+        substep<EXT>(P, C.pyb_dt, flags, g, drag_sum, dw, k, avx, avy, avz);
+        drag_sum = cur_sum;
+    }
+
+    // ---- cache refresh: rpy of the new quaternion (BaseAviary.py:518) ------------------------------
+    quat_to_rpy(k.qx, k.qy, k.qz, k.qw, c.roll, c.pitch, c.yaw);
+
+    // ---- task: reward / terminated / truncated -------------------------------------------------------
+    float rew = -1.0f;
+    bool term = false, trunc = false;
+    if (C.task != GPD_TASK_NONE) {
+        const float ex = tgx - k.px, ey = tgy - k.py, ez = tgz - k.pz;
+        const float my_dist = fast_sqrt(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
+        const float d2 = my_dist * my_dist;
+        const float my_rew = fmaxf(0.0f, fmaf(-d2, d2, 2.0f));
+        const bool my_out = fabsf(k.px) > C.xy_bound || fabsf(k.py) > C.xy_bound || k.pz > C.z_bound ||
+                            fabsf(c.roll) > C.tilt_bound || fabsf(c.pitch) > C.tilt_bound;
+        if (!MULTI) {
+            rew = my_rew;
+            term = my_dist < C.term_dist;
+            trunc = my_out || (c.counter > C.trunc_counter);   // tested BEFORE the increment (App. B.7)
+        } else {
+            wg_barrier();
+            sh_red[L.tid] = my_rew; sh_red[kBlock + L.tid] = my_dist; sh_red[2 * kBlock + L.tid] = my_out ? 1.0f : 0.0f;
+            wg_barrier();
+            const int base = L.le * D;
+            float r = 0.0f, dsum = 0.0f, o = 0.0f;
+            for (int j = 0; j < D; ++j) {                      // sequential, like the reference's loops
+                r += sh_red[base + j]; dsum += sh_red[kBlock + base + j]; o += sh_red[2 * kBlock + base + j];
+            }
+            rew = r;
+            term = dsum < C.term_dist;
+            trunc = (o > 0.0f) || (c.counter > C.trunc_counter);
+        }
+    }
+    const bool do_reset = C.auto_reset && (term || trunc);
+    c.counter = do_reset ? 0 : c.counter + C.substeps;        // BaseAviary.py:382 / :460
+    out.rew = rew; out.term = term; out.trunc = trunc; out.reset = do_reset;
+
+    // ---- observation; same-step auto-reset ----------------------------------------------------------------
+    c.l0 = rpm[0]; c.l1 = rpm[1]; c.l2 = rpm[2]; c.l3 = rpm[3];
+    if (do_reset) {
+        out.to[0] = k.px; out.to[1] = k.py; out.to[2] = k.pz; out.to[3] = c.roll; out.to[4] = c.pitch; out.to[5] = c.yaw;
+        out.to[6] = k.vx; out.to[7] = k.vy; out.to[8] = k.vz; out.to[9] = avx; out.to[10] = avy; out.to[11] = avz;
+        if (ip_regs) k = Kin{ip0, ip1, ip2, ip3, ip4, ip5, ip6, 0, 0, 0, 0, 0, 0};
+        else k = Kin{ipose[0], ipose[1], ipose[2], ipose[3], ipose[4], ipose[5], ipose[6], 0, 0, 0, 0, 0, 0};
+        quat_to_rpy(k.qx, k.qy, k.qz, k.qw, c.roll, c.pitch, c.yaw);
+        avx = avy = avz = 0.0f;
+        c.l0 = c.l1 = c.l2 = c.l3 = 0.0f;                      // last_clipped_action zeroed (BaseAviary.py:468)
+    }
+    out.o[0] = k.px; out.o[1] = k.py; out.o[2] = k.pz; out.o[3] = c.roll; out.o[4] = c.pitch; out.o[5] = c.yaw;
+    out.o[6] = k.vx; out.o[7] = k.vy; out.o[8] = k.vz; out.o[9] = avx; out.o[10] = avy; out.o[11] = avz;
+}
+
+struct Span {             // internal: how the K steps of one launch are laid out in memory
+    int32_t num_steps;
+    int64_t action_stride;   // floats between the action blocks of consecutive steps (0: same action each step)
+    int64_t obs_stride;      // floats between the obs12 (and term_obs12) blocks of consecutive steps
+    int64_t env_stride;      // elements between the reward / terminated / truncated rows of consecutive steps
+};
+
+// the raw action words of one drone (AW = 4, 3 or 1 floats per drone, row-major), one load instruction
+template <int AW>
+__device__ __forceinline__ float4 load_action(const float* __restrict__ action, uint32_t n) {
+    const char* p = reinterpret_cast<const char*>(action) + n * static_cast<uint32_t>(AW * 4);
+    if (AW == 1) return make_float4(*reinterpret_cast<const float*>(p), 0.0f, 0.0f, 0.0f);
+    if (AW == 3) {
+        const float* ap = reinterpret_cast<const float*>(p);
+        return make_float4(ap[0], ap[1], ap[2], 0.0f);
+    }
+    return *reinterpret_cast<const float4*>(p);
+}
+
+// Loads everything a launch needs once per drone: kinematics, DSLPID members, last RPMs, step counter, task
+// target, (rollout: reset pose).  Branch-free on purpose: every load is issued back to back and ONE wait
+// covers them all (a load inside a branch makes the compiler wait for it -- a full memory round trip --
+// before the next one is even issued).  Lanes without a drone read drone 0's rows.
+template <bool PID, bool EXT>
+__device__ __forceinline__ void load_carry(const GpdState& S, const GpdStepCfg& C, const uint32_t flags, const Lane& L,
+                                           const float* __restrict__ target_pos, const float* __restrict__ ipl,
+                                           Carry& c, float& tgx, float& tgy, float& tgz, float ip[7]) {
+    const int64_t ld = S.ld;
+    const uint32_t off4 = L.n * 4u;
+    Kin& k = c.k;
+    k.px = ld_row(S.kin, ld, 0, off4); k.py = ld_row(S.kin, ld, 1, off4); k.pz = ld_row(S.kin, ld, 2, off4);
+    k.qx = ld_row(S.kin, ld, 3, off4); k.qy = ld_row(S.kin, ld, 4, off4); k.qz = ld_row(S.kin, ld, 5, off4);
+    k.qw = ld_row(S.kin, ld, 6, off4);
+    k.vx = ld_row(S.kin, ld, 7, off4); k.vy = ld_row(S.kin, ld, 8, off4); k.vz = ld_row(S.kin, ld, 9, off4);
+    k.wx = ld_row(S.kin, ld, 10, off4); k.wy = ld_row(S.kin, ld, 11, off4); k.wz = ld_row(S.kin, ld, 12, off4);
+    c.counter = S.step_counter[L.env];                       // every drone of an aviary reads its aviary's counter
+    // target (task NONE: the host passes a readable dummy, the values are not used)
+    const float* tp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(target_pos) +
+                                                     (C.target_per_env ? L.n * 12u : static_cast<uint32_t>(L.d) * 12u));
+    tgx = tp[0]; tgy = tp[1]; tgz = tp[2];
+    c.s = Pid{0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (PID) {
+        Pid& s = c.s;
+        s.ipx = ld_row(S.pid, ld, 0, off4); s.ipy = ld_row(S.pid, ld, 1, off4); s.ipz = ld_row(S.pid, ld, 2, off4);
+        s.lr = ld_row(S.pid, ld, 3, off4); s.lp = ld_row(S.pid, ld, 4, off4); s.ly = ld_row(S.pid, ld, 5, off4);
+        s.irx = ld_row(S.pid, ld, 6, off4); s.iry = ld_row(S.pid, ld, 7, off4); s.irz = ld_row(S.pid, ld, 8, off4);
+    }
+    c.l0 = c.l1 = c.l2 = c.l3 = 0.0f;
+    if (EXT) {
+        // without the drag term the last RPMs are not needed: the loads then go to the (cached) first kin rows
+        const float* lr = (flags & GPD_PHYS_DRAG) ? S.last_rpm : S.kin;
+        c.l0 = ld_row(lr, ld, 0, off4); c.l1 = ld_row(lr, ld, 1, off4); c.l2 = ld_row(lr, ld, 2, off4); c.l3 = ld_row(lr, ld, 3, off4);
+    }
+    ip[0] = ipl[0]; ip[1] = ipl[1]; ip[2] = ipl[2]; ip[3] = ipl[3]; ip[4] = ipl[4]; ip[5] = ipl[5]; ip[6] = ipl[6];
+}
+
+template <bool PID>
+__device__ __forceinline__ void store_carry(const GpdState& S, const Lane& L, const Carry& c) {
+    const int64_t ld = S.ld;
+    const uint32_t off4 = L.n * 4u;
+    const Kin& k = c.k;
+    if (L.d == 0) S.step_counter[L.env] = c.counter;
+    st_row(S.kin, ld, 0, off4, k.px); st_row(S.kin, ld, 1, off4, k.py); st_row(S.kin, ld, 2, off4, k.pz);
+    st_row(S.kin, ld, 3, off4, k.qx); st_row(S.kin, ld, 4, off4, k.qy); st_row(S.kin, ld, 5, off4, k.qz);
+    st_row(S.kin, ld, 6, off4, k.qw);
+    st_row(S.kin, ld, 7, off4, k.vx); st_row(S.kin, ld, 8, off4, k.vy); st_row(S.kin, ld, 9, off4, k.vz);
+    st_row(S.kin, ld, 10, off4, k.wx); st_row(S.kin, ld, 11, off4, k.wy); st_row(S.kin, ld, 12, off4, k.wz);
+    if (S.last_rpm) {
+        st_row(S.last_rpm, ld, 0, off4, c.l0); st_row(S.last_rpm, ld, 1, off4, c.l1);
+        st_row(S.last_rpm, ld, 2, off4, c.l2); st_row(S.last_rpm, ld, 3, off4, c.l3);
+    }
+    if (PID) {
+        const Pid& s = c.s;
+        st_row(S.pid, ld, 0, off4, s.ipx); st_row(S.pid, ld, 1, off4, s.ipy); st_row(S.pid, ld, 2, off4, s.ipz);
+        st_row(S.pid, ld, 3, off4, s.lr); st_row(S.pid, ld, 4, off4, s.lp); st_row(S.pid, ld, 5, off4, s.ly);
+        st_row(S.pid, ld, 6, off4, s.irx); st_row(S.pid, ld, 7, off4, s.iry); st_row(S.pid, ld, 8, off4, s.irz);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gpd_step: ONE env step per launch.  One lane per drone; the lane loads its state, steps, and stores state,
+// observation row and the aviary's reward / flags itself (latency matters more than anything here: at
+// N = 65 536 a launch lasts ~5 us).
+// ------------------------------------------------------------------------------------------------
+template <bool PID, bool EXT, bool MULTI, int AW>
 __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     const GpdParams P, const GpdState S, const GpdStepCfg C, const float* __restrict__ action,
     const float* __restrict__ target_pos, const float* __restrict__ init_pose, float* __restrict__ obs12,
@@ -324,218 +609,199 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     const int D = MULTI ? C.drones_per_env : 1;
     const int tid = threadIdx.x;
     const uint32_t N = static_cast<uint32_t>(C.num_envs) * static_cast<uint32_t>(D);
-    // MULTI: whole aviaries per workgroup, one lane per drone.  Single-drone aviaries: L = lanes_per_wave
-    // (16/32/64) active lanes per 64-wide wavefront -- a batch too small to fill the chip is spread over
-    // more wavefronts so that every SIMD has 2-4 waves to interleave (the kernel is bound by the latency of
-    // one wave's dependent instruction chain there, not by issue slots or bandwidth).
-    const int L = MULTI ? 64 : C.lanes_per_wave;
-    const int lanes = MULTI ? (kBlock / D) * D : (kBlock / 64) * L;
-    const uint32_t n = MULTI ? blockIdx.x * lanes + tid : (blockIdx.x * (kBlock / 64) + (tid >> 6)) * L + (tid & 63);
-    const uint32_t off4 = n * 4u;
-    const bool active = (MULTI ? (tid < lanes) : ((tid & 63) < L)) && (n < N);
-    const int le = MULTI ? tid / D : tid;                    // env index inside the workgroup
-    const int d = MULTI ? tid - le * D : 0;                  // drone index inside the env
-    const uint32_t env = MULTI ? blockIdx.x * (lanes / D) + le : n;
-    const int64_t ld = S.ld;
+    // MULTI: whole aviaries per workgroup, one lane per drone.  Single-drone aviaries: LW = lanes_per_wave
+    // (16/32/64) active lanes per 64-wide wavefront (tuning knob, see GpdStepCfg).
+    const int LW = MULTI ? 64 : C.lanes_per_wave;
+    const int lanes = MULTI ? (kBlock / D) * D : (kBlock / 64) * LW;
+    const uint32_t n_raw = MULTI ? blockIdx.x * lanes + tid : (blockIdx.x * (kBlock / 64) + (tid >> 6)) * LW + (tid & 63);
+    Lane L;
+    L.tid = tid;
+    L.active = (MULTI ? (tid < lanes) : ((tid & 63) < LW)) && (n_raw < N);
+    L.n = L.active ? n_raw : 0u;
+    L.le = MULTI ? (tid < lanes ? tid / D : 0) : tid;
+    L.d = MULTI ? (L.active ? tid - L.le * D : 0) : 0;
+    L.env = MULTI ? (L.active ? blockIdx.x * (lanes / D) + L.le : 0u) : L.n;
 
     __shared__ float sh_pos[MULTI ? 3 * kBlock : 1];         // downwash: positions of the env's drones
     __shared__ float sh_red[MULTI ? 3 * kBlock : 1];         // reward | distance | out-of-bounds per drone
-    __shared__ int sh_flag[MULTI ? kBlock : 1];              // per-env done flag / counter broadcast
 
-    // ---- load state ------------------------------------------------------------------------------
-    Kin k;
-    if (active) {
-        k.px = ld_row(S.kin, ld, 0, off4); k.py = ld_row(S.kin, ld, 1, off4); k.pz = ld_row(S.kin, ld, 2, off4);
-        k.qx = ld_row(S.kin, ld, 3, off4); k.qy = ld_row(S.kin, ld, 4, off4); k.qz = ld_row(S.kin, ld, 5, off4);
-        k.qw = ld_row(S.kin, ld, 6, off4);
-        k.vx = ld_row(S.kin, ld, 7, off4); k.vy = ld_row(S.kin, ld, 8, off4); k.vz = ld_row(S.kin, ld, 9, off4);
-        k.wx = ld_row(S.kin, ld, 10, off4); k.wy = ld_row(S.kin, ld, 11, off4); k.wz = ld_row(S.kin, ld, 12, off4);
-    } else {
-        k = Kin{0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
-    }
-    // everything the tail of the kernel needs from memory is requested NOW, together with the state, so
-    // that no second round trip sits between the physics and the stores (a load issued inside the task
-    // section costs a full ~1 us memory latency on the critical path of a launch that lasts ~5 us)
-    int counter = 0;
-    float tgx = 0.0f, tgy = 0.0f, tgz = 0.0f;
-    if (active) {
-        if (!MULTI || d == 0) counter = S.step_counter[env];
-        if (C.task != GPD_TASK_NONE) {
-            const float* tp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(target_pos) +
-                                                             (C.target_per_env ? n * 12u : static_cast<uint32_t>(d) * 12u));
-            tgx = tp[0]; tgy = tp[1]; tgz = tp[2];
-        }
-    }
-
-    // ---- action -> RPM (computed ONCE per env step from the cached state, BaseAviary.py:341) -----
-    float rpm[4] = {0, 0, 0, 0};
-    if (!PID) {
-        if (active) {
-            if (C.act_type == GPD_ACT_ONE_D_RPM) {
-                const float r = P.hover_rpm * (1.0f + 0.05f * ld_row(action, 0, 0, off4));
-                rpm[0] = rpm[1] = rpm[2] = rpm[3] = r;
-            } else {
-                const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(action) + n * 16u);
-                if (C.act_type == GPD_ACT_RAW_RPM) {
-                    rpm[0] = clampf(a.x, 0.0f, P.max_rpm); rpm[1] = clampf(a.y, 0.0f, P.max_rpm);
-                    rpm[2] = clampf(a.z, 0.0f, P.max_rpm); rpm[3] = clampf(a.w, 0.0f, P.max_rpm);
-                } else if (C.act_type == GPD_ACT_DIRECT_RPM) {
-                    rpm[0] = a.x; rpm[1] = a.y; rpm[2] = a.z; rpm[3] = a.w;
-                } else {   // GPD_ACT_RPM: NOT clipped
-                    rpm[0] = P.hover_rpm * (1.0f + 0.05f * a.x); rpm[1] = P.hover_rpm * (1.0f + 0.05f * a.y);
-                    rpm[2] = P.hover_rpm * (1.0f + 0.05f * a.z); rpm[3] = P.hover_rpm * (1.0f + 0.05f * a.w);
-                }
-            }
-        }
-    } else {
-        Pid s{0, 0, 0, 0, 0, 0, 0, 0, 0};
-        float tx = k.px, ty = k.py, tz = k.pz, tyaw = 0.0f, tvx = 0.0f, tvy = 0.0f, tvz = 0.0f;
-        float roll, pitch, yaw;
-        quat_to_rpy(k.qx, k.qy, k.qz, k.qw, roll, pitch, yaw);
-        if (active) {
-            s.ipx = ld_row(S.pid, ld, 0, off4); s.ipy = ld_row(S.pid, ld, 1, off4); s.ipz = ld_row(S.pid, ld, 2, off4);
-            s.lr = ld_row(S.pid, ld, 3, off4); s.lp = ld_row(S.pid, ld, 4, off4); s.ly = ld_row(S.pid, ld, 5, off4);
-            s.irx = ld_row(S.pid, ld, 6, off4); s.iry = ld_row(S.pid, ld, 7, off4); s.irz = ld_row(S.pid, ld, 8, off4);
-            if (C.act_type == GPD_ACT_PID) {
-                // waypoint limited to a 1 m approach step (_calculateNextStep, BaseAviary.py:1132-1150)
-                const float* ap = reinterpret_cast<const float*>(reinterpret_cast<const char*>(action) + n * 12u);
-                const float ax = ap[0], ay = ap[1], az = ap[2];
-                const float dx = ax - k.px, dy = ay - k.py, dz = az - k.pz;
-                const float d2 = dx * dx + dy * dy + dz * dz;
-                if (fast_sqrt(d2) <= 1.0f) { tx = ax; ty = ay; tz = az; }
-                else { const float id = fast_rsq(d2); tx = k.px + dx * id; ty = k.py + dy * id; tz = k.pz + dz * id; }
-            } else if (C.act_type == GPD_ACT_VEL) {
-                const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(action) + n * 16u);
-                const float nn2 = a.x * a.x + a.y * a.y + a.z * a.z;
-                const float sp = P.speed_limit * fabsf(a.w);
-                if (nn2 != 0.0f) { const float in = fast_rsq(nn2); tvx = sp * (a.x * in); tvy = sp * (a.y * in); tvz = sp * (a.z * in); }
-                tyaw = yaw;                                   // keep the current yaw (:220)
-            } else {   // GPD_ACT_ONE_D_PID
-                tz = k.pz + 0.1f * ld_row(action, 0, 0, off4);
-            }
-        }
-        const Mat3 R = quat_to_mat(k.qx, k.qy, k.qz, k.qw);
-        dslpid(P, C.ctrl_dt, C.inv_ctrl_dt, k, roll, pitch, yaw, R, tx, ty, tz, tyaw, tvx, tvy, tvz, 0.0f, 0.0f, 0.0f, s,
-               rpm, nullptr, nullptr);
-        if (active) {
-            st_row(S.pid, ld, 0, off4, s.ipx); st_row(S.pid, ld, 1, off4, s.ipy); st_row(S.pid, ld, 2, off4, s.ipz);
-            st_row(S.pid, ld, 3, off4, s.lr); st_row(S.pid, ld, 4, off4, s.lp); st_row(S.pid, ld, 5, off4, s.ly);
-            st_row(S.pid, ld, 6, off4, s.irx); st_row(S.pid, ld, 7, off4, s.iry); st_row(S.pid, ld, 8, off4, s.irz);
-        }
-    }
-
-    // ---- S physics sub-steps, state in registers ---------------------------------------------------
     const uint32_t flags = EXT ? C.physics_flags : 0u;
-    const float cur_sum = ((rpm[0] + rpm[1]) + rpm[2]) + rpm[3];
-    float drag_sum = cur_sum;
-    if (EXT && (flags & GPD_PHYS_DRAG)) {
-        // the first sub-step sees the PREVIOUS env step's action (BaseAviary.py:359,372)
-        if (active) {
-            drag_sum = ((ld_row(S.last_rpm, ld, 0, off4) + ld_row(S.last_rpm, ld, 1, off4)) +
-                        ld_row(S.last_rpm, ld, 2, off4)) + ld_row(S.last_rpm, ld, 3, off4);
-        }
+    Carry c;
+    float tgx, tgy, tgz, ip[7];
+    const float4 act = load_action<AW>(action, L.n);
+    // a single step reads its reset pose only if it resets (in env_step); the slots `ip` are filled from a cached row
+    const float* ipose = reinterpret_cast<const float*>(reinterpret_cast<const char*>(init_pose) +
+                                                        (C.init_per_env ? L.n * 28u : static_cast<uint32_t>(L.d) * 28u));
+    load_carry<PID, EXT>(S, C, flags, L, target_pos, S.kin, c, tgx, tgy, tgz, ip);
+    c.roll = c.pitch = c.yaw = 0.0f;
+    if (PID) quat_to_rpy(c.k.qx, c.k.qy, c.k.qz, c.k.qw, c.roll, c.pitch, c.yaw);
+
+    StepOut out;
+    env_step<PID, EXT, MULTI>(P, C, flags, D, L, act, tgx, tgy, tgz, false, ipose, ip[0], ip[1], ip[2], ip[3], ip[4], ip[5],
+                              ip[6], sh_pos, sh_red, c, out);
+    if (!L.active) return;
+    if (L.d == 0) {
+        reward[L.env] = out.rew;
+        terminated[L.env] = out.term ? 1 : 0;
+        truncated[L.env] = out.trunc ? 1 : 0;
     }
-    float avx = 0.0f, avy = 0.0f, avz = 0.0f;
-    for (int s = 0; s < C.substeps; ++s) {
-        float dw = 0.0f;
-        if (EXT && MULTI && (flags & GPD_PHYS_DW)) {
-            // every drone sees the same pre-sub-step snapshot of its aviary (BaseAviary.py:346-347,798)
-            __syncthreads();
-            sh_pos[tid] = k.px; sh_pos[kBlock + tid] = k.py; sh_pos[2 * kBlock + tid] = k.pz;
-            __syncthreads();
-            const int base = le * D;
-            for (int j = 0; j < D; ++j) {
-                const float dz = sh_pos[2 * kBlock + base + j] - k.pz;
-                const float ddx = sh_pos[base + j] - k.px, ddy = sh_pos[kBlock + base + j] - k.py;
-                const float dxy2 = ddx * ddx + ddy * ddy;
-                if (dz > 0.0f && dxy2 < 100.0f) {            // dz > 0 and dxy < 10 m
-                    const float ratio = (0.25f * P.prop_radius) * fast_rcp(dz);
-                    const float alpha = P.dw_coeff[0] * (ratio * ratio);
-                    const float beta = P.dw_coeff[1] * dz + P.dw_coeff[2];
-                    const float ib = fast_rcp(beta);
-                    dw += -alpha * expf(-0.5f * (dxy2 * (ib * ib)));
+    if (out.reset && term_obs12)
+        store_obs12(term_obs12, L.n, out.to[0], out.to[1], out.to[2], out.to[3], out.to[4], out.to[5], out.to[6], out.to[7],
+                    out.to[8], out.to[9], out.to[10], out.to[11]);
+    store_carry<PID>(S, L, c);
+    store_obs12(obs12, L.n, out.o[0], out.o[1], out.o[2], out.o[3], out.o[4], out.o[5], out.o[6], out.o[7], out.o[8],
+                out.o[9], out.o[10], out.o[11]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gpd_rollout: K env steps per launch.  The drone state is loaded ONCE, lives in VGPRs for all K steps and
+// all sub-steps, and is stored ONCE.  A 320-thread workgroup holds two kinds of wavefronts:
+//   * 4 COMPUTE waves (256 lanes, one drone each).  Per step a lane prefetches the NEXT step's action row from
+//     HBM (its only global memory instruction in the loop, so the wait for it is a wait for loads only), steps,
+//     and writes its observation row and the aviary's reward / flags to an LDS slot;
+//   * 1 STORE wave that copies the previous step's LDS slot to HBM as fully coalesced 1 KiB dwordx4 bursts (the
+//     row-major observation block of a workgroup is contiguous in memory, so the LDS hop also turns the compute
+//     lanes' 48-byte-strided rows into whole cache lines).  It issues only stores and never waits for them.
+// Why: gfx950 counts loads and stores on ONE in-order counter (vmcnt).  A wave that both prefetches its next
+// action and stores its outputs can only wait for "the load" by also waiting for every store issued before
+// it, and a store takes > 1 us to be acknowledged -- ~0.4 us per step measured at one wave per SIMD.  With the
+// split, loads and stores live on different waves' counters and the only per-step synchronisation is one
+// s_barrier (plus an LDS wait).
+// ------------------------------------------------------------------------------------------------
+constexpr int kStoreLanes = 64;
+constexpr int kRollThreads = kBlock + kStoreLanes;
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte vector at 4-byte alignment
+
+template <bool PID, bool EXT, bool MULTI, int AW>
+__global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
+    const GpdParams P, const GpdState S, const GpdStepCfg C, const Span T, const float* __restrict__ action,
+    const float* __restrict__ target_pos, const float* __restrict__ init_pose, float* __restrict__ obs12,
+    float* __restrict__ reward, uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
+    float* __restrict__ term_obs12) {
+    const int D = MULTI ? C.drones_per_env : 1;
+    const int tid = threadIdx.x;
+    const uint32_t N = static_cast<uint32_t>(C.num_envs) * static_cast<uint32_t>(D);
+    const int lanes = MULTI ? (kBlock / D) * D : kBlock;             // drones per workgroup
+    const uint32_t block_base = blockIdx.x * static_cast<uint32_t>(lanes);
+    const uint32_t left = N - block_base;                            // > 0 by construction of the grid
+    const int lanes_valid = left < static_cast<uint32_t>(lanes) ? static_cast<int>(left) : lanes;
+    const int envs_block = lanes / D;
+    const uint32_t env_base = blockIdx.x * static_cast<uint32_t>(envs_block);
+    const int envs_valid = lanes_valid / D;
+    const int K = T.num_steps;
+    const uint32_t flags = EXT ? C.physics_flags : 0u;
+    // workgroup barriers inside one env step (env_step): the store wave has to take part in each of them
+    const int step_barriers = MULTI ? (((flags & GPD_PHYS_DW) ? 2 * C.substeps : 0) + (C.task != GPD_TASK_NONE ? 2 : 0)) : 0;
+
+    __shared__ __attribute__((aligned(16))) float sh_obs[2 * kBlock * 12];           // obs rows of 2 steps
+    __shared__ __attribute__((aligned(16))) float sh_rew[2 * kBlock];
+    __shared__ __attribute__((aligned(16))) uint8_t sh_term[2 * kBlock];
+    __shared__ __attribute__((aligned(16))) uint8_t sh_trunc[2 * kBlock];
+    __shared__ float sh_pos[MULTI ? 3 * kBlock : 1];
+    __shared__ float sh_red[MULTI ? 3 * kBlock : 1];
+
+    if (tid >= kBlock) {
+        // ======================= store wave ===========================================================
+        const int m = tid - kBlock;
+        auto drain = [&](int step) {                                 // LDS slot of `step` -> HBM
+            const int b = step & 1;
+            float* og = obs12 + step * T.obs_stride + static_cast<int64_t>(block_base) * 12;
+            const float4* ol = reinterpret_cast<const float4*>(sh_obs + b * (kBlock * 12));
+            const int chunks = lanes_valid * 3;                      // 16-byte chunks; chunk of lane m: j*64 + m
+            float4 v[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) v[j] = ol[j * kStoreLanes + m];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const int cidx = j * kStoreLanes + m;
+                if (cidx < chunks) {
+                    f4u w = {v[j].x, v[j].y, v[j].z, v[j].w};
+                    *reinterpret_cast<f4u*>(og + cidx * 4) = w;
                 }
             }
-        }
-        substep<EXT>(P, C.pyb_dt, flags, rpm, drag_sum, dw, k, avx, avy, avz);
-        drag_sum = cur_sum;
-    }
-
-    // ---- cache refresh: rpy of the new quaternion (BaseAviary.py:518) --------------------------------
-    float roll, pitch, yaw;
-    quat_to_rpy(k.qx, k.qy, k.qz, k.qw, roll, pitch, yaw);
-
-    // ---- task: reward / terminated / truncated ---------------------------------------------------------
-    float rew = -1.0f;
-    bool term = false, trunc = false;
-    if (C.task != GPD_TASK_NONE) {
-        float my_rew = 0.0f, my_dist = 0.0f;
-        bool my_out = false;
-        if (active) {
-            const float ex = tgx - k.px, ey = tgy - k.py, ez = tgz - k.pz;
-            my_dist = fast_sqrt(ex * ex + ey * ey + ez * ez);
-            const float d2 = my_dist * my_dist;
-            my_rew = fmaxf(0.0f, 2.0f - d2 * d2);
-            my_out = fabsf(k.px) > C.xy_bound || fabsf(k.py) > C.xy_bound || k.pz > C.z_bound ||
-                     fabsf(roll) > C.tilt_bound || fabsf(pitch) > C.tilt_bound;
-        }
-        if (!MULTI) {
-            rew = my_rew;
-            term = my_dist < C.term_dist;
-            trunc = my_out || (counter > C.trunc_counter);   // tested BEFORE the increment (App. B.7)
-        } else {
-            __syncthreads();
-            sh_red[tid] = my_rew; sh_red[kBlock + tid] = my_dist; sh_red[2 * kBlock + tid] = my_out ? 1.0f : 0.0f;
-            if (active && d == 0) sh_flag[tid] = counter;
-            __syncthreads();
-            const int base = le * D;
-            float r = 0.0f, dsum = 0.0f, o = 0.0f;
-            for (int j = 0; j < D; ++j) {                      // sequential, like the reference's loops
-                r += sh_red[base + j]; dsum += sh_red[kBlock + base + j]; o += sh_red[2 * kBlock + base + j];
+            float* rg = reward + step * T.env_stride + env_base;
+            uint8_t* tg = terminated + step * T.env_stride + env_base;
+            uint8_t* ug = truncated + step * T.env_stride + env_base;
+            if (envs_valid == kBlock && ((reinterpret_cast<uintptr_t>(tg) | reinterpret_cast<uintptr_t>(ug)) & 3) == 0) {
+                const float4 rv = reinterpret_cast<const float4*>(sh_rew + b * kBlock)[m];
+                f4u w = {rv.x, rv.y, rv.z, rv.w};
+                *reinterpret_cast<f4u*>(rg + m * 4) = w;
+                reinterpret_cast<uint32_t*>(tg)[m] = reinterpret_cast<const uint32_t*>(sh_term + b * kBlock)[m];
+                reinterpret_cast<uint32_t*>(ug)[m] = reinterpret_cast<const uint32_t*>(sh_trunc + b * kBlock)[m];
+            } else {
+                for (int e = m; e < envs_valid; e += kStoreLanes) {
+                    rg[e] = sh_rew[b * kBlock + e];
+                    tg[e] = sh_term[b * kBlock + e];
+                    ug[e] = sh_trunc[b * kBlock + e];
+                }
             }
-            counter = sh_flag[base];
-            rew = r;
-            term = dsum < C.term_dist;
-            trunc = (o > 0.0f) || (counter > C.trunc_counter);
+        };
+        for (int t = 0; t < K; ++t) {
+            for (int i = 0; i < step_barriers; ++i) wg_barrier();    // (the compute waves' env_step barriers)
+            if (t > 0) drain(t - 1);                                 // overlaps the compute waves' step t
+            wg_barrier();                                            // end of step t
         }
-    } else if (MULTI) {
-        __syncthreads();
-        if (active && d == 0) sh_flag[tid] = counter;
-        __syncthreads();
-        counter = sh_flag[le * D];
-    }
-    if (!active) return;
-
-    const bool done = term || trunc;
-    const bool do_reset = C.auto_reset && done;
-    if (d == 0) {
-        reward[env] = rew;
-        terminated[env] = term ? 1 : 0;
-        truncated[env] = trunc ? 1 : 0;
-        S.step_counter[env] = do_reset ? 0 : counter + C.substeps;
+        drain(K - 1);
+        return;
     }
 
-    // ---- store state / observation -----------------------------------------------------------------------
-    float l0 = rpm[0], l1 = rpm[1], l2 = rpm[2], l3 = rpm[3];
-    if (do_reset) {
-        if (term_obs12) store_obs12(term_obs12, n, k.px, k.py, k.pz, roll, pitch, yaw, k.vx, k.vy, k.vz, avx, avy, avz);
-        const float* ip = reinterpret_cast<const float*>(reinterpret_cast<const char*>(init_pose) +
-                                                         (C.init_per_env ? n * 28u : static_cast<uint32_t>(d) * 28u));
-        k = Kin{ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], ip[6], 0, 0, 0, 0, 0, 0};
-        quat_to_rpy(k.qx, k.qy, k.qz, k.qw, roll, pitch, yaw);
-        avx = avy = avz = 0.0f;
-        l0 = l1 = l2 = l3 = 0.0f;                              // last_clipped_action zeroed (BaseAviary.py:468)
+    // ======================= compute waves ================================================================
+    Lane L;
+    L.tid = tid;
+    L.active = tid < lanes_valid;
+    L.n = L.active ? block_base + tid : 0u;
+    L.le = MULTI ? (tid < lanes ? tid / D : 0) : tid;
+    L.d = MULTI ? (L.active ? tid - L.le * D : 0) : 0;
+    L.env = MULTI ? (L.active ? env_base + L.le : 0u) : L.n;
+
+    Carry c;
+    float tgx, tgy, tgz, ip[7];
+    float4 act = load_action<AW>(action, L.n);
+    // the rollout keeps its reset pose in registers: no dependent global load inside the step loop
+    const float* ipose = reinterpret_cast<const float*>(reinterpret_cast<const char*>(init_pose) +
+                                                        (C.init_per_env ? L.n * 28u : static_cast<uint32_t>(L.d) * 28u));
+    load_carry<PID, EXT>(S, C, flags, L, target_pos, C.auto_reset ? ipose : S.kin, c, tgx, tgy, tgz, ip);
+    // Everything requested above has to have arrived before the step loop starts (the empty asm makes the values
+    // live here; the explicit wait lets the compiler's wait-count bookkeeping start the loop with nothing pending,
+    // otherwise it would re-wait, conservatively, inside every iteration).
+    asm volatile("" :: "v"(c.k.px), "v"(c.k.py), "v"(c.k.pz), "v"(c.k.qx), "v"(c.k.qy), "v"(c.k.qz), "v"(c.k.qw), "v"(c.k.vx),
+                       "v"(c.k.vy), "v"(c.k.vz), "v"(c.k.wx), "v"(c.k.wy), "v"(c.k.wz), "v"(act.x), "v"(act.y), "v"(act.z),
+                       "v"(act.w), "v"(tgx), "v"(tgy), "v"(tgz), "v"(c.counter), "v"(ip[0]), "v"(ip[1]), "v"(ip[2]),
+                       "v"(ip[3]), "v"(ip[4]), "v"(ip[5]), "v"(ip[6]) : "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0), expcnt/lgkmcnt untouched
+    c.roll = c.pitch = c.yaw = 0.0f;
+    if (PID) quat_to_rpy(c.k.qx, c.k.qy, c.k.qz, c.k.qw, c.roll, c.pitch, c.yaw);
+
+    float* tobs_t = term_obs12;
+    for (int t = 0; t < K; ++t) {
+        // prefetch the next step's action row (the last step re-reads its own block): the only global memory
+        // instruction of the loop body, consumed a whole step later
+        const int tn = (t + 1 < K) ? t + 1 : t;
+        const float4 act_next = load_action<AW>(action + tn * T.action_stride, L.n);
+        StepOut out;
+        env_step<PID, EXT, MULTI>(P, C, flags, D, L, act, tgx, tgy, tgz, true, ipose, ip[0], ip[1], ip[2], ip[3], ip[4],
+                                  ip[5], ip[6], sh_pos, sh_red, c, out);
+        const int b = t & 1;
+        float4* ol = reinterpret_cast<float4*>(sh_obs + b * (kBlock * 12) + tid * 12);
+        ol[0] = make_float4(out.o[0], out.o[1], out.o[2], out.o[3]);
+        ol[1] = make_float4(out.o[4], out.o[5], out.o[6], out.o[7]);
+        ol[2] = make_float4(out.o[8], out.o[9], out.o[10], out.o[11]);
+        if (L.active && L.d == 0) {
+            sh_rew[b * kBlock + L.le] = out.rew;
+            sh_term[b * kBlock + L.le] = out.term ? 1 : 0;
+            sh_trunc[b * kBlock + L.le] = out.trunc ? 1 : 0;
+        }
+        if (tobs_t) {
+            if (out.reset && L.active)
+                store_obs12(tobs_t, L.n, out.to[0], out.to[1], out.to[2], out.to[3], out.to[4], out.to[5], out.to[6],
+                            out.to[7], out.to[8], out.to[9], out.to[10], out.to[11]);
+            tobs_t += T.obs_stride;
+        }
+        act = act_next;
+        wg_barrier();                                                // end of step t
     }
-    st_row(S.kin, ld, 0, off4, k.px); st_row(S.kin, ld, 1, off4, k.py); st_row(S.kin, ld, 2, off4, k.pz);
-    st_row(S.kin, ld, 3, off4, k.qx); st_row(S.kin, ld, 4, off4, k.qy); st_row(S.kin, ld, 5, off4, k.qz);
-    st_row(S.kin, ld, 6, off4, k.qw);
-    st_row(S.kin, ld, 7, off4, k.vx); st_row(S.kin, ld, 8, off4, k.vy); st_row(S.kin, ld, 9, off4, k.vz);
-    st_row(S.kin, ld, 10, off4, k.wx); st_row(S.kin, ld, 11, off4, k.wy); st_row(S.kin, ld, 12, off4, k.wz);
-    if (S.last_rpm) {
-        st_row(S.last_rpm, ld, 0, off4, l0); st_row(S.last_rpm, ld, 1, off4, l1);
-        st_row(S.last_rpm, ld, 2, off4, l2); st_row(S.last_rpm, ld, 3, off4, l3);
-    }
-    store_obs12(obs12, n, k.px, k.py, k.pz, roll, pitch, yaw, k.vx, k.vy, k.vz, avx, avy, avz);
+    if (L.active) store_carry<PID>(S, L, c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -634,18 +900,85 @@ __global__ __launch_bounds__(kBlock) void gpd_state20_kernel(const GpdState S, c
     w[4] = make_float4(l0, l1, l2, l3);
 }
 
-template <bool PID, bool EXT>
-hipError_t launch_step(bool multi, dim3 grid, hipStream_t st, const GpdParams& P, const GpdState& S,
-                       const GpdStepCfg& C, const float* action, const float* target_pos, const float* init_pose,
+template <bool PID, bool EXT, int AW>
+hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const GpdState& S, const GpdStepCfg& C,
+                       const Span& T, const float* action, const float* target_pos, const float* init_pose,
                        float* obs12, float* reward, uint8_t* terminated, uint8_t* truncated, float* term_obs12) {
-    if (multi) {
-        hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, true>), grid, dim3(kBlock), 0, st, P, S, C, action, target_pos,
-                           init_pose, obs12, reward, terminated, truncated, term_obs12);
+    const int64_t N = static_cast<int64_t>(C.num_envs) * C.drones_per_env;
+    if (T.num_steps == 1) {      // gpd_step, or a rollout of one step: the low-latency single-step kernel
+        const int lanes = multi ? (kBlock / C.drones_per_env) * C.drones_per_env : (kBlock / 64) * C.lanes_per_wave;
+        const dim3 grid(static_cast<unsigned>((N + lanes - 1) / lanes));
+        if (multi) {
+            hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, true, AW>), grid, dim3(kBlock), 0, st, P, S, C, action,
+                               target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+        } else {
+            hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, false, AW>), grid, dim3(kBlock), 0, st, P, S, C, action,
+                               target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+        }
     } else {
-        hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, false>), grid, dim3(kBlock), 0, st, P, S, C, action, target_pos,
-                           init_pose, obs12, reward, terminated, truncated, term_obs12);
+        const int lanes = multi ? (kBlock / C.drones_per_env) * C.drones_per_env : kBlock;
+        const dim3 grid(static_cast<unsigned>((N + lanes - 1) / lanes));
+        if (multi) {
+            hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, true, AW>), grid, dim3(kRollThreads), 0, st, P, S, C, T,
+                               action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+        } else {
+            hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, false, AW>), grid, dim3(kRollThreads), 0, st, P, S, C, T,
+                               action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+        }
     }
     return hipGetLastError();
+}
+
+// argument checks + launch shared by gpd_step (K = 1) and gpd_rollout
+int step_impl(const char* who, const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, const Span& T,
+              const float* action, const float* target_pos, const float* init_pose, float* obs12, float* reward,
+              uint8_t* terminated, uint8_t* truncated, float* term_obs12, void* stream) {
+    auto bad = [&](int code, const char* msg) { return fail(code, (std::string(who) + ": " + msg).c_str()); };
+    if (!params || !state || !cfg) return bad(GPD_EINVAL, "NULL params/state/cfg");
+    if (!state->kin || !state->step_counter) return bad(GPD_EINVAL, "NULL state.kin/step_counter");
+    if (!action || !obs12 || !reward || !terminated || !truncated)
+        return bad(GPD_EINVAL, "NULL action/obs12/reward/terminated/truncated");
+    if (cfg->num_envs <= 0 || cfg->drones_per_env <= 0 || cfg->substeps <= 0)
+        return bad(GPD_EINVAL, "num_envs, drones_per_env and substeps must be positive");
+    if (cfg->drones_per_env > kBlock) return bad(GPD_ERANGE, "drones_per_env > 256 is not supported");
+    if (cfg->act_type < GPD_ACT_RPM || cfg->act_type > GPD_ACT_DIRECT_RPM) return bad(GPD_EINVAL, "unknown act_type");
+    if (cfg->task < GPD_TASK_NONE || cfg->task > GPD_TASK_MULTIHOVER) return bad(GPD_EINVAL, "unknown task");
+    if (cfg->physics_flags & ~7u) return bad(GPD_EINVAL, "unknown physics flag");
+    const int64_t N = static_cast<int64_t>(cfg->num_envs) * cfg->drones_per_env;
+    if (state->ld < N) return bad(GPD_EINVAL, "state.ld < num_envs*drones_per_env");
+    if (N > (1LL << 26)) return bad(GPD_ERANGE, "more than 2^26 drones per launch (32-bit byte offsets)");
+    const bool pid = cfg->act_type == GPD_ACT_PID || cfg->act_type == GPD_ACT_VEL || cfg->act_type == GPD_ACT_ONE_D_PID;
+    if (pid && !state->pid) return bad(GPD_EINVAL, "PID action type needs state.pid");
+    if (pid && params->pid_kf <= 0.0f)
+        return bad(GPD_ENOTSUP, "no DSLPID controller for this airframe (CF2X/CF2P only)");
+    if ((cfg->physics_flags & GPD_PHYS_DRAG) && !state->last_rpm) return bad(GPD_EINVAL, "GPD_PHYS_DRAG needs state.last_rpm");
+    if (cfg->task != GPD_TASK_NONE && !target_pos) return bad(GPD_EINVAL, "task needs target_pos");
+    if (cfg->auto_reset && !init_pose) return bad(GPD_EINVAL, "auto_reset needs init_pose");
+    const bool multi = cfg->drones_per_env > 1;
+    GpdStepCfg c = *cfg;
+    if (c.lanes_per_wave == 0) c.lanes_per_wave = 64;
+    if (c.lanes_per_wave != 16 && c.lanes_per_wave != 32 && c.lanes_per_wave != 64)
+        return bad(GPD_EINVAL, "lanes_per_wave must be 0, 16, 32 or 64");
+    const int min_lanes = multi ? (kBlock / cfg->drones_per_env) * cfg->drones_per_env : (kBlock / 64) * c.lanes_per_wave;
+    if ((N + min_lanes - 1) / min_lanes > 0x7fffffffLL) return bad(GPD_ERANGE, "too many drones for one launch");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool ext = cfg->physics_flags != 0;
+    // task NONE never uses the target: hand the kernel a readable dummy so that its load section is branch-free
+    if (cfg->task == GPD_TASK_NONE) { target_pos = state->kin; c.target_per_env = 0; }
+    hipError_t e;
+#define GPD_LAUNCH(PID_, EXT_, AW_)                                                                                  \
+    launch_step<PID_, EXT_, AW_>(multi, st, *params, *state, c, T, action, target_pos, init_pose, obs12, reward, \
+                                 terminated, truncated, term_obs12)
+    switch (cfg->act_type) {
+        case GPD_ACT_PID: e = ext ? GPD_LAUNCH(true, true, 3) : GPD_LAUNCH(true, false, 3); break;
+        case GPD_ACT_VEL: e = ext ? GPD_LAUNCH(true, true, 4) : GPD_LAUNCH(true, false, 4); break;
+        case GPD_ACT_ONE_D_PID: e = ext ? GPD_LAUNCH(true, true, 1) : GPD_LAUNCH(true, false, 1); break;
+        case GPD_ACT_ONE_D_RPM: e = ext ? GPD_LAUNCH(false, true, 1) : GPD_LAUNCH(false, false, 1); break;
+        default: e = ext ? GPD_LAUNCH(false, true, 4) : GPD_LAUNCH(false, false, 4); break;
+    }
+#undef GPD_LAUNCH
+    if (e != hipSuccess) return hip_fail(e, who);
+    return 0;
 }
 
 }  // namespace
@@ -668,53 +1001,21 @@ void gpd_struct_sizes(int32_t out[3]) {
 int gpd_step(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, const float* action,
              const float* target_pos, const float* init_pose, float* obs12, float* reward, uint8_t* terminated,
              uint8_t* truncated, float* term_obs12, void* stream) {
-    if (!params || !state || !cfg) return fail(GPD_EINVAL, "gpd_step: NULL params/state/cfg");
-    if (!state->kin || !state->step_counter) return fail(GPD_EINVAL, "gpd_step: NULL state.kin/step_counter");
-    if (!action || !obs12 || !reward || !terminated || !truncated)
-        return fail(GPD_EINVAL, "gpd_step: NULL action/obs12/reward/terminated/truncated");
-    if (cfg->num_envs <= 0 || cfg->drones_per_env <= 0 || cfg->substeps <= 0)
-        return fail(GPD_EINVAL, "gpd_step: num_envs, drones_per_env and substeps must be positive");
-    if (cfg->drones_per_env > kBlock) return fail(GPD_ERANGE, "gpd_step: drones_per_env > 256 is not supported");
-    if (cfg->act_type < GPD_ACT_RPM || cfg->act_type > GPD_ACT_DIRECT_RPM)
-        return fail(GPD_EINVAL, "gpd_step: unknown act_type");
-    if (cfg->task < GPD_TASK_NONE || cfg->task > GPD_TASK_MULTIHOVER) return fail(GPD_EINVAL, "gpd_step: unknown task");
-    if (cfg->physics_flags & ~7u) return fail(GPD_EINVAL, "gpd_step: unknown physics flag");
-    const int64_t N = static_cast<int64_t>(cfg->num_envs) * cfg->drones_per_env;
-    if (state->ld < N) return fail(GPD_EINVAL, "gpd_step: state.ld < num_envs*drones_per_env");
-    if (N > (1LL << 26)) return fail(GPD_ERANGE, "gpd_step: more than 2^26 drones per launch (32-bit byte offsets)");
-    const bool pid = cfg->act_type == GPD_ACT_PID || cfg->act_type == GPD_ACT_VEL || cfg->act_type == GPD_ACT_ONE_D_PID;
-    if (pid && !state->pid) return fail(GPD_EINVAL, "gpd_step: PID action type needs state.pid");
-    if (pid && params->pid_kf <= 0.0f)
-        return fail(GPD_ENOTSUP, "gpd_step: no DSLPID controller for this airframe (CF2X/CF2P only)");
-    if ((cfg->physics_flags & GPD_PHYS_DRAG) && !state->last_rpm)
-        return fail(GPD_EINVAL, "gpd_step: GPD_PHYS_DRAG needs state.last_rpm");
-    if (cfg->task != GPD_TASK_NONE && !target_pos) return fail(GPD_EINVAL, "gpd_step: task needs target_pos");
-    if (cfg->auto_reset && !init_pose) return fail(GPD_EINVAL, "gpd_step: auto_reset needs init_pose");
-    const bool multi = cfg->drones_per_env > 1;
-    GpdStepCfg c = *cfg;
-    if (c.lanes_per_wave == 0) c.lanes_per_wave = 64;
-    if (c.lanes_per_wave != 16 && c.lanes_per_wave != 32 && c.lanes_per_wave != 64)
-        return fail(GPD_EINVAL, "gpd_step: lanes_per_wave must be 0, 16, 32 or 64");
-    const int lanes = multi ? (kBlock / cfg->drones_per_env) * cfg->drones_per_env : (kBlock / 64) * c.lanes_per_wave;
-    const int64_t blocks = (N + lanes - 1) / lanes;
-    if (blocks > 0x7fffffffLL) return fail(GPD_ERANGE, "gpd_step: too many drones for one launch");
-    const dim3 grid(static_cast<unsigned>(blocks));
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool ext = cfg->physics_flags != 0;
-    hipError_t e;
-    if (pid) {
-        e = ext ? launch_step<true, true>(multi, grid, st, *params, *state, c, action, target_pos, init_pose, obs12,
-                                          reward, terminated, truncated, term_obs12)
-                : launch_step<true, false>(multi, grid, st, *params, *state, c, action, target_pos, init_pose,
-                                           obs12, reward, terminated, truncated, term_obs12);
-    } else {
-        e = ext ? launch_step<false, true>(multi, grid, st, *params, *state, c, action, target_pos, init_pose,
-                                           obs12, reward, terminated, truncated, term_obs12)
-                : launch_step<false, false>(multi, grid, st, *params, *state, c, action, target_pos, init_pose,
-                                            obs12, reward, terminated, truncated, term_obs12);
-    }
-    if (e != hipSuccess) return hip_fail(e, "gpd_step launch");
-    return 0;
+    const Span T{1, 0, 0, 0};
+    return step_impl("gpd_step", params, state, cfg, T, action, target_pos, init_pose, obs12, reward, terminated,
+                     truncated, term_obs12, stream);
+}
+
+int gpd_rollout(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, int32_t num_steps,
+                const float* actions, int64_t action_step_stride, const float* target_pos, const float* init_pose,
+                float* obs12, int64_t obs_step_stride, float* reward, uint8_t* terminated, uint8_t* truncated,
+                int64_t env_step_stride, float* term_obs12, void* stream) {
+    if (num_steps <= 0) return fail(GPD_EINVAL, "gpd_rollout: num_steps must be positive");
+    if (action_step_stride < 0 || obs_step_stride < 0 || env_step_stride < 0)
+        return fail(GPD_EINVAL, "gpd_rollout: strides must be non-negative");
+    const Span T{num_steps, action_step_stride, obs_step_stride, env_step_stride};
+    return step_impl("gpd_rollout", params, state, cfg, T, actions, target_pos, init_pose, obs12, reward, terminated,
+                     truncated, term_obs12, stream);
 }
 
 int gpd_reset(const GpdState* state, const float* init_pose, int32_t init_per_env, const uint8_t* mask,

@@ -27,6 +27,10 @@ _ACT_DIM = {0: 4, 1: 3, 2: 4, 3: 1, 4: 1, 5: 4, 6: 4}
 _PID_ACTS = (1, 2, 4)
 
 
+def action_needs_fix(a, device):
+    return a.device != device or a.dtype != torch.float32 or not a.is_contiguous()
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
@@ -173,6 +177,81 @@ class SimCore:
                                    _ptr(self.term_obs12), self._stream())
         _native.check(rc, "gpd_step")
         return self.obs12, self.reward, self.terminated, self.truncated
+
+    def rollout(self, actions: torch.Tensor, num_steps: int = None, last_only: bool = False,
+                update_latest: bool = True):
+        """K consecutive env steps of every aviary in ONE kernel launch (`gpd_rollout`).
+
+        `actions`: float32 device tensor `[K, E*D*A]` (any shape with K leading and E*D*A trailing
+        elements): step t uses block t.  With `num_steps=K` and a single action block (E*D*A elements) the
+        same action is applied K times (e.g. ActionType.PID holding one waypoint).
+
+        Returns `(obs12 [K,N,12], reward [K,E], terminated [K,E], truncated [K,E])` -- persistent buffers that
+        the next rollout of the same length overwrites -- or, with `last_only=True`, only the last step's
+        values in the usual `step()` output tensors.  Bitwise identical to K calls of `step()`.
+        """
+        per = self.N * self.A
+        if action_needs_fix(actions, self.device):
+            actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        if num_steps is None:
+            if actions.numel() % per != 0 or actions.numel() == 0:
+                raise ValueError(f"actions has {actions.numel()} elements, expected K x {self.N}x{self.A}")
+            K, a_stride = actions.numel() // per, per
+        else:
+            K = int(num_steps)
+            if actions.numel() == per:
+                a_stride = 0
+            elif actions.numel() == K * per:
+                a_stride = per
+            else:
+                raise ValueError(f"actions has {actions.numel()} elements, expected {per} or {K}x{per}")
+        if K < 1:
+            raise ValueError("num_steps must be >= 1")
+        if last_only:
+            obs, rew, term, trunc, tobs = self.obs12, self.reward, self.terminated, self.truncated, self.term_obs12
+            o_stride = e_stride = 0
+        else:
+            buf = self._rollout_buffers(K)
+            obs, rew, term, trunc, tobs = buf
+            o_stride, e_stride = self.N * 12, self.E
+        with torch.cuda.device(self.device):
+            rc = self.lib.gpd_rollout(ctypes.byref(self._params), ctypes.byref(self._state), ctypes.byref(self._cfg),
+                                      K, _ptr(actions), a_stride, _ptr(self.target), _ptr(self.init_pose),
+                                      _ptr(obs), o_stride, _ptr(rew), _ptr(term), _ptr(trunc), e_stride,
+                                      _ptr(tobs), self._stream())
+        _native.check(rc, "gpd_rollout")
+        if not last_only and update_latest:
+            self.obs12.copy_(obs[K - 1]); self.reward.copy_(rew[K - 1])
+            self.terminated.copy_(term[K - 1]); self.truncated.copy_(trunc[K - 1])
+        return obs, rew, term, trunc
+
+    def _rollout_buffers(self, K: int):
+        buf = getattr(self, "_rollout_buf", None)
+        if buf is None or buf[0].shape[0] != K:
+            dev = self.device
+            buf = (torch.zeros((K, self.N, 12), dtype=torch.float32, device=dev),
+                   torch.zeros((K, self.E), dtype=torch.float32, device=dev),
+                   torch.zeros((K, self.E), dtype=torch.bool, device=dev),
+                   torch.zeros((K, self.E), dtype=torch.bool, device=dev),
+                   torch.zeros((K, self.N, 12), dtype=torch.float32, device=dev) if self.term_obs12 is not None else None)
+            self._rollout_buf = buf
+        return buf
+
+    def bytes_per_rollout(self, K: int, action_stride_zero: bool = False, last_only: bool = False) -> int:
+        """Algorithmic HBM bytes of one `rollout()` of K steps: the state once, and per step the action
+        row in, the observation row and the aviary's reward + flags out."""
+        state = 2 * 13 * 4
+        if self.uses_pid:
+            state += 2 * 9 * 4
+        if self.physics_flags & PHYS_DRAG:
+            state += 4 * 4
+        if self.last_rpm is not None:
+            state += 4 * 4
+        ka = 1 if action_stride_zero else K
+        ko = 1 if last_only else K
+        per_drone = state + ka * self.A * 4 + ko * 12 * 4
+        per_env = 2 * 4 + ko * (4 + 2)
+        return per_drone * self.N + per_env * self.E
 
     def state_vectors(self) -> torch.Tensor:
         """[N,20] state vectors in `_getDroneStateVector` order (BaseAviary.py:559-561)."""

@@ -69,6 +69,7 @@ class GpdParams(ctypes.Structure):
         ("gnd_eff_coeff", ctypes.c_float), ("prop_radius", ctypes.c_float), ("gnd_eff_h_clip", ctypes.c_float),
         ("drag_coeff", ctypes.c_float * 3), ("dw_coeff", ctypes.c_float * 3),
         ("hover_rpm", ctypes.c_float), ("max_rpm", ctypes.c_float),
+        ("hover_thrust", ctypes.c_float), ("hover_resid", ctypes.c_float), ("km_over_kf", ctypes.c_float),
         ("pid_gravity", ctypes.c_float), ("pid_kf", ctypes.c_float), ("pid_inv_4kf", ctypes.c_float),
         ("p_for", ctypes.c_float * 3), ("i_for", ctypes.c_float * 3), ("d_for", ctypes.c_float * 3),
         ("p_tor", ctypes.c_float * 3), ("i_tor", ctypes.c_float * 3), ("d_tor", ctypes.c_float * 3),
@@ -168,6 +169,10 @@ class DroneParams:
         s.gnd_eff_coeff, s.prop_radius, s.gnd_eff_h_clip = self.GND_EFF_COEFF, self.PROP_RADIUS, self.GND_EFF_H_CLIP
         s.dw_coeff[0], s.dw_coeff[1], s.dw_coeff[2] = self.DW_COEFF_1, self.DW_COEFF_2, self.DW_COEFF_3
         s.hover_rpm, s.max_rpm = self.HOVER_RPM, self.MAX_RPM
+        h32 = float(np.float32(self.HOVER_RPM))
+        s.hover_thrust = self.GRAVITY / 4
+        s.hover_resid = self.KF * h32 * h32 - self.GRAVITY / 4
+        s.km_over_kf = self.KM / self.KF
         if pid_model in MIXER:
             cp = pid_params or (self if pid_model == self.DRONE_MODEL else DroneParams(pid_model))
             s.pid_gravity = pid_g * cp.M

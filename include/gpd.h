@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GPD_ABI_VERSION 1
+#define GPD_ABI_VERSION 2
 
 /* DroneModel (utils/enums.py:3-8) */
 enum { GPD_MODEL_CF2X = 0, GPD_MODEL_CF2P = 1, GPD_MODEL_RACE = 2 };
@@ -88,6 +88,13 @@ typedef struct GpdParams {
     float drag_coeff[3];
     float dw_coeff[3];
     float hover_rpm, max_rpm;  /* envs/BaseAviary.py:118-119 */
+    /* Rotor thrusts are carried as deviations from the hover thrust F_h = GRAVITY/4 (= KF*HOVER_RPM^2
+     * exactly, envs/BaseAviary.py:118): g_i = KF*rpm_i^2 - F_h evaluated without cancellation, so that
+     * "thrust minus weight" and the thrust differences that make the torques keep full fp32 relative
+     * accuracy near hover (host-computed in float64): */
+    float hover_thrust;        /* F_h = GRAVITY/4 */
+    float hover_resid;         /* KF*float(HOVER_RPM)^2 - F_h: what rounding HOVER_RPM to fp32 leaves */
+    float km_over_kf;          /* KM/KF */
     /* DSLPID (the RL aviaries always build CF2X controllers, envs/BaseRLAviary.py:75-76) */
     float pid_gravity, pid_kf; /* control/BaseControl.py:35-37 */
     float pid_inv_4kf;         /* 1/(4*pid_kf), host-computed in float64 */
@@ -173,6 +180,38 @@ int gpd_step(const GpdParams* params, const GpdState* state, const GpdStepCfg* c
              const float* action, const float* target_pos, const float* init_pose,
              float* obs12, float* reward, uint8_t* terminated, uint8_t* truncated,
              float* term_obs12, void* stream);
+
+/*
+ * K consecutive env.step() calls in ONE launch.  Replaces the caller's stepping loop around
+ * BaseAviary.step when the actions of the K steps are known up front: open-loop RPM sequences, and
+ * closed-loop DSLPID tracking of a precomputed waypoint list -- the loops of examples/pid.py:132-167
+ * and examples/downwash.py:93-113 (`for i in range(...): obs, ... = env.step(action)` with
+ * `TARGET_POS[wp_counters[j]]` as the controller's target) -- or a fixed action
+ * (action_step_stride == 0, e.g. ActionType.PID holding one waypoint, examples/learn.py:157-192 with a
+ * constant policy output).  The drone state is read once, kept in registers for all K steps and
+ * written once; per step only the action row is read and the observation row / reward / flags are
+ * written, so the per-step HBM traffic drops from ~182 B to ~70 B per drone and the ~2 us
+ * launch-to-launch latency is paid once per K steps instead of once per step.  Bitwise identical to
+ * K calls of gpd_step (same instructions in the same order).
+ *
+ *   num_steps          K >= 1
+ *   actions            step t reads [E*D][A] at actions + t*action_step_stride (floats);
+ *                      action_step_stride = 0 repeats one action block for all K steps
+ *   obs12              step t writes [E*D][12] at obs12 + t*obs_step_stride (floats); stride 0 keeps
+ *                      only the last step's observation (each step overwrites the block)
+ *   reward/terminated/truncated
+ *                      step t writes [E] at base + t*env_step_stride (elements); stride 0 keeps only
+ *                      the last step's values
+ *   term_obs12         NULL, or laid out like obs12 (same stride): with auto_reset, the rows of step t
+ *                      of the envs that ended at step t receive the last observation of the episode
+ *   everything else as in gpd_step.
+ */
+int gpd_rollout(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg,
+                int32_t num_steps, const float* actions, int64_t action_step_stride,
+                const float* target_pos, const float* init_pose,
+                float* obs12, int64_t obs_step_stride,
+                float* reward, uint8_t* terminated, uint8_t* truncated, int64_t env_step_stride,
+                float* term_obs12, void* stream);
 
 /*
  * Masked reset.  Replaces BaseAviary.reset/_housekeeping (envs/BaseAviary.py:220-255, 451-477)

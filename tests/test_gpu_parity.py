@@ -7,6 +7,8 @@ All tests here need a real MI355X (`-m gpu`).  Tolerances (fp32 kernel vs fp64 o
         err_g(t) = ||x32_g - x64_g||_inf / max(||x64_g||_inf over batch and time, floor_g)
     with floors 1 m, 1, 1 m/s, 1 rad/s, 1 rad; bound 1e-4 after 1920 physics steps.
 """
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -91,7 +93,7 @@ def _actions(rng, act, shape, hover_rpm):
 def test_one_step_parity(gpu_device, model, act, flags, D, S):
     if model == "racer" and act in ("pid", "vel", "one_d_pid"):
         pytest.skip("no DSLPID controller for the racer")
-    rng = np.random.default_rng(abs(hash((model, act, flags, D, S))) % (2 ** 31))
+    rng = np.random.default_rng(zlib.crc32(repr((model, act, flags, D, S)).encode()))
     E = 2048 // D
     task = "none" if act == "raw_rpm" else ("hover" if D == 1 else "multihover")
     xyz, rpy = _random_scene(rng, E, D)

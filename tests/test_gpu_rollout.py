@@ -1,0 +1,117 @@
+"""`gpd_rollout` (K env steps per launch, state in registers) against K calls of `gpd_step` -- bitwise --
+and against the float64 oracle stepped K times."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import urdf
+from oracle.batched_oracle import BatchedAviary
+from test_gpu_parity import _actions, _core, _oracle_kin, _random_scene, _sync_from_oracle
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # act, flags, D, S, model
+    ("rpm", 0, 1, 1, "cf2x"), ("rpm", 0, 1, 8, "cf2p"), ("one_d_rpm", 7, 1, 2, "racer"), ("pid", 0, 1, 1, "cf2x"),
+    ("pid", 7, 3, 2, "cf2x"), ("vel", 2, 2, 4, "cf2p"), ("one_d_pid", 5, 8, 1, "cf2x"), ("raw_rpm", 7, 5, 2, "racer"),
+    ("rpm", 4, 2, 8, "cf2x"),
+]
+
+
+def _pair(act, flags, D, S, model, dev, E, rng, auto_reset=True, keep_term=True):
+    task = "none" if act == "raw_rpm" else ("hover" if D == 1 else "multihover")
+    xyz, rpy = _random_scene(rng, E, D)
+    tgt = None if task == "none" else xyz + np.array([0, 0, 0.3])
+    mk = lambda: _core(model, E, D, flags, S, act, task, xyz, rpy, dev, auto_reset=auto_reset, target=tgt,  # noqa: E731
+                       keep_term=keep_term)
+    return mk(), mk()
+
+
+@pytest.mark.parametrize("act,flags,D,S,model", CASES)
+def test_rollout_is_bitwise_k_steps(gpu_device, act, flags, D, S, model):
+    """Same state, same actions: one rollout of K steps == K single-step launches, bit for bit, including the
+    same-step auto-reset (short episodes so that resets happen inside the rollout), the terminal observations,
+    the DSLPID members, last RPMs and step counters."""
+    rng = np.random.default_rng(zlib.crc32(repr((act, flags, D, S, model)).encode()))
+    E, K = 1536 // D, 24
+    a, b = _pair(act, flags, D, S, model, gpu_device, E, rng)
+    for c in (a, b):   # episodes of 10 physics steps -> several resets within K steps
+        c._cfg.trunc_counter = 10
+    # give the state some velocity so the PID memories / drag see non-trivial values
+    kin = a.kin.clone()
+    kin[7:13] = torch.as_tensor(rng.uniform(-0.5, 0.5, size=(6, a.ld)), dtype=torch.float32, device=gpu_device)
+    a.set_state(kin=kin[:, :a.N]); b.set_state(kin=kin[:, :b.N])
+    acts = torch.as_tensor(_actions(rng, act, (K, E, D), a.P.HOVER_RPM).astype(np.float32), device=gpu_device)
+    obs_s, rew_s, te_s, tr_s, tobs_s = [], [], [], [], []
+    for k in range(K):
+        o, r, te, tr = a.step(acts[k])
+        obs_s.append(o.clone()); rew_s.append(r.clone()); te_s.append(te.clone()); tr_s.append(tr.clone())
+        tobs_s.append(a.term_obs12.clone())
+    obs, rew, te, tr = b.rollout(acts)
+    assert act == "raw_rpm" or torch.stack(tr_s).any(), "test must exercise the auto-reset"
+    assert torch.equal(torch.stack(obs_s), obs)
+    assert torch.equal(torch.stack(rew_s), rew)
+    assert torch.equal(torch.stack(te_s), te) and torch.equal(torch.stack(tr_s), tr)
+    for name in ("kin", "last_rpm", "pid", "step_counter", "obs12", "reward", "terminated", "truncated"):
+        x, y = getattr(a, name), getattr(b, name)
+        if x is not None:
+            assert torch.equal(x, y), name
+    # terminal observations: rollout row t holds the rows written at step t; the single-step buffer accumulates
+    tob = b._rollout_buf[4]
+    done = (torch.stack(te_s) | torch.stack(tr_s))                                     # [K, E]
+    for k in range(K):
+        m = done[k].repeat_interleave(D)
+        assert torch.equal(tob[k][m], tobs_s[k][m])
+
+
+def test_rollout_strides_zero(gpu_device):
+    """action stride 0 (hold one action) and last_only outputs."""
+    rng = np.random.default_rng(3)
+    E, K = 4096, 16
+    a, b = _pair("pid", 0, 1, 2, "cf2x", gpu_device, E, rng, auto_reset=False, keep_term=False)
+    act = torch.as_tensor(_actions(rng, "pid", (E, 1), a.P.HOVER_RPM).astype(np.float32), device=gpu_device)
+    for _ in range(K):
+        a.step(act)
+    b.rollout(act, num_steps=K, last_only=True)
+    for name in ("kin", "last_rpm", "pid", "step_counter", "obs12", "reward", "terminated", "truncated"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+
+
+@pytest.mark.parametrize("act,flags,D,S", [("rpm", 0, 1, 8), ("pid", 7, 4, 1)])
+def test_rollout_against_oracle(gpu_device, act, flags, D, S):
+    """K-step rollout vs the float64 oracle stepped K times (north-star metric, < 1e-4)."""
+    rng = np.random.default_rng(17 + D)
+    E, K = 2048 // D, 30
+    task = "hover" if D == 1 else "multihover"
+    xyz, rpy = _random_scene(rng, E, D)
+    if D > 1:   # keep the downwash Gaussian well-conditioned (see test_open_loop_with_all_force_terms)
+        xyz = rng.uniform(-0.02, 0.02, size=(E, D, 3)) + np.arange(D)[None, :, None] * np.array([0.12, 0.0, 0.3]) + \
+            np.array([0, 0, 0.8])
+        rpy = rng.uniform(-0.05, 0.05, size=(E, D, 3))
+    orc = BatchedAviary(urdf("cf2x"), "cf2x", num_envs=E, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy,
+                        physics_flags=flags, pyb_freq=240, ctrl_freq=240 // S, act=act, task=task,
+                        pid_urdf_path=urdf("cf2x"))
+    core = _core("cf2x", E, D, flags, S, act, task, xyz, rpy, gpu_device, target=orc.TARGET_POS)
+    _sync_from_oracle(core, orc)
+    if act == "pid":
+        acts = (xyz + np.array([0, 0, 0.2]) + 0.05 * rng.uniform(-1, 1, size=(K, E, D, 3))).astype(np.float32)
+    else:
+        acts = (0.02 * rng.uniform(-1, 1, size=(K, E, D, 4))).astype(np.float32)
+    obs, rew, te, tr = core.rollout(torch.as_tensor(acts, device=gpu_device))
+    o64 = []
+    r64 = []
+    for k in range(K):
+        o, r, _, _, _ = orc.step(acts[k].astype(np.float64))
+        o64.append(o.reshape(E * D, 12)); r64.append(r)
+    o64, r64 = np.stack(o64), np.stack(r64)
+    o32 = obs.cpu().numpy().astype(np.float64)
+    scale = np.maximum(np.abs(o64).max(axis=(0, 1)), 1.0)
+    err = np.abs(o32 - o64) / scale
+    print("obs12 col err", err.max(axis=(0, 1)))
+    assert err.max() < 1e-4
+    np.testing.assert_allclose(rew.cpu().numpy(), r64, rtol=1e-4, atol=1e-4)
+    kin = core.kin[:, :E * D].cpu().numpy().astype(np.float64)
+    ref = _oracle_kin(orc)
+    assert (np.abs(kin - ref) / np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1.0)).max() < 1e-4
+    np.testing.assert_array_equal(core.step_counter.cpu().numpy(), orc.step_counter)
