@@ -122,23 +122,25 @@ __device__ __forceinline__ Mat3 quat_to_mat(float x, float y, float z, float w) 
     return R;
 }
 
-// pybullet_getEulerFromQuaternion incl. its gimbal branches (envs/BaseAviary.py:518)
+// pybullet_getEulerFromQuaternion incl. its gimbal branches (envs/BaseAviary.py:518).  The regular branch is
+// evaluated straight-line for every lane; the two gimbal branches (|sarg| >= 0.99999, i.e. pitch within 0.26 deg
+// of +-90 deg) are a fix-up that is skipped unless some lane of the wave needs it.
 __device__ __forceinline__ void quat_to_rpy(float x, float y, float z, float w,
                                             float& roll, float& pitch, float& yaw) {
 #pragma clang fp contract(off)
     const float sarg = -2.0f * fmaf(x, z, -(w * y));
-    if (sarg <= -0.99999f) {
-        roll = 0.0f; pitch = -1.57079632679489661923f; yaw = 2.0f * atan2_poly(x, -y);
-    } else if (sarg >= 0.99999f) {
-        roll = 0.0f; pitch = 1.57079632679489661923f; yaw = 2.0f * atan2_poly(-x, y);
-    } else {
-        const float ww_zz = fmaf(w, w, z * z);                   // squ + sqz
-        const float xx_yy = fmaf(x, x, y * y);                   // sqx + sqy
-        const float ww_yy = fmaf(w, w, -(y * y));                // squ - sqy
-        const float xx_zz = fmaf(x, x, -(z * z));                // sqx - sqz
-        roll = atan2_poly(2.0f * fmaf(y, z, w * x), ww_zz - xx_yy);     // squ - sqx - sqy + sqz
-        pitch = asin_poly(sarg);
-        yaw = atan2_poly(2.0f * fmaf(x, y, w * z), ww_yy + xx_zz);      // squ + sqx - sqy - sqz
+    const float ww_zz = fmaf(w, w, z * z);                       // squ + sqz
+    const float xx_yy = fmaf(x, x, y * y);                       // sqx + sqy
+    const float ww_yy = fmaf(w, w, -(y * y));                    // squ - sqy
+    const float xx_zz = fmaf(x, x, -(z * z));                    // sqx - sqz
+    roll = atan2_poly(2.0f * fmaf(y, z, w * x), ww_zz - xx_yy);  // squ - sqx - sqy + sqz
+    pitch = asin_poly(fminf(fmaxf(sarg, -1.0f), 1.0f));          // (clamp: only matters on the gimbal lanes, overwritten below)
+    yaw = atan2_poly(2.0f * fmaf(x, y, w * z), ww_yy + xx_zz);   // squ + sqx - sqy - sqz
+    if (__builtin_expect(fabsf(sarg) >= 0.99999f, 0)) {
+        const bool neg = sarg < 0.0f;
+        roll = 0.0f;
+        pitch = neg ? -1.57079632679489661923f : 1.57079632679489661923f;
+        yaw = 2.0f * (neg ? atan2_poly(x, -y) : atan2_poly(-x, y));
     }
 }
 
@@ -309,13 +311,14 @@ __device__ __forceinline__ void substep(const GpdParams& P, float h, uint32_t fl
         sincosf(n * h * 0.5f, &sn, &cs);
         sc = sn / n;
     }
-    if (n2 > 1e-16f) {                                     // !np.isclose(|w|, 0)  (|w| <= 1e-8 keeps q)
+    {
         const float lx = fmaf(k.wx, k.qw, fmaf(k.wz, k.qy, -(k.wy * k.qz)));
         const float ly = fmaf(k.wy, k.qw, fmaf(k.wx, k.qz, -(k.wz * k.qx)));
         const float lz = fmaf(k.wz, k.qw, fmaf(k.wy, k.qx, -(k.wx * k.qy)));
         const float lw = -fmaf(k.wz, k.qz, fmaf(k.wy, k.qy, k.wx * k.qx));
-        k.qx = fmaf(sc, lx, cs * k.qx); k.qy = fmaf(sc, ly, cs * k.qy);
-        k.qz = fmaf(sc, lz, cs * k.qz); k.qw = fmaf(sc, lw, cs * k.qw);
+        const bool turn = n2 > 1e-16f;                     // !np.isclose(|w|, 0): |w| <= 1e-8 keeps q  (select, no branch)
+        k.qx = turn ? fmaf(sc, lx, cs * k.qx) : k.qx; k.qy = turn ? fmaf(sc, ly, cs * k.qy) : k.qy;
+        k.qz = turn ? fmaf(sc, lz, cs * k.qz) : k.qz; k.qw = turn ? fmaf(sc, lw, cs * k.qw) : k.qw;
     }
     // world angular velocity handed to the state store: PRE-update rotation, post-update rates (:873)
     avx = fmaf(R.r02, k.wz, fmaf(R.r01, k.wy, R.r00 * k.wx));
@@ -381,7 +384,7 @@ struct StepOut {          // what one env step hands to the stores
     bool term, trunc, reset;
 };
 
-template <bool PID, bool EXT, bool MULTI>
+template <bool PID, bool EXT, bool MULTI, int AW>
 __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C, const uint32_t flags, const int D,
                                          const Lane& L, const float4 act, const float tgx, const float tgy,
                                          const float tgz, const bool ip_regs, const float* __restrict__ ipose,
@@ -393,35 +396,33 @@ __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C
     float rpm[4] = {0, 0, 0, 0};
     float g[4];                                              // rotor thrusts minus the hover thrust
     if (!PID) {
-        if (C.act_type == GPD_ACT_ONE_D_RPM) {
+        if (AW == 1) {     // GPD_ACT_ONE_D_RPM
             const float e = 0.05f * act.x;
             rpm[0] = rpm[1] = rpm[2] = rpm[3] = fmaf(P.hover_rpm, e, P.hover_rpm);
             g[0] = g[1] = g[2] = g[3] = thrust_dev_norm(P, e);
-        } else if (C.act_type == GPD_ACT_RAW_RPM) {
-            rpm[0] = clampf(act.x, 0.0f, P.max_rpm); rpm[1] = clampf(act.y, 0.0f, P.max_rpm);
-            rpm[2] = clampf(act.z, 0.0f, P.max_rpm); rpm[3] = clampf(act.w, 0.0f, P.max_rpm);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) g[i] = thrust_dev(P, rpm[i]);
-        } else if (C.act_type == GPD_ACT_DIRECT_RPM) {
-            rpm[0] = act.x; rpm[1] = act.y; rpm[2] = act.z; rpm[3] = act.w;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) g[i] = thrust_dev(P, rpm[i]);
-        } else {   // GPD_ACT_RPM: NOT clipped
+        } else if (C.act_type == GPD_ACT_RPM) {   // NOT clipped
             const float e0 = 0.05f * act.x, e1 = 0.05f * act.y, e2 = 0.05f * act.z, e3 = 0.05f * act.w;
             rpm[0] = fmaf(P.hover_rpm, e0, P.hover_rpm); rpm[1] = fmaf(P.hover_rpm, e1, P.hover_rpm);
             rpm[2] = fmaf(P.hover_rpm, e2, P.hover_rpm); rpm[3] = fmaf(P.hover_rpm, e3, P.hover_rpm);
             g[0] = thrust_dev_norm(P, e0); g[1] = thrust_dev_norm(P, e1);
             g[2] = thrust_dev_norm(P, e2); g[3] = thrust_dev_norm(P, e3);
+        } else {           // GPD_ACT_RAW_RPM (clipped to [0, MAX_RPM], envs/CtrlAviary.py:140) or GPD_ACT_DIRECT_RPM (as is)
+            const bool clip = C.act_type == GPD_ACT_RAW_RPM;
+            const float lo = clip ? 0.0f : -3.0e38f, hi = clip ? P.max_rpm : 3.0e38f;
+            rpm[0] = clampf(act.x, lo, hi); rpm[1] = clampf(act.y, lo, hi);
+            rpm[2] = clampf(act.z, lo, hi); rpm[3] = clampf(act.w, lo, hi);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[i] = thrust_dev(P, rpm[i]);
         }
     } else {
         float tx = k.px, ty = k.py, tz = k.pz, tyaw = 0.0f, tvx = 0.0f, tvy = 0.0f, tvz = 0.0f;
-        if (C.act_type == GPD_ACT_PID) {
+        if (AW == 3) {     // GPD_ACT_PID
             // waypoint limited to a 1 m approach step (_calculateNextStep, BaseAviary.py:1132-1150)
             const float dx = act.x - k.px, dy = act.y - k.py, dz = act.z - k.pz;
             const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
             if (fast_sqrt(d2) <= 1.0f) { tx = act.x; ty = act.y; tz = act.z; }
             else { const float id = fast_rsq(d2); tx = fmaf(dx, id, k.px); ty = fmaf(dy, id, k.py); tz = fmaf(dz, id, k.pz); }
-        } else if (C.act_type == GPD_ACT_VEL) {
+        } else if (AW == 4) {   // GPD_ACT_VEL
             const float nn2 = fmaf(act.z, act.z, fmaf(act.y, act.y, act.x * act.x));
             const float sp = P.speed_limit * fabsf(act.w);
             if (nn2 != 0.0f) { const float in = fast_rsq(nn2); tvx = sp * (act.x * in); tvy = sp * (act.y * in); tvz = sp * (act.z * in); }
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     if (PID) quat_to_rpy(c.k.qx, c.k.qy, c.k.qz, c.k.qw, c.roll, c.pitch, c.yaw);
 
     StepOut out;
-    env_step<PID, EXT, MULTI>(P, C, flags, D, L, act, tgx, tgy, tgz, false, ipose, ip[0], ip[1], ip[2], ip[3], ip[4], ip[5],
+    env_step<PID, EXT, MULTI, AW>(P, C, flags, D, L, act, tgx, tgy, tgz, false, ipose, ip[0], ip[1], ip[2], ip[3], ip[4], ip[5],
                               ip[6], sh_pos, sh_red, c, out);
     if (!L.active) return;
     if (L.d == 0) {
@@ -704,39 +705,55 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
     if (tid >= kBlock) {
         // ======================= store wave ===========================================================
         const int m = tid - kBlock;
+        const bool full = lanes_valid == kBlock && envs_valid == kBlock &&
+                          ((reinterpret_cast<uintptr_t>(terminated) | reinterpret_cast<uintptr_t>(truncated) |
+                            static_cast<uintptr_t>(T.env_stride)) & 3) == 0;
+        const uint32_t lane16 = static_cast<uint32_t>(m) * 16u;
         auto drain = [&](int step) {                                 // LDS slot of `step` -> HBM
             const int b = step & 1;
-            float* og = obs12 + step * T.obs_stride + static_cast<int64_t>(block_base) * 12;
-            const float4* ol = reinterpret_cast<const float4*>(sh_obs + b * (kBlock * 12));
-            const int chunks = lanes_valid * 3;                      // 16-byte chunks; chunk of lane m: j*64 + m
-            float4 v[12];
-#pragma unroll
-            for (int j = 0; j < 12; ++j) v[j] = ol[j * kStoreLanes + m];
-#pragma unroll
-            for (int j = 0; j < 12; ++j) {
-                const int cidx = j * kStoreLanes + m;
-                if (cidx < chunks) {
-                    f4u w = {v[j].x, v[j].y, v[j].z, v[j].w};
-                    *reinterpret_cast<f4u*>(og + cidx * 4) = w;
-                }
-            }
+            char* og = reinterpret_cast<char*>(obs12 + step * T.obs_stride + static_cast<int64_t>(block_base) * 12);
+            const char* ol = reinterpret_cast<const char*>(sh_obs + b * (kBlock * 12));
             float* rg = reward + step * T.env_stride + env_base;
             uint8_t* tg = terminated + step * T.env_stride + env_base;
             uint8_t* ug = truncated + step * T.env_stride + env_base;
-            if (envs_valid == kBlock && ((reinterpret_cast<uintptr_t>(tg) | reinterpret_cast<uintptr_t>(ug)) & 3) == 0) {
-                const float4 rv = reinterpret_cast<const float4*>(sh_rew + b * kBlock)[m];
+            if (full) {
+                // a whole workgroup of single-drone aviaries: 12 + 1 unconditional 1 KiB bursts and two 256 B ones,
+                // <uniform base> + <lane offset> + <immediate> addressing
+                float4 v[12];
+#pragma unroll
+                for (int j = 0; j < 12; ++j) v[j] = *reinterpret_cast<const float4*>(ol + lane16 + j * 1024);
+                const float4 rv = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sh_rew + b * kBlock) + lane16);
+                const uint32_t tv = reinterpret_cast<const uint32_t*>(sh_term + b * kBlock)[m];
+                const uint32_t uv = reinterpret_cast<const uint32_t*>(sh_trunc + b * kBlock)[m];
+#pragma unroll
+                for (int j = 0; j < 12; ++j) {
+                    f4u w = {v[j].x, v[j].y, v[j].z, v[j].w};
+                    *reinterpret_cast<f4u*>(og + lane16 + j * 1024) = w;
+                }
                 f4u w = {rv.x, rv.y, rv.z, rv.w};
-                *reinterpret_cast<f4u*>(rg + m * 4) = w;
-                reinterpret_cast<uint32_t*>(tg)[m] = reinterpret_cast<const uint32_t*>(sh_term + b * kBlock)[m];
-                reinterpret_cast<uint32_t*>(ug)[m] = reinterpret_cast<const uint32_t*>(sh_trunc + b * kBlock)[m];
-            } else {
-                for (int e = m; e < envs_valid; e += kStoreLanes) {
-                    rg[e] = sh_rew[b * kBlock + e];
-                    tg[e] = sh_term[b * kBlock + e];
-                    ug[e] = sh_trunc[b * kBlock + e];
+                *reinterpret_cast<f4u*>(reinterpret_cast<char*>(rg) + lane16) = w;
+                reinterpret_cast<uint32_t*>(tg)[m] = tv;
+                reinterpret_cast<uint32_t*>(ug)[m] = uv;
+                return;
+            }
+            const int chunks = lanes_valid * 3;                      // 16-byte chunks; chunk of lane m: j*64 + m
+            float4 v[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) v[j] = *reinterpret_cast<const float4*>(ol + lane16 + j * 1024);
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                if (j * kStoreLanes + m < chunks) {
+                    f4u w = {v[j].x, v[j].y, v[j].z, v[j].w};
+                    *reinterpret_cast<f4u*>(og + lane16 + j * 1024) = w;
                 }
             }
+            for (int e = m; e < envs_valid; e += kStoreLanes) {
+                rg[e] = sh_rew[b * kBlock + e];
+                tg[e] = sh_term[b * kBlock + e];
+                ug[e] = sh_trunc[b * kBlock + e];
+            }
         };
+        __builtin_amdgcn_s_setprio(0);                               // fills the issue gaps of the compute wave it shares a SIMD with
         for (int t = 0; t < K; ++t) {
             for (int i = 0; i < step_barriers; ++i) wg_barrier();    // (the compute waves' env_step barriers)
             if (t > 0) drain(t - 1);                                 // overlaps the compute waves' step t
@@ -747,6 +764,7 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
     }
 
     // ======================= compute waves ================================================================
+    __builtin_amdgcn_s_setprio(2);
     Lane L;
     L.tid = tid;
     L.active = tid < lanes_valid;
@@ -773,31 +791,28 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
     c.roll = c.pitch = c.yaw = 0.0f;
     if (PID) quat_to_rpy(c.k.qx, c.k.qy, c.k.qz, c.k.qw, c.roll, c.pitch, c.yaw);
 
-    float* tobs_t = term_obs12;
+    float* const tobs_t = term_obs12;
     for (int t = 0; t < K; ++t) {
         // prefetch the next step's action row (the last step re-reads its own block): the only global memory
         // instruction of the loop body, consumed a whole step later
         const int tn = (t + 1 < K) ? t + 1 : t;
         const float4 act_next = load_action<AW>(action + tn * T.action_stride, L.n);
         StepOut out;
-        env_step<PID, EXT, MULTI>(P, C, flags, D, L, act, tgx, tgy, tgz, true, ipose, ip[0], ip[1], ip[2], ip[3], ip[4],
+        env_step<PID, EXT, MULTI, AW>(P, C, flags, D, L, act, tgx, tgy, tgz, true, ipose, ip[0], ip[1], ip[2], ip[3], ip[4],
                                   ip[5], ip[6], sh_pos, sh_red, c, out);
         const int b = t & 1;
         float4* ol = reinterpret_cast<float4*>(sh_obs + b * (kBlock * 12) + tid * 12);
         ol[0] = make_float4(out.o[0], out.o[1], out.o[2], out.o[3]);
         ol[1] = make_float4(out.o[4], out.o[5], out.o[6], out.o[7]);
         ol[2] = make_float4(out.o[8], out.o[9], out.o[10], out.o[11]);
-        if (L.active && L.d == 0) {
+        if (!MULTI || (L.active && L.d == 0)) {                      // (single-drone aviaries: every lane owns a slot)
             sh_rew[b * kBlock + L.le] = out.rew;
             sh_term[b * kBlock + L.le] = out.term ? 1 : 0;
             sh_trunc[b * kBlock + L.le] = out.trunc ? 1 : 0;
         }
-        if (tobs_t) {
-            if (out.reset && L.active)
-                store_obs12(tobs_t, L.n, out.to[0], out.to[1], out.to[2], out.to[3], out.to[4], out.to[5], out.to[6],
-                            out.to[7], out.to[8], out.to[9], out.to[10], out.to[11]);
-            tobs_t += T.obs_stride;
-        }
+        if (out.reset && tobs_t && L.active)
+            store_obs12(tobs_t + t * T.obs_stride, L.n, out.to[0], out.to[1], out.to[2], out.to[3], out.to[4], out.to[5],
+                        out.to[6], out.to[7], out.to[8], out.to[9], out.to[10], out.to[11]);
         act = act_next;
         wg_barrier();                                                // end of step t
     }
