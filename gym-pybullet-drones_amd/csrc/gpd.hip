@@ -522,6 +522,7 @@ struct Span {             // internal: how the K steps of one launch are laid ou
     int64_t action_stride;   // floats between the action blocks of consecutive steps (0: same action each step)
     int64_t obs_stride;      // floats between the obs12 (and term_obs12) blocks of consecutive steps
     int64_t env_stride;      // elements between the reward / terminated / truncated rows of consecutive steps
+    int32_t ring;            // gpd_rollout: LDS output slots per workgroup (2 or 4), chosen at launch
 };
 
 // the raw action words of one drone (AW = 4, 3 or 1 floats per drone, row-major), one load instruction
@@ -671,8 +672,27 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
 // ------------------------------------------------------------------------------------------------
 constexpr int kStoreLanes = 64;
 constexpr int kRollThreads = kBlock + kStoreLanes;
+// LDS output ring (dynamic shared memory, sized at launch): `ring` slots of kSlotBytes each.  A small batch (one
+// workgroup per CU) gets 4 slots -- the compute waves may run up to 3 steps ahead of the store wave; a large one
+// gets 2 so that more workgroups fit a CU (160 KiB of LDS).  ring is a power of two.
+constexpr int kSlotBytes = kBlock * 12 * 4 + kBlock * 4 + kBlock + kBlock;   // obs rows | rewards | terminated | truncated
+
+// LDS flags of the compute-wave -> store-wave hand-off.  Plain volatile accesses are enough: one wave's LDS
+// instructions execute in order, so a flag written after the data is seen after the data (the empty asm keeps the
+// compiler from reordering them).
+typedef __attribute__((address_space(3))) int lds_int_t;             // (explicit LDS address space: ds_read/ds_write, not flat)
+typedef int i4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) i4v lds_i4v_t;
+__device__ __forceinline__ int lds_peek(int* p) { return *reinterpret_cast<volatile lds_int_t*>((lds_int_t*)p); }
+__device__ __forceinline__ i4v lds_peek4(int* p) { return *reinterpret_cast<volatile lds_i4v_t*>((lds_i4v_t*)p); }
+__device__ __forceinline__ void lds_poke(int* p, int v) {
+    asm volatile("" ::: "memory");
+    *reinterpret_cast<volatile lds_int_t*>((lds_int_t*)p) = v;
+    asm volatile("" ::: "memory");
+}
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte vector at 4-byte alignment
+typedef float f4v __attribute__((ext_vector_type(4)));
 
 template <bool PID, bool EXT, bool MULTI, int AW>
 __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
@@ -695,12 +715,25 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
     // workgroup barriers inside one env step (env_step): the store wave has to take part in each of them
     const int step_barriers = MULTI ? (((flags & GPD_PHYS_DW) ? 2 * C.substeps : 0) + (C.task != GPD_TASK_NONE ? 2 : 0)) : 0;
 
-    __shared__ __attribute__((aligned(16))) float sh_obs[2 * kBlock * 12];           // obs rows of 2 steps
-    __shared__ __attribute__((aligned(16))) float sh_rew[2 * kBlock];
-    __shared__ __attribute__((aligned(16))) uint8_t sh_term[2 * kBlock];
-    __shared__ __attribute__((aligned(16))) uint8_t sh_trunc[2 * kBlock];
+    // Output ring: slot = step & (ring-1).  Single-drone aviaries hand over through flags (no barrier: a compute
+    // wave never waits for its siblings, and only waits for the store wave when it is ring-1 steps ahead);
+    // multi-drone aviaries already synchronise the workgroup inside every step (downwash snapshot, aviary
+    // reductions) and keep the simpler two-slot, one-more-barrier-per-step hand-off.
+    extern __shared__ __attribute__((aligned(16))) char sh_ring[];
+    const int ring = MULTI ? 2 : T.ring;
+    auto slot_obs = [&](int b) { return reinterpret_cast<float*>(sh_ring + b * kSlotBytes); };
+    auto slot_rew = [&](int b) { return reinterpret_cast<float*>(sh_ring + b * kSlotBytes + kBlock * 48); };
+    auto slot_term = [&](int b) { return reinterpret_cast<uint8_t*>(sh_ring + b * kSlotBytes + kBlock * 52); };
+    auto slot_trunc = [&](int b) { return reinterpret_cast<uint8_t*>(sh_ring + b * kSlotBytes + kBlock * 53); };
+    __shared__ __attribute__((aligned(16))) int sh_prog[4];          // steps written, per compute wave
+    __shared__ int sh_drained;                                       // steps copied to HBM by the store wave
     __shared__ float sh_pos[MULTI ? 3 * kBlock : 1];
     __shared__ float sh_red[MULTI ? 3 * kBlock : 1];
+    if (!MULTI) {
+        if (tid < 4) sh_prog[tid] = 0;
+        if (tid == 4) sh_drained = 0;
+        wg_barrier();                                                // the only barrier of the single-drone rollout
+    }
 
     if (tid >= kBlock) {
         // ======================= store wave ===========================================================
@@ -710,9 +743,9 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
                             static_cast<uintptr_t>(T.env_stride)) & 3) == 0;
         const uint32_t lane16 = static_cast<uint32_t>(m) * 16u;
         auto drain = [&](int step) {                                 // LDS slot of `step` -> HBM
-            const int b = step & 1;
+            const int b = step & (ring - 1);
             char* og = reinterpret_cast<char*>(obs12 + step * T.obs_stride + static_cast<int64_t>(block_base) * 12);
-            const char* ol = reinterpret_cast<const char*>(sh_obs + b * (kBlock * 12));
+            const char* ol = reinterpret_cast<const char*>(slot_obs(b));
             float* rg = reward + step * T.env_stride + env_base;
             uint8_t* tg = terminated + step * T.env_stride + env_base;
             uint8_t* ug = truncated + step * T.env_stride + env_base;
@@ -722,9 +755,9 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
                 float4 v[12];
 #pragma unroll
                 for (int j = 0; j < 12; ++j) v[j] = *reinterpret_cast<const float4*>(ol + lane16 + j * 1024);
-                const float4 rv = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sh_rew + b * kBlock) + lane16);
-                const uint32_t tv = reinterpret_cast<const uint32_t*>(sh_term + b * kBlock)[m];
-                const uint32_t uv = reinterpret_cast<const uint32_t*>(sh_trunc + b * kBlock)[m];
+                const float4 rv = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(slot_rew(b)) + lane16);
+                const uint32_t tv = reinterpret_cast<const uint32_t*>(slot_term(b))[m];
+                const uint32_t uv = reinterpret_cast<const uint32_t*>(slot_trunc(b))[m];
 #pragma unroll
                 for (int j = 0; j < 12; ++j) {
                     f4u w = {v[j].x, v[j].y, v[j].z, v[j].w};
@@ -748,12 +781,26 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
                 }
             }
             for (int e = m; e < envs_valid; e += kStoreLanes) {
-                rg[e] = sh_rew[b * kBlock + e];
-                tg[e] = sh_term[b * kBlock + e];
-                ug[e] = sh_trunc[b * kBlock + e];
+                rg[e] = slot_rew(b)[e];
+                tg[e] = slot_term(b)[e];
+                ug[e] = slot_trunc(b)[e];
             }
         };
         __builtin_amdgcn_s_setprio(0);                               // fills the issue gaps of the compute wave it shares a SIMD with
+        if (!MULTI) {
+            for (int t = 0; t < K; ++t) {
+                for (;;) {                                           // until all four compute waves have written step t
+                    const i4v pr = lds_peek4(sh_prog);
+                    const int lo = min(min(pr.x, pr.y), min(pr.z, pr.w));
+                    if (__builtin_amdgcn_readfirstlane(lo) > t) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                drain(t);
+                __builtin_amdgcn_s_waitcnt(0xC07F);                  // the slot has been read (lgkmcnt(0)) ...
+                lds_poke(&sh_drained, t + 1);                        // ... and may be overwritten
+            }
+            return;
+        }
         for (int t = 0; t < K; ++t) {
             for (int i = 0; i < step_barriers; ++i) wg_barrier();    // (the compute waves' env_step barriers)
             if (t > 0) drain(t - 1);                                 // overlaps the compute waves' step t
@@ -775,7 +822,11 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
 
     Carry c;
     float tgx, tgy, tgz, ip[7];
-    float4 act = load_action<AW>(action, L.n);
+    // Action rows are prefetched TWO steps ahead into three rotating register sets (a0, a1, a2): with the store
+    // wave's bursts ahead of it in the CU's memory pipeline a row takes > 1 us to arrive, longer than one step.
+    // The loop is unrolled by three so that the rotation needs no register copies (a copy of a set whose load is
+    // still in flight would have to wait for it).  Past the last step the loads re-read the last block.
+    auto fetch = [&](int step) { return load_action<AW>(action + (step < K ? step : K - 1) * T.action_stride, L.n); };
     // the rollout keeps its reset pose in registers: no dependent global load inside the step loop
     const float* ipose = reinterpret_cast<const float*>(reinterpret_cast<const char*>(init_pose) +
                                                         (C.init_per_env ? L.n * 28u : static_cast<uint32_t>(L.d) * 28u));
@@ -784,37 +835,59 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
     // live here; the explicit wait lets the compiler's wait-count bookkeeping start the loop with nothing pending,
     // otherwise it would re-wait, conservatively, inside every iteration).
     asm volatile("" :: "v"(c.k.px), "v"(c.k.py), "v"(c.k.pz), "v"(c.k.qx), "v"(c.k.qy), "v"(c.k.qz), "v"(c.k.qw), "v"(c.k.vx),
-                       "v"(c.k.vy), "v"(c.k.vz), "v"(c.k.wx), "v"(c.k.wy), "v"(c.k.wz), "v"(act.x), "v"(act.y), "v"(act.z),
-                       "v"(act.w), "v"(tgx), "v"(tgy), "v"(tgz), "v"(c.counter), "v"(ip[0]), "v"(ip[1]), "v"(ip[2]),
+                       "v"(c.k.vy), "v"(c.k.vz), "v"(c.k.wx), "v"(c.k.wy), "v"(c.k.wz), "v"(tgx), "v"(tgy), "v"(tgz), "v"(c.counter), "v"(ip[0]), "v"(ip[1]), "v"(ip[2]),
                        "v"(ip[3]), "v"(ip[4]), "v"(ip[5]), "v"(ip[6]) : "memory");
     __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0), expcnt/lgkmcnt untouched
     c.roll = c.pitch = c.yaw = 0.0f;
     if (PID) quat_to_rpy(c.k.qx, c.k.qy, c.k.qz, c.k.qw, c.roll, c.pitch, c.yaw);
 
     float* const tobs_t = term_obs12;
-    for (int t = 0; t < K; ++t) {
-        // prefetch the next step's action row (the last step re-reads its own block): the only global memory
-        // instruction of the loop body, consumed a whole step later
-        const int tn = (t + 1 < K) ? t + 1 : t;
-        const float4 act_next = load_action<AW>(action + tn * T.action_stride, L.n);
+    auto do_step = [&](const int t, const float4 act) {
         StepOut out;
         env_step<PID, EXT, MULTI, AW>(P, C, flags, D, L, act, tgx, tgy, tgz, true, ipose, ip[0], ip[1], ip[2], ip[3], ip[4],
-                                  ip[5], ip[6], sh_pos, sh_red, c, out);
-        const int b = t & 1;
-        float4* ol = reinterpret_cast<float4*>(sh_obs + b * (kBlock * 12) + tid * 12);
+                                      ip[5], ip[6], sh_pos, sh_red, c, out);
+        const int b = t & (ring - 1);
+        if (!MULTI && t >= ring) {                                   // slot b still holds step t-ring: has it been drained?
+            while (__builtin_amdgcn_readfirstlane(lds_peek(&sh_drained)) < t - ring + 1) __builtin_amdgcn_s_sleep(1);
+        }
+        float4* ol = reinterpret_cast<float4*>(slot_obs(b) + tid * 12);
         ol[0] = make_float4(out.o[0], out.o[1], out.o[2], out.o[3]);
         ol[1] = make_float4(out.o[4], out.o[5], out.o[6], out.o[7]);
         ol[2] = make_float4(out.o[8], out.o[9], out.o[10], out.o[11]);
         if (!MULTI || (L.active && L.d == 0)) {                      // (single-drone aviaries: every lane owns a slot)
-            sh_rew[b * kBlock + L.le] = out.rew;
-            sh_term[b * kBlock + L.le] = out.term ? 1 : 0;
-            sh_trunc[b * kBlock + L.le] = out.trunc ? 1 : 0;
+            slot_rew(b)[L.le] = out.rew;
+            slot_term(b)[L.le] = out.term ? 1 : 0;
+            slot_trunc(b)[L.le] = out.trunc ? 1 : 0;
         }
-        if (out.reset && tobs_t && L.active)
-            store_obs12(tobs_t + t * T.obs_stride, L.n, out.to[0], out.to[1], out.to[2], out.to[3], out.to[4], out.to[5],
-                        out.to[6], out.to[7], out.to[8], out.to[9], out.to[10], out.to[11]);
-        act = act_next;
-        wg_barrier();                                                // end of step t
+        if (out.reset && tobs_t && L.active) {
+            // Terminal observation of an aviary that ended (rare).  Issued through inline asm on purpose: the
+            // compiler's wait-count pass does not see these stores, so they cannot make its waits for the
+            // action prefetch conservative (vmcnt(0) in every iteration); stores the pass does not know about can
+            // only make a counter-based wait longer, never too short (vmcnt is in-order).
+            float* row = reinterpret_cast<float*>(reinterpret_cast<char*>(tobs_t + t * T.obs_stride) + L.n * 48u);
+            f4v q0 = {out.to[0], out.to[1], out.to[2], out.to[3]}, q1 = {out.to[4], out.to[5], out.to[6], out.to[7]},
+                q2 = {out.to[8], out.to[9], out.to[10], out.to[11]};
+            asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16\n\t"
+                         "global_store_dwordx4 %0, %3, off offset:32" :: "v"(row), "v"(q0), "v"(q1), "v"(q2) : "memory");
+        }
+        if (MULTI) wg_barrier();                                     // end of step t
+        else lds_poke(&sh_prog[tid >> 6], t + 1);                    // this wave's rows of step t are in the slot
+    };
+    // (a0 and a1 are requested AFTER the wait above, so that the loop is entered in the state every iteration
+    // leaves behind -- two rows in flight, a0 the older -- and the compiler's wait counts stay exact)
+    float4 a0 = fetch(0), a1, a2;
+    __builtin_amdgcn_sched_barrier(0);                               // (a0 must be the older of the two)
+    a1 = fetch(1);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int t = 0; t < K; t += 3) {
+        a2 = fetch(t + 2);
+        do_step(t, a0);
+        if (t + 1 >= K) break;
+        a0 = fetch(t + 3);
+        do_step(t + 1, a1);
+        if (t + 2 >= K) break;
+        a1 = fetch(t + 4);
+        do_step(t + 2, a2);
     }
     if (L.active) store_carry<PID>(S, L, c);
 }
@@ -933,11 +1006,14 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
     } else {
         const int lanes = multi ? (kBlock / C.drones_per_env) * C.drones_per_env : kBlock;
         const dim3 grid(static_cast<unsigned>((N + lanes - 1) / lanes));
+        Span Tr = T;
+        Tr.ring = (!multi && grid.x <= 2u * 256u) ? 4 : 2;          // <= 2 workgroups per CU: LDS is not what limits occupancy
+        const size_t lds = static_cast<size_t>(Tr.ring) * kSlotBytes;
         if (multi) {
-            hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, true, AW>), grid, dim3(kRollThreads), 0, st, P, S, C, T,
+            hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, true, AW>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
                                action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
         } else {
-            hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, false, AW>), grid, dim3(kRollThreads), 0, st, P, S, C, T,
+            hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, false, AW>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
                                action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
         }
     }
@@ -1016,7 +1092,7 @@ void gpd_struct_sizes(int32_t out[3]) {
 int gpd_step(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, const float* action,
              const float* target_pos, const float* init_pose, float* obs12, float* reward, uint8_t* terminated,
              uint8_t* truncated, float* term_obs12, void* stream) {
-    const Span T{1, 0, 0, 0};
+    const Span T{1, 0, 0, 0, 2};
     return step_impl("gpd_step", params, state, cfg, T, action, target_pos, init_pose, obs12, reward, terminated,
                      truncated, term_obs12, stream);
 }
@@ -1028,7 +1104,7 @@ int gpd_rollout(const GpdParams* params, const GpdState* state, const GpdStepCfg
     if (num_steps <= 0) return fail(GPD_EINVAL, "gpd_rollout: num_steps must be positive");
     if (action_step_stride < 0 || obs_step_stride < 0 || env_step_stride < 0)
         return fail(GPD_EINVAL, "gpd_rollout: strides must be non-negative");
-    const Span T{num_steps, action_step_stride, obs_step_stride, env_step_stride};
+    const Span T{num_steps, action_step_stride, obs_step_stride, env_step_stride, 2};
     return step_impl("gpd_rollout", params, state, cfg, T, actions, target_pos, init_pose, obs12, reward, terminated,
                      truncated, term_obs12, stream);
 }
