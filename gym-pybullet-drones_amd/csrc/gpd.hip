@@ -517,6 +517,9 @@ __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C
     out.o[6] = k.vx; out.o[7] = k.vy; out.o[8] = k.vz; out.o[9] = avx; out.o[10] = avy; out.o[11] = avz;
 }
 
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte vector at 4-byte alignment
+typedef float f4v __attribute__((ext_vector_type(4)));
+
 struct Span {             // internal: how the K steps of one launch are laid out in memory
     int32_t num_steps;
     int64_t action_stride;   // floats between the action blocks of consecutive steps (0: same action each step)
@@ -626,6 +629,7 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
 
     __shared__ float sh_pos[MULTI ? 3 * kBlock : 1];         // downwash: positions of the env's drones
     __shared__ float sh_red[MULTI ? 3 * kBlock : 1];         // reward | distance | out-of-bounds per drone
+    __shared__ __attribute__((aligned(16))) float sh_rows[kBlock * 12];   // obs rows, for the coalesced store of large batches
 
     const uint32_t flags = EXT ? C.physics_flags : 0u;
     Carry c;
@@ -641,7 +645,41 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     StepOut out;
     env_step<PID, EXT, MULTI, AW>(P, C, flags, D, L, act, tgx, tgy, tgz, false, ipose, ip[0], ip[1], ip[2], ip[3], ip[4], ip[5],
                               ip[6], sh_pos, sh_red, c, out);
-    if (!L.active) return;
+    // Observation rows.  A lane's row is 48 bytes, so a wave's direct stores are 48-byte-strided pieces of cache
+    // lines; in the bandwidth-bound regime (large batches) the wave transposes its 64 rows through LDS and
+    // stores three fully coalesced 1 KiB bursts instead (the rows of a wave are contiguous in memory).  Small
+    // batches are latency-bound and store directly (one LDS round trip less on the critical path).
+    if (C.lanes_per_wave == 64 && N >= (1u << 18)) {
+        float4* mine = reinterpret_cast<float4*>(sh_rows + tid * 12);
+        mine[0] = make_float4(out.o[0], out.o[1], out.o[2], out.o[3]);
+        mine[1] = make_float4(out.o[4], out.o[5], out.o[6], out.o[7]);
+        mine[2] = make_float4(out.o[8], out.o[9], out.o[10], out.o[11]);
+        const int wave0 = tid & ~63;                                  // first lane of this wave
+        const uint32_t n0 = n_raw - static_cast<uint32_t>(tid & 63);  // first drone of this wave
+        if (n0 < N) {
+            // valid rows of this wave: its lanes that own a drone (whole aviaries per workgroup: `lanes` may be < 256)
+            uint32_t rows = static_cast<uint32_t>(lanes - wave0 < 64 ? (lanes - wave0 > 0 ? lanes - wave0 : 0) : 64);
+            if (N - n0 < rows) rows = N - n0;
+            const char* src = reinterpret_cast<const char*>(sh_rows + wave0 * 12);
+            char* dst = reinterpret_cast<char*>(obs12) + static_cast<size_t>(n0) * 48u;
+            const uint32_t off = static_cast<uint32_t>(tid & 63) * 16u;
+            __builtin_amdgcn_s_waitcnt(0xC07F);                       // this wave's rows are in LDS (same wave: no barrier)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float4 v = *reinterpret_cast<const float4*>(src + off + j * 1024);
+                if (off + j * 1024 < rows * 48u) {
+                    f4u w = {v.x, v.y, v.z, v.w};
+                    *reinterpret_cast<f4u*>(dst + off + j * 1024) = w;
+                }
+            }
+        }
+        if (!L.active) return;
+    } else {
+        if (!L.active) return;
+        store_obs12(obs12, L.n, out.o[0], out.o[1], out.o[2], out.o[3], out.o[4], out.o[5], out.o[6], out.o[7], out.o[8],
+                    out.o[9], out.o[10], out.o[11]);
+    }
     if (L.d == 0) {
         reward[L.env] = out.rew;
         terminated[L.env] = out.term ? 1 : 0;
@@ -651,8 +689,6 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
         store_obs12(term_obs12, L.n, out.to[0], out.to[1], out.to[2], out.to[3], out.to[4], out.to[5], out.to[6], out.to[7],
                     out.to[8], out.to[9], out.to[10], out.to[11]);
     store_carry<PID>(S, L, c);
-    store_obs12(obs12, L.n, out.o[0], out.o[1], out.o[2], out.o[3], out.o[4], out.o[5], out.o[6], out.o[7], out.o[8],
-                out.o[9], out.o[10], out.o[11]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -691,8 +727,7 @@ __device__ __forceinline__ void lds_poke(int* p, int v) {
     asm volatile("" ::: "memory");
 }
 
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte vector at 4-byte alignment
-typedef float f4v __attribute__((ext_vector_type(4)));
+
 
 template <bool PID, bool EXT, bool MULTI, int AW>
 __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
