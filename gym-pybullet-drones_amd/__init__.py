@@ -19,6 +19,7 @@ from ._gym_shim import register as _register
 __version__ = "0.1.0"
 
 _register(id='ctrl-aviary-v0', entry_point='gym_pybullet_drones_amd.envs:CtrlAviary')
+_register(id='velocity-aviary-v0', entry_point='gym_pybullet_drones_amd.envs:VelocityAviary')
 _register(id='hover-aviary-v0', entry_point='gym_pybullet_drones_amd.envs:HoverAviary')
 _register(id='multihover-aviary-v0', entry_point='gym_pybullet_drones_amd.envs:MultiHoverAviary')
 
@@ -28,7 +29,7 @@ def install_as(name: str = "gym_pybullet_drones"):
     me = sys.modules[__name__]
     sys.modules[name] = me
     for sub in ("envs", "envs.BaseAviary", "envs.BaseRLAviary", "envs.HoverAviary", "envs.MultiHoverAviary",
-                "envs.CtrlAviary", "envs.VectorAviary", "control", "control.BaseControl", "control.DSLPIDControl",
-                "utils", "utils.enums"):
+                "envs.CtrlAviary", "envs.VelocityAviary", "envs.VectorAviary", "control", "control.BaseControl",
+                "control.DSLPIDControl", "utils", "utils.enums", "utils.Logger", "utils.utils"):
         sys.modules[f"{name}.{sub}"] = importlib.import_module(f"{__name__}.{sub}")
     return me

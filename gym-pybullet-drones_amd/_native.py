@@ -70,6 +70,8 @@ _SIGNATURES = {
     "gpd_rollout": (ctypes.c_int, [ctypes.POINTER(GpdParams), ctypes.POINTER(GpdState), ctypes.POINTER(GpdStepCfg),
                                    ctypes.c_int32, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_int64, _P, _P, _P,
                                    ctypes.c_int64, _P, _P]),
+    "gpd_full_obs": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P,
+                                    ctypes.c_int64, _P, ctypes.c_int64, _P, _P, ctypes.c_int64, _P]),
     "gpd_reset": (ctypes.c_int, [ctypes.POINTER(GpdState), _P, ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_int32,
                                  ctypes.c_int32, _P, _P]),
     "gpd_pid": (ctypes.c_int, [ctypes.POINTER(GpdParams), _P, ctypes.c_int64, ctypes.c_float, _P, _P, _P, _P, _P, _P,

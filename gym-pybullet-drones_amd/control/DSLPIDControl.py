@@ -125,26 +125,27 @@ class DSLPIDControl(DSLPIDControlBatch):
         raise ValueError("[ERROR] in DSLPIDControl._one23DInterface()")
 
 
-def pid_rpm_for_action(env, action):
+def pid_rpm_for_action(env, action, act_type=None):
     """RPMs the embedded controllers of a `BaseRLAviary` produce for `action` (advances their state).
 
     Host-side twin of the kernel's PID action decoding (`envs/BaseRLAviary.py:193-235`), used only when
     someone calls `BaseRLAviary._preprocessAction` directly; `step()` does all of this in the kernel.
     """
     core = env._core
+    act_type = act_type or env.ACT_TYPE
     n, dev = env.NUM_DRONES, core.device
     pos, quat, vel, rpy = env.pos, env.quat, env.vel, env.rpy
     tpos, trpy, tvel = pos.copy(), np.zeros((n, 3)), np.zeros((n, 3))
     for k in range(n):
         a = action[k]
-        if env.ACT_TYPE == ActionType.PID:
+        if act_type == ActionType.PID:
             tpos[k] = env._calculateNextStep(pos[k], a, 1)
-        elif env.ACT_TYPE == ActionType.VEL:
+        elif act_type == ActionType.VEL:
             nn = np.linalg.norm(a[0:3])
             unit = a[0:3] / nn if nn != 0 else np.zeros(3)
             trpy[k, 2] = rpy[k, 2]
             tvel[k] = env.SPEED_LIMIT * np.abs(a[3]) * unit
-        elif env.ACT_TYPE == ActionType.ONE_D_PID:
+        elif act_type == ActionType.ONE_D_PID:
             tpos[k] = pos[k] + 0.1 * np.array([0, 0, a[0]])
     rpm = torch.empty((n, 4), dtype=torch.float32, device=dev)
     args = [_f32(x, n, k, dev) for x, k in ((pos, 3), (quat, 4), (vel, 3), (tpos, 3), (trpy, 3), (tvel, 3))]

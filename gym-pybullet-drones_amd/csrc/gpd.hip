@@ -964,6 +964,53 @@ __global__ __launch_bounds__(kBlock) void gpd_reset_kernel(const GpdState S, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// Full KIN observation rows: [ pos | rpy | vel | ang_v | the H most recent actions, oldest first ]
+// (envs/BaseRLAviary.py:307-320).  Pure data movement: one lane per output float, so that a wave writes 256
+// contiguous bytes; the source of a float is the obs12 row, an action row of this call, or -- for steps before
+// the call -- the per-drone action ring.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void gpd_full_obs_kernel(
+    int K, uint32_t N, int A, int H, int pos, const float* __restrict__ obs12, int64_t obs_stride,
+    const float* __restrict__ actions, int64_t act_stride, const float* __restrict__ hist, float* __restrict__ out,
+    int64_t out_stride) {
+    const uint32_t W = 12u + static_cast<uint32_t>(H * A);
+    const uint32_t per_step = N * W;                        // floats per step (< 2^32 by the host-side check)
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    const int t = blockIdx.y;
+    if (j >= per_step) return;
+    const uint32_t n = j / W, col = j - n * W;
+    float v;
+    if (col < 12u) {
+        v = obs12[t * obs_stride + static_cast<int64_t>(n) * 12 + col];
+    } else {
+        const uint32_t i = (col - 12u) / static_cast<uint32_t>(A), a = (col - 12u) - i * static_cast<uint32_t>(A);
+        const int s = t - (H - 1) + static_cast<int>(i);    // step of this call the action belongs to (< 0: earlier)
+        if (s >= 0) {
+            v = actions[s * act_stride + static_cast<int64_t>(n) * A + a];
+        } else {
+            int q = (pos + 1 + s) % H;                      // ring slot of global step (last + 1 + s)
+            if (q < 0) q += H;
+            v = hist[(static_cast<int64_t>(n) * H + q) * A + a];
+        }
+    }
+    out[t * out_stride + j] = v;
+}
+
+// pushes the actions of the K steps of a call into the per-drone ring [N][H][A] (the last H of them survive)
+__global__ __launch_bounds__(kBlock) void gpd_hist_push_kernel(int K, uint32_t N, int A, int H, int pos,
+                                                               const float* __restrict__ actions, int64_t act_stride,
+                                                               float* __restrict__ hist) {
+    const uint32_t NA = N * static_cast<uint32_t>(A);
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    const int back = blockIdx.y;                            // 0 = the newest step of the call, 1 = the one before ...
+    const int s = K - 1 - back;
+    if (j >= NA || s < 0) return;
+    const uint32_t n = j / static_cast<uint32_t>(A), a = j - n * static_cast<uint32_t>(A);
+    const int q = (pos + 1 + s) % H;
+    hist[(static_cast<int64_t>(n) * H + q) * A + a] = actions[s * act_stride + j];
+}
+
+// ------------------------------------------------------------------------------------------------
 // standalone batched DSLPIDControl.computeControl
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void gpd_pid_kernel(
@@ -1142,6 +1189,40 @@ int gpd_rollout(const GpdParams* params, const GpdState* state, const GpdStepCfg
     const Span T{num_steps, action_step_stride, obs_step_stride, env_step_stride, 2};
     return step_impl("gpd_rollout", params, state, cfg, T, actions, target_pos, init_pose, obs12, reward, terminated,
                      truncated, term_obs12, stream);
+}
+
+int gpd_full_obs(int32_t num_steps, int32_t n_drones, int32_t act_dim, int32_t hist_len, int32_t hist_pos,
+                 const float* obs12, int64_t obs_step_stride, const float* actions, int64_t action_step_stride,
+                 float* act_hist, float* obs_full, int64_t full_step_stride, void* stream) {
+    if (!actions || !act_hist) return fail(GPD_EINVAL, "gpd_full_obs: NULL actions/act_hist");
+    if (obs_full && !obs12) return fail(GPD_EINVAL, "gpd_full_obs: obs_full needs obs12");
+    if (num_steps <= 0 || n_drones <= 0 || hist_len <= 0 || act_dim <= 0 || act_dim > 4)
+        return fail(GPD_EINVAL, "gpd_full_obs: num_steps, n_drones, hist_len must be positive and act_dim in 1..4");
+    if (hist_pos < 0 || hist_pos >= hist_len) return fail(GPD_EINVAL, "gpd_full_obs: hist_pos outside [0, hist_len)");
+    if (obs_step_stride < 0 || action_step_stride < 0 || full_step_stride < 0)
+        return fail(GPD_EINVAL, "gpd_full_obs: strides must be non-negative");
+    const int64_t W = 12 + static_cast<int64_t>(hist_len) * act_dim;
+    if (static_cast<int64_t>(n_drones) * W >= (1LL << 32) || num_steps > 65535)
+        return fail(GPD_ERANGE, "gpd_full_obs: n_drones*(12+hist_len*act_dim) must be < 2^32 and num_steps <= 65535");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (obs_full) {
+        const int64_t per_step = static_cast<int64_t>(n_drones) * W;
+        const dim3 grid(static_cast<unsigned>((per_step + kBlock - 1) / kBlock), static_cast<unsigned>(num_steps));
+        hipLaunchKernelGGL(gpd_full_obs_kernel, grid, dim3(kBlock), 0, st, num_steps, static_cast<uint32_t>(n_drones),
+                           act_dim, hist_len, hist_pos, obs12, obs_step_stride, actions, action_step_stride, act_hist,
+                           obs_full, full_step_stride);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "gpd_full_obs launch");
+    }
+    // the ring is read by the kernel above and updated by the next one: same stream, in order
+    const int keep = num_steps < hist_len ? num_steps : hist_len;
+    const int64_t NA = static_cast<int64_t>(n_drones) * act_dim;
+    const dim3 grid2(static_cast<unsigned>((NA + kBlock - 1) / kBlock), static_cast<unsigned>(keep));
+    hipLaunchKernelGGL(gpd_hist_push_kernel, grid2, dim3(kBlock), 0, st, num_steps, static_cast<uint32_t>(n_drones), act_dim,
+                       hist_len, hist_pos, actions, action_step_stride, act_hist);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gpd_full_obs (ring update) launch");
+    return 0;
 }
 
 int gpd_reset(const GpdState* state, const float* init_pose, int32_t init_per_env, const uint8_t* mask,

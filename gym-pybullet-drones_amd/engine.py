@@ -225,6 +225,46 @@ class SimCore:
             self.terminated.copy_(term[K - 1]); self.truncated.copy_(trunc[K - 1])
         return obs, rew, term, trunc
 
+    # ---- action history / full KIN observation rows (envs/BaseRLAviary.py:65-67, 153-154, 187, 307-320) ----
+    def enable_history(self, hist_len: int):
+        """Allocate the per-drone action ring [N, H, A] (zeros, like the reference's pre-filled deque; never cleared
+        by a reset, App. B.2)."""
+        self.H = int(hist_len)
+        self.act_hist = torch.zeros((self.N, self.H, self.A), dtype=torch.float32, device=self.device)
+        self.hist_pos = self.H - 1
+        self.obs_full = torch.zeros((self.N, 12 + self.H * self.A), dtype=torch.float32, device=self.device)
+        self._full_buf = None
+
+    def full_obs(self, actions: torch.Tensor, obs12: torch.Tensor = None, num_steps: int = 1, want_rows: bool = True):
+        """After `step(action)` / `rollout(actions)`: push the action(s) into the ring and (want_rows) assemble the
+        full observation rows `[K, N, 12 + H*A]` (K = 1: the persistent `obs_full` [N, 12 + H*A]) in one kernel.
+        `actions`: what was passed to step/rollout; `obs12`: its observation output (default: the latest)."""
+        K = int(num_steps)
+        per = self.N * self.A
+        if action_needs_fix(actions, self.device):
+            actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        a_stride = 0 if actions.numel() == per else per
+        if actions.numel() not in (per, K * per):
+            raise ValueError(f"actions has {actions.numel()} elements, expected {per} or {K}x{per}")
+        W = 12 + self.H * self.A
+        out = None
+        if want_rows:
+            if K == 1:
+                out = self.obs_full
+            else:
+                if self._full_buf is None or self._full_buf.shape[0] != K:
+                    self._full_buf = torch.zeros((K, self.N, W), dtype=torch.float32, device=self.device)
+                out = self._full_buf
+            if obs12 is None:
+                obs12 = self.obs12 if K == 1 else self._rollout_buf[0]
+        with torch.cuda.device(self.device):
+            rc = self.lib.gpd_full_obs(K, self.N, self.A, self.H, self.hist_pos, _ptr(obs12) if want_rows else _ptr(None),
+                                       self.N * 12, _ptr(actions), a_stride, _ptr(self.act_hist), _ptr(out), self.N * W,
+                                       self._stream())
+        _native.check(rc, "gpd_full_obs")
+        self.hist_pos = (self.hist_pos + K) % self.H
+        return out
+
     def _rollout_buffers(self, K: int):
         buf = getattr(self, "_rollout_buf", None)
         if buf is None or buf[0].shape[0] != K:

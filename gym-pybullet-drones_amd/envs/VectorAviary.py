@@ -78,11 +78,7 @@ class VectorAviary:
         self.ACTION_BUFFER_SIZE = int(ctrl_freq // 2)
         self.OBS_DIM = 12 + (self.ACTION_BUFFER_SIZE * self.ACT_DIM if full_obs else 0)
         if full_obs:
-            # doubled ring: the action of step t is written to slots p and p+H (p = t mod H), so the
-            # window [p+1, p+1+H) always holds the last H actions oldest-first, contiguously
-            H = self.ACTION_BUFFER_SIZE
-            self._hist = torch.zeros((self.core.N, 2 * H, self.ACT_DIM), dtype=torch.float32, device=self.device)
-            self._hist_pos = H - 1
+            self.core.enable_history(self.ACTION_BUFFER_SIZE)
 
     # ---- gymnasium-VectorEnv-like surface ----------------------------------------------------
     @property
@@ -91,35 +87,48 @@ class VectorAviary:
 
     def _obs(self):
         E, D = self.NUM_ENVS, self.NUM_DRONES
-        o = self.core.obs12.view(E, D, 12)
         if not self.full_obs:
-            return o
-        return torch.cat([o, self.action_history().reshape(E, D, -1)], dim=-1)
+            return self.core.obs12.view(E, D, 12)
+        return self.core.obs_full.view(E, D, self.OBS_DIM)
 
     def action_history(self) -> torch.Tensor:
-        """(E*D, H, A) view of the last H actions, oldest first (zero-copy)."""
-        H, p = self.ACTION_BUFFER_SIZE, self._hist_pos
-        return self._hist[:, p + 1:p + 1 + H, :]
+        """(E*D, H, A) copy of the last H actions, oldest first."""
+        H, p = self.ACTION_BUFFER_SIZE, self.core.hist_pos
+        return torch.roll(self.core.act_hist, shifts=-(p + 1), dims=1)
 
     def reset(self, seed=None, options=None, mask=None):
-        """Reset all aviaries (or those selected by the boolean/uint8 tensor `mask` [E])."""
+        """Reset all aviaries (or those selected by the boolean/uint8 tensor `mask` [E]).  As in the reference the
+        action history (and the embedded PID state) survives a reset."""
         self.core.reset(mask=mask)
+        if self.full_obs:      # rows of the reset poses with the unchanged history tail (ring not advanced)
+            self._refresh_full_obs()
         return self._obs(), {}
+
+    def _refresh_full_obs(self):
+        c = self.core
+        c.obs_full[:, :12].copy_(c.obs12)
+        c.obs_full[:, 12:].copy_(self.action_history().reshape(c.N, -1))
 
     def step(self, action: torch.Tensor):
         """action: float32 tensor (E, D, A) on `self.device` -> (obs, reward[E], terminated[E], truncated[E], info)."""
-        if self.full_obs:
-            H = self.ACTION_BUFFER_SIZE
-            p = (self._hist_pos + 1) % H
-            a = action.reshape(self.core.N, self.ACT_DIM).to(torch.float32)
-            self._hist[:, p, :] = a
-            self._hist[:, p + H, :] = a
-            self._hist_pos = p
         _, reward, terminated, truncated = self.core.step(action)
+        if self.full_obs:
+            self.core.full_obs(action)                       # ring push + row assembly, one more launch
         info = {}
         if self.core.term_obs12 is not None:
             info["terminal_observation"] = self.core.term_obs12.view(self.NUM_ENVS, self.NUM_DRONES, 12)
         return self._obs(), reward, terminated, truncated, info
+
+    def rollout(self, actions: torch.Tensor):
+        """K env steps in ONE launch (`gpd_rollout`): actions (K, E, D, A) known up front (open-loop sequences,
+        DSLPID waypoint lists).  Returns (obs (K,E,D,OBS_DIM), reward (K,E), terminated (K,E), truncated (K,E))."""
+        K = actions.shape[0]
+        obs, reward, terminated, truncated = self.core.rollout(actions)
+        if self.full_obs:
+            obs = self.core.full_obs(actions, obs12=obs, num_steps=K)
+            if K > 1:
+                self.core.obs_full.copy_(obs[K - 1])
+        return obs.view(K, self.NUM_ENVS, self.NUM_DRONES, -1), reward, terminated, truncated
 
     def state_vectors(self) -> torch.Tensor:
         """(E, D, 20) `_getDroneStateVector`-ordered states (needs `track_rpm=True` for the RPM columns)."""
@@ -162,3 +171,94 @@ class VectorCtrlAviary(VectorAviary):
         super().__init__(num_envs=num_envs, num_drones=num_drones, drone_model=drone_model, initial_xyzs=initial_xyzs,
                          initial_rpys=initial_rpys, physics=physics, pyb_freq=pyb_freq, ctrl_freq=ctrl_freq,
                          act="raw_rpm", task="none", **kw)
+
+
+class VectorVelocityAviary(VectorAviary):
+    """E x `VelocityAviary`: velocity commands `[vx, vy, vz, fraction of SPEED_LIMIT]` tracked by the embedded DSLPID
+    controllers (`GPD_ACT_VEL`), no task; `state_vectors()` gives the (E, D, 20) observation of the reference class."""
+
+    def __init__(self, num_envs: int, num_drones: int = 1, drone_model: DroneModel = DroneModel.CF2X,
+                 initial_xyzs=None, initial_rpys=None, physics: Physics = Physics.DYN, pyb_freq: int = 240,
+                 ctrl_freq: int = 240, **kw):
+        kw.setdefault("auto_reset", False)
+        kw.setdefault("track_rpm", True)
+        super().__init__(num_envs=num_envs, num_drones=num_drones, drone_model=drone_model, initial_xyzs=initial_xyzs,
+                         initial_rpys=initial_rpys, physics=physics, pyb_freq=pyb_freq, ctrl_freq=ctrl_freq,
+                         act=ActionType.VEL, task="none", **kw)
+
+
+class VecEnvAdapter:
+    """Stable-Baselines3 `VecEnv`-shaped front end of a `VectorAviary` (duck-typed: SB3 is not installed here).
+
+    Follows `DummyVecEnv` (what `examples/learn.py:54-58` builds through `make_vec_env`): numpy in / numpy out,
+    `dones = terminated | truncated`, aviaries that end are reset inside the same `step_wait()` and report the
+    last observation of the finished episode as `infos[i]["terminal_observation"]` together with
+    `infos[i]["TimeLimit.truncated"]`.  Observations are `(num_envs, D, 12 [+ H*A])` (squeezed to
+    `(num_envs, 12 [+ H*A])` for one drone per aviary when `squeeze=True`).  The device tensors of the last step
+    stay available as `last` for a GPU-resident learner that does not want the host copies.
+    """
+
+    def __init__(self, env: "VectorAviary", squeeze: bool = False):
+        if not env.core.auto_reset:
+            raise ValueError("VecEnvAdapter needs a VectorAviary built with auto_reset=True")
+        self.env = env
+        self.num_envs = env.NUM_ENVS
+        self.squeeze = bool(squeeze and env.NUM_DRONES == 1)
+        from .._gym_shim import spaces
+        D, W, A = env.NUM_DRONES, env.OBS_DIM, env.ACT_DIM
+        oshape, ashape = ((W,), (A,)) if self.squeeze else ((D, W), (D, A))
+        self.observation_space = spaces.Box(low=np.full(oshape, -np.inf), high=np.full(oshape, np.inf), dtype=np.float32)
+        self.action_space = spaces.Box(low=-np.ones(ashape), high=np.ones(ashape), dtype=np.float32)
+        self._actions = None
+        self.last = None
+        if env.core.term_obs12 is None:     # terminal observations are part of the VecEnv contract
+            env.core.term_obs12 = torch.zeros((env.core.N, 12), dtype=torch.float32, device=env.device)
+
+    def _np_obs(self, obs):
+        o = obs.cpu().numpy()
+        return o[:, 0, :] if self.squeeze else o
+
+    def reset(self):
+        obs, _ = self.env.reset()
+        return self._np_obs(obs)
+
+    def step_async(self, actions):
+        a = torch.as_tensor(np.asarray(actions, dtype=np.float32), device=self.env.device)
+        self._actions = a.reshape(self.num_envs, self.env.NUM_DRONES, self.env.ACT_DIM)
+
+    def step_wait(self):
+        env = self.env
+        obs, reward, terminated, truncated, _ = env.step(self._actions)
+        self.last = (obs, reward, terminated, truncated)
+        packed = torch.stack([reward, terminated.to(torch.float32), truncated.to(torch.float32)]).cpu().numpy()
+        rew, term, trunc = packed[0], packed[1] != 0, packed[2] != 0
+        dones = term | trunc
+        infos = [{} for _ in range(self.num_envs)]
+        idx = np.flatnonzero(dones)
+        if idx.size:
+            tobs = env.core.term_obs12.view(self.num_envs, env.NUM_DRONES, 12)[torch.as_tensor(idx, device=env.device)].cpu().numpy()
+            if env.full_obs:    # the history tail of the terminal observation is the one of the returned row
+                tail = obs[torch.as_tensor(idx, device=env.device)][..., 12:].cpu().numpy()
+                tobs = np.concatenate([tobs, tail], axis=-1)
+            for j, i in enumerate(idx):
+                infos[i]["terminal_observation"] = tobs[j, 0] if self.squeeze else tobs[j]
+                infos[i]["TimeLimit.truncated"] = bool(trunc[i] and not term[i])
+        return self._np_obs(obs), rew, dones, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        self.env.close()
+
+    def get_attr(self, name, indices=None):
+        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
+        return [getattr(self.env, name)] * n
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
+        return [False] * n
+
+    def seed(self, seed=None):
+        return [seed] * self.num_envs          # the simulator is deterministic: nothing draws random numbers

@@ -3,7 +3,9 @@ from .BaseRLAviary import BaseRLAviary
 from .CtrlAviary import CtrlAviary
 from .HoverAviary import HoverAviary
 from .MultiHoverAviary import MultiHoverAviary
-from .VectorAviary import VectorAviary, VectorCtrlAviary, VectorHoverAviary, VectorMultiHoverAviary
+from .VelocityAviary import VelocityAviary
+from .VectorAviary import (VecEnvAdapter, VectorAviary, VectorCtrlAviary, VectorHoverAviary, VectorMultiHoverAviary,
+                           VectorVelocityAviary)
 
-__all__ = ["BaseAviary", "BaseRLAviary", "CtrlAviary", "HoverAviary", "MultiHoverAviary", "VectorAviary",
-           "VectorCtrlAviary", "VectorHoverAviary", "VectorMultiHoverAviary"]
+__all__ = ["BaseAviary", "BaseRLAviary", "CtrlAviary", "HoverAviary", "MultiHoverAviary", "VelocityAviary", "VectorAviary",
+           "VectorCtrlAviary", "VectorHoverAviary", "VectorMultiHoverAviary", "VectorVelocityAviary", "VecEnvAdapter"]

@@ -214,6 +214,26 @@ int gpd_rollout(const GpdParams* params, const GpdState* state, const GpdStepCfg
                 float* term_obs12, void* stream);
 
 /*
+ * Full KIN observation rows with the action-history tail, and the action ring behind them.  Replaces the
+ * action buffer of BaseRLAviary (envs/BaseRLAviary.py:65-67 deque, :153-154 zero pre-fill, :187 append; never
+ * cleared by reset()) and the row assembly of BaseRLAviary._computeObs (:307-320):
+ *     row = [ pos | rpy | vel | ang_v | a(t-H+1) ... a(t) ]      H = ctrl_freq // 2, oldest action first
+ * for the num_steps steps of a gpd_step / gpd_rollout call (call it after the step call, same stream).
+ *
+ *   act_hist      [n_drones][hist_len][act_dim] in/out: per-drone ring of the raw actions; slot hist_pos holds
+ *                 the most recent action BEFORE this call (a zeroed ring with hist_pos = hist_len-1 is the
+ *                 reference's initial state).  On return it also holds the actions of this call; the caller
+ *                 advances its hist_pos by num_steps modulo hist_len.
+ *   obs12         the step call's observation blocks, step t at obs12 + t*obs_step_stride
+ *   actions       the step call's action blocks,      step t at actions + t*action_step_stride (0: held action)
+ *   obs_full      [num_steps][n_drones][12 + hist_len*act_dim] out, step t at obs_full + t*full_step_stride;
+ *                 NULL: only update the ring
+ */
+int gpd_full_obs(int32_t num_steps, int32_t n_drones, int32_t act_dim, int32_t hist_len, int32_t hist_pos,
+                 const float* obs12, int64_t obs_step_stride, const float* actions, int64_t action_step_stride,
+                 float* act_hist, float* obs_full, int64_t full_step_stride, void* stream);
+
+/*
  * Masked reset.  Replaces BaseAviary.reset/_housekeeping (envs/BaseAviary.py:220-255, 451-477)
  * for the envs whose mask byte is non-zero (mask == NULL: all).  Sets pos/quat to init_pose,
  * vel, rpy_rates, last_rpm and step_counter to zero and writes the initial obs12 rows.  As in

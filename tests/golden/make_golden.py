@@ -31,6 +31,8 @@ Scenarios (seeds and shapes are part of the fixture):
   dslpid_calls      DSLPIDControl.computeControl on random states/targets (cf2x and cf2p)
   force_models      the forces `_groundEffect`, `_drag`, `_downwash` request from PyBullet
                     (captured by the shim) for random multi-drone configurations
+  velocity_aviary   examples/pid_velocity.py: the reference's VelocityAviary DYN, 4 drones, piecewise-constant
+                    velocity commands (incl. a zero-direction command), 48 Hz ctrl / 240 Hz physics, 200 steps
 """
 import importlib.util
 import os
@@ -78,10 +80,12 @@ def load_reference():
     from gym_pybullet_drones.envs.HoverAviary import HoverAviary
     from gym_pybullet_drones.envs.MultiHoverAviary import MultiHoverAviary
     from gym_pybullet_drones.envs.CtrlAviary import CtrlAviary
+    from gym_pybullet_drones.envs.VelocityAviary import VelocityAviary
     from gym_pybullet_drones.control.DSLPIDControl import DSLPIDControl
     from gym_pybullet_drones.utils import enums
     return shim, dict(HoverAviary=HoverAviary, MultiHoverAviary=MultiHoverAviary,
-                      CtrlAviary=CtrlAviary, DSLPIDControl=DSLPIDControl, enums=enums)
+                      CtrlAviary=CtrlAviary, VelocityAviary=VelocityAviary, DSLPIDControl=DSLPIDControl,
+                      enums=enums)
 
 
 def _silence():
@@ -325,6 +329,32 @@ def main():
 
     save("force_models_cf2x", **force_models(E.DroneModel.CF2X))
     save("force_models_racer", **force_models(E.DroneModel.RACE))
+
+    # ---- examples/pid_velocity.py scenario on the reference's VelocityAviary(DYN) ---------------------
+    def velocity_aviary(model, n=4, ctrl_hz=48, steps=200):
+        vrng = np.random.default_rng(777)                  # own generator: the fixtures above do not depend on it
+        init_xyzs = np.array([[0, 0, .1], [.3, 0, .1], [.6, 0, .1], [0.9, 0, .1]])[:n]
+        init_rpys = np.array([[0, 0, 0], [0, 0, np.pi / 3], [0, 0, np.pi / 4], [0, 0, np.pi / 2]])[:n]
+        with _silence():
+            env = ref["VelocityAviary"](drone_model=model, num_drones=n, initial_xyzs=init_xyzs, initial_rpys=init_rpys,
+                                        physics=E.Physics.DYN, pyb_freq=240, ctrl_freq=ctrl_hz)
+        # piecewise-constant commands like the example's, plus a zero-direction command (unit vector = 0 branch)
+        acts = np.zeros((steps, n, 4))
+        for k in range(steps):
+            seg = k // 40
+            r = np.random.default_rng(1000 + seg)
+            acts[k] = np.hstack([r.uniform(-1, 1, size=(n, 3)), r.uniform(0.2, 1, size=(n, 1))])
+        acts[80:90, 1, 0:3] = 0.0
+        acts += 0.0 * vrng.uniform(size=acts.shape)
+        obs_l, rr_l = [], []
+        for k in range(steps):
+            obs, _, _, _, _ = env.step(acts[k])
+            obs_l.append(np.array(obs))
+            rr_l.append(np.array(env.rpy_rates))
+        return dict(init_xyzs=init_xyzs, init_rpys=init_rpys, actions=acts, obs=np.array(obs_l), rpy_rates=np.array(rr_l),
+                    ctrl_hz=np.int64(ctrl_hz), speed_limit=np.float64(env.SPEED_LIMIT))
+
+    save("velocity_aviary_cf2x", **velocity_aviary(E.DroneModel.CF2X))
 
 
 if __name__ == "__main__":

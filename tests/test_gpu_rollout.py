@@ -122,3 +122,36 @@ def test_rollout_against_oracle(gpu_device, act, flags, D, S):
     ref = _oracle_kin(orc)
     assert (np.abs(kin - ref) / np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1.0)).max() < 1e-4
     np.testing.assert_array_equal(core.step_counter.cpu().numpy(), orc.step_counter)
+
+
+@pytest.mark.parametrize("act,D,ctrl", [("rpm", 1, 30), ("pid", 2, 48), ("one_d_rpm", 1, 240)])
+def test_full_observation_rows_step_vs_rollout(gpu_device, act, D, ctrl):
+    """The (12 + H*A) observation rows (kinematics + the last H actions, oldest first, BaseRLAviary.py:307-320)
+    assembled after K single steps and after rollouts of the same actions are identical; the history survives
+    resets and spans the boundary between two rollouts."""
+    from gym_pybullet_drones_amd.envs import VectorAviary
+    from gym_pybullet_drones_amd.utils.enums import ActionType
+    rng = np.random.default_rng(5)
+    E, K = 300, 7
+    mk = lambda: VectorAviary(E, D, act=ActionType(act), ctrl_freq=ctrl, task="hover" if D == 1 else "multihover",  # noqa: E731
+                              full_obs=True, auto_reset=True, episode_len_sec=0.05, device=gpu_device)
+    a, b = mk(), mk()
+    H, A = a.ACTION_BUFFER_SIZE, a.ACT_DIM
+    acts = torch.as_tensor(rng.uniform(-1, 1, size=(2 * K, E, D, A)).astype(np.float32), device=gpu_device)
+    rows = []
+    for k in range(2 * K):
+        o, *_ = a.step(acts[k])
+        rows.append(o.clone())
+    rows = torch.stack(rows)
+    o1 = b.rollout(acts[:K])[0].clone()          # (rollout outputs are persistent buffers, overwritten by the next call)
+    o2, *_ = b.rollout(acts[K:])
+    assert o1.shape == (K, E, D, 12 + H * A)
+    assert torch.equal(torch.cat([o1, o2]), rows)
+    # the tail is exactly the sent actions (zeros before the first step)
+    tail = rows[-1][..., 12:].reshape(E, D, H, A).cpu().numpy()
+    sent = acts.cpu().numpy()
+    for h in range(H):
+        idx = 2 * K - 1 - (H - 1) + h
+        want = sent[idx] if idx >= 0 else np.zeros((E, D, A), dtype=np.float32)
+        np.testing.assert_array_equal(tail[:, :, h, :], want)
+    assert torch.equal(a.action_history(), b.action_history())

@@ -1,0 +1,102 @@
+"""The wider drop-in surface on the GPU: VelocityAviary against the reference's own run (fixture), the batched
+VectorVelocityAviary, the SB3-VecEnv-shaped adapter, and Logger export of device state vectors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_fixture_velocity_aviary(gpu_device):
+    """examples/pid_velocity.py scenario: the drop-in `VelocityAviary` (GPD_ACT_VEL fused in the kernel) against the
+    reference's VelocityAviary(DYN), 4 drones, 48 Hz control / 240 Hz physics.  Tight while the DSLPID attitude loop
+    has not yet amplified fp32 rounding (first 20 steps), bounded afterwards (chatter on the +-3200 torque clip)."""
+    from gym_pybullet_drones_amd.envs import VectorVelocityAviary, VelocityAviary
+    from gym_pybullet_drones_amd.utils.enums import DroneModel, Physics
+    g = golden("velocity_aviary_cf2x")
+    n, hz = g["init_xyzs"].shape[0], int(g["ctrl_hz"])
+    env = VelocityAviary(drone_model=DroneModel.CF2X, num_drones=n, initial_xyzs=g["init_xyzs"], initial_rpys=g["init_rpys"],
+                         physics=Physics.DYN, pyb_freq=240, ctrl_freq=hz, device=gpu_device)
+    assert env.SPEED_LIMIT == pytest.approx(float(g["speed_limit"]))
+    assert env.action_space.shape == (n, 4) and env.observation_space.shape == (n, 20)
+    vec = VectorVelocityAviary(3, n, initial_xyzs=g["init_xyzs"], initial_rpys=g["init_rpys"], ctrl_freq=hz, device=gpu_device)
+    obs0, info = env.reset()
+    assert obs0.shape == (n, 20) and info == {"answer": 42}
+    for k in range(g["obs"].shape[0]):
+        obs, rew, term, trunc, info = env.step(g["actions"][k])
+        vec.step(torch.as_tensor(np.broadcast_to(g["actions"][k], (3, n, 4)).astype(np.float32), device=gpu_device))
+        assert rew == -1 and term is False and trunc is False
+        ref = g["obs"][k]
+        # rounding-level differences grow ~10x per 4 control steps in this loop (the body rates first) until they
+        # saturate at the chatter amplitude: tight early, by field group; bounded later
+        e = np.abs(obs - ref)
+        if k < 12:
+            assert e[:, 0:13].max() < 1e-5 and e[:, 13:16].max() < 1e-3 and e[:, 16:20].max() < 2.0, (k, e.max(axis=0))
+        elif k < 24:
+            assert e[:, 0:3].max() < 1e-4 and e[:, 3:10].max() < 3e-3 and e[:, 10:13].max() < 2e-3, (k, e.max(axis=0))
+        else:
+            assert e[:, 0:3].max() < 0.05, k
+        # the batched class computes the same thing for each of its aviaries, bit for bit
+        sv = vec.state_vectors().cpu().numpy()
+        assert np.array_equal(sv[0], sv[2])
+        np.testing.assert_array_equal(sv[1].astype(np.float64), obs)
+
+
+def test_vecenv_adapter_follows_dummyvecenv(gpu_device):
+    """numpy in/out, dones = terminated | truncated, same-step reset with info["terminal_observation"] and
+    info["TimeLimit.truncated"] (what SB3's DummyVecEnv + Monitor give examples/learn.py)."""
+    from gym_pybullet_drones_amd.envs import VecEnvAdapter, VectorHoverAviary
+    from gym_pybullet_drones_amd.utils.enums import ActionType
+    E = 64
+    base = VectorHoverAviary(E, act=ActionType.ONE_D_RPM, ctrl_freq=30, full_obs=True, episode_len_sec=0.2, device=gpu_device)
+    venv = VecEnvAdapter(base, squeeze=True)
+    H = 15
+    assert venv.num_envs == E and venv.observation_space.shape == (12 + H,) and venv.action_space.shape == (1,)
+    obs = venv.reset()
+    assert obs.shape == (E, 12 + H) and obs.dtype == np.float32
+    rng = np.random.default_rng(0)
+    seen_done = False
+    for k in range(12):
+        a = rng.uniform(-1, 1, size=(E, 1)).astype(np.float32)
+        prev = obs
+        obs, rew, dones, infos = venv.step(a)
+        assert obs.shape == (E, 12 + H) and rew.shape == (E,) and dones.dtype == bool and len(infos) == E
+        np.testing.assert_array_equal(obs[:, -1], a[:, 0])                 # newest action is the last history entry
+        for i in np.flatnonzero(dones):
+            seen_done = True
+            t = infos[i]["terminal_observation"]
+            assert t.shape == (12 + H,) and infos[i]["TimeLimit.truncated"] in (True, False)
+            assert obs[i, 2] == pytest.approx(0.1125, abs=1e-6)            # returned obs: first one of the new episode
+            assert t[2] != pytest.approx(0.1125, abs=1e-6) or abs(a[i, 0]) < 1e-3
+        for i in np.flatnonzero(~dones):
+            assert infos[i] == {}
+    assert seen_done                                                        # 0.2 s episodes at 30 Hz: truncation on step 8
+    assert venv.env_is_wrapped(object) == [False] * E and venv.get_attr("CTRL_FREQ")[0] == 30
+
+
+def test_logger_export_of_device_states(gpu_device, tmp_path):
+    """Logger.log_batch on (N,20) state vectors from the device == N x Logger.log on the rows; CSV/npz files load."""
+    from gym_pybullet_drones_amd.envs import VectorCtrlAviary
+    from gym_pybullet_drones_amd.utils.Logger import Logger
+    n, T = 3, 10
+    env = VectorCtrlAviary(1, n, ctrl_freq=48, device=gpu_device)
+    a, b = Logger(48, output_folder=str(tmp_path / "a"), num_drones=n), Logger(48, output_folder=str(tmp_path / "b"), num_drones=n)
+    rpm = torch.full((1, n, 4), float(env.HOVER_RPM) * 1.02, device=gpu_device)
+    for k in range(T):
+        env.step(rpm)
+        sv = env.state_vectors().view(n, 20)
+        a.log_batch(k / 48, sv)
+        rows = sv.cpu().numpy()
+        for j in range(n):
+            b.log(j, k / 48, rows[j])
+    a.trim()
+    np.testing.assert_array_equal(a.states, b.states)
+    np.testing.assert_array_equal(a.timestamps, b.timestamps)
+    assert a.states.shape == (n, 16, T) and np.all(a.states[:, 12:16, -1] > 14000)       # rpm columns
+    assert np.all(np.diff(a.states[:, 2, :], axis=1) > 0)                                   # climbing
+    d = a.save_as_csv("t")
+    z = np.loadtxt(d + "/z0.csv", delimiter=",")
+    assert z.shape == (T, 2) and z[-1, 1] == pytest.approx(a.states[0, 2, -1])
+    a.save()

@@ -168,3 +168,24 @@ open({str(tmp_path)!r} + f"/ok{{rank}}", "w").write("ok")
                          capture_output=True, text=True, timeout=300, env=env)
     assert res.returncode == 0, res.stdout + res.stderr
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_logger_layout_and_files(tmp_path):
+    """Reference layout: states (N,16,T) = [pos, vel, rpy, ang_vel, rpm] re-ordered from the 20-float state vector
+    (utils/Logger.py:117), growing arrays when duration_sec = 0, one CSV per signal and drone."""
+    from gym_pybullet_drones_amd.utils.Logger import Logger
+    from gym_pybullet_drones_amd.utils.utils import str2bool
+    lg = Logger(logging_freq_hz=10, output_folder=str(tmp_path / "r"), num_drones=2)
+    for k in range(5):
+        for j in range(2):
+            lg.log(j, k / 10, np.arange(20, dtype=float) + 100 * j + k, control=np.arange(12, dtype=float))
+    assert lg.states.shape == (2, 16, 5) and lg.controls.shape == (2, 12, 5)
+    np.testing.assert_array_equal(lg.states[1, :, 2], np.r_[0:3, 10:13, 7:10, 13:20] + 102.0)
+    d = lg.save_as_csv("x")
+    names = sorted(os.listdir(d))
+    assert len(names) == 2 * 23 and "rpm3-1.csv" in names and "yar0.csv" in names
+    pre = Logger(logging_freq_hz=10, output_folder=str(tmp_path / "p"), num_drones=1, duration_sec=1)
+    assert pre.states.shape == (1, 16, 10)
+    pre.log(0, 0.0, np.zeros(20)); pre.log(0, 0.1, np.ones(20))
+    assert pre.counters[0] == 2 and pre.states[0, 0, 1] == 1
+    assert str2bool("yes") is True and str2bool("0") is False

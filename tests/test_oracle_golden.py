@@ -131,3 +131,20 @@ def test_force_models_match_reference(model):
             np.testing.assert_allclose(env.drag_force_body(g["last_rpm"][t, i], i), g["drag_body"][t, i], rtol=1e-12, atol=1e-18)
             np.testing.assert_allclose(env.downwash_force(i), g["dw"][t, i], rtol=1e-12, atol=1e-18)
     assert g["gnd_on"][0, 0] == 0 and g["gnd_on"][0, 1:].all()      # |roll| > pi/2 switches it off
+
+
+def test_velocity_aviary_matches_reference():
+    """examples/pid_velocity.py: the reference's VelocityAviary(DYN), 4 drones, 48 Hz control / 240 Hz physics.
+    Tight for the first 20 steps; at 48 Hz the DSLPID attitude loop rides its torque clip and amplifies
+    rounding-level differences (see test_batched_against_golden_hover_pid), so later steps are held to 1e-6."""
+    g = golden("velocity_aviary_cf2x")
+    n = g["init_xyzs"].shape[0]
+    env = OracleAviary(urdf("cf2x"), "cf2x", num_drones=n, initial_xyzs=g["init_xyzs"], initial_rpys=g["init_rpys"],
+                       pyb_freq=240, ctrl_freq=int(g["ctrl_hz"]), act="vel", task="none")
+    assert env.C.SPEED_LIMIT == pytest.approx(float(g["speed_limit"]), rel=1e-15)
+    for k in range(g["obs"].shape[0]):
+        env.step(g["actions"][k])
+        sv = np.array([env._getDroneStateVector(i) for i in range(n)])
+        tol = dict(rtol=1e-9, atol=1e-10) if k < 20 else dict(rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(sv[:, :16], g["obs"][k][:, :16], err_msg=f"step {k}", **tol)
+        np.testing.assert_allclose(sv[:, 16:], g["obs"][k][:, 16:], rtol=tol["rtol"], atol=1e-3, err_msg=f"rpm, step {k}")
