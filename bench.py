@@ -90,10 +90,27 @@ def cpu_baseline(w, budget_s=12.0):
         n += 16
     dt = time.perf_counter() - t0
     S = 240 // w["ctrl"]
-    return {"value": n * D * S / dt, "unit": "drone-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n} env.step() of ONE aviary ({D} drone(s), S={S}) through oracle/aviary_oracle.py "
-                      f"(float64 per-drone numpy loop restating BaseAviary._dynamics + BaseRLAviary + task) in {dt:.1f}s "
-                      f"on 1 host core; PyBullet (Physics.PYB) is not installable in this image"}
+    out = {"value": n * D * S / dt, "unit": "drone-steps/s", "cores": 1, "kind": "port",
+           "sample": f"{n} env.step() of ONE aviary ({D} drone(s), S={S}) through oracle/aviary_oracle.py "
+                     f"(float64 per-drone numpy loop restating BaseAviary._dynamics + BaseRLAviary + task) in {dt:.1f}s "
+                     f"on 1 host core; PyBullet (Physics.PYB) is not installable in this image"}
+    try:    # second figure: the same arithmetic compiled (oracle/gpd_oracle.c, scalar float64, one core)
+        from oracle.c_oracle import CAviary
+        Ec = 2048
+        c = CAviary(urdf, "cf2x", Ec, D, physics_flags=w["phys"], pyb_freq=240, ctrl_freq=w["ctrl"], act=w["act"],
+                    task=w["task"] if w["task"] != "hover" or D == 1 else "multihover")
+        ac = rng.uniform(-1, 1, size=(8, Ec, D, A))
+        c.step(ac[0])
+        m, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 3.0:
+            c.step(ac[m % 8])
+            m += 1
+        dtc = time.perf_counter() - t0
+        out["c_port"] = {"value": m * Ec * D * S / dtc, "unit": "drone-steps/s", "cores": 1,
+                         "sample": f"{m} steps of {Ec} aviaries through oracle/gpd_oracle.c (gcc -O2, scalar float64) in {dtc:.1f}s"}
+    except Exception as e:   # the C restatement is optional test infrastructure
+        out["c_port"] = {"error": str(e)[:200]}
+    return out
 
 
 def measure(mode, args, env, actions, gather, device, world, POOL):
@@ -113,10 +130,6 @@ def measure(mode, args, env, actions, gather, device, world, POOL):
         gather_k = gdist.ObsAllGather(POOL * core.N, 12, device=device)   # one larger collective per rollout
 
     def one_rollout():
-        if os.environ.get("GPD_BENCH_HOLD") or os.environ.get("GPD_BENCH_LAST"):   # diagnostics only
-            a = actions[0] if os.environ.get("GPD_BENCH_HOLD") else actions
-            core.rollout(a, num_steps=POOL, last_only=bool(os.environ.get("GPD_BENCH_LAST")), update_latest=False)
-            return
         obs = core.rollout(actions, update_latest=False)[0]
         if gather_k is not None:
             gather_k(obs.view(-1, 12))
@@ -184,8 +197,8 @@ def measure(mode, args, env, actions, gather, device, world, POOL):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8192)
-    ap.add_argument("--warmup", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=32768)
+    ap.add_argument("--warmup", type=int, default=2048)
     ap.add_argument("--workload", default="hover65536_240hz", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="rollout", choices=["rollout", "graph", "eager"],
                     help="rollout: gpd_rollout, 64 env steps per launch (state in registers, actions pre-staged); "

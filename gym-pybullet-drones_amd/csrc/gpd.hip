@@ -910,19 +910,30 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
     };
     // (a0 and a1 are requested AFTER the wait above, so that the loop is entered in the state every iteration
     // leaves behind -- two rows in flight, a0 the older -- and the compiler's wait counts stay exact)
-    float4 a0 = fetch(0), a1, a2;
-    __builtin_amdgcn_sched_barrier(0);                               // (a0 must be the older of the two)
-    a1 = fetch(1);
-    __builtin_amdgcn_sched_barrier(0);
-    for (int t = 0; t < K; t += 3) {
-        a2 = fetch(t + 2);
-        do_step(t, a0);
-        if (t + 1 >= K) break;
-        a0 = fetch(t + 3);
-        do_step(t + 1, a1);
-        if (t + 2 >= K) break;
-        a1 = fetch(t + 4);
-        do_step(t + 2, a2);
+    if (!PID) {
+        float4 a0 = fetch(0), a1, a2;
+        __builtin_amdgcn_sched_barrier(0);                           // (a0 must be the older of the two)
+        a1 = fetch(1);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < K; t += 3) {
+            a2 = fetch(t + 2);
+            do_step(t, a0);
+            if (t + 1 >= K) break;
+            a0 = fetch(t + 3);
+            do_step(t + 1, a1);
+            if (t + 2 >= K) break;
+            a1 = fetch(t + 4);
+            do_step(t + 2, a2);
+        }
+    } else {
+        // The DSLPID step body is ~2x longer (the row has time to arrive within one step) and three copies of it
+        // would not sit well in the instruction cache: one step of look-ahead, one copy of the body.
+        float4 act = fetch(0);
+        for (int t = 0; t < K; ++t) {
+            const float4 act_next = fetch(t + 1);
+            do_step(t, act);
+            act = act_next;
+        }
     }
     if (L.active) store_carry<PID>(S, L, c);
 }
