@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py — throughput of the fused HIP step on synthetic hover batches.
+"""bench.py — throughput of the fused HIP env step on synthetic hover batches.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--mode graph|eager]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--mode rollout|graph|eager]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one `env.step()` of EVERY aviary on this rank = one launch of the fused kernel.
-Default workload `hover65536_240hz` (BASELINE.json's metric): 65 536 HoverAviaries per GPU (1 drone
-each), Physics.DYN, ActionType.RPM, pyb_freq = ctrl_freq = 240 Hz (one physics step per env step,
-so env-steps == drone-steps), same-step auto-reset on, actions pre-generated on the device and
-changed every step.  Weak scaling: every rank owns its own 65 536 aviaries; no data-path collective
-unless `--allgather` asks for the optional RCCL all-gather of the observation shards.
+One "step" = one `env.step()` of EVERY aviary on this rank: the action of that step is read, the physics is
+integrated, and the step's observation rows, rewards and terminated/truncated flags are written (same-step
+auto-reset on).  Default workload `hover65536_240hz` (BASELINE.json's metric): 65 536 HoverAviaries per GPU (1 drone
+each), Physics.DYN, ActionType.RPM, pyb_freq = ctrl_freq = 240 Hz (one physics step per env step, so env-steps ==
+drone-steps); actions are pre-generated on the device and different every step.
 
-Rank 0 prints ONE JSON line (metric/value/unit + roofline + cpu_baseline, see DESIGN.md §Measurement).
+Launch modes:
+  rollout  (default, the headline `value`) `gpd_rollout`: 64 consecutive env steps per kernel launch -- the 64 action
+           blocks are staged in HBM, every step's outputs are written, the drone state stays in registers;
+  graph    one `gpd_step` launch per env step, 64 launches captured in a hipGraph (the pattern of an RL loop that
+           runs a policy between steps); measured as well in the default run and reported under
+           `one_launch_per_step`;
+  eager    one host launch per step.
+Weak scaling: every rank owns its own 65 536 aviaries; no data-path collective unless `--allgather` asks for the
+optional RCCL all-gather of the observation shards.
+
+Rank 0 prints ONE JSON line (metric/value/unit + roofline + cpu_baseline, see DESIGN.md §5).
 """
 import argparse
 import json
@@ -187,7 +196,8 @@ def measure(mode, args, env, actions, gather, device, world, POOL):
     return {
         "K": K, "W": W, "wall": wall, "value": n_total * core.S * K / wall, "env_steps_per_s": n_total * K / wall,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "gpd_step_kernel",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "gpd_rollout_kernel" if mode == "rollout" else "gpd_step_kernel",
                      "env_steps_per_launch": steps_per_launch, "bytes_per_launch": bytes_launch,
                      "bytes_per_drone_per_env_step": bytes_launch / (core.N * steps_per_launch),
                      "launch_us_hip_events": launch_us},
@@ -257,7 +267,7 @@ def main():
             for key, roof in ((f"{args.workload}:{launch}", out["roofline"]),
                               (f"{args.workload}:graph", second["roofline"] if second else None)):
                 rec = table.get(key)
-                if rec and roof is not None:
+                if rec and roof is not None and rec.get("traffic_bytes"):
                     roof["traffic"] = rec["traffic_bytes"]
                     roof["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
                     roof["rocprof_kernel_avg_us"] = rec["rocprof_kernel_avg_ns"] / 1e3
