@@ -220,13 +220,14 @@ def main():
     args = ap.parse_args()
 
     from gym_pybullet_drones_amd import dist as gdist
-    rank, world, local = gdist.init_from_env("nccl" if args.gpus > 1 else None)
+    # (GPD_DIST_BACKEND / GPD_BENCH_SINGLE_DEVICE: test hooks -- run the multi-rank code path with gloo on one GPU)
+    rank, world, local = gdist.init_from_env(os.environ.get("GPD_DIST_BACKEND", "nccl") if args.gpus > 1 else None)
     if args.gpus != world:
         if rank == 0:
             print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run", file=sys.stderr)
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    device = torch.device("cuda", local if world > 1 else 0)
+    device = torch.device("cuda", local if world > 1 and not os.environ.get("GPD_BENCH_SINGLE_DEVICE") else 0)
     torch.cuda.set_device(device)
 
     w = WORKLOADS[args.workload]
