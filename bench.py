@@ -48,14 +48,27 @@ WORKLOADS = {
     "hover65536_pid_240hz": dict(E=65536, D=1, phys=0, ctrl=240, act="pid", task="hover"),
     "hover4m_240hz": dict(E=4194304, D=1, phys=0, ctrl=240, act="rpm", task="hover"),
     "hover16m_240hz": dict(E=16777216, D=1, phys=0, ctrl=240, act="rpm", task="hover"),
+    # ONE aviary of 65 536 drones, pairwise downwash over the whole swarm (gpd_downwash_global + gpd_step per sub-step)
+    "swarm65536_ext_240hz": dict(E=1, D=65536, phys=7, ctrl=240, act="raw_rpm", task="none", swarm=True),
 }
 
 
 def make_env(w, device, seed):
-    from gym_pybullet_drones_amd.envs import VectorAviary
-    from gym_pybullet_drones_amd.utils.enums import ActionType
+    from gym_pybullet_drones_amd.envs import SwarmAviary, VectorAviary
+    from gym_pybullet_drones_amd.utils.enums import ActionType, Physics
     E, D = w["E"], w["D"]
     rng = np.random.default_rng(seed)
+    if w.get("swarm"):
+        # 12 layers 1 m apart, a 4 m lattice per layer (74 x 74 sites) with +-0.3 m jitter: ~300 m x 300 m, 32 x 32 grid cells
+        side = int(np.ceil(np.sqrt(D / 12)))
+        idx = rng.permutation(side * side * 12)[:D]
+        layer, site = idx // (side * side), idx % (side * side)
+        xy = np.stack([(site % side) * 4.0, (site // side) * 4.0], axis=1) - 2.0 * side + rng.uniform(-0.3, 0.3, size=(D, 2))
+        xyz = np.concatenate([xy, (1.0 + layer)[:, None]], axis=1)
+        env = SwarmAviary(D, initial_xyzs=xyz, initial_rpys=rng.uniform(-0.05, 0.05, size=(D, 3)), physics=Physics.PYB_GND_DRAG_DW,
+                          pyb_freq=240, ctrl_freq=w["ctrl"], act="raw_rpm", device=device)
+        env.NUM_ENVS, env.ACT_DIM = 1, 4
+        return env
     if D == 1:
         xyz = np.array([0, 0, 0.1125]) + rng.uniform(-0.5, 0.5, size=(E, D, 3)) * np.array([1, 1, 0])
     else:   # drones stacked 0.3 m apart so downwash / ground effect are active
@@ -72,6 +85,8 @@ def make_actions(w, env, device, seed, pool):
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     a = torch.rand((pool, env.NUM_ENVS, env.NUM_DRONES, env.ACT_DIM), generator=g, device=device) * 2 - 1
+    if w["act"] == "raw_rpm":
+        a = float(env.HOVER_RPM) * (1 + 0.05 * a)
     if w["act"] == "pid":
         a = a * 0.5
         a[..., 2] += 1.0
@@ -237,6 +252,8 @@ def main():
     core = env.core
     gather = gdist.ObsAllGather(core.N, 12, device=device) if args.allgather else None
 
+    if w.get("swarm") and args.mode == "rollout":
+        args.mode = "graph"          # a single world needs the downwash of every sub-step's snapshot: one step per launch group
     second = None
     if args.mode == "rollout" and not args.no_second_leg:
         second = measure("graph", args, env, actions, gather, device, world, POOL)

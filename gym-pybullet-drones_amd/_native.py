@@ -26,7 +26,7 @@ class GpdError(RuntimeError):
 class GpdState(ctypes.Structure):
     """mirror of `struct GpdState`"""
     _fields_ = [("kin", ctypes.c_void_p), ("last_rpm", ctypes.c_void_p), ("pid", ctypes.c_void_p),
-                ("step_counter", ctypes.c_void_p), ("ld", ctypes.c_int64)]
+                ("step_counter", ctypes.c_void_p), ("ld", ctypes.c_int64), ("dw_force", ctypes.c_void_p)]
 
 
 class GpdStepCfg(ctypes.Structure):
@@ -72,6 +72,9 @@ _SIGNATURES = {
                                    ctypes.c_int64, _P, _P]),
     "gpd_full_obs": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P,
                                     ctypes.c_int64, _P, ctypes.c_int64, _P, _P, ctypes.c_int64, _P]),
+    "gpd_downwash_global": (ctypes.c_int, [ctypes.POINTER(GpdParams), _P, ctypes.c_int64, ctypes.c_int32, ctypes.c_float,
+                                           ctypes.c_float, ctypes.c_float, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P, _P,
+                                           _P]),
     "gpd_reset": (ctypes.c_int, [ctypes.POINTER(GpdState), _P, ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_int32,
                                  ctypes.c_int32, _P, _P]),
     "gpd_pid": (ctypes.c_int, [ctypes.POINTER(GpdParams), _P, ctypes.c_int64, ctypes.c_float, _P, _P, _P, _P, _P, _P,

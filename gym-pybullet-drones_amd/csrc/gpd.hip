@@ -373,6 +373,7 @@ struct Carry {            // what a drone carries from one env step to the next
     Pid s;                // DSLPID members
     float l0, l1, l2, l3; // last_clipped_action
     int counter;          // the aviary's step counter
+    float dw_in;          // downwash force computed outside the kernel (one aviary of > 256 drones), else 0
     float roll, pitch, yaw;   // rpy of the cached pose (BaseAviary.py:518), carried from the tail of one step to
                               // the top of the next (DSLPID reads it there)
 };
@@ -443,7 +444,7 @@ __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C
     float drag_sum = (EXT && (flags & GPD_PHYS_DRAG)) ? ((c.l0 + c.l1) + c.l2) + c.l3 : cur_sum;
     float avx = 0.0f, avy = 0.0f, avz = 0.0f;
     for (int ss = 0; ss < C.substeps; ++ss) {
-        float dw = 0.0f;
+        float dw = (EXT && !MULTI) ? c.dw_in : 0.0f;
         if (EXT && MULTI && (flags & GPD_PHYS_DW)) {
             // every drone sees the same pre-sub-step snapshot of its aviary (BaseAviary.py:346-347,798)
             wg_barrier();
@@ -573,6 +574,12 @@ __device__ __forceinline__ void load_carry(const GpdState& S, const GpdStepCfg& 
         // without the drag term the last RPMs are not needed: the loads then go to the (cached) first kin rows
         const float* lr = (flags & GPD_PHYS_DRAG) ? S.last_rpm : S.kin;
         c.l0 = ld_row(lr, ld, 0, off4); c.l1 = ld_row(lr, ld, 1, off4); c.l2 = ld_row(lr, ld, 2, off4); c.l3 = ld_row(lr, ld, 3, off4);
+    }
+    c.dw_in = 0.0f;
+    if (EXT) {
+        const bool ext_dw = (flags & GPD_PHYS_DW) && S.dw_force != nullptr;
+        const float v = ld_row(ext_dw ? S.dw_force : S.kin, ld, 0, off4);      // (unused case: a cached kin row)
+        c.dw_in = ext_dw ? v : 0.0f;
     }
     ip[0] = ipl[0]; ip[1] = ipl[1]; ip[2] = ipl[2]; ip[3] = ipl[3]; ip[4] = ipl[4]; ip[5] = ipl[5]; ip[6] = ipl[6];
 }
@@ -1022,6 +1029,109 @@ __global__ __launch_bounds__(kBlock) void gpd_hist_push_kernel(int K, uint32_t N
 }
 
 // ------------------------------------------------------------------------------------------------
+// Downwash inside ONE aviary of any size (envs/BaseAviary.py:785-811): uniform 2-D grid, counting sort by cell,
+// 3x3 neighbourhood search.  Four small kernels per physics sub-step.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cell_of(float x, float y, float inv_cell, float x0, float y0, int nx, int ny) {
+    int cx = static_cast<int>(floorf((x - x0) * inv_cell)), cy = static_cast<int>(floorf((y - y0) * inv_cell));
+    cx = cx < 0 ? 0 : (cx >= nx ? nx - 1 : cx);
+    cy = cy < 0 ? 0 : (cy >= ny ? ny - 1 : cy);
+    return cy * nx + cx;
+}
+
+__global__ __launch_bounds__(kBlock) void dwg_count_kernel(const float* __restrict__ kin, int64_t ld, int n, float inv_cell,
+                                                           float x0, float y0, int nx, int ny, int* __restrict__ count) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    atomicAdd(&count[cell_of(kin[i], kin[ld + i], inv_cell, x0, y0, nx, ny)], 1);
+}
+
+// exclusive scan of count[0..cells) into start[0..cells], one workgroup; count is zeroed for the scatter's cursors
+__global__ __launch_bounds__(1024) void dwg_scan_kernel(int* __restrict__ count, int* __restrict__ start, int cells) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (cells + 1023) / 1024;
+    const int lo = t * per, hi = min(lo + per, cells);
+    int s = 0;
+    for (int c = lo; c < hi; ++c) s += count[c];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {            // Hillis-Steele inclusive scan of the 1024 partial sums
+        const int v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = t == 0 ? 0 : part[t - 1];
+    for (int c = lo; c < hi; ++c) { const int k = count[c]; start[c] = run; run += k; count[c] = 0; }
+    if (t == 1023) start[cells] = part[1023];
+}
+
+__global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const float* __restrict__ kin, int64_t ld, int n, float inv_cell,
+                                                             float x0, float y0, int nx, int ny, int* __restrict__ cursor,
+                                                             const int* __restrict__ start, int* __restrict__ order,
+                                                             float4* __restrict__ sorted) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float x = kin[i], y = kin[ld + i], z = kin[2 * ld + i];
+    const int c = cell_of(x, y, inv_cell, x0, y0, nx, ny);
+    const int slot = start[c] + atomicAdd(&cursor[c], 1);
+    order[slot] = i;
+    sorted[slot] = make_float4(x, y, z, __int_as_float(c));
+}
+
+// One workgroup per grid cell: the candidates of the cell's 3x3 neighbourhood (three contiguous runs of the sorted
+// array, one per cell row) are staged through LDS in tiles of 512, and every drone of the cell (one lane each, in
+// passes of 256) sweeps the tile -- LDS broadcast reads instead of a dependent global load per candidate.
+constexpr int kDwTile = 512;
+__global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, int nx, int ny,
+                                                           const int* __restrict__ start, const int* __restrict__ order,
+                                                           const float4* __restrict__ sorted, float* __restrict__ dw_out) {
+    __shared__ float4 tile[kDwTile];
+    const int c = blockIdx.x;
+    const int cy = c / nx, cx = c - cy * nx;
+    const int m0 = start[c], m1 = start[c + 1];            // the drones of this cell
+    if (m0 == m1) return;
+    const int xa = cx > 0 ? cx - 1 : 0, xb = cx < nx - 1 ? cx + 1 : nx - 1;
+    const float kr = 0.25f * P.prop_radius;
+    for (int base = m0; base < m1; base += kBlock) {       // passes of 256 drones
+        const int s = base + threadIdx.x;
+        const bool have = s < m1;
+        const float4 me = have ? sorted[s] : make_float4(0.0f, 0.0f, 3.0e38f, 0.0f);   // (no drone: nothing is above it)
+        long long acc = 0;                                 // sum of contributions in units of 2^-30 N: order-independent
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = cy + dy;
+            if (yy < 0 || yy >= ny) continue;              // (uniform)
+            const int t0 = start[yy * nx + xa], t1 = start[yy * nx + xb + 1];   // the 3 cells of a row are contiguous
+            for (int tb = t0; tb < t1; tb += kDwTile) {
+                const int cnt = min(kDwTile, t1 - tb);
+                __syncthreads();
+                for (int j = threadIdx.x; j < cnt; j += kBlock) tile[j] = sorted[tb + j];
+                __syncthreads();
+#pragma unroll 4
+                for (int j = 0; j < cnt; ++j) {
+                    const float4 o = tile[j];
+                    const float dz = o.z - me.z;
+                    const float ddx = o.x - me.x, ddy = o.y - me.y;
+                    const float dxy2 = fmaf(ddy, ddy, ddx * ddx);
+                    if (dz > 0.0f && dxy2 < 100.0f) {      // dz > 0 and dxy < 10 m  (:800-801)
+                        const float ratio = kr * fast_rcp(dz);
+                        const float alpha = P.dw_coeff[0] * (ratio * ratio);
+                        const float beta = fmaf(P.dw_coeff[1], dz, P.dw_coeff[2]);
+                        const float ib = fast_rcp(beta);
+                        const float arg = 0.5f * (dxy2 * (ib * ib));
+                        // exp(-40) = 4e-18: below the 2^-31 N the fixed-point sum resolves for any alpha < 1e8 N -- most
+                        // candidates of the 3x3 cells end here without evaluating the exponential
+                        if (arg < 40.0f || alpha > 1.0e8f) acc += __float2ll_rn((alpha * expf(-arg)) * 1073741824.0f);
+                    }
+                }
+            }
+        }
+        if (have) dw_out[order[s]] = -static_cast<float>(static_cast<double>(acc) * (1.0 / 1073741824.0));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // standalone batched DSLPIDControl.computeControl
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void gpd_pid_kernel(
@@ -1233,6 +1343,32 @@ int gpd_full_obs(int32_t num_steps, int32_t n_drones, int32_t act_dim, int32_t h
                        hist_len, hist_pos, actions, action_step_stride, act_hist);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gpd_full_obs (ring update) launch");
+    return 0;
+}
+
+int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, int32_t n, float cell, float x0,
+                        float y0, int32_t nx, int32_t ny, int32_t* cell_count, int32_t* cell_start, int32_t* order,
+                        float* sorted_xyzc, float* dw_out, void* stream) {
+    if (!params || !kin || !cell_count || !cell_start || !order || !sorted_xyzc || !dw_out)
+        return fail(GPD_EINVAL, "gpd_downwash_global: NULL argument");
+    if (n <= 0 || ld < n) return fail(GPD_EINVAL, "gpd_downwash_global: need 0 < n <= ld");
+    if (!(cell >= 10.0f)) return fail(GPD_EINVAL, "gpd_downwash_global: cell must be >= 10 m (the model's lateral cut-off)");
+    if (nx <= 0 || ny <= 0 || static_cast<int64_t>(nx) * ny > 65536)
+        return fail(GPD_ERANGE, "gpd_downwash_global: need 1 <= nx*ny <= 65536");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int cells = nx * ny;
+    const float inv_cell = 1.0f / cell;
+    hipError_t e = hipMemsetAsync(cell_count, 0, sizeof(int32_t) * (cells + 1), st);
+    if (e != hipSuccess) return hip_fail(e, "gpd_downwash_global memset");
+    const dim3 grid(static_cast<unsigned>((n + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(dwg_count_kernel, grid, dim3(kBlock), 0, st, kin, ld, n, inv_cell, x0, y0, nx, ny, cell_count);
+    hipLaunchKernelGGL(dwg_scan_kernel, dim3(1), dim3(1024), 0, st, cell_count, cell_start, cells);
+    hipLaunchKernelGGL(dwg_scatter_kernel, grid, dim3(kBlock), 0, st, kin, ld, n, inv_cell, x0, y0, nx, ny, cell_count,
+                       cell_start, order, reinterpret_cast<float4*>(sorted_xyzc));
+    hipLaunchKernelGGL(dwg_force_kernel, dim3(static_cast<unsigned>(cells)), dim3(kBlock), 0, st, *params, nx, ny, cell_start,
+                       order, reinterpret_cast<const float4*>(sorted_xyzc), dw_out);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gpd_downwash_global launch");
     return 0;
 }
 

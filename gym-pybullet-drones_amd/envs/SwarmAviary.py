@@ -1,0 +1,125 @@
+"""`SwarmAviary`: ONE aviary of N drones, any N — with the pairwise downwash of the whole swarm.
+
+The reference simulates one world per aviary and couples its drones only through `_downwash`
+(`envs/BaseAviary.py:785-811`): an O(N²) Python loop over every pair with `dz > 0` and `dxy < 10 m`, once per
+physics sub-step, on the positions all drones had at the start of the sub-step (`:346-347`).  The fused step
+kernel covers aviaries of up to 256 drones (one workgroup, positions exchanged through LDS).  This class is the
+large-world counterpart: the swarm is stepped as N single-drone lanes of the same kernel, and
+the downwash force of each drone is computed per sub-step by `gpd_downwash_global` — uniform 10 m grid, counting
+sort by cell, 3×3-cell neighbourhood search, order-independent fixed-point accumulation — and handed to the step
+kernel as `state.dw_force`.
+
+Interface: `CtrlAviary`-like.  `step(action)` takes raw RPMs `(N, 4)` clipped to `[0, MAX_RPM]`
+(`envs/CtrlAviary.py:140`) — or, with `act=ActionType.PID`, waypoints `(N, 3)` tracked by N `DSLPIDControl`s
+(`examples/downwash.py:93-113`) — and returns the `(N, 20)` state vectors.  Everything stays on the GPU.
+One process / one GPU: a single world does not shard by aviary.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _native, engine
+from ..control.DSLPIDControl import DSLPIDControlBatch
+from ..params import DroneParams
+from ..utils.enums import ACT_DIRECT_RPM, ActionType, DroneModel, PHYS_DW, Physics
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class SwarmAviary:
+    """One world, `num_drones` drones, explicit integrator + the selected force models over the whole swarm."""
+
+    def __init__(self, num_drones: int, drone_model: DroneModel = DroneModel.CF2X, initial_xyzs=None, initial_rpys=None,
+                 physics: Physics = Physics.PYB_DW, pyb_freq: int = 240, ctrl_freq: int = 240, act="raw_rpm",
+                 world_min=None, world_max=None, cell: float = 10.0, device=None):
+        if pyb_freq % ctrl_freq != 0:
+            raise ValueError("[ERROR] in SwarmAviary.__init__(), pyb_freq is not divisible by ctrl_freq.")
+        if act not in ("raw_rpm", ActionType.RPM, ActionType.PID):
+            raise ValueError("SwarmAviary supports act = 'raw_rpm', ActionType.RPM or ActionType.PID")
+        self.NUM_DRONES = N = int(num_drones)
+        self.DRONE_MODEL, self.PHYSICS, self.ACT_TYPE = drone_model, physics, act
+        self.PYB_FREQ, self.CTRL_FREQ = pyb_freq, ctrl_freq
+        self.PYB_STEPS_PER_CTRL = pyb_freq // ctrl_freq
+        self.CTRL_TIMESTEP, self.PYB_TIMESTEP = 1. / ctrl_freq, 1. / pyb_freq
+        P = DroneParams(drone_model)
+        self.HOVER_RPM, self.MAX_RPM = P.HOVER_RPM, P.MAX_RPM
+        if initial_xyzs is None:
+            initial_xyzs = P.default_init_xyzs(N)
+        xyz = np.asarray(initial_xyzs, dtype=np.float64).reshape(N, 1, 3)
+        rpy = np.zeros((N, 1, 3)) if initial_rpys is None else np.asarray(initial_rpys, dtype=np.float64).reshape(N, 1, 3)
+        self.INIT_XYZS, self.INIT_RPYS = xyz[:, 0], rpy[:, 0]
+        # the kernel runs N single-drone lanes, one physics sub-step per launch; actions arrive as RPMs
+        self.core = engine.SimCore(drone_model=drone_model, num_envs=N, drones_per_env=1, physics=physics, pyb_freq=pyb_freq,
+                                   ctrl_freq=pyb_freq, act_code=ACT_DIRECT_RPM, task=engine.TASK_NONE, initial_xyzs=xyz,
+                                   initial_rpys=rpy, auto_reset=False, track_rpm=True, device=device)
+        self.device = dev = self.core.device
+        self.flags = self.core.physics_flags
+        self.ctrl = DSLPIDControlBatch(N, drone_model, device=dev) if act == ActionType.PID else None
+        # ---- downwash grid ------------------------------------------------------------------------
+        self.cell = float(cell)
+        lo = xyz[:, 0, :2].min(axis=0) - 2 * self.cell if world_min is None else np.asarray(world_min, dtype=np.float64)
+        hi = xyz[:, 0, :2].max(axis=0) + 2 * self.cell if world_max is None else np.asarray(world_max, dtype=np.float64)
+        self.x0, self.y0 = float(lo[0]), float(lo[1])
+        self.nx = max(1, int(np.ceil((hi[0] - lo[0]) / self.cell)))
+        self.ny = max(1, int(np.ceil((hi[1] - lo[1]) / self.cell)))
+        while self.nx * self.ny > 65536:          # coarser cells keep the search exact (cell >= 10 m), only less selective
+            self.cell *= 2
+            self.nx, self.ny = max(1, int(np.ceil((hi[0] - lo[0]) / self.cell))), max(1, int(np.ceil((hi[1] - lo[1]) / self.cell)))
+        cells = self.nx * self.ny
+        i32 = dict(dtype=torch.int32, device=dev)
+        self._count, self._start = torch.zeros(cells + 1, **i32), torch.zeros(cells + 1, **i32)
+        self._order = torch.zeros(N, **i32)
+        self._sorted = torch.zeros((N, 4), dtype=torch.float32, device=dev)
+        self.dw_force = torch.zeros(self.core.ld, dtype=torch.float32, device=dev)
+        if self.flags & PHYS_DW:
+            self.core._state.dw_force = self.dw_force.data_ptr()
+        self.step_counter = 0
+
+    # ------------------------------------------------------------------------------------------
+    def downwash(self) -> torch.Tensor:
+        """Body-z downwash force of every drone for the current positions (`gpd_downwash_global`) -> [N] view."""
+        c = self.core
+        with torch.cuda.device(self.device):
+            rc = c.lib.gpd_downwash_global(ctypes.byref(c._params), _ptr(c.kin), c.ld, self.NUM_DRONES, self.cell, self.x0,
+                                           self.y0, self.nx, self.ny, _ptr(self._count), _ptr(self._start), _ptr(self._order),
+                                           _ptr(self._sorted), _ptr(self.dw_force), c._stream())
+        _native.check(rc, "gpd_downwash_global")
+        return self.dw_force[:self.NUM_DRONES]
+
+    def reset(self, seed=None, options=None):
+        self.core.reset()
+        if self.ctrl is not None:
+            self.ctrl.reset()
+        self.step_counter = 0
+        return self.state_vectors(), {"answer": 42}
+
+    def _rpm(self, action: torch.Tensor) -> torch.Tensor:
+        N = self.NUM_DRONES
+        a = torch.as_tensor(action, dtype=torch.float32, device=self.device)
+        if self.ACT_TYPE == "raw_rpm":
+            return a.reshape(N, 4).clamp(0.0, float(self.MAX_RPM))
+        if self.ACT_TYPE == ActionType.RPM:
+            return float(self.HOVER_RPM) * (1.0 + 0.05 * a.reshape(N, 4))
+        k = self.core.kin[:, :N]
+        rpm, _, _ = self.ctrl.computeControl(self.CTRL_TIMESTEP, k[0:3].t(), k[3:7].t(), k[7:10].t(), None, a.reshape(N, 3))
+        return rpm
+
+    def step(self, action):
+        """One control step = PYB_STEPS_PER_CTRL × { downwash of the snapshot, one physics sub-step }."""
+        rpm = self._rpm(action).contiguous()
+        for _ in range(self.PYB_STEPS_PER_CTRL):
+            if self.flags & PHYS_DW:
+                self.downwash()
+            self.core.step(rpm)
+        self.step_counter += self.PYB_STEPS_PER_CTRL
+        return self.state_vectors(), -1, False, False, {"answer": 42}
+
+    def state_vectors(self) -> torch.Tensor:
+        """(N, 20) `_getDroneStateVector` rows (envs/BaseAviary.py:559-561)."""
+        return self.core.state_vectors()
+
+    def close(self):
+        pass

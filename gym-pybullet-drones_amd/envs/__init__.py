@@ -3,9 +3,10 @@ from .BaseRLAviary import BaseRLAviary
 from .CtrlAviary import CtrlAviary
 from .HoverAviary import HoverAviary
 from .MultiHoverAviary import MultiHoverAviary
+from .SwarmAviary import SwarmAviary
 from .VelocityAviary import VelocityAviary
 from .VectorAviary import (VecEnvAdapter, VectorAviary, VectorCtrlAviary, VectorHoverAviary, VectorMultiHoverAviary,
                            VectorVelocityAviary)
 
 __all__ = ["BaseAviary", "BaseRLAviary", "CtrlAviary", "HoverAviary", "MultiHoverAviary", "VelocityAviary", "VectorAviary",
-           "VectorCtrlAviary", "VectorHoverAviary", "VectorMultiHoverAviary", "VectorVelocityAviary", "VecEnvAdapter"]
+           "VectorCtrlAviary", "VectorHoverAviary", "VectorMultiHoverAviary", "VectorVelocityAviary", "VecEnvAdapter", "SwarmAviary"]

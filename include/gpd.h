@@ -119,6 +119,9 @@ typedef struct GpdState {
                               PID action type is used */
     int32_t* step_counter; /* [num_envs] physics steps since reset (envs/BaseAviary.py:460,382) */
     int64_t ld;            /* row pitch in floats */
+    float* dw_force;       /* [ld] or NULL: body-z downwash force per drone computed OUTSIDE the step kernel
+                              (gpd_downwash_global, for one aviary of more than 256 drones); used with
+                              GPD_PHYS_DW when drones_per_env == 1, added in every sub-step of the call */
 } GpdState;
 
 /* Per-call configuration of gpd_step */
@@ -232,6 +235,29 @@ int gpd_rollout(const GpdParams* params, const GpdState* state, const GpdStepCfg
 int gpd_full_obs(int32_t num_steps, int32_t n_drones, int32_t act_dim, int32_t hist_len, int32_t hist_pos,
                  const float* obs12, int64_t obs_step_stride, const float* actions, int64_t action_step_stride,
                  float* act_hist, float* obs_full, int64_t full_step_stride, void* stream);
+
+/*
+ * Downwash forces inside ONE aviary of n drones, any n (the step kernel itself handles aviaries of up to 256
+ * drones).  Replaces the O(n^2) Python loop of BaseAviary._downwash (envs/BaseAviary.py:785-811) over all pairs
+ * with  dz = z_j - z_i > 0  and  dxy < 10 m:
+ *     F_i = - sum_j  DW1 * (PROP_RADIUS / (4 dz))^2 * exp(-0.5 * (dxy / (DW2*dz + DW3))^2)        (body z of drone i)
+ * by binning the drones into a uniform 2-D grid of `cell` >= 10 m squares (counting sort by cell) and searching
+ * the 3x3 neighbourhood of each drone's cell.  Drones outside the grid are clamped into its border cells (still
+ * exact: every candidate pair is distance-tested; only the pruning degrades).  The per-drone sum is accumulated
+ * in 64-bit fixed point (2^-30 N), so the result does not depend on the order the sort leaves the neighbours in.
+ *
+ *   kin, ld       the state block of gpd_step (rows 0..2 = positions are read)
+ *   cell, x0, y0, nx, ny   grid: cell size [m] (>= 10), lower-left corner, cells per side (nx*ny <= 65536)
+ *   cell_count    [nx*ny + 1] int32 scratch       cell_start  [nx*ny + 1] int32 scratch
+ *   order         [n] int32 scratch (drone index of sorted slot)
+ *   sorted_xyzc   [n][4] float scratch (x, y, z, cell id as int bits), sorted by cell
+ *   dw_out        [n] out: the force of drone i at dw_out[i]  (pass it to gpd_step as state.dw_force)
+ * Call it once per physics sub-step, before the gpd_step launch of that sub-step (positions are the snapshot every
+ * drone sees, envs/BaseAviary.py:346-347).
+ */
+int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, int32_t n, float cell, float x0,
+                        float y0, int32_t nx, int32_t ny, int32_t* cell_count, int32_t* cell_start, int32_t* order,
+                        float* sorted_xyzc, float* dw_out, void* stream);
 
 /*
  * Masked reset.  Replaces BaseAviary.reset/_housekeeping (envs/BaseAviary.py:220-255, 451-477)

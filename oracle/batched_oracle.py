@@ -130,6 +130,18 @@ class BatchedAviary:
     def obs12(self):
         return np.concatenate([self.pos, self.rpy, self.vel, self.ang_v], axis=-1)
 
+    def downwash_force_all(self):
+        """[E, D] body-z downwash force on every drone from the drones above it in its aviary
+        (envs/BaseAviary.py:798-804, all pairs with dz > 0 and dxy < 10)."""
+        C = self.C
+        dz = self.pos[:, None, :, 2] - self.pos[:, :, None, 2]            # [E, i, j] = z_j - z_i
+        dxy = _norm(self.pos[:, None, :, 0:2] - self.pos[:, :, None, 0:2])
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            alpha = C.DW_COEFF_1 * (C.PROP_RADIUS / (4 * dz)) ** 2
+            beta = C.DW_COEFF_2 * dz + C.DW_COEFF_3
+            term = -alpha * np.exp(-.5 * (dxy / beta) ** 2)
+        return np.sum(np.where((dz > 0) & (dxy < 10), term, 0.0), axis=-1)
+
     def state20(self):
         return np.concatenate([self.pos, self.quat, self.rpy, self.vel, self.ang_v, self.last_rpm], axis=-1)
 
@@ -180,13 +192,7 @@ class BatchedAviary:
             f = f + np.where(on[..., None], gnd, 0.0)
         fz = np.sum(f, axis=-1)
         if self.PHYS & PHYS_DW:
-            dz = self.pos[:, None, :, 2] - self.pos[:, :, None, 2]            # [E, i, j] = z_j - z_i
-            dxy = _norm(self.pos[:, None, :, 0:2] - self.pos[:, :, None, 0:2])
-            with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
-                alpha = C.DW_COEFF_1 * (C.PROP_RADIUS / (4 * dz)) ** 2
-                beta = C.DW_COEFF_2 * dz + C.DW_COEFF_3
-                term = -alpha * np.exp(-.5 * (dxy / beta) ** 2)
-            fz = fz + np.sum(np.where((dz > 0) & (dxy < 10), term, 0.0), axis=-1)
+            fz = fz + self.downwash_force_all()
         F = R[..., :, 2] * fz[..., None]
         F[..., 2] -= C.GRAVITY
         if self.PHYS & PHYS_DRAG:

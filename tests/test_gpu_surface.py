@@ -100,3 +100,75 @@ def test_logger_export_of_device_states(gpu_device, tmp_path):
     z = np.loadtxt(d + "/z0.csv", delimiter=",")
     assert z.shape == (T, 2) and z[-1, 1] == pytest.approx(a.states[0, 2, -1])
     a.save()
+
+
+@pytest.mark.parametrize("N,act", [(1500, "raw_rpm"), (700, "pid")])
+def test_swarm_aviary_global_downwash(gpu_device, N, act):
+    """ONE aviary of N > 256 drones: gpd_downwash_global (grid binning) + the single-drone step kernel against the
+    float64 oracle's O(N^2) loop (envs/BaseAviary.py:785-811).  Drones spread over 60 m x 40 m in 0.3 m layers so that
+    many pairs sit inside the 10 m cut-off, several grid cells are populated and dz stays away from the model's
+    singularities (dz -> 0+, dz = 0.6875 m) for the pairs that matter."""
+    from conftest import urdf
+    from gym_pybullet_drones_amd.envs import SwarmAviary
+    from gym_pybullet_drones_amd.utils.enums import ActionType, Physics
+    from oracle.batched_oracle import BatchedAviary
+    rng = np.random.default_rng(N)
+    # 12 layers 1 m apart; inside a layer a 4 m lattice with +-0.3 m jitter (same-layer drones stay >= 3 m apart: the
+    # model's alpha ~ 1/dz^2 is singular for dz -> 0+), the lattices of the layers aligned so that drones DO fly in each
+    # other's wake (dxy <= 0.85 m for vertical neighbours)
+    sites = np.array([(x, y) for x in np.arange(-28, 29, 4.0) for y in np.arange(-18, 19, 4.0)])     # 15 x 10
+    idx = rng.permutation(len(sites) * 12)[:N]
+    layer, site = idx // len(sites), idx % len(sites)
+    xyz = np.concatenate([sites[site] + rng.uniform(-0.3, 0.3, size=(N, 2)), (1.0 + 1.0 * layer)[:, None]], axis=1)
+    rpy = rng.uniform(-0.05, 0.05, size=(N, 3))
+    S = 2
+    env = SwarmAviary(N, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.PYB_GND_DRAG_DW, pyb_freq=240, ctrl_freq=120,
+                      act="raw_rpm" if act == "raw_rpm" else ActionType.PID, device=gpu_device)
+    orc = BatchedAviary(urdf("cf2x"), "cf2x", num_envs=1, num_drones=N, initial_xyzs=xyz[None], initial_rpys=rpy[None],
+                        physics_flags=7, pyb_freq=240, ctrl_freq=120, act="raw_rpm" if act == "raw_rpm" else "pid", task="none",
+                        pid_urdf_path=urdf("cf2x"))
+    assert env.nx * env.ny >= 12
+    # the force itself, on the initial snapshot
+    f = env.downwash().cpu().numpy().astype(np.float64)
+    ref = orc.downwash_force_all()[0]
+    # exp(-(dxy/beta)^2/2) with |beta| = 0.05 m for the nearest layer has a relative condition number of (dxy/beta)^2 ~ 30
+    # against coordinates that fp32 holds to 2e-6 m at |x| ~ 30 m: 3e-3 relative on the individual forces
+    np.testing.assert_allclose(f, ref, rtol=3e-3, atol=1e-7)
+    assert (np.abs(ref) > 1e-4).mean() > 0.3                # the scene does exercise the term
+    for k in range(6):
+        if act == "raw_rpm":
+            a = (env.HOVER_RPM * (1 + 0.05 * rng.uniform(-1, 1, size=(N, 4)))).astype(np.float32)
+            oa = a.astype(np.float64)[None]
+        else:
+            a = (xyz + rng.uniform(-0.2, 0.2, size=(N, 3))).astype(np.float32)
+            oa = a.astype(np.float64)[None]
+        sv, *_ = env.step(torch.as_tensor(a, device=gpu_device))
+        orc.step(oa)
+        got = sv.cpu().numpy().astype(np.float64)
+        want = orc.state20()[0]
+        scale = np.maximum(np.abs(want).max(axis=0), 1.0)
+        err = np.abs(got[:, :16] - want[:, :16]) / scale[:16]
+        assert err.max() < (3e-4 if act == "raw_rpm" else 1e-3), (k, err.max(axis=0))
+    assert env.step_counter == 6 * S
+
+
+def test_swarm_downwash_is_order_independent_and_matches_the_workgroup_path(gpu_device):
+    """(1) permuting the drones permutes the forces, bit for bit (fixed-point accumulation); (2) for an aviary small
+    enough for the fused kernel (D = 200) the global path and the in-kernel LDS path agree."""
+    from gym_pybullet_drones_amd.envs import SwarmAviary, VectorCtrlAviary
+    from gym_pybullet_drones_amd.utils.enums import Physics
+    rng = np.random.default_rng(4)
+    N = 200
+    xyz = np.stack([rng.uniform(-8, 8, N), rng.uniform(-8, 8, N), 1.0 + 0.3 * rng.integers(0, 10, N) + rng.uniform(-0.01, 0.01, N)], 1)
+    perm = rng.permutation(N)
+    a = SwarmAviary(N, initial_xyzs=xyz, physics=Physics.PYB_DW, device=gpu_device)
+    b = SwarmAviary(N, initial_xyzs=xyz[perm], physics=Physics.PYB_DW, world_min=(-30, -30), world_max=(30, 30), device=gpu_device)
+    fa, fb = a.downwash().clone(), b.downwash().clone()
+    assert torch.equal(fa[torch.as_tensor(perm, device=gpu_device)], fb)
+    v = VectorCtrlAviary(1, N, initial_xyzs=xyz, physics=Physics.PYB_DW, ctrl_freq=240, device=gpu_device)
+    rpm = torch.full((N, 4), float(a.HOVER_RPM), device=gpu_device)
+    for _ in range(5):
+        sa, *_ = a.step(rpm)
+        v.step(rpm.view(1, N, 4))
+    sv = v.state_vectors().view(N, 20)
+    assert torch.allclose(sa, sv, rtol=0, atol=2e-6)
