@@ -884,13 +884,17 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
     if (PID) quat_to_rpy(c.k.qx, c.k.qy, c.k.qz, c.k.qw, c.roll, c.pitch, c.yaw);
 
     float* const tobs_t = term_obs12;
+    int drained_seen = 0;                                            // last value of sh_drained this wave has read
     auto do_step = [&](const int t, const float4 act) {
         StepOut out;
         env_step<PID, EXT, MULTI, AW>(P, C, flags, D, L, act, tgx, tgy, tgz, true, ipose, ip[0], ip[1], ip[2], ip[3], ip[4],
                                       ip[5], ip[6], sh_pos, sh_red, c, out);
         const int b = t & (ring - 1);
-        if (!MULTI && t >= ring) {                                   // slot b still holds step t-ring: has it been drained?
-            while (__builtin_amdgcn_readfirstlane(lds_peek(&sh_drained)) < t - ring + 1) __builtin_amdgcn_s_sleep(1);
+        if (!MULTI && t - ring + 1 > drained_seen) {                 // slot b may still hold step t-ring: has it been drained?
+            // (the flag is re-read only when the last value seen does not already clear this step: the store wave
+            // normally runs one step behind, so one read clears the next ring-1 steps)
+            while ((drained_seen = __builtin_amdgcn_readfirstlane(lds_peek(&sh_drained))) < t - ring + 1)
+                __builtin_amdgcn_s_sleep(1);
         }
         float4* ol = reinterpret_cast<float4*>(slot_obs(b) + tid * 12);
         ol[0] = make_float4(out.o[0], out.o[1], out.o[2], out.o[3]);
