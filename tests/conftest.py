@@ -29,4 +29,8 @@ def gpu_device():
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    # the in-tree library normally travels with the snapshot; on a fresh checkout build it (hipcc is in the image)
+    from gym_pybullet_drones_amd import _native
+    if not os.path.exists(_native.LIB_PATH):
+        _native.build(verbose=True)
     return torch.device("cuda:0")
