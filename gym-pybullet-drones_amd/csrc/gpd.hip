@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -385,7 +386,7 @@ struct StepOut {          // what one env step hands to the stores
     bool term, trunc, reset;
 };
 
-template <bool PID, bool EXT, bool MULTI, int AW>
+template <bool PID, bool EXT, bool MULTI, int AW, int ACT = -1>   // ACT >= 0: the action type is a compile-time constant
 __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C, const uint32_t flags, const int D,
                                          const Lane& L, const float4 act, const float tgx, const float tgy,
                                          const float tgz, const bool ip_regs, const float* __restrict__ ipose,
@@ -393,6 +394,7 @@ __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C
                                          const float ip4, const float ip5, const float ip6, float* sh_pos,
                                          float* sh_red, Carry& c, StepOut& out) {
     Kin& k = c.k;
+    const int act_type = ACT >= 0 ? ACT : C.act_type;
     // ---- action -> RPM (computed ONCE per env step from the cached state, BaseAviary.py:341) -----
     float rpm[4] = {0, 0, 0, 0};
     float g[4];                                              // rotor thrusts minus the hover thrust
@@ -401,14 +403,14 @@ __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C
             const float e = 0.05f * act.x;
             rpm[0] = rpm[1] = rpm[2] = rpm[3] = fmaf(P.hover_rpm, e, P.hover_rpm);
             g[0] = g[1] = g[2] = g[3] = thrust_dev_norm(P, e);
-        } else if (C.act_type == GPD_ACT_RPM) {   // NOT clipped
+        } else if (act_type == GPD_ACT_RPM) {   // NOT clipped
             const float e0 = 0.05f * act.x, e1 = 0.05f * act.y, e2 = 0.05f * act.z, e3 = 0.05f * act.w;
             rpm[0] = fmaf(P.hover_rpm, e0, P.hover_rpm); rpm[1] = fmaf(P.hover_rpm, e1, P.hover_rpm);
             rpm[2] = fmaf(P.hover_rpm, e2, P.hover_rpm); rpm[3] = fmaf(P.hover_rpm, e3, P.hover_rpm);
             g[0] = thrust_dev_norm(P, e0); g[1] = thrust_dev_norm(P, e1);
             g[2] = thrust_dev_norm(P, e2); g[3] = thrust_dev_norm(P, e3);
         } else {           // GPD_ACT_RAW_RPM (clipped to [0, MAX_RPM], envs/CtrlAviary.py:140) or GPD_ACT_DIRECT_RPM (as is)
-            const bool clip = C.act_type == GPD_ACT_RAW_RPM;
+            const bool clip = act_type == GPD_ACT_RAW_RPM;
             const float lo = clip ? 0.0f : -3.0e38f, hi = clip ? P.max_rpm : 3.0e38f;
             rpm[0] = clampf(act.x, lo, hi); rpm[1] = clampf(act.y, lo, hi);
             rpm[2] = clampf(act.z, lo, hi); rpm[3] = clampf(act.w, lo, hi);
@@ -950,6 +952,118 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// gpd_rollout for single-drone aviaries: K env steps per launch with NO helper wave and NO workgroup
+// synchronisation at all.  256-thread workgroups, one drone per lane; per step a lane
+//   * prefetches the action row two steps ahead (three rotating register sets, loop unrolled x3),
+//   * steps (env_step, everything in registers),
+//   * writes its 48-byte observation row into its wave's 3 KiB LDS patch, and the wave stores the patch as three
+//     fully coalesced 1 KiB dwordx4 bursts (the 64 rows of a wave are contiguous in memory); reward and flags go
+//     out directly (already coalesced).
+// Every global memory instruction of the loop body is UNCONDITIONAL -- this is what makes it fast: gfx950 counts
+// loads and stores on one in-order counter, and only with a fixed number of operations per step can the wait for
+// "the row requested two steps ago" be an exact `vmcnt(14)` (the two younger loads and the twelve stores of the two
+// steps in between may still be in flight) instead of a wait for every store issued so far (a store takes > 1 us
+// to be acknowledged).  Lanes without a drone (ragged last workgroup) are exact CLONES of drone 0 -- same state,
+// same action row, same arithmetic, hence the same bits -- and store to drone 0's addresses: a benign duplicate
+// write instead of a branch around the stores.  (Calls that ask for terminal observations -- conditional stores -- use
+// the compute-wave + store-wave kernel above.)
+// ------------------------------------------------------------------------------------------------
+template <bool PID, bool EXT, int AW, int ACT>
+__global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
+    const GpdParams P, const GpdState S, const GpdStepCfg C, const Span T, const float* __restrict__ action,
+    const float* __restrict__ target_pos, const float* __restrict__ init_pose, float* __restrict__ obs12,
+    float* __restrict__ reward, uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
+    float* __restrict__ term_obs12) {
+    const int tid = threadIdx.x;
+    const uint32_t N = static_cast<uint32_t>(C.num_envs);
+    const uint32_t n_raw = blockIdx.x * static_cast<uint32_t>(kBlock) + tid;
+    const int K = T.num_steps;
+    const uint32_t flags = EXT ? C.physics_flags : 0u;
+    Lane L;
+    L.tid = tid; L.le = tid; L.d = 0;
+    L.active = n_raw < N;
+    L.n = L.active ? n_raw : 0u;
+    L.env = L.n;
+
+    __shared__ __attribute__((aligned(16))) float sh_rows[kBlock * 12];
+    float dummy_lds[1];                                              // (env_step's LDS arguments are unused without MULTI)
+
+    // loop-invariant addressing of this lane's three 16-byte chunks of its wave's 3 KiB row patch
+    const int wave0 = tid & ~63, lane = tid & 63;
+    const uint32_t n0 = blockIdx.x * static_cast<uint32_t>(kBlock) + wave0;      // first drone of this wave
+    const uint32_t rows = n0 < N ? ((N - n0 < 64u) ? N - n0 : 64u) : 0u;         // lanes of this wave that own a drone
+    uint32_t goff[3];
+    const char* lsrc = reinterpret_cast<const char*>(sh_rows + wave0 * 12) + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const uint32_t cidx = static_cast<uint32_t>(j * 64 + lane), r = cidx / 3u, part = cidx - 3u * r;
+        goff[j] = (r < rows ? (n0 + r) * 48u : 0u) + part * 16u;    // a clone's row goes to drone 0's row
+    }
+    const uint32_t eoff4 = L.env * 4u;
+
+    Carry c;
+    float tgx, tgy, tgz, ip[7];
+    auto fetch = [&](int step) { return load_action<AW>(action + (step < K ? step : K - 1) * T.action_stride, L.n); };
+    const float* ipose = reinterpret_cast<const float*>(reinterpret_cast<const char*>(init_pose) +
+                                                        (C.init_per_env ? L.n * 28u : 0u));
+    load_carry<PID, EXT>(S, C, flags, L, target_pos, C.auto_reset ? ipose : S.kin, c, tgx, tgy, tgz, ip);
+    asm volatile("" :: "v"(c.k.px), "v"(c.k.py), "v"(c.k.pz), "v"(c.k.qx), "v"(c.k.qy), "v"(c.k.qz), "v"(c.k.qw), "v"(c.k.vx),
+                       "v"(c.k.vy), "v"(c.k.vz), "v"(c.k.wx), "v"(c.k.wy), "v"(c.k.wz), "v"(tgx), "v"(tgy), "v"(tgz),
+                       "v"(c.counter), "v"(ip[0]), "v"(ip[1]), "v"(ip[2]), "v"(ip[3]), "v"(ip[4]), "v"(ip[5]), "v"(ip[6])
+                 : "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0): the loop starts with nothing pending
+    c.roll = c.pitch = c.yaw = 0.0f;
+    if (PID) quat_to_rpy(c.k.qx, c.k.qy, c.k.qz, c.k.qw, c.roll, c.pitch, c.yaw);
+
+    (void)term_obs12;   // (terminal observations: the host routes such calls to gpd_rollout_kernel -- a conditional
+                        // store in this loop body would make the wait counts conservative again)
+    auto do_step = [&](const int t, const float4 act) {
+        StepOut out;
+        env_step<PID, EXT, false, AW, ACT>(P, C, flags, 1, L, act, tgx, tgy, tgz, true, ipose, ip[0], ip[1], ip[2], ip[3],
+                                           ip[4], ip[5], ip[6], dummy_lds, dummy_lds, c, out);
+        // row -> the wave's LDS patch -> three coalesced bursts (same wave: program order + an LDS wait, no barrier)
+        float4* mine = reinterpret_cast<float4*>(sh_rows + tid * 12);
+        mine[0] = make_float4(out.o[0], out.o[1], out.o[2], out.o[3]);
+        mine[1] = make_float4(out.o[4], out.o[5], out.o[6], out.o[7]);
+        mine[2] = make_float4(out.o[8], out.o[9], out.o[10], out.o[11]);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        char* og = reinterpret_cast<char*>(obs12 + t * T.obs_stride);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(lsrc + j * 1024);
+            f4u w = {v.x, v.y, v.z, v.w};
+            *reinterpret_cast<f4u*>(og + goff[j]) = w;
+        }
+        __builtin_amdgcn_wave_barrier();                             // (the next step's row writes stay behind these reads)
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(reward + t * T.env_stride) + eoff4) = out.rew;
+        (terminated + t * T.env_stride)[L.env] = out.term ? 1 : 0;
+        (truncated + t * T.env_stride)[L.env] = out.trunc ? 1 : 0;
+    };
+    // Action rows, three steps per loop iteration: the rows of the NEXT iteration (b0..b2) are requested at the top of
+    // this one and claimed at its end with an explicit vmcnt(18) -- "everything but the youngest 18 operations", i.e.
+    // but the 3 x 6 stores of this iteration's steps, has completed.  The rows had three steps of arithmetic to arrive,
+    // the wait never touches a store younger than three steps, and no load is in flight across the loop's back edge
+    // (where the compiler's wait-count bookkeeping would otherwise fall back to a wait for nearly every store).
+    float4 a0 = fetch(0), a1 = fetch(1), a2 = fetch(2);
+    asm volatile("" :: "v"(a0.x), "v"(a0.y), "v"(a0.z), "v"(a0.w), "v"(a1.x), "v"(a1.y), "v"(a1.z), "v"(a1.w), "v"(a2.x),
+                       "v"(a2.y), "v"(a2.z), "v"(a2.w) : "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int t = 0; t < K; t += 3) {
+        const float4 b0 = fetch(t + 3), b1 = fetch(t + 4), b2 = fetch(t + 5);
+        do_step(t, a0);
+        if (t + 1 >= K) break;
+        do_step(t + 1, a1);
+        if (t + 2 >= K) break;
+        do_step(t + 2, a2);
+        asm volatile("" :: "v"(b0.x), "v"(b0.y), "v"(b0.z), "v"(b0.w), "v"(b1.x), "v"(b1.y), "v"(b1.z), "v"(b1.w), "v"(b2.x),
+                           "v"(b2.y), "v"(b2.z), "v"(b2.w) : "memory");
+        a0 = b0; a1 = b1; a2 = b2;
+    }
+    if (L.active) store_carry<PID>(S, L, c);
+}
+
+// ------------------------------------------------------------------------------------------------
 // masked reset (envs/BaseAviary.py:451-477)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void gpd_reset_kernel(const GpdState S, const float* __restrict__ init_pose,
@@ -1195,7 +1309,7 @@ __global__ __launch_bounds__(kBlock) void gpd_state20_kernel(const GpdState S, c
     w[4] = make_float4(l0, l1, l2, l3);
 }
 
-template <bool PID, bool EXT, int AW>
+template <bool PID, bool EXT, int AW, int ACT>
 hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const GpdState& S, const GpdStepCfg& C,
                        const Span& T, const float* action, const float* target_pos, const float* init_pose,
                        float* obs12, float* reward, uint8_t* terminated, uint8_t* truncated, float* term_obs12) {
@@ -1216,9 +1330,15 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
         Span Tr = T;
         Tr.ring = (!multi && grid.x <= 2u * 256u) ? 4 : 2;          // <= 2 workgroups per CU: LDS is not what limits occupancy
         const size_t lds = static_cast<size_t>(Tr.ring) * kSlotBytes;
+        static const bool store_wave_variant = getenv("GPD_ROLLOUT_STOREWAVE") != nullptr;   // A/B switch, diagnostics only
         if (multi) {
             hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, true, AW>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
                                action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+        } else if (!PID && !store_wave_variant && term_obs12 == nullptr) {
+            // (DSLPID action types keep the store-wave kernel: three unrolled copies of their ~2x longer step body do
+            // not sit well in the instruction cache -- measured 1.50 vs 1.47 us per step)
+            hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT>), grid, dim3(kBlock), 0, st, P, S, C, Tr, action, target_pos,
+                               init_pose, obs12, reward, terminated, truncated, term_obs12);
         } else {
             hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, false, AW>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
                                action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
@@ -1264,15 +1384,21 @@ int step_impl(const char* who, const GpdParams* params, const GpdState* state, c
     // task NONE never uses the target: hand the kernel a readable dummy so that its load section is branch-free
     if (cfg->task == GPD_TASK_NONE) { target_pos = state->kin; c.target_per_env = 0; }
     hipError_t e;
-#define GPD_LAUNCH(PID_, EXT_, AW_)                                                                                  \
-    launch_step<PID_, EXT_, AW_>(multi, st, *params, *state, c, T, action, target_pos, init_pose, obs12, reward, \
-                                 terminated, truncated, term_obs12)
+#define GPD_LAUNCH(PID_, EXT_, AW_, ACT_)                                                                            \
+    launch_step<PID_, EXT_, AW_, ACT_>(multi, st, *params, *state, c, T, action, target_pos, init_pose, obs12, reward, \
+                                       terminated, truncated, term_obs12)
     switch (cfg->act_type) {
-        case GPD_ACT_PID: e = ext ? GPD_LAUNCH(true, true, 3) : GPD_LAUNCH(true, false, 3); break;
-        case GPD_ACT_VEL: e = ext ? GPD_LAUNCH(true, true, 4) : GPD_LAUNCH(true, false, 4); break;
-        case GPD_ACT_ONE_D_PID: e = ext ? GPD_LAUNCH(true, true, 1) : GPD_LAUNCH(true, false, 1); break;
-        case GPD_ACT_ONE_D_RPM: e = ext ? GPD_LAUNCH(false, true, 1) : GPD_LAUNCH(false, false, 1); break;
-        default: e = ext ? GPD_LAUNCH(false, true, 4) : GPD_LAUNCH(false, false, 4); break;
+        case GPD_ACT_PID: e = ext ? GPD_LAUNCH(true, true, 3, GPD_ACT_PID) : GPD_LAUNCH(true, false, 3, GPD_ACT_PID); break;
+        case GPD_ACT_VEL: e = ext ? GPD_LAUNCH(true, true, 4, GPD_ACT_VEL) : GPD_LAUNCH(true, false, 4, GPD_ACT_VEL); break;
+        case GPD_ACT_ONE_D_PID:
+            e = ext ? GPD_LAUNCH(true, true, 1, GPD_ACT_ONE_D_PID) : GPD_LAUNCH(true, false, 1, GPD_ACT_ONE_D_PID); break;
+        case GPD_ACT_ONE_D_RPM:
+            e = ext ? GPD_LAUNCH(false, true, 1, GPD_ACT_ONE_D_RPM) : GPD_LAUNCH(false, false, 1, GPD_ACT_ONE_D_RPM); break;
+        case GPD_ACT_RAW_RPM:
+            e = ext ? GPD_LAUNCH(false, true, 4, GPD_ACT_RAW_RPM) : GPD_LAUNCH(false, false, 4, GPD_ACT_RAW_RPM); break;
+        case GPD_ACT_DIRECT_RPM:
+            e = ext ? GPD_LAUNCH(false, true, 4, GPD_ACT_DIRECT_RPM) : GPD_LAUNCH(false, false, 4, GPD_ACT_DIRECT_RPM); break;
+        default: e = ext ? GPD_LAUNCH(false, true, 4, GPD_ACT_RPM) : GPD_LAUNCH(false, false, 4, GPD_ACT_RPM); break;
     }
 #undef GPD_LAUNCH
     if (e != hipSuccess) return hip_fail(e, who);

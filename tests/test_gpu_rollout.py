@@ -36,13 +36,16 @@ RAGGED = [  # act, flags, D, S, model, E, K: ragged last workgroups, whole-aviar
 ]
 
 
+@pytest.mark.parametrize("keep_term", [True, False])
 @pytest.mark.parametrize("act,flags,D,S,model,E,K", [c + (1536 // c[2], 24) for c in CASES] + RAGGED)
-def test_rollout_is_bitwise_k_steps(gpu_device, act, flags, D, S, model, E, K):
+def test_rollout_is_bitwise_k_steps(gpu_device, act, flags, D, S, model, E, K, keep_term):
     """Same state, same actions: one rollout of K steps == K single-step launches, bit for bit, including the
     same-step auto-reset (short episodes so that resets happen inside the rollout), the terminal observations,
-    the DSLPID members, last RPMs and step counters."""
+    the DSLPID members, last RPMs and step counters.  `keep_term` selects the kernel: single-drone aviaries without
+    terminal observations and without DSLPID run `gpd_rollout1_kernel` (no helper wave; lanes of a ragged last
+    workgroup are clones of drone 0), everything else the compute-wave + store-wave kernel."""
     rng = np.random.default_rng(zlib.crc32(repr((act, flags, D, S, model)).encode()))
-    a, b = _pair(act, flags, D, S, model, gpu_device, E, rng)
+    a, b = _pair(act, flags, D, S, model, gpu_device, E, rng, keep_term=keep_term)
     for c in (a, b):   # episodes of 10 physics steps -> several resets within K steps
         c._cfg.trunc_counter = 10
     # give the state some velocity so the PID memories / drag see non-trivial values
@@ -54,7 +57,8 @@ def test_rollout_is_bitwise_k_steps(gpu_device, act, flags, D, S, model, E, K):
     for k in range(K):
         o, r, te, tr = a.step(acts[k])
         obs_s.append(o.clone()); rew_s.append(r.clone()); te_s.append(te.clone()); tr_s.append(tr.clone())
-        tobs_s.append(a.term_obs12.clone())
+        if keep_term:
+            tobs_s.append(a.term_obs12.clone())
     obs, rew, te, tr = b.rollout(acts)
     assert act == "raw_rpm" or K * S <= 10 or torch.stack(tr_s).any(), "test must exercise the auto-reset"
     assert torch.equal(torch.stack(obs_s), obs)
@@ -64,6 +68,8 @@ def test_rollout_is_bitwise_k_steps(gpu_device, act, flags, D, S, model, E, K):
         x, y = getattr(a, name), getattr(b, name)
         if x is not None:
             assert torch.equal(x, y), name
+    if not keep_term:
+        return
     # terminal observations: rollout row t holds the rows written at step t; the single-step buffer accumulates
     tob = b._rollout_buf[4]
     done = (torch.stack(te_s) | torch.stack(tr_s))                                     # [K, E]
