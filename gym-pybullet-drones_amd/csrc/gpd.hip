@@ -672,8 +672,7 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
             const char* src = reinterpret_cast<const char*>(sh_rows + wave0 * 12);
             char* dst = reinterpret_cast<char*>(obs12) + static_cast<size_t>(n0) * 48u;
             const uint32_t off = static_cast<uint32_t>(tid & 63) * 16u;
-            __builtin_amdgcn_s_waitcnt(0xC07F);                       // this wave's rows are in LDS (same wave: no barrier)
-            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_wave_barrier();                          // same wave: the LDS executes its instructions in order
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const float4 v = *reinterpret_cast<const float4*>(src + off + j * 1024);
@@ -1021,12 +1020,13 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
         StepOut out;
         env_step<PID, EXT, false, AW, ACT>(P, C, flags, 1, L, act, tgx, tgy, tgz, true, ipose, ip[0], ip[1], ip[2], ip[3],
                                            ip[4], ip[5], ip[6], dummy_lds, dummy_lds, c, out);
-        // row -> the wave's LDS patch -> three coalesced bursts (same wave: program order + an LDS wait, no barrier)
+        // row -> the wave's LDS patch -> three coalesced bursts.  Same wave on both sides: the LDS executes a wave's
+        // instructions in order, so the reads below see the writes without any wait or barrier (the wave_barrier only
+        // pins the order for the compiler).
         float4* mine = reinterpret_cast<float4*>(sh_rows + tid * 12);
         mine[0] = make_float4(out.o[0], out.o[1], out.o[2], out.o[3]);
         mine[1] = make_float4(out.o[4], out.o[5], out.o[6], out.o[7]);
         mine[2] = make_float4(out.o[8], out.o[9], out.o[10], out.o[11]);
-        __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
         char* og = reinterpret_cast<char*>(obs12 + t * T.obs_stride);
 #pragma unroll

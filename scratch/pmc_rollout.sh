@@ -11,7 +11,7 @@ import csv, glob, collections
 agg = collections.defaultdict(list)
 for f in glob.glob("gpurun_out/pmcr_$tag/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "gpd_step_kernel" in row["Kernel_Name"] or "gpd_rollout_kernel" in row["Kernel_Name"]:
+        if "gpd_step_kernel" in row["Kernel_Name"] or "gpd_rollout" in row["Kernel_Name"]:
             agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, v in sorted(agg.items()):
     print("$tag", k, "mean per dispatch %.6g" % (sum(v)/len(v)), "n", len(v))
