@@ -1045,20 +1045,34 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     // but the 3 x 6 stores of this iteration's steps, has completed.  The rows had three steps of arithmetic to arrive,
     // the wait never touches a store younger than three steps, and no load is in flight across the loop's back edge
     // (where the compiler's wait-count bookkeeping would otherwise fall back to a wait for nearly every store).
-    float4 a0 = fetch(0), a1 = fetch(1), a2 = fetch(2);
-    asm volatile("" :: "v"(a0.x), "v"(a0.y), "v"(a0.z), "v"(a0.w), "v"(a1.x), "v"(a1.y), "v"(a1.z), "v"(a1.w), "v"(a2.x),
-                       "v"(a2.y), "v"(a2.z), "v"(a2.w) : "memory");
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    for (int t = 0; t < K; t += 3) {
-        const float4 b0 = fetch(t + 3), b1 = fetch(t + 4), b2 = fetch(t + 5);
-        do_step(t, a0);
-        if (t + 1 >= K) break;
-        do_step(t + 1, a1);
-        if (t + 2 >= K) break;
-        do_step(t + 2, a2);
-        asm volatile("" :: "v"(b0.x), "v"(b0.y), "v"(b0.z), "v"(b0.w), "v"(b1.x), "v"(b1.y), "v"(b1.z), "v"(b1.w), "v"(b2.x),
-                           "v"(b2.y), "v"(b2.z), "v"(b2.w) : "memory");
-        a0 = b0; a1 = b1; a2 = b2;
+    if (!PID) {
+        float4 a0 = fetch(0), a1 = fetch(1), a2 = fetch(2);
+        asm volatile("" :: "v"(a0.x), "v"(a0.y), "v"(a0.z), "v"(a0.w), "v"(a1.x), "v"(a1.y), "v"(a1.z), "v"(a1.w), "v"(a2.x),
+                           "v"(a2.y), "v"(a2.z), "v"(a2.w) : "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        for (int t = 0; t < K; t += 3) {
+            const float4 b0 = fetch(t + 3), b1 = fetch(t + 4), b2 = fetch(t + 5);
+            do_step(t, a0);
+            if (t + 1 >= K) break;
+            do_step(t + 1, a1);
+            if (t + 2 >= K) break;
+            do_step(t + 2, a2);
+            asm volatile("" :: "v"(b0.x), "v"(b0.y), "v"(b0.z), "v"(b0.w), "v"(b1.x), "v"(b1.y), "v"(b1.z), "v"(b1.w),
+                               "v"(b2.x), "v"(b2.y), "v"(b2.z), "v"(b2.w) : "memory");
+            a0 = b0; a1 = b1; a2 = b2;
+        }
+    } else {
+        // DSLPID action types: the step body is ~2x longer (a row arrives within one step) and three copies of it would
+        // not sit well in the instruction cache -- one step per iteration, the next row claimed with an exact vmcnt(6)
+        float4 a = fetch(0);
+        asm volatile("" :: "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w) : "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        for (int t = 0; t < K; ++t) {
+            const float4 b = fetch(t + 1);
+            do_step(t, a);
+            asm volatile("" :: "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w) : "memory");
+            a = b;
+        }
     }
     if (L.active) store_carry<PID>(S, L, c);
 }
@@ -1334,9 +1348,7 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
         if (multi) {
             hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, true, AW>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
                                action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
-        } else if (!PID && !store_wave_variant && term_obs12 == nullptr) {
-            // (DSLPID action types keep the store-wave kernel: three unrolled copies of their ~2x longer step body do
-            // not sit well in the instruction cache -- measured 1.50 vs 1.47 us per step)
+        } else if (!store_wave_variant && term_obs12 == nullptr) {
             hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT>), grid, dim3(kBlock), 0, st, P, S, C, Tr, action, target_pos,
                                init_pose, obs12, reward, terminated, truncated, term_obs12);
         } else {
