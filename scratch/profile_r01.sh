@@ -29,8 +29,8 @@ def stats(tag):
     return []
 for tag in ("trace_default", "trace_hover4m", "trace_hover16m"):
     out[tag] = stats(tag)
-for run, kern in (("hover65536_rollout", "gpd_rollout_kernel"), ("hover65536_step", "gpd_step_kernel"),
-                  ("hover4m_rollout", "gpd_rollout_kernel"), ("hover16m_step", "gpd_step_kernel")):
+for run, kern in (("hover65536_rollout", "gpd_rollout"), ("hover65536_step", "gpd_step_kernel"),
+                  ("hover4m_rollout", "gpd_rollout"), ("hover16m_step", "gpd_step_kernel")):
     rec = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         vals = []
