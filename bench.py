@@ -149,43 +149,58 @@ def measure(mode, args, env, actions, gather, device, world, POOL):
         if gather is not None:
             gather(core.obs12)
 
-    gather_k = None
+    # exactly K timed steps: K // POOL full groups (a POOL-step rollout / a replay of the POOL-step graph) plus one
+    # group of K % POOL steps (a shorter rollout / a second, shorter graph)
+    K, W = args.steps, args.warmup
+    rem = K % POOL if mode != "eager" else 0
+    if mode != "eager":
+        W = (W + POOL - 1) // POOL * POOL          # (untimed warm-up: whole groups only, reported as run)
+
+    gathers = {}
     if mode == "rollout" and gather is not None:
-        gather_k = gdist.ObsAllGather(POOL * core.N, 12, device=device)   # one larger collective per rollout
+        for n in {POOL, rem} - {0}:
+            gathers[n] = gdist.ObsAllGather(n * core.N, 12, device=device)   # one larger collective per rollout
 
-    def one_rollout():
-        obs = core.rollout(actions, update_latest=False)[0]
-        if gather_k is not None:
-            gather_k(obs.view(-1, 12))
+    def one_rollout(n):
+        obs = core.rollout(actions[:n], update_latest=False)[0]
+        if n in gathers:
+            gathers[n](obs.view(-1, 12))
 
-    graph = None
+    graphs = {}
     if mode == "rollout":
-        one_rollout()
+        one_rollout(POOL)
+        if rem:
+            one_rollout(rem)
     else:
-        for i in range(min(args.warmup, 64)):
+        for i in range(min(max(W, 1), 64)):
             one_step(i)
     torch.cuda.synchronize()
     if mode == "graph":
-        stream = torch.cuda.Stream(device)
-        stream.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(stream):
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
-                for i in range(POOL):
-                    one_step(i)
-        torch.cuda.current_stream(device).wait_stream(stream)
+        for n in {POOL, rem} - {0}:
+            stream = torch.cuda.Stream(device)
+            stream.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(stream):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    for i in range(n):
+                        one_step(i)
+            torch.cuda.current_stream(device).wait_stream(stream)
+            graphs[n] = g
 
     def run(k):
         if mode == "eager":
             for i in range(k):
                 one_step(i)
-        else:
-            assert k % POOL == 0
-            for _ in range(k // POOL):
-                one_rollout() if mode == "rollout" else graph.replay()
+            return
+        for n in [POOL] * (k // POOL) + ([k % POOL] if k % POOL else []):
+            if mode == "rollout":
+                one_rollout(n)
+            elif n in graphs:
+                graphs[n].replay()
+            else:                       # (a warm-up remainder the timed region does not need a graph for)
+                for i in range(n):
+                    one_step(i)
 
-    K = args.steps if mode == "eager" else (args.steps + POOL - 1) // POOL * POOL
-    W = args.warmup if mode == "eager" else (args.warmup + POOL - 1) // POOL * POOL
     run(W)
     torch.cuda.synchronize()
     if world > 1:
@@ -202,17 +217,23 @@ def measure(mode, args, env, actions, gather, device, world, POOL):
     t1 = time.perf_counter()
     wall = gdist.max_over_ranks(t1 - t0, device=device)
     ev_ms = ev0.elapsed_time(ev1)
-    launches = K // POOL if mode == "rollout" else K
-    bytes_launch = core.bytes_per_rollout(POOL) if mode == "rollout" else core.bytes_per_step()
+    # roofline of the dominant kernel: algorithmic bytes of all launches of the timed region / its HIP-event time
+    if mode == "rollout":
+        launches = K // POOL + (1 if rem else 0)
+        bytes_total = (K // POOL) * core.bytes_per_rollout(POOL) + (core.bytes_per_rollout(rem) if rem else 0)
+    else:
+        launches, bytes_total = K, K * core.bytes_per_step()
+    bytes_launch = bytes_total / launches
     launch_us = ev_ms * 1e3 / launches
-    achieved = bytes_launch / (launch_us * 1e-6) / 1e9
+    achieved = bytes_total / (ev_ms * 1e-3) / 1e9
     n_total = core.N * world
-    steps_per_launch = POOL if mode == "rollout" else 1
+    steps_per_launch = K / launches
     return {
         "K": K, "W": W, "wall": wall, "value": n_total * core.S * K / wall, "env_steps_per_s": n_total * K / wall,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "gpd_rollout_kernel" if mode == "rollout" else "gpd_step_kernel",
+                     "kernel": ("gpd_rollout1_kernel" if core.D == 1 else "gpd_rollout_kernel") if mode == "rollout"
+                     else "gpd_step_kernel",
                      "env_steps_per_launch": steps_per_launch, "bytes_per_launch": bytes_launch,
                      "bytes_per_drone_per_env_step": bytes_launch / (core.N * steps_per_launch),
                      "launch_us_hip_events": launch_us},

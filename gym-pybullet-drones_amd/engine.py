@@ -221,8 +221,10 @@ class SimCore:
                                       _ptr(tobs), self._stream())
         _native.check(rc, "gpd_rollout")
         if not last_only and update_latest:
-            self.obs12.copy_(obs[K - 1]); self.reward.copy_(rew[K - 1])
-            self.terminated.copy_(term[K - 1]); self.truncated.copy_(trunc[K - 1])
+            self.obs12.copy_(obs[K - 1])
+            self.reward.copy_(rew[K - 1])
+            self.terminated.copy_(term[K - 1])
+            self.truncated.copy_(trunc[K - 1])
         return obs, rew, term, trunc
 
     # ---- action history / full KIN observation rows (envs/BaseRLAviary.py:65-67, 153-154, 187, 307-320) ----
@@ -266,15 +268,20 @@ class SimCore:
         return out
 
     def _rollout_buffers(self, K: int):
-        buf = getattr(self, "_rollout_buf", None)
-        if buf is None or buf[0].shape[0] != K:
+        """Persistent output buffers of a K-step rollout (kept per K: the two most recent lengths stay allocated)."""
+        cache = self.__dict__.setdefault("_rollout_cache", {})
+        buf = cache.get(K)
+        if buf is None:
             dev = self.device
             buf = (torch.zeros((K, self.N, 12), dtype=torch.float32, device=dev),
                    torch.zeros((K, self.E), dtype=torch.float32, device=dev),
                    torch.zeros((K, self.E), dtype=torch.bool, device=dev),
                    torch.zeros((K, self.E), dtype=torch.bool, device=dev),
                    torch.zeros((K, self.N, 12), dtype=torch.float32, device=dev) if self.term_obs12 is not None else None)
-            self._rollout_buf = buf
+            while len(cache) >= 2:
+                cache.pop(next(iter(cache)))
+            cache[K] = buf
+        self._rollout_buf = buf
         return buf
 
     def bytes_per_rollout(self, K: int, action_stride_zero: bool = False, last_only: bool = False) -> int:
