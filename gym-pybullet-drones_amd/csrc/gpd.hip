@@ -71,6 +71,9 @@ struct Mat3 {
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+// exp(x) for x <= 0 as 2^(x log2 e): v_exp_f32 (1 ulp) after one rounded product -- relative error <= (1 + |x|) 6e-8,
+// two instructions instead of OCML's ~20.  Used for the downwash Gaussian (evaluated for every pair of an aviary).
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
 // The three functions below are inlined at several places of the step kernel (rpy at the top of a step for
 // DSLPID, at its tail for the observation, after an auto-reset).  FMA contraction is switched OFF inside them
@@ -367,6 +370,8 @@ struct Lane {             // which drone a lane works on
     int tid;              // compute-lane index inside the workgroup (0 .. kBlock-1)
     int le, d;            // aviary / drone-in-aviary inside the workgroup
     bool active;
+    bool shfl;            // MULTI: the D drones of an aviary are D aligned lanes of ONE wave (D a power of two <= 64):
+                          // they exchange through a wave-local LDS patch, without workgroup barriers
 };
 
 struct Carry {            // what a drone carries from one env step to the next
@@ -449,21 +454,33 @@ __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C
         float dw = (EXT && !MULTI) ? c.dw_in : 0.0f;
         if (EXT && MULTI && (flags & GPD_PHYS_DW)) {
             // every drone sees the same pre-sub-step snapshot of its aviary (BaseAviary.py:346-347,798)
-            wg_barrier();
-            sh_pos[L.tid] = k.px; sh_pos[kBlock + L.tid] = k.py; sh_pos[2 * kBlock + L.tid] = k.pz;
-            wg_barrier();
-            const int base = L.le * D;
-            for (int j = 0; j < D; ++j) {
-                const float dz = sh_pos[2 * kBlock + base + j] - k.pz;
-                const float ddx = sh_pos[base + j] - k.px, ddy = sh_pos[kBlock + base + j] - k.py;
+            auto wake_of = [&](float xj, float yj, float zj) {   // drone j above this one: its wake's push (:798-804)
+                const float dz = zj - k.pz;
+                const float ddx = xj - k.px, ddy = yj - k.py;
                 const float dxy2 = fmaf(ddy, ddy, ddx * ddx);
                 if (dz > 0.0f && dxy2 < 100.0f) {            // dz > 0 and dxy < 10 m
                     const float ratio = (0.25f * P.prop_radius) * fast_rcp(dz);
                     const float alpha = P.dw_coeff[0] * (ratio * ratio);
                     const float beta = fmaf(P.dw_coeff[1], dz, P.dw_coeff[2]);
                     const float ib = fast_rcp(beta);
-                    dw -= alpha * expf(-0.5f * (dxy2 * (ib * ib)));
+                    dw -= alpha * fast_exp(-0.5f * (dxy2 * (ib * ib)));
                 }
+            };
+            if (L.shfl) {
+                // the aviary is D aligned lanes of THIS wave: one 16-byte LDS write per lane, one broadcast read per
+                // mate, and neither a barrier nor a wait in between (the LDS executes a wave's instructions in order)
+                float4* sp = reinterpret_cast<float4*>(sh_pos);
+                __builtin_amdgcn_wave_barrier();
+                sp[L.tid] = make_float4(k.px, k.py, k.pz, 0.0f);
+                __builtin_amdgcn_wave_barrier();
+                const int base = L.le * D;
+                for (int j = 0; j < D; ++j) { const float4 o = sp[base + j]; wake_of(o.x, o.y, o.z); }
+            } else {
+                wg_barrier();
+                sh_pos[L.tid] = k.px; sh_pos[kBlock + L.tid] = k.py; sh_pos[2 * kBlock + L.tid] = k.pz;
+                wg_barrier();
+                const int base = L.le * D;
+                for (int j = 0; j < D; ++j) wake_of(sh_pos[base + j], sh_pos[kBlock + base + j], sh_pos[2 * kBlock + base + j]);
             }
         }
         substep<EXT>(P, C.pyb_dt, flags, g, drag_sum, dw, k, avx, avy, avz);
@@ -488,13 +505,26 @@ __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C
             term = my_dist < C.term_dist;
             trunc = my_out || (c.counter > C.trunc_counter);   // tested BEFORE the increment (App. B.7)
         } else {
-            wg_barrier();
-            sh_red[L.tid] = my_rew; sh_red[kBlock + L.tid] = my_dist; sh_red[2 * kBlock + L.tid] = my_out ? 1.0f : 0.0f;
-            wg_barrier();
-            const int base = L.le * D;
             float r = 0.0f, dsum = 0.0f, o = 0.0f;
-            for (int j = 0; j < D; ++j) {                      // sequential, like the reference's loops
-                r += sh_red[base + j]; dsum += sh_red[kBlock + base + j]; o += sh_red[2 * kBlock + base + j];
+            const float my_o = my_out ? 1.0f : 0.0f;
+            if (L.shfl) {                                      // wave-local LDS exchange, as for the downwash
+                float4* sr = reinterpret_cast<float4*>(sh_red);
+                __builtin_amdgcn_wave_barrier();
+                sr[L.tid] = make_float4(my_rew, my_dist, my_o, 0.0f);
+                __builtin_amdgcn_wave_barrier();
+                const int base = L.le * D;
+                for (int j = 0; j < D; ++j) {                  // sequential, like the reference's loops
+                    const float4 v = sr[base + j];
+                    r += v.x; dsum += v.y; o += v.z;
+                }
+            } else {
+                wg_barrier();
+                sh_red[L.tid] = my_rew; sh_red[kBlock + L.tid] = my_dist; sh_red[2 * kBlock + L.tid] = my_o;
+                wg_barrier();
+                const int base = L.le * D;
+                for (int j = 0; j < D; ++j) {                  // sequential, like the reference's loops
+                    r += sh_red[base + j]; dsum += sh_red[kBlock + base + j]; o += sh_red[2 * kBlock + base + j];
+                }
             }
             rew = r;
             term = dsum < C.term_dist;
@@ -635,9 +665,10 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     L.le = MULTI ? (tid < lanes ? tid / D : 0) : tid;
     L.d = MULTI ? (L.active ? tid - L.le * D : 0) : 0;
     L.env = MULTI ? (L.active ? blockIdx.x * (lanes / D) + L.le : 0u) : L.n;
+    L.shfl = MULTI && D <= 64 && (D & (D - 1)) == 0;
 
-    __shared__ float sh_pos[MULTI ? 3 * kBlock : 1];         // downwash: positions of the env's drones
-    __shared__ float sh_red[MULTI ? 3 * kBlock : 1];         // reward | distance | out-of-bounds per drone
+    __shared__ __attribute__((aligned(16))) float sh_pos[MULTI ? 4 * kBlock : 4];   // downwash: positions of the env's drones
+    __shared__ __attribute__((aligned(16))) float sh_red[MULTI ? 4 * kBlock : 4];   // reward | distance | out-of-bounds per drone
     __shared__ __attribute__((aligned(16))) float sh_rows[kBlock * 12];   // obs rows, for the coalesced store of large batches
 
     const uint32_t flags = EXT ? C.physics_flags : 0u;
@@ -755,27 +786,30 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
     const int envs_valid = lanes_valid / D;
     const int K = T.num_steps;
     const uint32_t flags = EXT ? C.physics_flags : 0u;
+    // multi-drone aviaries that fit D aligned lanes of a wave exchange wave-locally: no barrier inside a step
+    const bool shfl = MULTI && D <= 64 && (D & (D - 1)) == 0;
+    const bool use_flags = !MULTI || shfl;                           // hand-over protocol: LDS flags, or one barrier per step
     // workgroup barriers inside one env step (env_step): the store wave has to take part in each of them
-    const int step_barriers = MULTI ? (((flags & GPD_PHYS_DW) ? 2 * C.substeps : 0) + (C.task != GPD_TASK_NONE ? 2 : 0)) : 0;
+    const int step_barriers = (MULTI && !shfl) ? (((flags & GPD_PHYS_DW) ? 2 * C.substeps : 0) + (C.task != GPD_TASK_NONE ? 2 : 0)) : 0;
 
     // Output ring: slot = step & (ring-1).  Single-drone aviaries hand over through flags (no barrier: a compute
     // wave never waits for its siblings, and only waits for the store wave when it is ring-1 steps ahead);
     // multi-drone aviaries already synchronise the workgroup inside every step (downwash snapshot, aviary
     // reductions) and keep the simpler two-slot, one-more-barrier-per-step hand-off.
     extern __shared__ __attribute__((aligned(16))) char sh_ring[];
-    const int ring = MULTI ? 2 : T.ring;
+    const int ring = use_flags ? T.ring : 2;
     auto slot_obs = [&](int b) { return reinterpret_cast<float*>(sh_ring + b * kSlotBytes); };
     auto slot_rew = [&](int b) { return reinterpret_cast<float*>(sh_ring + b * kSlotBytes + kBlock * 48); };
     auto slot_term = [&](int b) { return reinterpret_cast<uint8_t*>(sh_ring + b * kSlotBytes + kBlock * 52); };
     auto slot_trunc = [&](int b) { return reinterpret_cast<uint8_t*>(sh_ring + b * kSlotBytes + kBlock * 53); };
     __shared__ __attribute__((aligned(16))) int sh_prog[4];          // steps written, per compute wave
     __shared__ int sh_drained;                                       // steps copied to HBM by the store wave
-    __shared__ float sh_pos[MULTI ? 3 * kBlock : 1];
-    __shared__ float sh_red[MULTI ? 3 * kBlock : 1];
-    if (!MULTI) {
+    __shared__ __attribute__((aligned(16))) float sh_pos[MULTI ? 4 * kBlock : 4];
+    __shared__ __attribute__((aligned(16))) float sh_red[MULTI ? 4 * kBlock : 4];
+    if (use_flags) {
         if (tid < 4) sh_prog[tid] = 0;
         if (tid == 4) sh_drained = 0;
-        wg_barrier();                                                // the only barrier of the single-drone rollout
+        wg_barrier();                                                // the only barrier of a flag-synchronised rollout
     }
 
     if (tid >= kBlock) {
@@ -830,7 +864,7 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
             }
         };
         __builtin_amdgcn_s_setprio(0);                               // fills the issue gaps of the compute wave it shares a SIMD with
-        if (!MULTI) {
+        if (use_flags) {
             for (int t = 0; t < K; ++t) {
                 for (;;) {                                           // until all four compute waves have written step t
                     const i4v pr = lds_peek4(sh_prog);
@@ -862,6 +896,7 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
     L.le = MULTI ? (tid < lanes ? tid / D : 0) : tid;
     L.d = MULTI ? (L.active ? tid - L.le * D : 0) : 0;
     L.env = MULTI ? (L.active ? env_base + L.le : 0u) : L.n;
+    L.shfl = shfl;
 
     Carry c;
     float tgx, tgy, tgz, ip[7];
@@ -891,7 +926,7 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
         env_step<PID, EXT, MULTI, AW>(P, C, flags, D, L, act, tgx, tgy, tgz, true, ipose, ip[0], ip[1], ip[2], ip[3], ip[4],
                                       ip[5], ip[6], sh_pos, sh_red, c, out);
         const int b = t & (ring - 1);
-        if (!MULTI && t - ring + 1 > drained_seen) {                 // slot b may still hold step t-ring: has it been drained?
+        if (use_flags && t - ring + 1 > drained_seen) {              // slot b may still hold step t-ring: has it been drained?
             // (the flag is re-read only when the last value seen does not already clear this step: the store wave
             // normally runs one step behind, so one read clears the next ring-1 steps)
             while ((drained_seen = __builtin_amdgcn_readfirstlane(lds_peek(&sh_drained))) < t - ring + 1)
@@ -917,7 +952,7 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
             asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16\n\t"
                          "global_store_dwordx4 %0, %3, off offset:32" :: "v"(row), "v"(q0), "v"(q1), "v"(q2) : "memory");
         }
-        if (MULTI) wg_barrier();                                     // end of step t
+        if (!use_flags) wg_barrier();                                // end of step t
         else lds_poke(&sh_prog[tid >> 6], t + 1);                    // this wave's rows of step t are in the slot
     };
     // (a0 and a1 are requested AFTER the wait above, so that the loop is entered in the state every iteration
@@ -979,7 +1014,7 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     const int K = T.num_steps;
     const uint32_t flags = EXT ? C.physics_flags : 0u;
     Lane L;
-    L.tid = tid; L.le = tid; L.d = 0;
+    L.tid = tid; L.le = tid; L.d = 0; L.shfl = false;
     L.active = n_raw < N;
     L.n = L.active ? n_raw : 0u;
     L.env = L.n;
@@ -1254,7 +1289,7 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, in
                         const float arg = 0.5f * (dxy2 * (ib * ib));
                         // exp(-40) = 4e-18: below the 2^-31 N the fixed-point sum resolves for any alpha < 1e8 N -- most
                         // candidates of the 3x3 cells end here without evaluating the exponential
-                        if (arg < 40.0f || alpha > 1.0e8f) acc += __float2ll_rn((alpha * expf(-arg)) * 1073741824.0f);
+                        if (arg < 40.0f || alpha > 1.0e8f) acc += __float2ll_rn((alpha * fast_exp(-arg)) * 1073741824.0f);
                     }
                 }
             }
@@ -1342,7 +1377,8 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
         const int lanes = multi ? (kBlock / C.drones_per_env) * C.drones_per_env : kBlock;
         const dim3 grid(static_cast<unsigned>((N + lanes - 1) / lanes));
         Span Tr = T;
-        Tr.ring = (!multi && grid.x <= 2u * 256u) ? 4 : 2;          // <= 2 workgroups per CU: LDS is not what limits occupancy
+        const bool shfl = multi && C.drones_per_env <= 64 && (C.drones_per_env & (C.drones_per_env - 1)) == 0;
+        Tr.ring = ((!multi || shfl) && grid.x <= 2u * 256u) ? 4 : 2;   // <= 2 workgroups per CU: LDS is not what limits occupancy
         const size_t lds = static_cast<size_t>(Tr.ring) * kSlotBytes;
         static const bool store_wave_variant = getenv("GPD_ROLLOUT_STOREWAVE") != nullptr;   // A/B switch, diagnostics only
         if (multi) {
