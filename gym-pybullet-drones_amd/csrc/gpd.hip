@@ -1199,10 +1199,13 @@ __global__ __launch_bounds__(kBlock) void gpd_hist_push_kernel(int K, uint32_t N
 // Downwash inside ONE aviary of any size (envs/BaseAviary.py:785-811): uniform 2-D grid, counting sort by cell,
 // 3x3 neighbourhood search.  Four small kernels per physics sub-step.
 // ------------------------------------------------------------------------------------------------
+// cell of a position: the grid is periodic (cells wrap around), so drones that leave the box the grid was laid over
+// keep spreading over all cells instead of piling up at its border; far-apart drones that alias into neighbouring
+// cells are rejected by the exact distance test
 __device__ __forceinline__ int cell_of(float x, float y, float inv_cell, float x0, float y0, int nx, int ny) {
-    int cx = static_cast<int>(floorf((x - x0) * inv_cell)), cy = static_cast<int>(floorf((y - y0) * inv_cell));
-    cx = cx < 0 ? 0 : (cx >= nx ? nx - 1 : cx);
-    cy = cy < 0 ? 0 : (cy >= ny ? ny - 1 : cy);
+    int cx = static_cast<int>(floorf((x - x0) * inv_cell)) % nx, cy = static_cast<int>(floorf((y - y0) * inv_cell)) % ny;
+    cx = cx < 0 ? cx + nx : cx;
+    cy = cy < 0 ? cy + ny : cy;
     return cy * nx + cx;
 }
 
@@ -1259,17 +1262,15 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, in
     const int cy = c / nx, cx = c - cy * nx;
     const int m0 = start[c], m1 = start[c + 1];            // the drones of this cell
     if (m0 == m1) return;
-    const int xa = cx > 0 ? cx - 1 : 0, xb = cx < nx - 1 ? cx + 1 : nx - 1;
     const float kr = 0.25f * P.prop_radius;
     for (int base = m0; base < m1; base += kBlock) {       // passes of 256 drones
         const int s = base + threadIdx.x;
         const bool have = s < m1;
         const float4 me = have ? sorted[s] : make_float4(0.0f, 0.0f, 3.0e38f, 0.0f);   // (no drone: nothing is above it)
         long long acc = 0;                                 // sum of contributions in units of 2^-30 N: order-independent
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int yy = cy + dy;
-            if (yy < 0 || yy >= ny) continue;              // (uniform)
-            const int t0 = start[yy * nx + xa], t1 = start[yy * nx + xb + 1];   // the 3 cells of a row are contiguous
+        for (int nb = 0; nb < 9; ++nb) {                   // the 3x3 neighbourhood, periodic (nx, ny >= 3: nine distinct cells)
+            const int yy = (cy + nb / 3 - 1 + ny) % ny, xx = (cx + nb % 3 - 1 + nx) % nx;
+            const int t0 = start[yy * nx + xx], t1 = start[yy * nx + xx + 1];
             for (int tb = t0; tb < t1; tb += kDwTile) {
                 const int cnt = min(kDwTile, t1 - tb);
                 __syncthreads();
@@ -1531,8 +1532,8 @@ int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, i
         return fail(GPD_EINVAL, "gpd_downwash_global: NULL argument");
     if (n <= 0 || ld < n) return fail(GPD_EINVAL, "gpd_downwash_global: need 0 < n <= ld");
     if (!(cell >= 10.0f)) return fail(GPD_EINVAL, "gpd_downwash_global: cell must be >= 10 m (the model's lateral cut-off)");
-    if (nx <= 0 || ny <= 0 || static_cast<int64_t>(nx) * ny > 65536)
-        return fail(GPD_ERANGE, "gpd_downwash_global: need 1 <= nx*ny <= 65536");
+    if (nx < 3 || ny < 3 || static_cast<int64_t>(nx) * ny > 65536)
+        return fail(GPD_ERANGE, "gpd_downwash_global: need nx, ny >= 3 (periodic 3x3 search) and nx*ny <= 65536");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int cells = nx * ny;
     const float inv_cell = 1.0f / cell;

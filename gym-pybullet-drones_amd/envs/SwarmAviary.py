@@ -5,7 +5,7 @@ The reference simulates one world per aviary and couples its drones only through
 physics sub-step, on the positions all drones had at the start of the sub-step (`:346-347`).  The fused step
 kernel covers aviaries of up to 256 drones (one workgroup, positions exchanged through LDS).  This class is the
 large-world counterpart: the swarm is stepped as N single-drone lanes of the same kernel, and
-the downwash force of each drone is computed per sub-step by `gpd_downwash_global` — uniform 10 m grid, counting
+the downwash force of each drone is computed per sub-step by `gpd_downwash_global` — uniform, periodic 10 m grid, counting
 sort by cell, 3×3-cell neighbourhood search, order-independent fixed-point accumulation — and handed to the step
 kernel as `state.dw_force`.
 
@@ -63,11 +63,11 @@ class SwarmAviary:
         lo = xyz[:, 0, :2].min(axis=0) - 2 * self.cell if world_min is None else np.asarray(world_min, dtype=np.float64)
         hi = xyz[:, 0, :2].max(axis=0) + 2 * self.cell if world_max is None else np.asarray(world_max, dtype=np.float64)
         self.x0, self.y0 = float(lo[0]), float(lo[1])
-        self.nx = max(1, int(np.ceil((hi[0] - lo[0]) / self.cell)))
-        self.ny = max(1, int(np.ceil((hi[1] - lo[1]) / self.cell)))
+        self.nx = max(3, int(np.ceil((hi[0] - lo[0]) / self.cell)))
+        self.ny = max(3, int(np.ceil((hi[1] - lo[1]) / self.cell)))
         while self.nx * self.ny > 65536:          # coarser cells keep the search exact (cell >= 10 m), only less selective
             self.cell *= 2
-            self.nx, self.ny = max(1, int(np.ceil((hi[0] - lo[0]) / self.cell))), max(1, int(np.ceil((hi[1] - lo[1]) / self.cell)))
+            self.nx, self.ny = max(3, int(np.ceil((hi[0] - lo[0]) / self.cell))), max(3, int(np.ceil((hi[1] - lo[1]) / self.cell)))
         cells = self.nx * self.ny
         i32 = dict(dtype=torch.int32, device=dev)
         self._count, self._start = torch.zeros(cells + 1, **i32), torch.zeros(cells + 1, **i32)

@@ -242,12 +242,13 @@ int gpd_full_obs(int32_t num_steps, int32_t n_drones, int32_t act_dim, int32_t h
  * with  dz = z_j - z_i > 0  and  dxy < 10 m:
  *     F_i = - sum_j  DW1 * (PROP_RADIUS / (4 dz))^2 * exp(-0.5 * (dxy / (DW2*dz + DW3))^2)        (body z of drone i)
  * by binning the drones into a uniform 2-D grid of `cell` >= 10 m squares (counting sort by cell) and searching
- * the 3x3 neighbourhood of each drone's cell.  Drones outside the grid are clamped into its border cells (still
- * exact: every candidate pair is distance-tested; only the pruning degrades).  The per-drone sum is accumulated
+ * the 3x3 neighbourhood of each drone's cell.  The grid is periodic: a drone outside the box the grid was laid over
+ * lands in the cell its coordinates wrap to (still exact: every candidate pair is distance-tested, aliased far-apart
+ * drones are rejected; the swarm may spread without piling up in border cells).  The per-drone sum is accumulated
  * in 64-bit fixed point (2^-30 N), so the result does not depend on the order the sort leaves the neighbours in.
  *
  *   kin, ld       the state block of gpd_step (rows 0..2 = positions are read)
- *   cell, x0, y0, nx, ny   grid: cell size [m] (>= 10), lower-left corner, cells per side (nx*ny <= 65536)
+ *   cell, x0, y0, nx, ny   grid: cell size [m] (>= 10), lower-left corner, cells per side (nx, ny >= 3, nx*ny <= 65536)
  *   cell_count    [nx*ny + 1] int32 scratch       cell_start  [nx*ny + 1] int32 scratch
  *   order         [n] int32 scratch (drone index of sorted slot)
  *   sorted_xyzc   [n][4] float scratch (x, y, z, cell id as int bits), sorted by cell
