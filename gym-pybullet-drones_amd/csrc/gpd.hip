@@ -2,11 +2,21 @@
 //
 // One wavefront lane per drone.  A lane loads its 13 kinematic floats from the structure-of-arrays
 // state (each field a contiguous float[N] => a wave's load of one field is one coalesced 256 B
-// transaction), keeps them in VGPRs across all `substeps` physics sub-steps, and stores them back
-// once; the per-airframe constants arrive BY VALUE in the kernel-argument segment and therefore
-// live in SGPRs (they are wave-uniform).  No MFMA: there is no dense contraction on this path.
+// transaction), keeps them in VGPRs across all physics sub-steps -- and, in a rollout, across all K env
+// steps of the launch -- and stores them back once; the per-airframe constants arrive BY VALUE in the
+// kernel-argument segment and therefore live in SGPRs (they are wave-uniform).  No MFMA: there is no
+// dense contraction on this path.
 //
-// What is fused (reference = utiasDSL/gym-pybullet-drones, gym_pybullet_drones/...):
+// Kernels:
+//   gpd_step_kernel      one env step per launch                                  (gpd_step)
+//   gpd_rollout1_kernel  K env steps per launch, single-drone aviaries            (gpd_rollout)
+//   gpd_rollout_kernel   K env steps per launch, compute waves + a store wave     (gpd_rollout: multi-drone
+//                        aviaries, terminal observations)
+//   gpd_full_obs_kernel / gpd_hist_push_kernel   action ring + full KIN rows      (gpd_full_obs)
+//   dwg_*_kernel         downwash inside one aviary of any size, grid binning     (gpd_downwash_global)
+//   gpd_reset_kernel, gpd_pid_kernel, gpd_state20_kernel
+//
+// What one env step fuses (env_step; reference = utiasDSL/gym-pybullet-drones, gym_pybullet_drones/...):
 //   action -> RPM                      envs/BaseRLAviary.py:187-239, envs/CtrlAviary.py:140
 //   DSLPID position + attitude loops   control/DSLPIDControl.py:187-259
 //   S x { forces/torques, Euler eqn, semi-implicit Euler, exact quaternion update }
@@ -18,14 +28,16 @@
 //   reward / terminated / truncated    envs/HoverAviary.py:68-117, envs/MultiHoverAviary.py:75-130
 //   step counter, same-step auto-reset envs/BaseAviary.py:382, 451-477
 //
-// Arithmetic: fp32, FMA contraction on (hipcc default), NO -ffast-math.  The kernel at N = 65 536 is
-// bound by the length of one wave's dependent VALU chain (one wave per SIMD), so the hot functions are
-// written for few instructions at <= 2 ulp instead of calling the branchy IEEE/OCML versions:
+// Arithmetic: fp32, NO -ffast-math, FP contraction OFF with every fused multiply-add written as fmaf() (a drone's
+// trajectory is bit-identical in every kernel variant, batch size and lane).  At N = 65 536 the kernels are
+// bound by the instruction issue of one wave per SIMD, so the hot functions are written for few instructions
+// at <= 2 ulp instead of calling the branchy IEEE/OCML versions:
 //   1/x, sqrt, 1/sqrt      v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 (1 ulp)
 //   quaternion exponential cos(t) and sin(t)/t as even polynomials in t^2 (no sqrt, no division, no
 //                          range reduction; |t| <= 1 rad per sub-step, exact OCML path beyond)
 //   atan2 / asin           one odd minimax polynomial on [0,1] (abs err 7e-8) + octant fix-up
-// Build: hipcc -O3 --offload-arch=gfx950 -fPIC -shared
+//   rotor thrusts          carried as deviations from the hover thrust (no cancellation near hover)
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -shared
 #include <hip/hip_runtime.h>
 
 #include <cstdio>

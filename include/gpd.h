@@ -22,8 +22,10 @@
  *   - drone n = env * drones_per_env + d (the D drones of one aviary are adjacent);
  *   - quaternions are (x, y, z, w), as in the reference's state vector
  *     (envs/BaseAviary.py:559);
- *   - all arithmetic is fp32 with FMA contraction, no -ffast-math; reciprocals/square roots are the
- *     1-ulp hardware instructions and atan2/asin/sin/cos are <= 2-ulp polynomials (csrc/gpd.hip).
+ *   - all arithmetic is fp32, no -ffast-math; FP contraction is off and every fused multiply-add is explicit in the
+ *     source, so a drone's trajectory is bit-identical in every kernel variant (gpd_step vs gpd_rollout, aviary
+ *     size, batch size, lane); reciprocals/square roots are the 1-ulp hardware instructions and
+ *     atan2/asin/sin/cos are <= 2-ulp polynomials (csrc/gpd.hip).
  */
 #ifndef GPD_H
 #define GPD_H
