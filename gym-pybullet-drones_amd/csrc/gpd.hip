@@ -863,9 +863,9 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
                 const uint32_t tv = reinterpret_cast<const uint32_t*>(slot_term(b))[m];
                 const uint32_t uv = reinterpret_cast<const uint32_t*>(slot_trunc(b))[m];
 #pragma unroll
-                for (int j = 0; j < 12; ++j) {
-                    f4u w = {v[j].x, v[j].y, v[j].z, v[j].w};
-                    *reinterpret_cast<f4u*>(og + lane16 + j * 1024) = w;
+                for (int j = 0; j < 12; ++j) {                       // (write-once streams: non-temporal)
+                    f4v w = {v[j].x, v[j].y, v[j].z, v[j].w};
+                    __builtin_nontemporal_store(w, reinterpret_cast<f4v*>(og + lane16 + j * 1024));
                 }
                 f4u w = {rv.x, rv.y, rv.z, rv.w};
                 *reinterpret_cast<f4u*>(reinterpret_cast<char*>(rg) + lane16) = w;
@@ -880,8 +880,8 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
 #pragma unroll
             for (int j = 0; j < 12; ++j) {
                 if (j * kStoreLanes + m < chunks) {
-                    f4u w = {v[j].x, v[j].y, v[j].z, v[j].w};
-                    *reinterpret_cast<f4u*>(og + lane16 + j * 1024) = w;
+                    f4v w = {v[j].x, v[j].y, v[j].z, v[j].w};
+                    __builtin_nontemporal_store(w, reinterpret_cast<f4v*>(og + lane16 + j * 1024));
                 }
             }
             for (int e = m; e < envs_valid; e += kStoreLanes) {
