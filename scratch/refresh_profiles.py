@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Copy the judged summaries of gpurun_out/prof_r01 (scratch/profile_r01.sh) and the bench JSON lines into profiles/."""
+import glob, json, os, shutil
+for f in glob.glob("profiles/r01_pmc_*") + glob.glob("profiles/r01_trace_*") + glob.glob("profiles/r01_bench_*") + ["profiles/r01_summary.json"]:
+    if os.path.exists(f): os.remove(f)
+for f in glob.glob("gpurun_out/prof_r01/*.csv"):
+    shutil.copy(f, "profiles/r01_" + os.path.basename(f))
+shutil.copy("gpurun_out/prof_r01/summary.json", "profiles/r01_summary.json")
+shutil.copy("gpurun_out/bench_default.json", "profiles/r01_bench_default.json")
+for w in ("hover65536_30hz", "hover65536_pid_240hz", "stack8x8192_ext_240hz", "multihover2x16384_240hz", "hover4m_240hz",
+          "hover16m_240hz", "swarm65536_ext_240hz"):
+    if os.path.exists(f"gpurun_out/bench_{w}.json"):
+        shutil.copy(f"gpurun_out/bench_{w}.json", f"profiles/r01_bench_{w}.json")
+d = json.load(open("profiles/r01_summary.json"))
+def kern(tag, name):
+    for r in d[tag]:
+        if name in r["Name"]: return float(r["AverageNs"])
+def rec(p, avg):
+    f, w = d[p]["FETCH_SIZE_KB_per_dispatch"], d[p]["WRITE_SIZE_KB_per_dispatch"]
+    return {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "traffic_bytes": 2 * f * 1024 + w * 1024, "rocprof_kernel_avg_ns": avg}
+out = {
+ "_comment": "HBM traffic per kernel dispatch from rocprofv3 --pmc (separate passes for FETCH_SIZE and WRITE_SIZE; scratch/profile_r01.sh). bytes = 2*FETCH_SIZE_KB*1024 + WRITE_SIZE_KB*1024: on gfx950 FETCH_SIZE reports half of the bytes of a coalesced stream (MI355X_MICROARCH.md, HBM section); with the x2, reads match the algorithmic read bytes to 2% and WRITE_SIZE matches the algorithmic write bytes to 1% in all four runs. Keys are '<bench workload>:<launch mode>'; a rollout dispatch is 64 env steps. rocprof_kernel_avg_ns is from the --kernel-trace --stats pass of the same command (profiles/r01_trace_*_kernel_stats.csv).",
+ "round": 1,
+ "hover65536_240hz:rollout64": rec("pmc_hover65536_rollout", kern("trace_default", "gpd_rollout")),
+ "hover65536_240hz:graph": rec("pmc_hover65536_step", kern("trace_default", "gpd_step_kernel")),
+ "hover4m_240hz:rollout64": rec("pmc_hover4m_rollout", kern("trace_hover4m", "gpd_rollout")),
+ "hover4m_240hz:graph": {"rocprof_kernel_avg_ns": kern("trace_hover4m", "gpd_step_kernel"), "traffic_bytes": None},
+ "hover16m_240hz:graph": rec("pmc_hover16m_step", kern("trace_hover16m", "gpd_step_kernel")),
+}
+json.dump(out, open("profiles/hbm_traffic.json", "w"), indent=1)
+for k, v in out.items():
+    if isinstance(v, dict): print(k, {a: (round(b) if isinstance(b, float) else b) for a, b in v.items()})
