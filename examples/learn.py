@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Reinforcement learning on the batched HoverAviary, entirely on the GPU.
+
+The reference's `examples/learn.py` trains SB3's PPO on ONE `HoverAviary` (`make_vec_env(..., n_envs=1)`,
+`ActionType.ONE_D_RPM`, stop at a mean episode reward of 474).  Stable-Baselines3 is not available here, and a
+single-environment loop is not what this package is for: this script is a compact PPO (clipped surrogate, GAE,
+Gaussian policy, the 64x64 tanh MLPs of SB3's `MlpPolicy`) in plain PyTorch that steps thousands of aviaries per
+kernel launch -- observations, actions, rewards and resets never leave the device.
+
+Usage:  python examples/learn.py [--num_envs 4096] [--iters 60] [--target 474]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from gym_pybullet_drones_amd.envs import VectorHoverAviary  # noqa: E402
+from gym_pybullet_drones_amd.utils.enums import ActionType  # noqa: E402
+
+
+class ActorCritic(torch.nn.Module):
+    def __init__(self, obs_dim, act_dim):
+        super().__init__()
+        mlp = lambda out: torch.nn.Sequential(torch.nn.Linear(obs_dim, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64),  # noqa: E731
+                                              torch.nn.Tanh(), torch.nn.Linear(64, out))
+        self.pi, self.v = mlp(act_dim), mlp(1)
+        self.log_std = torch.nn.Parameter(torch.full((act_dim,), -0.5))
+
+    def dist(self, obs):
+        return torch.distributions.Normal(self.pi(obs), self.log_std.exp())
+
+
+def run(num_envs=4096, iters=60, horizon=128, target=474.0, epochs=4, minibatches=8, lr=1e-3, gamma=0.99, lam=0.95, clip=0.2,
+        seed=0, device="cuda:0", verbose=True):
+    torch.manual_seed(seed)
+    env = VectorHoverAviary(num_envs, act=ActionType.ONE_D_RPM, ctrl_freq=30, full_obs=True, auto_reset=True, device=device)
+    dev, E = env.device, num_envs
+    obs_dim, act_dim = env.OBS_DIM, env.ACT_DIM
+    net = ActorCritic(obs_dim, act_dim).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=lr)
+    obs = env.reset()[0].view(E, obs_dim).clone()
+    ep_ret, ep_len = torch.zeros(E, device=dev), torch.zeros(E, device=dev)
+    history, t0, sim_steps = [], time.time(), 0
+    for it in range(iters):
+        O = torch.empty((horizon, E, obs_dim), device=dev)
+        A = torch.empty((horizon, E, act_dim), device=dev)
+        LP, R, Dn, V = (torch.empty((horizon, E), device=dev) for _ in range(4))
+        finished = []
+        with torch.no_grad():
+            for t in range(horizon):
+                d = net.dist(obs)
+                a = d.sample()
+                O[t], A[t], LP[t], V[t] = obs, a, d.log_prob(a).sum(-1), net.v(obs).squeeze(-1)
+                nobs, r, term, trunc, _ = env.step(a.clamp(-1, 1).view(E, 1, act_dim))
+                done = term | trunc
+                R[t], Dn[t] = r, done.float()
+                ep_ret += r
+                ep_len += 1
+                if done.any():
+                    finished.append(ep_ret[done].clone())
+                    ep_ret[done] = 0
+                    ep_len[done] = 0
+                obs = nobs.view(E, obs_dim).clone()
+            sim_steps += horizon * E
+            last_v = net.v(obs).squeeze(-1)
+            adv, gae = torch.empty_like(R), torch.zeros(E, device=dev)
+            for t in reversed(range(horizon)):                      # GAE(lambda); an episode end cuts the bootstrap
+                nv = last_v if t == horizon - 1 else V[t + 1]
+                delta = R[t] + gamma * nv * (1 - Dn[t]) - V[t]
+                gae = delta + gamma * lam * (1 - Dn[t]) * gae
+                adv[t] = gae
+            ret = adv + V
+        o, a, lp, ad, rt = O.view(-1, obs_dim), A.view(-1, act_dim), LP.view(-1), adv.view(-1), ret.view(-1)
+        ad = (ad - ad.mean()) / (ad.std() + 1e-8)
+        n = o.shape[0]
+        for _ in range(epochs):
+            perm = torch.randperm(n, device=dev)
+            for mb in perm.chunk(minibatches):
+                d = net.dist(o[mb])
+                ratio = (d.log_prob(a[mb]).sum(-1) - lp[mb]).exp()
+                pg = -torch.min(ratio * ad[mb], ratio.clamp(1 - clip, 1 + clip) * ad[mb]).mean()
+                vl = (net.v(o[mb]).squeeze(-1) - rt[mb]).pow(2).mean()
+                loss = pg + 0.5 * vl - 0.0 * d.entropy().sum(-1).mean()
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(net.parameters(), 0.5)
+                opt.step()
+        if finished:
+            mean_ret = float(torch.cat(finished).mean())
+            history.append(mean_ret)
+            if verbose:
+                print(f"[learn.py] iter {it:3d}  episodes {sum(len(f) for f in finished):6d}  mean episode reward {mean_ret:7.2f}  "
+                      f"({sim_steps / (time.time() - t0):.3g} env-steps/s incl. learning)")
+            if mean_ret >= target:
+                break
+    # deterministic evaluation: one full episode of every aviary with the mean action
+    obs = env.reset()[0].view(E, obs_dim)
+    tot, alive = torch.zeros(E, device=dev), torch.ones(E, dtype=torch.bool, device=dev)
+    with torch.no_grad():
+        for _ in range(242):
+            obs_n, r, term, trunc, _ = env.step(net.pi(obs).clamp(-1, 1).view(E, 1, act_dim))
+            tot += r * alive
+            alive &= ~(term | trunc)
+            obs = obs_n.view(E, obs_dim)
+    eval_ret = float(tot.mean())
+    if verbose:
+        print(f"[learn.py] deterministic evaluation over {E} episodes: mean reward {eval_ret:.2f} (target {target}), "
+              f"wall {time.time() - t0:.1f}s")
+    return history, eval_ret
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser(description="PPO on VectorHoverAviary (GPU-resident)")
+    ap.add_argument("--num_envs", default=4096, type=int)
+    ap.add_argument("--iters", default=60, type=int)
+    ap.add_argument("--target", default=474.0, type=float)
+    ap.add_argument("--seed", default=0, type=int)
+    a = ap.parse_args()
+    run(num_envs=a.num_envs, iters=a.iters, target=a.target, seed=a.seed)

@@ -46,3 +46,13 @@ def test_rollout(gpu_device):
     m = _load("rollout")
     shape = m.run(num_envs=2048, steps=32, device=gpu_device)
     assert tuple(shape) == (32, 2048, 1, 12 + 15)
+
+
+def test_learn(gpu_device):
+    """examples/learn.py: PPO on 2048 GPU-resident HoverAviaries (the reference's learn.py trains SB3-PPO on one
+    aviary and stops at a mean episode reward of 474 -- essentially the bang-bang optimum of this task: 484 minus the
+    ~10 lost while climbing 0.89 m at +-10 % thrust).  A few seconds of training must get most of the way there."""
+    m = _load("learn")
+    history, eval_ret = m.run(num_envs=2048, iters=25, verbose=False, device=gpu_device)
+    assert history[0] < 250                      # an untrained policy drifts away / times out low
+    assert eval_ret > 440 and max(history) > 430
