@@ -87,6 +87,19 @@ __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsq
 // two instructions instead of OCML's ~20.  Used for the downwash Gaussian (evaluated for every pair of an aviary).
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
+// Rare per-lane cases (gimbal lock, a tumbling drone, an episode end) are entered through a WAVE-UNIFORM test marked
+// unlikely: the hot path pays one compare and one not-taken scalar branch (~11 cycles, scratch/issue.hip), and the
+// rare block sits out of line.  The plain divergent `if` the compiler would emit instead -- s_and_saveexec +
+// s_cbranch_execz around an in-line block -- costs a TAKEN branch (~60 cycles: the instruction buffer refills) on
+// every step, and with one wave per SIMD nothing hides it.
+__device__ __forceinline__ uint64_t lane_mask_opaque(bool p) {
+    uint64_t m = __builtin_amdgcn_ballot_w64(p);
+    asm volatile("" : "+s"(m));      // opaque: otherwise `if (any_lane(p)) if (p)` is folded back into the divergent `if (p)`
+    return m;
+}
+// (a macro: __builtin_expect has to sit in the `if` itself -- returned from an inlined function it is dropped before inlining)
+#define any_lane(p) __builtin_expect(lane_mask_opaque(p) != 0, 0)
+
 // The three functions below are inlined at several places of the step kernel (rpy at the top of a step for
 // DSLPID, at its tail for the observation, after an auto-reset).  FMA contraction is switched OFF inside them
 // and every fused operation is written out, so that each inlined copy rounds identically: a K-step rollout
@@ -152,11 +165,15 @@ __device__ __forceinline__ void quat_to_rpy(float x, float y, float z, float w,
     roll = atan2_poly(2.0f * fmaf(y, z, w * x), ww_zz - xx_yy);  // squ - sqx - sqy + sqz
     pitch = asin_poly(fminf(fmaxf(sarg, -1.0f), 1.0f));          // (clamp: only matters on the gimbal lanes, overwritten below)
     yaw = atan2_poly(2.0f * fmaf(x, y, w * z), ww_yy + xx_zz);   // squ + sqx - sqy - sqz
-    if (__builtin_expect(fabsf(sarg) >= 0.99999f, 0)) {
-        const bool neg = sarg < 0.0f;
-        roll = 0.0f;
-        pitch = neg ? -1.57079632679489661923f : 1.57079632679489661923f;
-        yaw = 2.0f * (neg ? atan2_poly(x, -y) : atan2_poly(-x, y));
+    const bool gimbal = fabsf(sarg) >= 0.99999f;
+    if (any_lane(gimbal)) {
+        asm volatile("; gimbal lock: rare");                // (keeps the wave-uniform branch from being merged with the lane test)
+        if (gimbal) {
+            const bool neg = sarg < 0.0f;
+            roll = 0.0f;
+            pitch = neg ? -1.57079632679489661923f : 1.57079632679489661923f;
+            yaw = 2.0f * (neg ? atan2_poly(x, -y) : atan2_poly(-x, y));
+        }
     }
 }
 
@@ -287,19 +304,18 @@ __device__ __forceinline__ void substep(const GpdParams& P, float h, uint32_t fl
         Fy = fmaf(-(P.drag_coeff[1] * k.vy), wsum, Fy);
         Fz = fmaf(-(P.drag_coeff[2] * k.vz), wsum, Fz);
     }
-    // z torque from KM*rpm_i^2 = (KM/KF)*(F_h + g_i): alternating signs, F_h cancels (ground effect not included, :842)
-    float tz = P.km_over_kf * (((-g[0] + g[1]) - g[2]) + g[3]);
-    if (P.drone_model == GPD_MODEL_RACE) tz = -tz;
-    float tx, ty;
-    if (P.drone_model == GPD_MODEL_CF2P) {
-        tx = (f1 - f3) * P.L;
-        ty = (-f0 + f2) * P.L;
-    } else {
-        const float arm = P.L * 0.70710678118654752440f;   // L / sqrt(2)
-        tx = (((f0 + f1) - f2) - f3) * arm;
-        ty = (((-f0 + f1) + f2) - f3) * arm;
-        if (P.drone_model == GPD_MODEL_CF2X) tx = -tx;
-    }
+    // z torque from KM*rpm_i^2 = (KM/KF)*(F_h + g_i): alternating signs, F_h cancels (ground effect not included, :842).
+    // The airframe variants are folded into signed constants and one bit-select: no branch and no per-step select chain
+    // (negating a factor negates the product exactly, so the bits are those of "compute, then flip the sign").
+    const float kz = (P.drone_model == GPD_MODEL_RACE) ? -P.km_over_kf : P.km_over_kf;
+    const float tz = kz * (((-g[0] + g[1]) - g[2]) + g[3]);
+    const float arm = P.L * 0.70710678118654752440f;        // L / sqrt(2)
+    const float arm_x = (P.drone_model == GPD_MODEL_CF2X) ? -arm : arm;
+    const float tx_x = (((f0 + f1) - f2) - f3) * arm_x, ty_x = (((-f0 + f1) + f2) - f3) * arm;   // CF2X / RACE
+    const float tx_p = (f1 - f3) * P.L, ty_p = (-f0 + f2) * P.L;                                 // CF2P
+    const uint32_t plus = (P.drone_model == GPD_MODEL_CF2P) ? 0xffffffffu : 0u;
+    float tx = __uint_as_float((__float_as_uint(tx_p) & plus) | (__float_as_uint(tx_x) & ~plus));
+    float ty = __uint_as_float((__float_as_uint(ty_p) & plus) | (__float_as_uint(ty_x) & ~plus));
     // Euler's rotation equation with diagonal J
     const float jwx = P.J[0] * k.wx, jwy = P.J[1] * k.wy, jwz = P.J[2] * k.wz;
     tx -= fmaf(k.wy, jwz, -(k.wz * jwy));
@@ -315,17 +331,19 @@ __device__ __forceinline__ void substep(const GpdParams& P, float h, uint32_t fl
     //   rates up to 480 rad/s at 240 Hz): no sqrt, no division, no range reduction.
     const float n2 = fmaf(k.wz, k.wz, fmaf(k.wy, k.wy, k.wx * k.wx));
     const float u = n2 * (0.25f * h * h);
-    float cs, sc;
-    if (__builtin_expect(u <= 1.0f, 1)) {
-        cs = fmaf(fmaf(fmaf(fmaf(2.412107309e-05f, u, -1.388295778e-03f), u, 4.166645522e-02f), u, -4.999999736e-01f),
-                  u, 9.999999995e-01f);
-        sc = fmaf(fmaf(fmaf(fmaf(2.693749890e-06f, u, -1.983586443e-04f), u, 8.333314057e-03f), u, -1.666666643e-01f),
-                  u, 1.0f) * (0.5f * h);
-    } else {   // tumbling faster than 480 rad/s: exact path
-        const float n = sqrtf(n2);
-        float sn;
-        sincosf(n * h * 0.5f, &sn, &cs);
-        sc = sn / n;
+    float cs = fmaf(fmaf(fmaf(fmaf(2.412107309e-05f, u, -1.388295778e-03f), u, 4.166645522e-02f), u, -4.999999736e-01f),
+                    u, 9.999999995e-01f);
+    float sc = fmaf(fmaf(fmaf(fmaf(2.693749890e-06f, u, -1.983586443e-04f), u, 8.333314057e-03f), u, -1.666666643e-01f),
+                    u, 1.0f) * (0.5f * h);
+    const bool tumbling = !(u <= 1.0f);                    // faster than 480 rad/s (at 240 Hz): exact path
+    if (any_lane(tumbling)) {
+        asm volatile("; tumbling: rare");
+        if (tumbling) {
+            const float n = sqrtf(n2);
+            float sn;
+            sincosf(n * h * 0.5f, &sn, &cs);
+            sc = sn / n;
+        }
     }
     {
         const float lx = fmaf(k.wx, k.qw, fmaf(k.wz, k.qy, -(k.wy * k.qz)));
@@ -406,18 +424,14 @@ struct StepOut {          // what one env step hands to the stores
     bool term, trunc, reset;
 };
 
-template <bool PID, bool EXT, bool MULTI, int AW, int ACT = -1>   // ACT >= 0: the action type is a compile-time constant
-__device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C, const uint32_t flags, const int D,
-                                         const Lane& L, const float4 act, const float tgx, const float tgy,
-                                         const float tgz, const bool ip_regs, const float* __restrict__ ipose,
-                                         const float ip0, const float ip1, const float ip2, const float ip3,
-                                         const float ip4, const float ip5, const float ip6, float* sh_pos,
-                                         float* sh_red, Carry& c, StepOut& out) {
-    Kin& k = c.k;
+// action -> RPM (computed ONCE per env step from the cached state, BaseAviary.py:341) and the rotor thrusts minus the
+// hover thrust.  DSLPID action types advance the controller members in c.s and read the cached rpy in c.
+template <bool PID, int AW, int ACT>
+__device__ __forceinline__ void map_action(const GpdParams& P, const GpdStepCfg& C, const float4 act, Carry& c,
+                                           float rpm[4], float g[4]) {
+    const Kin& k = c.k;
     const int act_type = ACT >= 0 ? ACT : C.act_type;
-    // ---- action -> RPM (computed ONCE per env step from the cached state, BaseAviary.py:341) -----
-    float rpm[4] = {0, 0, 0, 0};
-    float g[4];                                              // rotor thrusts minus the hover thrust
+    rpm[0] = rpm[1] = rpm[2] = rpm[3] = 0.0f;
     if (!PID) {
         if (AW == 1) {     // GPD_ACT_ONE_D_RPM
             const float e = 0.05f * act.x;
@@ -459,12 +473,45 @@ __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C
 #pragma unroll
         for (int i = 0; i < 4; ++i) g[i] = thrust_dev(P, rpm[i]);
     }
+}
+
+// reward / terminated / truncated of a single-drone aviary (envs/HoverAviary.py:68-132); `counter` is the aviary's
+// step counter BEFORE this step's increment (App. B.7)
+__device__ __forceinline__ void task_single(const GpdStepCfg& C, float px, float py, float pz, float roll, float pitch,
+                                            int counter, float tgx, float tgy, float tgz, float& rew, bool& term,
+                                            bool& trunc) {
+    const float ex = tgx - px, ey = tgy - py, ez = tgz - pz;
+    const float my_dist = fast_sqrt(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
+    const float d2 = my_dist * my_dist;
+    rew = fmaxf(0.0f, fmaf(-d2, d2, 2.0f));
+    // (bitwise | on purpose: five compares and four scalar ORs instead of a short-circuit's exec-mask branches)
+    const bool my_out = (fabsf(px) > C.xy_bound) | (fabsf(py) > C.xy_bound) | (pz > C.z_bound) |
+                        (fabsf(roll) > C.tilt_bound) | (fabsf(pitch) > C.tilt_bound);
+    term = my_dist < C.term_dist;
+    trunc = my_out | (counter > C.trunc_counter);
+}
+
+// ACT >= 0: the action type is a compile-time constant; S1: so is substeps == 1
+template <bool PID, bool EXT, bool MULTI, int AW, int ACT = -1, bool S1 = false>
+__device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C, const uint32_t flags, const int D,
+                                         const Lane& L, const float4 act, const float tgx, const float tgy,
+                                         const float tgz, const bool ip_regs, const float* __restrict__ ipose,
+                                         const float ip0, const float ip1, const float ip2, const float ip3,
+                                         const float ip4, const float ip5, const float ip6, float* sh_pos,
+                                         float* sh_red, Carry& c, StepOut& out) {
+    Kin& k = c.k;
+    float rpm[4], g[4];                                      // RPMs; rotor thrusts minus the hover thrust
+    map_action<PID, AW, ACT>(P, C, act, c, rpm, g);
 
     // ---- S physics sub-steps, state in registers -------------------------------------------------
     const float cur_sum = ((rpm[0] + rpm[1]) + rpm[2]) + rpm[3];
     // the first sub-step of a step sees the PREVIOUS env step's action (BaseAviary.py:359,372)
     float drag_sum = (EXT && (flags & GPD_PHYS_DRAG)) ? ((c.l0 + c.l1) + c.l2) + c.l3 : cur_sum;
     float avx = 0.0f, avy = 0.0f, avz = 0.0f;
+    if (S1 && !(EXT && MULTI)) {
+        // ctrl_freq == pyb_freq, known at compile time: straight-line, no loop branches (two taken branches per step)
+        substep<EXT>(P, C.pyb_dt, flags, g, drag_sum, EXT ? c.dw_in : 0.0f, k, avx, avy, avz);
+    } else
     for (int ss = 0; ss < C.substeps; ++ss) {
         float dw = (EXT && !MULTI) ? c.dw_in : 0.0f;
         if (EXT && MULTI && (flags & GPD_PHYS_DW)) {
@@ -508,18 +555,24 @@ __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C
     // ---- task: reward / terminated / truncated -------------------------------------------------------
     float rew = -1.0f;
     bool term = false, trunc = false;
-    if (C.task != GPD_TASK_NONE) {
-        const float ex = tgx - k.px, ey = tgy - k.py, ez = tgz - k.pz;
-        const float my_dist = fast_sqrt(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
-        const float d2 = my_dist * my_dist;
-        const float my_rew = fmaxf(0.0f, fmaf(-d2, d2, 2.0f));
-        const bool my_out = fabsf(k.px) > C.xy_bound || fabsf(k.py) > C.xy_bound || k.pz > C.z_bound ||
-                            fabsf(c.roll) > C.tilt_bound || fabsf(c.pitch) > C.tilt_bound;
-        if (!MULTI) {
-            rew = my_rew;
-            term = my_dist < C.term_dist;
-            trunc = my_out || (c.counter > C.trunc_counter);   // tested BEFORE the increment (App. B.7)
-        } else {
+    if (!MULTI) {
+        // evaluated unconditionally and masked by the (uniform) task switch: selects, no branch in the step body
+        // (GPD_TASK_NONE hands the kernel a readable dummy target)
+        float r;
+        bool te, tr;
+        task_single(C, k.px, k.py, k.pz, c.roll, c.pitch, c.counter, tgx, tgy, tgz, r, te, tr);
+        const bool has_task = C.task != GPD_TASK_NONE;
+        rew = has_task ? r : -1.0f;
+        term = has_task & te;
+        trunc = has_task & tr;
+    } else if (C.task != GPD_TASK_NONE) {
+        {
+            const float ex = tgx - k.px, ey = tgy - k.py, ez = tgz - k.pz;
+            const float my_dist = fast_sqrt(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
+            const float d2 = my_dist * my_dist;
+            const float my_rew = fmaxf(0.0f, fmaf(-d2, d2, 2.0f));
+            const bool my_out = fabsf(k.px) > C.xy_bound || fabsf(k.py) > C.xy_bound || k.pz > C.z_bound ||
+                                fabsf(c.roll) > C.tilt_bound || fabsf(c.pitch) > C.tilt_bound;
             float r = 0.0f, dsum = 0.0f, o = 0.0f;
             const float my_o = my_out ? 1.0f : 0.0f;
             if (L.shfl) {                                      // wave-local LDS exchange, as for the downwash
@@ -552,7 +605,7 @@ __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C
 
     // ---- observation; same-step auto-reset ----------------------------------------------------------------
     c.l0 = rpm[0]; c.l1 = rpm[1]; c.l2 = rpm[2]; c.l3 = rpm[3];
-    if (do_reset) {
+    if (any_lane(do_reset)) { asm volatile("; episode end"); if (do_reset) {
         out.to[0] = k.px; out.to[1] = k.py; out.to[2] = k.pz; out.to[3] = c.roll; out.to[4] = c.pitch; out.to[5] = c.yaw;
         out.to[6] = k.vx; out.to[7] = k.vy; out.to[8] = k.vz; out.to[9] = avx; out.to[10] = avy; out.to[11] = avz;
         if (ip_regs) k = Kin{ip0, ip1, ip2, ip3, ip4, ip5, ip6, 0, 0, 0, 0, 0, 0};
@@ -560,7 +613,7 @@ __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C
         quat_to_rpy(k.qx, k.qy, k.qz, k.qw, c.roll, c.pitch, c.yaw);
         avx = avy = avz = 0.0f;
         c.l0 = c.l1 = c.l2 = c.l3 = 0.0f;                      // last_clipped_action zeroed (BaseAviary.py:468)
-    }
+    } }
     out.o[0] = k.px; out.o[1] = k.py; out.o[2] = k.pz; out.o[3] = c.roll; out.o[4] = c.pitch; out.o[5] = c.yaw;
     out.o[6] = k.vx; out.o[7] = k.vy; out.o[8] = k.vz; out.o[9] = avx; out.o[10] = avy; out.o[11] = avz;
 }
@@ -1013,6 +1066,61 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Per-step outputs of a single-drone rollout lane (shared by the two kernels below).
+//   * observation row -> the wave's LDS patch -> three coalesced 1 KiB bursts (the 64 rows of a wave are contiguous in
+//     memory), software-pipelined by one step: the bursts of step t - 1, read back from the patch a whole step ago (the
+//     LDS round trip is never waited for), go out first; then this step's row is written to the patch and read back
+//     into `pend`.  Same wave on both sides: the LDS executes a wave's instructions in order, so the reads see the
+//     writes without any wait or barrier (the wave_barrier only pins the order for the compiler).  At step 0 the bursts
+//     carry zeros to step 0's rows, which step 1 then overwrites (same lane, same addresses, program order): every
+//     store is unconditional.
+//   * reward and flags go out directly (already coalesced).
+//   * addressing: <uniform running pointer in SGPRs> + <32-bit lane offset>, the global_store "saddr + voffset" form;
+//     the empty asm keeps the zero-extension of the offsets inside the loop (hoisted, it turns every store into a
+//     64-bit VALU add plus a flat-addressed store).
+// ------------------------------------------------------------------------------------------------
+struct RollOut {
+    char* og_prev; char* og; char* rg; uint8_t* tg; uint8_t* ug;     // obs block of the previous / this step, reward, flags
+    int64_t obs_step, env_step;                                     // bytes / elements between consecutive steps
+    uint32_t g0, g1, g2, e4, e1;                                    // lane offsets: three bursts, reward word, flag byte
+    float4* mine; const char* lsrc;                                 // this lane's row in the patch; its three burst chunks
+    f4v pend[3];                                                    // the previous step's three bursts
+    __device__ __forceinline__ RollOut(float* obs12, float* reward, uint8_t* terminated, uint8_t* truncated, const Span& T,
+                                       const uint32_t goff[3], uint32_t eoff4, uint32_t env, float* row, const char* lsrc_)
+        : og_prev(reinterpret_cast<char*>(obs12)), og(reinterpret_cast<char*>(obs12)), rg(reinterpret_cast<char*>(reward)),
+          tg(terminated), ug(truncated), obs_step(T.obs_stride * 4), env_step(T.env_stride), g0(goff[0]), g1(goff[1]),
+          g2(goff[2]), e4(eoff4), e1(env), mine(reinterpret_cast<float4*>(row)), lsrc(lsrc_) {
+        pend[0] = pend[1] = pend[2] = f4v{0, 0, 0, 0};
+    }
+    __device__ __forceinline__ void bursts(char* base) {
+        asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2));
+        __builtin_nontemporal_store(pend[0], reinterpret_cast<f4v*>(base + g0));   // written once, streamed out
+        __builtin_nontemporal_store(pend[1], reinterpret_cast<f4v*>(base + g1));
+        __builtin_nontemporal_store(pend[2], reinterpret_cast<f4v*>(base + g2));
+    }
+    // `advance`: false on the first step of the launch (the pointers already address step 0)
+    __device__ __forceinline__ void emit(const StepOut& out, bool advance) {
+        if (advance) { og_prev = og; og += obs_step; rg += env_step * 4; tg += env_step; ug += env_step; }
+        bursts(og_prev);
+        mine[0] = make_float4(out.o[0], out.o[1], out.o[2], out.o[3]);
+        mine[1] = make_float4(out.o[4], out.o[5], out.o[6], out.o[7]);
+        mine[2] = make_float4(out.o[8], out.o[9], out.o[10], out.o[11]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(lsrc + j * 1024);
+            pend[j] = f4v{v.x, v.y, v.z, v.w};
+        }
+        __builtin_amdgcn_wave_barrier();                             // (the next step's row writes stay behind these reads)
+        asm volatile("" : "+v"(e4), "+v"(e1));
+        __builtin_nontemporal_store(out.rew, reinterpret_cast<float*>(rg + e4));
+        __builtin_nontemporal_store(static_cast<uint8_t>(out.term ? 1 : 0), tg + e1);
+        __builtin_nontemporal_store(static_cast<uint8_t>(out.trunc ? 1 : 0), ug + e1);
+    }
+    __device__ __forceinline__ void flush() { bursts(og); }          // after the last step
+};
+
+// ------------------------------------------------------------------------------------------------
 // gpd_rollout for single-drone aviaries: K env steps per launch with NO helper wave and NO workgroup
 // synchronisation at all.  256-thread workgroups, one drone per lane; per step a lane
 //   * prefetches the action row two steps ahead (three rotating register sets, loop unrolled x3),
@@ -1029,7 +1137,7 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
 // write instead of a branch around the stores.  (Calls that ask for terminal observations -- conditional stores -- use
 // the compute-wave + store-wave kernel above.)
 // ------------------------------------------------------------------------------------------------
-template <bool PID, bool EXT, int AW, int ACT>
+template <bool PID, bool EXT, int AW, int ACT, bool S1>
 __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     const GpdParams P, const GpdState S, const GpdStepCfg C, const Span T, const float* __restrict__ action,
     const float* __restrict__ target_pos, const float* __restrict__ init_pose, float* __restrict__ obs12,
@@ -1078,29 +1186,19 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
 
     (void)term_obs12;   // (terminal observations: the host routes such calls to gpd_rollout_kernel -- a conditional
                         // store in this loop body would make the wait counts conservative again)
+    RollOut ro(obs12, reward, terminated, truncated, T, goff, eoff4, L.env, sh_rows + tid * 12, lsrc);
+    auto emit = [&](const StepOut& out, bool advance) { ro.emit(out, advance); };
     auto do_step = [&](const int t, const float4 act) {
         StepOut out;
-        env_step<PID, EXT, false, AW, ACT>(P, C, flags, 1, L, act, tgx, tgy, tgz, true, ipose, ip[0], ip[1], ip[2], ip[3],
-                                           ip[4], ip[5], ip[6], dummy_lds, dummy_lds, c, out);
-        // row -> the wave's LDS patch -> three coalesced bursts.  Same wave on both sides: the LDS executes a wave's
-        // instructions in order, so the reads below see the writes without any wait or barrier (the wave_barrier only
-        // pins the order for the compiler).
-        float4* mine = reinterpret_cast<float4*>(sh_rows + tid * 12);
-        mine[0] = make_float4(out.o[0], out.o[1], out.o[2], out.o[3]);
-        mine[1] = make_float4(out.o[4], out.o[5], out.o[6], out.o[7]);
-        mine[2] = make_float4(out.o[8], out.o[9], out.o[10], out.o[11]);
-        __builtin_amdgcn_wave_barrier();
-        char* og = reinterpret_cast<char*>(obs12 + t * T.obs_stride);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(lsrc + j * 1024);
-            f4v w = {v.x, v.y, v.z, v.w};
-            __builtin_nontemporal_store(w, reinterpret_cast<f4v*>(og + goff[j]));   // written once, streamed out
-        }
-        __builtin_amdgcn_wave_barrier();                             // (the next step's row writes stay behind these reads)
-        __builtin_nontemporal_store(out.rew, reinterpret_cast<float*>(reinterpret_cast<char*>(reward + t * T.env_stride) + eoff4));
-        __builtin_nontemporal_store(static_cast<uint8_t>(out.term ? 1 : 0), terminated + t * T.env_stride + L.env);
-        __builtin_nontemporal_store(static_cast<uint8_t>(out.trunc ? 1 : 0), truncated + t * T.env_stride + L.env);
+        env_step<PID, EXT, false, AW, ACT, S1>(P, C, flags, 1, L, act, tgx, tgy, tgz, true, ipose, ip[0], ip[1], ip[2], ip[3],
+                                               ip[4], ip[5], ip[6], dummy_lds, dummy_lds, c, out);
+        // row -> the wave's LDS patch -> three coalesced bursts, software-pipelined by one step: the bursts of step
+        // t - 1 (read back from the patch a whole step ago, so the LDS round trip is never waited for) go out here, then
+        // this step's rows are written to the patch and read back into `pend` for the next step.  Same wave on both sides:
+        // the LDS executes a wave's instructions in order, so the reads see the writes without any wait or barrier (the
+        // wave_barrier only pins the order for the compiler).  At t = 0 the bursts carry zeros to step 0's rows, which
+        // step 1 then overwrites (same lane, same addresses, program order) -- an unconditional store, see above.
+        emit(out, t > 0);
     };
     // Action rows, three steps per loop iteration: the rows of the NEXT iteration (b0..b2) are requested at the top of
     // this one and claimed at its end with an explicit vmcnt(18) -- "everything but the youngest 18 operations", i.e.
@@ -1136,6 +1234,7 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
             a = b;
         }
     }
+    ro.flush();                                                      // the last step's bursts
     if (L.active) store_carry<PID>(S, L, c);
 }
 
@@ -1413,8 +1512,12 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
             hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, true, AW>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
                                action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
         } else if (!store_wave_variant && term_obs12 == nullptr) {
-            hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT>), grid, dim3(kBlock), 0, st, P, S, C, Tr, action, target_pos,
-                               init_pose, obs12, reward, terminated, truncated, term_obs12);
+            if (C.substeps == 1)
+                hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, true>), grid, dim3(kBlock), 0, st, P, S, C, Tr, action,
+                                   target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+            else
+                hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false>), grid, dim3(kBlock), 0, st, P, S, C, Tr, action,
+                                   target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
         } else {
             hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, false, AW>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
                                action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
