@@ -16,7 +16,10 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(CSRC, "libgpd.so")
 ABI_VERSION = 2
 
-HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
+# -mllvm -amdgpu-sched-strategy=max-ilp: interleaves independent dependency chains, which fills the one-wait-state hazard
+# behind every packed-fp32 result with useful work instead of s_nops (13 of 287 issue slots of a rollout step)
+HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize",
+               "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fPIC", "-shared"]
 
 
 class GpdError(RuntimeError):

@@ -37,7 +37,7 @@
 //                          range reduction; |t| <= 1 rad per sub-step, exact OCML path beyond)
 //   atan2 / asin           one odd minimax polynomial on [0,1] (abs err 7e-8) + octant fix-up
 //   rotor thrusts          carried as deviations from the hover thrust (no cancellation near hover)
-// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -shared
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-ilp -fPIC -shared
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -87,6 +87,16 @@ __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsq
 // two instructions instead of OCML's ~20.  Used for the downwash Gaussian (evaluated for every pair of an aviary).
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
+// Packed fp32 (v_pk_mul/add/fma_f32): TWO IEEE operations per instruction.  With one wave per SIMD the step is bound by
+// the rate at which a single wave issues instructions (~5.4 cycles each, whatever they are -- scratch/issue.hip), not by
+// the SIMD's arithmetic rate, so pairing two independent operations of the same kind halves their cost; each half
+// rounds exactly like the scalar instruction, so results do not change by a bit.  Used only where both halves are
+// naturally adjacent (no register shuffles); -fno-slp-vectorize keeps the compiler from pairing on its own (its
+// shuffles cost more issue slots than the pairs save).
+typedef float fp2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ fp2 fma2(fp2 a, fp2 b, fp2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ fp2 splat(float s) { return fp2{s, s}; }
+
 // Rare per-lane cases (gimbal lock, a tumbling drone, an episode end) are entered through a WAVE-UNIFORM test marked
 // unlikely: the hot path pays one compare and one not-taken scalar branch (~11 cycles, scratch/issue.hip), and the
 // rare block sits out of line.  The plain divergent `if` the compiler would emit instead -- s_and_saveexec +
@@ -130,6 +140,32 @@ __device__ __forceinline__ float atan2_poly(float y, float x) {
     return copysignf(p, y);
 }
 
+// two independent atan2 at once: the same operations as atan2_poly, the multiplies and the Horner chain as packed pairs
+__device__ __forceinline__ fp2 atan2_poly2(fp2 y, fp2 x) {
+#pragma clang fp contract(off)
+    const float ax0 = fabsf(x.x), ay0 = fabsf(y.x), ax1 = fabsf(x.y), ay1 = fabsf(y.y);
+    const float mx0 = fmaxf(ax0, ay0), mn0 = fminf(ax0, ay0), mx1 = fmaxf(ax1, ay1), mn1 = fminf(ax1, ay1);
+    fp2 t = fp2{mn0, mn1} * fp2{fast_rcp(mx0), fast_rcp(mx1)};
+    t = fp2{(mx0 == 0.0f) ? 0.0f : t.x, (mx1 == 0.0f) ? 0.0f : t.y};   // atan2(0, 0) = 0
+    const fp2 u = t * t;
+    fp2 p = splat(2.766283504e-03f);
+    p = fma2(p, u, splat(-1.573124913e-02f));
+    p = fma2(p, u, splat(4.213762361e-02f));
+    p = fma2(p, u, splat(-7.456854827e-02f));
+    p = fma2(p, u, splat(1.061837064e-01f));
+    p = fma2(p, u, splat(-1.419779779e-01f));
+    p = fma2(p, u, splat(1.999187203e-01f));
+    p = fma2(p, u, splat(-3.333303671e-01f));
+    p = fma2(p, u, splat(9.999999818e-01f));
+    p = p * t;
+    float p0 = p.x, p1 = p.y;
+    p0 = (ay0 > ax0) ? (1.57079632679489661923f - p0) : p0;
+    p1 = (ay1 > ax1) ? (1.57079632679489661923f - p1) : p1;
+    p0 = (x.x < 0.0f) ? (3.14159265358979323846f - p0) : p0;
+    p1 = (x.y < 0.0f) ? (3.14159265358979323846f - p1) : p1;
+    return fp2{copysignf(p0, y.x), copysignf(p1, y.y)};
+}
+
 // asin(s) = atan2(s, sqrt((1-s)(1+s))); the factored form keeps full relative accuracy near |s| = 1
 __device__ __forceinline__ float asin_poly(float s) {
 #pragma clang fp contract(off)
@@ -141,8 +177,10 @@ __device__ __forceinline__ float asin_poly(float s) {
 __device__ __forceinline__ Mat3 quat_to_mat(float x, float y, float z, float w) {
     const float d = fmaf(x, x, fmaf(y, y, fmaf(z, z, w * w)));
     const float s = 2.0f * fast_rcp(d);
-    const float xs = x * s, ys = y * s, zs = z * s;
-    const float wx = w * xs, wy = w * ys, wz = w * zs;
+    const fp2 xys = fp2{x, y} * splat(s);                     // (packed pairs, see fma2)
+    const float xs = xys.x, ys = xys.y, zs = z * s;
+    const fp2 wxy = splat(w) * xys;
+    const float wx = wxy.x, wy = wxy.y, wz = w * zs;
     Mat3 R;
     R.r00 = 1.0f - fmaf(y, ys, z * zs); R.r01 = fmaf(x, ys, -wz);           R.r02 = fmaf(x, zs, wy);
     R.r10 = fmaf(x, ys, wz);            R.r11 = 1.0f - fmaf(x, xs, z * zs); R.r12 = fmaf(y, zs, -wx);
@@ -162,9 +200,11 @@ __device__ __forceinline__ void quat_to_rpy(float x, float y, float z, float w,
     const float xx_yy = fmaf(x, x, y * y);                       // sqx + sqy
     const float ww_yy = fmaf(w, w, -(y * y));                    // squ - sqy
     const float xx_zz = fmaf(x, x, -(z * z));                    // sqx - sqz
-    roll = atan2_poly(2.0f * fmaf(y, z, w * x), ww_zz - xx_yy);  // squ - sqx - sqy + sqz
+    // roll = atan2(2(yz + wx), squ - sqx - sqy + sqz), yaw = atan2(2(xy + wz), squ + sqx - sqy - sqz): evaluated together
+    const fp2 ry = atan2_poly2(splat(2.0f) * fp2{fmaf(y, z, w * x), fmaf(x, y, w * z)}, fp2{ww_zz - xx_yy, ww_yy + xx_zz});
+    roll = ry.x;
     pitch = asin_poly(fminf(fmaxf(sarg, -1.0f), 1.0f));          // (clamp: only matters on the gimbal lanes, overwritten below)
-    yaw = atan2_poly(2.0f * fmaf(x, y, w * z), ww_yy + xx_zz);   // squ + sqx - sqy - sqz
+    yaw = ry.y;
     const bool gimbal = fabsf(sarg) >= 0.99999f;
     if (any_lane(gimbal)) {
         asm volatile("; gimbal lock: rare");                // (keeps the wave-uniform branch from being merged with the lane test)
@@ -296,7 +336,8 @@ __device__ __forceinline__ void substep(const GpdParams& P, float h, uint32_t fl
     float dev = ((f0 + f1) + f2) + f3;                     // total thrust minus GRAVITY
     if (EXT && (flags & GPD_PHYS_DW)) dev += dw_force;
     const float T = P.GRAVITY + dev;
-    float Fx = R.r02 * T, Fy = R.r12 * T, Fz = fmaf(R.r22, dev, -(P.GRAVITY * R.m22));
+    const fp2 Fxy = fp2{R.r02, R.r12} * splat(T);
+    float Fx = Fxy.x, Fy = Fxy.y, Fz = fmaf(R.r22, dev, -(P.GRAVITY * R.m22));
     if (EXT && (flags & GPD_PHYS_DRAG)) {
         // world force -DRAG_COEFF * v * sum(2*pi*rpm/60) (:771-774; R R^T cancels)
         const float wsum = drag_rpm_sum * (6.28318530717958647692f / 60.0f);
@@ -317,24 +358,30 @@ __device__ __forceinline__ void substep(const GpdParams& P, float h, uint32_t fl
     float tx = __uint_as_float((__float_as_uint(tx_p) & plus) | (__float_as_uint(tx_x) & ~plus));
     float ty = __uint_as_float((__float_as_uint(ty_p) & plus) | (__float_as_uint(ty_x) & ~plus));
     // Euler's rotation equation with diagonal J
-    const float jwx = P.J[0] * k.wx, jwy = P.J[1] * k.wy, jwz = P.J[2] * k.wz;
-    tx -= fmaf(k.wy, jwz, -(k.wz * jwy));
-    ty -= fmaf(k.wz, jwx, -(k.wx * jwz));
+    const fp2 jwxy = fp2{P.J[0], P.J[1]} * fp2{k.wx, k.wy};
+    const float jwx = jwxy.x, jwy = jwxy.y, jwz = P.J[2] * k.wz;
+    const fp2 txy = fp2{tx, ty} - fp2{fmaf(k.wy, jwz, -(k.wz * jwy)), fmaf(k.wz, jwx, -(k.wx * jwz))};
     const float tzz = tz - fmaf(k.wx, jwy, -(k.wy * jwx));
-    // semi-implicit Euler (:860-862): position uses the NEW velocity
-    k.vx = fmaf(h, Fx * P.inv_M, k.vx); k.vy = fmaf(h, Fy * P.inv_M, k.vy); k.vz = fmaf(h, Fz * P.inv_M, k.vz);
-    k.wx = fmaf(h, P.J_INV[0] * tx, k.wx); k.wy = fmaf(h, P.J_INV[1] * ty, k.wy); k.wz = fmaf(h, P.J_INV[2] * tzz, k.wz);
-    k.px = fmaf(h, k.vx, k.px); k.py = fmaf(h, k.vy, k.py); k.pz = fmaf(h, k.vz, k.pz);
+    // semi-implicit Euler (:860-862): position uses the NEW velocity; x and y as packed pairs
+    const fp2 hh = splat(h);
+    const fp2 vxy = fma2(hh, fp2{Fx, Fy} * splat(P.inv_M), fp2{k.vx, k.vy});
+    k.vx = vxy.x; k.vy = vxy.y; k.vz = fmaf(h, Fz * P.inv_M, k.vz);
+    const fp2 wxy = fma2(hh, fp2{P.J_INV[0], P.J_INV[1]} * txy, fp2{k.wx, k.wy});
+    k.wx = wxy.x; k.wy = wxy.y; k.wz = fmaf(h, P.J_INV[2] * tzz, k.wz);
+    const fp2 pxy = fma2(hh, vxy, fp2{k.px, k.py});
+    k.px = pxy.x; k.py = pxy.y; k.pz = fmaf(h, k.vz, k.pz);
     // exact exponential quaternion update q <- q (x) exp(w h / 2)  (:879-892)
     //   q' = cos(t) q + (sin(t)/|w|) (q (x) [w,0]),  t = |w| h / 2.  cos(t) and sin(t)/t are even functions
     //   of t, evaluated as minimax polynomials in u = t^2 (abs err 7e-8 / 5e-8 for t <= 1 rad, i.e. body
     //   rates up to 480 rad/s at 240 Hz): no sqrt, no division, no range reduction.
     const float n2 = fmaf(k.wz, k.wz, fmaf(k.wy, k.wy, k.wx * k.wx));
     const float u = n2 * (0.25f * h * h);
-    float cs = fmaf(fmaf(fmaf(fmaf(2.412107309e-05f, u, -1.388295778e-03f), u, 4.166645522e-02f), u, -4.999999736e-01f),
-                    u, 9.999999995e-01f);
-    float sc = fmaf(fmaf(fmaf(fmaf(2.693749890e-06f, u, -1.983586443e-04f), u, 8.333314057e-03f), u, -1.666666643e-01f),
-                    u, 1.0f) * (0.5f * h);
+    const fp2 uu = splat(u);                                  // (cos t, sin t / t): the two Horner chains as one packed chain
+    const fp2 csp = fma2(fma2(fma2(fma2(fp2{2.412107309e-05f, 2.693749890e-06f}, uu, fp2{-1.388295778e-03f, -1.983586443e-04f}), uu,
+                                  fp2{4.166645522e-02f, 8.333314057e-03f}), uu, fp2{-4.999999736e-01f, -1.666666643e-01f}), uu,
+                        fp2{9.999999995e-01f, 1.0f});
+    float cs = csp.x;
+    float sc = csp.y * (0.5f * h);
     const bool tumbling = !(u <= 1.0f);                    // faster than 480 rad/s (at 240 Hz): exact path
     if (any_lane(tumbling)) {
         asm volatile("; tumbling: rare");
@@ -351,12 +398,14 @@ __device__ __forceinline__ void substep(const GpdParams& P, float h, uint32_t fl
         const float lz = fmaf(k.wz, k.qw, fmaf(k.wy, k.qx, -(k.wx * k.qy)));
         const float lw = -fmaf(k.wz, k.qz, fmaf(k.wy, k.qy, k.wx * k.qx));
         const bool turn = n2 > 1e-16f;                     // !np.isclose(|w|, 0): |w| <= 1e-8 keeps q  (select, no branch)
-        k.qx = turn ? fmaf(sc, lx, cs * k.qx) : k.qx; k.qy = turn ? fmaf(sc, ly, cs * k.qy) : k.qy;
-        k.qz = turn ? fmaf(sc, lz, cs * k.qz) : k.qz; k.qw = turn ? fmaf(sc, lw, cs * k.qw) : k.qw;
+        const fp2 nxy = fma2(splat(sc), fp2{lx, ly}, splat(cs) * fp2{k.qx, k.qy});
+        const fp2 nzw = fma2(splat(sc), fp2{lz, lw}, splat(cs) * fp2{k.qz, k.qw});
+        k.qx = turn ? nxy.x : k.qx; k.qy = turn ? nxy.y : k.qy;
+        k.qz = turn ? nzw.x : k.qz; k.qw = turn ? nzw.y : k.qw;
     }
     // world angular velocity handed to the state store: PRE-update rotation, post-update rates (:873)
-    avx = fmaf(R.r02, k.wz, fmaf(R.r01, k.wy, R.r00 * k.wx));
-    avy = fmaf(R.r12, k.wz, fmaf(R.r11, k.wy, R.r10 * k.wx));
+    const fp2 axy = fma2(fp2{R.r02, R.r12}, splat(k.wz), fma2(fp2{R.r01, R.r11}, splat(k.wy), fp2{R.r00, R.r10} * splat(k.wx)));
+    avx = axy.x; avy = axy.y;
     avz = fmaf(R.r22, k.wz, fmaf(R.r21, k.wy, R.r20 * k.wx));
 }
 
@@ -438,11 +487,12 @@ __device__ __forceinline__ void map_action(const GpdParams& P, const GpdStepCfg&
             rpm[0] = rpm[1] = rpm[2] = rpm[3] = fmaf(P.hover_rpm, e, P.hover_rpm);
             g[0] = g[1] = g[2] = g[3] = thrust_dev_norm(P, e);
         } else if (act_type == GPD_ACT_RPM) {   // NOT clipped
-            const float e0 = 0.05f * act.x, e1 = 0.05f * act.y, e2 = 0.05f * act.z, e3 = 0.05f * act.w;
-            rpm[0] = fmaf(P.hover_rpm, e0, P.hover_rpm); rpm[1] = fmaf(P.hover_rpm, e1, P.hover_rpm);
-            rpm[2] = fmaf(P.hover_rpm, e2, P.hover_rpm); rpm[3] = fmaf(P.hover_rpm, e3, P.hover_rpm);
-            g[0] = thrust_dev_norm(P, e0); g[1] = thrust_dev_norm(P, e1);
-            g[2] = thrust_dev_norm(P, e2); g[3] = thrust_dev_norm(P, e3);
+            // rpm = HOVER_RPM*(1 + 0.05 a), g = thrust_dev_norm(0.05 a): rotors (0,1) and (2,3) as packed pairs
+            const fp2 e01 = splat(0.05f) * fp2{act.x, act.y}, e23 = splat(0.05f) * fp2{act.z, act.w};
+            const fp2 r01 = fma2(splat(P.hover_rpm), e01, splat(P.hover_rpm)), r23 = fma2(splat(P.hover_rpm), e23, splat(P.hover_rpm));
+            const fp2 g01 = splat(P.hover_thrust) * (e01 * (splat(2.0f) + e01)), g23 = splat(P.hover_thrust) * (e23 * (splat(2.0f) + e23));
+            rpm[0] = r01.x; rpm[1] = r01.y; rpm[2] = r23.x; rpm[3] = r23.y;
+            g[0] = g01.x; g[1] = g01.y; g[2] = g23.x; g[3] = g23.y;
         } else {           // GPD_ACT_RAW_RPM (clipped to [0, MAX_RPM], envs/CtrlAviary.py:140) or GPD_ACT_DIRECT_RPM (as is)
             const bool clip = act_type == GPD_ACT_RAW_RPM;
             const float lo = clip ? 0.0f : -3.0e38f, hi = clip ? P.max_rpm : 3.0e38f;
@@ -480,7 +530,8 @@ __device__ __forceinline__ void map_action(const GpdParams& P, const GpdStepCfg&
 __device__ __forceinline__ void task_single(const GpdStepCfg& C, float px, float py, float pz, float roll, float pitch,
                                             int counter, float tgx, float tgy, float tgz, float& rew, bool& term,
                                             bool& trunc) {
-    const float ex = tgx - px, ey = tgy - py, ez = tgz - pz;
+    const fp2 exy = fp2{tgx, tgy} - fp2{px, py};
+    const float ex = exy.x, ey = exy.y, ez = tgz - pz;
     const float my_dist = fast_sqrt(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
     const float d2 = my_dist * my_dist;
     rew = fmaxf(0.0f, fmaf(-d2, d2, 2.0f));
