@@ -571,13 +571,14 @@ __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C
                 const float dz = zj - k.pz;
                 const float ddx = xj - k.px, ddy = yj - k.py;
                 const float dxy2 = fmaf(ddy, ddy, ddx * ddx);
-                if (dz > 0.0f && dxy2 < 100.0f) {            // dz > 0 and dxy < 10 m
-                    const float ratio = (0.25f * P.prop_radius) * fast_rcp(dz);
-                    const float alpha = P.dw_coeff[0] * (ratio * ratio);
-                    const float beta = fmaf(P.dw_coeff[1], dz, P.dw_coeff[2]);
-                    const float ib = fast_rcp(beta);
-                    dw -= alpha * fast_exp(-0.5f * (dxy2 * (ib * ib)));
-                }
+                // evaluated for every mate and selected (no exec-mask branch per mate; a lane the test excludes may
+                // compute inf/NaN here, which the select discards)
+                const float ratio = (0.25f * P.prop_radius) * fast_rcp(dz);
+                const float alpha = P.dw_coeff[0] * (ratio * ratio);
+                const float beta = fmaf(P.dw_coeff[1], dz, P.dw_coeff[2]);
+                const float ib = fast_rcp(beta);
+                const float pushed = dw - alpha * fast_exp(-0.5f * (dxy2 * (ib * ib)));
+                dw = ((dz > 0.0f) & (dxy2 < 100.0f)) ? pushed : dw;   // dz > 0 and dxy < 10 m
             };
             if (L.shfl) {
                 // the aviary is D aligned lanes of THIS wave: one 16-byte LDS write per lane, one broadcast read per
@@ -587,7 +588,11 @@ __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C
                 sp[L.tid] = make_float4(k.px, k.py, k.pz, 0.0f);
                 __builtin_amdgcn_wave_barrier();
                 const int base = L.le * D;
-                for (int j = 0; j < D; ++j) { const float4 o = sp[base + j]; wake_of(o.x, o.y, o.z); }
+                // D is a power of two here: pairs (D = 2) or groups of four, so that the LDS reads of a group are issued
+                // together and the loop branch (a taken branch costs ~60 cycles at one wave per SIMD) is paid once per group
+                auto mate = [&](int j) { const float4 o = sp[base + j]; wake_of(o.x, o.y, o.z); };
+                if (D == 2) { mate(0); mate(1); }
+                else for (int j = 0; j < D; j += 4) { mate(j); mate(j + 1); mate(j + 2); mate(j + 3); }
             } else {
                 wg_barrier();
                 sh_pos[L.tid] = k.px; sh_pos[kBlock + L.tid] = k.py; sh_pos[2 * kBlock + L.tid] = k.pz;
@@ -632,10 +637,9 @@ __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C
                 sr[L.tid] = make_float4(my_rew, my_dist, my_o, 0.0f);
                 __builtin_amdgcn_wave_barrier();
                 const int base = L.le * D;
-                for (int j = 0; j < D; ++j) {                  // sequential, like the reference's loops
-                    const float4 v = sr[base + j];
-                    r += v.x; dsum += v.y; o += v.z;
-                }
+                auto mate = [&](int j) { const float4 v = sr[base + j]; r += v.x; dsum += v.y; o += v.z; };   // sequential, like the
+                if (D == 2) { mate(0); mate(1); }                                                               // reference's loops
+                else for (int j = 0; j < D; j += 4) { mate(j); mate(j + 1); mate(j + 2); mate(j + 3); }
             } else {
                 wg_barrier();
                 sh_red[L.tid] = my_rew; sh_red[kBlock + L.tid] = my_dist; sh_red[2 * kBlock + L.tid] = my_o;
