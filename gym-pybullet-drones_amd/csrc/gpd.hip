@@ -562,6 +562,16 @@ __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C
     if (S1 && !(EXT && MULTI)) {
         // ctrl_freq == pyb_freq, known at compile time: straight-line, no loop branches (two taken branches per step)
         substep<EXT>(P, C.pyb_dt, flags, g, drag_sum, EXT ? c.dw_in : 0.0f, k, avx, avy, avz);
+    } else if (!MULTI) {
+        // two sub-steps per iteration: half the loop branches (HoverAviary's default 30 Hz control is 8 sub-steps)
+        const float dw = EXT ? c.dw_in : 0.0f;
+        int ss = 0;
+        for (; ss + 1 < C.substeps; ss += 2) {
+            substep<EXT>(P, C.pyb_dt, flags, g, drag_sum, dw, k, avx, avy, avz);
+            substep<EXT>(P, C.pyb_dt, flags, g, cur_sum, dw, k, avx, avy, avz);
+            drag_sum = cur_sum;
+        }
+        if (ss < C.substeps) substep<EXT>(P, C.pyb_dt, flags, g, drag_sum, dw, k, avx, avy, avz);
     } else
     for (int ss = 0; ss < C.substeps; ++ss) {
         float dw = (EXT && !MULTI) ? c.dw_in : 0.0f;
