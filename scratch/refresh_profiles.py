@@ -11,6 +11,9 @@ for w in ("hover65536_30hz", "hover65536_pid_240hz", "stack8x8192_ext_240hz", "m
           "hover16m_240hz", "swarm65536_ext_240hz"):
     if os.path.exists(f"gpurun_out/bench_{w}.json"):
         shutil.copy(f"gpurun_out/bench_{w}.json", f"profiles/r01_bench_{w}.json")
+for src, dst in (("gpurun_out/sq_counters.txt", "profiles/r01_sq_counters.txt"), ("gpurun_out/issue_microbench.txt", "profiles/r01_issue_microbench.txt")):
+    if os.path.exists(src):
+        shutil.copy(src, dst)
 d = json.load(open("profiles/r01_summary.json"))
 def kern(tag, name):
     for r in d[tag]:
@@ -30,3 +33,14 @@ out = {
 json.dump(out, open("profiles/hbm_traffic.json", "w"), indent=1)
 for k, v in out.items():
     if isinstance(v, dict): print(k, {a: (round(b) if isinstance(b, float) else b) for a, b in v.items()})
+
+# the bench lines above were produced while profiles/hbm_traffic.json still held the previous table: re-inject the new one
+for f in glob.glob("profiles/r01_bench_*.json"):
+    b = json.load(open(f))
+    w = b["config"]["workload"]
+    for key, roof in ((f"{w}:{b['config'].get('launch')}", b.get("roofline")), (f"{w}:graph", (b.get("one_launch_per_step") or {}).get("roofline"))):
+        rec = out.get(key)
+        if rec and roof is not None and rec.get("traffic_bytes"):
+            roof["traffic"] = rec["traffic_bytes"]
+            roof["rocprof_kernel_avg_us"] = rec["rocprof_kernel_avg_ns"] / 1e3
+    json.dump(b, open(f, "w"))
