@@ -89,7 +89,8 @@ def _actions(rng, act, shape, hover_rpm):
 
 @pytest.mark.parametrize("model", ["cf2x", "cf2p", "racer"])
 @pytest.mark.parametrize("act", ["rpm", "one_d_rpm", "pid", "vel", "one_d_pid", "raw_rpm"])
-@pytest.mark.parametrize("flags,D,S", [(0, 1, 1), (0, 1, 8), (7, 1, 2), (7, 3, 2), (2, 2, 8), (5, 8, 1), (1, 5, 4)])
+@pytest.mark.parametrize("flags,D,S", [(0, 1, 1), (0, 1, 8), (7, 1, 2), (7, 3, 2), (2, 2, 8), (5, 8, 1), (1, 5, 4),
+                                       (7, 1, 3), (2, 1, 5)])   # (odd sub-step counts: the remainder of the 2x unrolled loop)
 def test_one_step_parity(gpu_device, model, act, flags, D, S):
     if model == "racer" and act in ("pid", "vel", "one_d_pid"):
         pytest.skip("no DSLPID controller for the racer")

@@ -33,6 +33,7 @@ RAGGED = [  # act, flags, D, S, model, E, K: ragged last workgroups, whole-aviar
     ("rpm", 0, 1, 1, "cf2x", 1000, 7), ("pid", 0, 1, 2, "cf2x", 257, 5), ("rpm", 4, 3, 1, "cf2x", 100, 8),
     ("one_d_rpm", 0, 1, 1, "cf2x", 5, 4), ("raw_rpm", 2, 7, 2, "cf2p", 37, 6), ("rpm", 0, 1, 1, "cf2x", 140001, 10),
     ("vel", 7, 2, 1, "cf2x", 70001, 5), ("rpm", 0, 1, 1, "cf2x", 1, 2),
+    ("rpm", 2, 1, 3, "cf2x", 300, 7), ("pid", 7, 1, 5, "cf2p", 200, 4),       # odd sub-step counts
 ]
 
 
