@@ -9,9 +9,9 @@
 //
 // Kernels:
 //   gpd_step_kernel      one env step per launch                                  (gpd_step)
-//   gpd_rollout1_kernel  K env steps per launch, single-drone aviaries            (gpd_rollout)
-//   gpd_rollout_kernel   K env steps per launch, compute waves + a store wave     (gpd_rollout: multi-drone
-//                        aviaries, terminal observations)
+//   gpd_rollout1_kernel  K env steps per launch, aviaries of 1, 2, 4 .. 64 drones (gpd_rollout)
+//   gpd_rollout_kernel   K env steps per launch, compute waves + a store wave     (gpd_rollout: other aviary
+//                        sizes, terminal observations)
 //   gpd_full_obs_kernel / gpd_hist_push_kernel   action ring + full KIN rows      (gpd_full_obs)
 //   dwg_*_kernel         downwash inside one aviary of any size, grid binning     (gpd_downwash_global)
 //   gpd_reset_kernel, gpd_pid_kernel, gpd_state20_kernel
@@ -1202,25 +1202,34 @@ struct RollOut {
 // write instead of a branch around the stores.  (Calls that ask for terminal observations -- conditional stores -- use
 // the compute-wave + store-wave kernel above.)
 // ------------------------------------------------------------------------------------------------
-template <bool PID, bool EXT, int AW, int ACT, bool S1>
+// MULTI: aviaries of D = 2, 4, ..., 64 drones (a power of two: D aligned lanes of one wave, wave-local exchange inside
+// env_step, no workgroup barrier).  Every lane of an aviary ends a step with the aviary's reward and flags and stores
+// them to the aviary's slot -- D identical writes instead of a branch; a lane without a drone is a clone of the drone of
+// aviary 0 with the same index d, so whole clone aviaries replay aviary 0 bit for bit.
+template <bool PID, bool EXT, int AW, int ACT, bool S1, bool MULTI>
 __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     const GpdParams P, const GpdState S, const GpdStepCfg C, const Span T, const float* __restrict__ action,
     const float* __restrict__ target_pos, const float* __restrict__ init_pose, float* __restrict__ obs12,
     float* __restrict__ reward, uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
     float* __restrict__ term_obs12) {
     const int tid = threadIdx.x;
-    const uint32_t N = static_cast<uint32_t>(C.num_envs);
+    const int D = MULTI ? C.drones_per_env : 1;
+    const uint32_t dmask = static_cast<uint32_t>(D - 1);
+    const uint32_t N = static_cast<uint32_t>(C.num_envs) * static_cast<uint32_t>(D);
     const uint32_t n_raw = blockIdx.x * static_cast<uint32_t>(kBlock) + tid;
     const int K = T.num_steps;
     const uint32_t flags = EXT ? C.physics_flags : 0u;
     Lane L;
-    L.tid = tid; L.le = tid; L.d = 0; L.shfl = false;
+    L.tid = tid; L.shfl = MULTI;
+    L.le = MULTI ? tid / D : tid;
+    L.d = MULTI ? static_cast<int>(tid & dmask) : 0;
     L.active = n_raw < N;
-    L.n = L.active ? n_raw : 0u;
-    L.env = L.n;
+    L.n = L.active ? n_raw : (tid & dmask);
+    L.env = MULTI ? (L.active ? n_raw / static_cast<uint32_t>(D) : 0u) : L.n;
 
     __shared__ __attribute__((aligned(16))) float sh_rows[kBlock * 12];
-    float dummy_lds[1];                                              // (env_step's LDS arguments are unused without MULTI)
+    __shared__ __attribute__((aligned(16))) float sh_pos[MULTI ? 4 * kBlock : 4];   // downwash: positions of the aviary's drones
+    __shared__ __attribute__((aligned(16))) float sh_red[MULTI ? 4 * kBlock : 4];   // reward | distance | out-of-bounds per drone
 
     // loop-invariant addressing of this lane's three 16-byte chunks of its wave's 3 KiB row patch
     const int wave0 = tid & ~63, lane = tid & 63;
@@ -1231,7 +1240,7 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const uint32_t cidx = static_cast<uint32_t>(j * 64 + lane), r = cidx / 3u, part = cidx - 3u * r;
-        goff[j] = (r < rows ? (n0 + r) * 48u : 0u) + part * 16u;    // a clone's row goes to drone 0's row
+        goff[j] = (r < rows ? (n0 + r) * 48u : (r & dmask) * 48u) + part * 16u;   // a clone's row goes to the row of its original
     }
     const uint32_t eoff4 = L.env * 4u;
 
@@ -1239,7 +1248,7 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     float tgx, tgy, tgz, ip[7];
     auto fetch = [&](int step) { return load_action<AW, true>(action + (step < K ? step : K - 1) * T.action_stride, L.n); };
     const float* ipose = reinterpret_cast<const float*>(reinterpret_cast<const char*>(init_pose) +
-                                                        (C.init_per_env ? L.n * 28u : 0u));
+                                                        (C.init_per_env ? L.n * 28u : static_cast<uint32_t>(L.d) * 28u));
     load_carry<PID, EXT>(S, C, flags, L, target_pos, C.auto_reset ? ipose : S.kin, c, tgx, tgy, tgz, ip);
     asm volatile("" :: "v"(c.k.px), "v"(c.k.py), "v"(c.k.pz), "v"(c.k.qx), "v"(c.k.qy), "v"(c.k.qz), "v"(c.k.qw), "v"(c.k.vx),
                        "v"(c.k.vy), "v"(c.k.vz), "v"(c.k.wx), "v"(c.k.wy), "v"(c.k.wz), "v"(tgx), "v"(tgy), "v"(tgz),
@@ -1255,8 +1264,8 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     auto emit = [&](const StepOut& out, bool advance) { ro.emit(out, advance); };
     auto do_step = [&](const int t, const float4 act) {
         StepOut out;
-        env_step<PID, EXT, false, AW, ACT, S1>(P, C, flags, 1, L, act, tgx, tgy, tgz, true, ipose, ip[0], ip[1], ip[2], ip[3],
-                                               ip[4], ip[5], ip[6], dummy_lds, dummy_lds, c, out);
+        env_step<PID, EXT, MULTI, AW, ACT, S1>(P, C, flags, D, L, act, tgx, tgy, tgz, true, ipose, ip[0], ip[1], ip[2], ip[3],
+                                               ip[4], ip[5], ip[6], sh_pos, sh_red, c, out);
         // row -> the wave's LDS patch -> three coalesced bursts, software-pipelined by one step: the bursts of step
         // t - 1 (read back from the patch a whole step ago, so the LDS round trip is never waited for) go out here, then
         // this step's rows are written to the patch and read back into `pend` for the next step.  Same wave on both sides:
@@ -1573,15 +1582,18 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
         Tr.ring = ((!multi || shfl) && grid.x <= 2u * 256u) ? 4 : 2;   // <= 2 workgroups per CU: LDS is not what limits occupancy
         const size_t lds = static_cast<size_t>(Tr.ring) * kSlotBytes;
         static const bool store_wave_variant = getenv("GPD_ROLLOUT_STOREWAVE") != nullptr;   // A/B switch, diagnostics only
-        if (multi) {
+        if (shfl && !store_wave_variant && term_obs12 == nullptr) {   // aviaries of 2..64 (power of two) drones: no helper wave either
+            hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false, true>), grid, dim3(kBlock), 0, st, P, S, C, Tr, action,
+                               target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+        } else if (multi) {
             hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, true, AW>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
                                action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
         } else if (!store_wave_variant && term_obs12 == nullptr) {
             if (C.substeps == 1)
-                hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, true>), grid, dim3(kBlock), 0, st, P, S, C, Tr, action,
+                hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, true, false>), grid, dim3(kBlock), 0, st, P, S, C, Tr, action,
                                    target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
             else
-                hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false>), grid, dim3(kBlock), 0, st, P, S, C, Tr, action,
+                hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false, false>), grid, dim3(kBlock), 0, st, P, S, C, Tr, action,
                                    target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
         } else {
             hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, false, AW>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
