@@ -1261,18 +1261,11 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     (void)term_obs12;   // (terminal observations: the host routes such calls to gpd_rollout_kernel -- a conditional
                         // store in this loop body would make the wait counts conservative again)
     RollOut ro(obs12, reward, terminated, truncated, T, goff, eoff4, L.env, sh_rows + tid * 12, lsrc);
-    auto emit = [&](const StepOut& out, bool advance) { ro.emit(out, advance); };
     auto do_step = [&](const int t, const float4 act) {
         StepOut out;
         env_step<PID, EXT, MULTI, AW, ACT, S1>(P, C, flags, D, L, act, tgx, tgy, tgz, true, ipose, ip[0], ip[1], ip[2], ip[3],
                                                ip[4], ip[5], ip[6], sh_pos, sh_red, c, out);
-        // row -> the wave's LDS patch -> three coalesced bursts, software-pipelined by one step: the bursts of step
-        // t - 1 (read back from the patch a whole step ago, so the LDS round trip is never waited for) go out here, then
-        // this step's rows are written to the patch and read back into `pend` for the next step.  Same wave on both sides:
-        // the LDS executes a wave's instructions in order, so the reads see the writes without any wait or barrier (the
-        // wave_barrier only pins the order for the compiler).  At t = 0 the bursts carry zeros to step 0's rows, which
-        // step 1 then overwrites (same lane, same addresses, program order) -- an unconditional store, see above.
-        emit(out, t > 0);
+        ro.emit(out, t > 0);                                          // (see RollOut: pipelined bursts, unconditional stores)
     };
     // Action rows, three steps per loop iteration: the rows of the NEXT iteration (b0..b2) are requested at the top of
     // this one and claimed at its end with an explicit vmcnt(18) -- "everything but the youngest 18 operations", i.e.
