@@ -1443,52 +1443,77 @@ __global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const float* __rest
     sorted[slot] = make_float4(x, y, z, __int_as_float(c));
 }
 
-// One workgroup per grid cell: the candidates of the cell's 3x3 neighbourhood (three contiguous runs of the sorted
-// array, one per cell row) are staged through LDS in tiles of 512, and every drone of the cell (one lane each, in
-// passes of 256) sweeps the tile -- LDS broadcast reads instead of a dependent global load per candidate.
-constexpr int kDwTile = 512;
+// One workgroup per grid cell; every drone of the cell sweeps the candidates of the cell's 3x3 neighbourhood, staged
+// through LDS (broadcast reads instead of a dependent global load per candidate).
+constexpr int kDwTile = 1024;     // candidates staged in LDS at a time (16 KiB)
 __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, int nx, int ny,
                                                            const int* __restrict__ start, const int* __restrict__ order,
                                                            const float4* __restrict__ sorted, float* __restrict__ dw_out) {
+    // The drones of the cell are taken 64 at a time, and ALL FOUR waves hold the same 64 (lane i of every wave = drone
+    // base + i): the waves split the CANDIDATES of a tile four ways instead of the drones -- a cell holds ~64 drones, so
+    // splitting the drones would leave three of the four waves sweeping for nobody.  The partial sums are 64-bit fixed
+    // point, hence the four-way split changes no bit of the result.
     __shared__ float4 tile[kDwTile];
+    __shared__ long long part[kBlock];
     const int c = blockIdx.x;
     const int cy = c / nx, cx = c - cy * nx;
     const int m0 = start[c], m1 = start[c + 1];            // the drones of this cell
     if (m0 == m1) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float kr = 0.25f * P.prop_radius;
-    for (int base = m0; base < m1; base += kBlock) {       // passes of 256 drones
-        const int s = base + threadIdx.x;
+    // The candidates of the 3x3 neighbourhood (periodic; nx, ny >= 3: nine distinct cells) are nine runs of the sorted
+    // array.  They are staged as ONE concatenated list, kDwTile at a time: one pair of barriers and one round of global
+    // loads per ~1000 candidates instead of per cell (the loads' latency sits between the two barriers).
+    int run0[9], pre[10];                                  // first element of each run; prefix sums of the run lengths
+    pre[0] = 0;
+#pragma unroll
+    for (int nb = 0; nb < 9; ++nb) {
+        const int yy = (cy + nb / 3 - 1 + ny) % ny, xx = (cx + nb % 3 - 1 + nx) % nx;
+        run0[nb] = start[yy * nx + xx];
+        pre[nb + 1] = pre[nb] + (start[yy * nx + xx + 1] - run0[nb]);
+    }
+    const int total = pre[9];
+    for (int base = m0; base < m1; base += 64) {           // groups of 64 drones
+        const int s = base + lane;
         const bool have = s < m1;
         const float4 me = have ? sorted[s] : make_float4(0.0f, 0.0f, 3.0e38f, 0.0f);   // (no drone: nothing is above it)
         long long acc = 0;                                 // sum of contributions in units of 2^-30 N: order-independent
-        for (int nb = 0; nb < 9; ++nb) {                   // the 3x3 neighbourhood, periodic (nx, ny >= 3: nine distinct cells)
-            const int yy = (cy + nb / 3 - 1 + ny) % ny, xx = (cx + nb % 3 - 1 + nx) % nx;
-            const int t0 = start[yy * nx + xx], t1 = start[yy * nx + xx + 1];
-            for (int tb = t0; tb < t1; tb += kDwTile) {
-                const int cnt = min(kDwTile, t1 - tb);
-                __syncthreads();
-                for (int j = threadIdx.x; j < cnt; j += kBlock) tile[j] = sorted[tb + j];
-                __syncthreads();
+        for (int v0 = 0; v0 < total; v0 += kDwTile) {
+            const int cnt = min(kDwTile, total - v0);
+            __syncthreads();
+            for (int j = threadIdx.x; j < cnt; j += kBlock) {
+                const int v = v0 + j;                      // position in the concatenated list -> run r, element src
+                int src = run0[0] + v;
+#pragma unroll
+                for (int q = 1; q < 9; ++q) src = (v >= pre[q]) ? run0[q] + (v - pre[q]) : src;
+                tile[j] = sorted[src];
+            }
+            __syncthreads();
 #pragma unroll 4
-                for (int j = 0; j < cnt; ++j) {
-                    const float4 o = tile[j];
-                    const float dz = o.z - me.z;
-                    const float ddx = o.x - me.x, ddy = o.y - me.y;
-                    const float dxy2 = fmaf(ddy, ddy, ddx * ddx);
-                    if (dz > 0.0f && dxy2 < 100.0f) {      // dz > 0 and dxy < 10 m  (:800-801)
-                        const float ratio = kr * fast_rcp(dz);
-                        const float alpha = P.dw_coeff[0] * (ratio * ratio);
-                        const float beta = fmaf(P.dw_coeff[1], dz, P.dw_coeff[2]);
-                        const float ib = fast_rcp(beta);
-                        const float arg = 0.5f * (dxy2 * (ib * ib));
-                        // exp(-40) = 4e-18: below the 2^-31 N the fixed-point sum resolves for any alpha < 1e8 N -- most
-                        // candidates of the 3x3 cells end here without evaluating the exponential
-                        if (arg < 40.0f || alpha > 1.0e8f) acc += __float2ll_rn((alpha * fast_exp(-arg)) * 1073741824.0f);
-                    }
+            for (int j = wave; j < cnt; j += 4) {          // this wave's quarter of the candidates
+                const float4 o = tile[j];
+                const float dz = o.z - me.z;
+                const float ddx = o.x - me.x, ddy = o.y - me.y;
+                const float dxy2 = fmaf(ddy, ddy, ddx * ddx);
+                if (dz > 0.0f && dxy2 < 100.0f) {          // dz > 0 and dxy < 10 m  (:800-801)
+                    const float ratio = kr * fast_rcp(dz);
+                    const float alpha = P.dw_coeff[0] * (ratio * ratio);
+                    const float beta = fmaf(P.dw_coeff[1], dz, P.dw_coeff[2]);
+                    const float ib = fast_rcp(beta);
+                    const float arg = 0.5f * (dxy2 * (ib * ib));
+                    // exp(-40) = 4e-18: below the 2^-31 N the fixed-point sum resolves for any alpha < 1e8 N -- most
+                    // candidates of the 3x3 cells end here without evaluating the exponential
+                    if (arg < 40.0f || alpha > 1.0e8f) acc += __float2ll_rn((alpha * fast_exp(-arg)) * 1073741824.0f);
                 }
             }
         }
-        if (have) dw_out[order[s]] = -static_cast<float>(static_cast<double>(acc) * (1.0 / 1073741824.0));
+        __syncthreads();                                   // (all waves are done with `part` of the previous group)
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        if (wave == 0 && have) {
+            const long long sum = (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
+            dw_out[order[s]] = -static_cast<float>(static_cast<double>(sum) * (1.0 / 1073741824.0));
+        }
     }
 }
 
