@@ -498,3 +498,52 @@ def test_size_limits_are_reported(gpu_device):
         core.rollout(torch.zeros((3, 5), device=gpu_device))                 # not K x N x A
     with pytest.raises(ValueError):
         core.rollout(torch.zeros((2, 4, 4), device=gpu_device), num_steps=3)  # neither one block nor K blocks
+
+
+def test_rare_paths_gimbal_lock_and_tumbling(gpu_device):
+    """The two rare per-lane cases of the step body, which the kernels enter through a wave-uniform unlikely test:
+    Bullet's gimbal-lock branches of the Euler extraction (pitch = +-90 deg exactly) and the exact quaternion
+    exponential for a drone that turns more than 1 rad per sub-step (> 480 rad/s at 240 Hz).  Mixed into a batch of
+    ordinary drones so that some waves take the rare block for a few lanes only, some for none."""
+    rng = np.random.default_rng(23)
+    E = 1000
+    xyz, rpy = _random_scene(rng, E, 1)
+    gimbal_up, gimbal_dn, spin = np.arange(3, E, 97), np.arange(11, E, 89), np.arange(5, E, 61)
+    rpy[gimbal_up, 0] = [0.3, np.pi / 2, 0.5]
+    rpy[gimbal_dn, 0] = [-0.2, -np.pi / 2, 1.0]
+    b = BatchedAviary(urdf("cf2x"), "cf2x", num_envs=E, num_drones=1, initial_xyzs=xyz, initial_rpys=rpy, pyb_freq=240,
+                      ctrl_freq=240, act="rpm", task="hover")
+    core = _core("cf2x", E, 1, 0, 1, "rpm", "hover", xyz, rpy, gpu_device, target=b.TARGET_POS)
+    # gimbal lanes: no rotation during the step (hover RPMs, zero rates) so the pose stays on the branch
+    b.rpy_rates[spin, 0] = rng.uniform(-1, 1, size=(len(spin), 3)) * np.array([700.0, 650.0, 900.0])
+    _sync_from_oracle(core, b)
+    kin0 = core.kin[:, :E].clone()
+    sarg = -2 * (b.quat[:, 0, 0] * b.quat[:, 0, 2] - b.quat[:, 0, 3] * b.quat[:, 0, 1])
+    assert (np.abs(sarg[gimbal_up]) >= 0.99999).all() and (np.abs(sarg[gimbal_dn]) >= 0.99999).all()
+    a = np.zeros((E, 1, 4), dtype=np.float32)
+    a[::2] = rng.uniform(-1, 1, size=a[::2].shape)
+    a[gimbal_up] = a[gimbal_dn] = 0.0
+    obs, *_ = b.step(a.astype(np.float64))
+    core.step(torch.as_tensor(a, device=gpu_device))
+    kin = core.kin[:, :E].cpu().numpy().astype(np.float64)
+    ref = _oracle_kin(b)
+    err = np.abs(kin - ref) / np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1.0)
+    assert err.max() < 2e-5, err.max(axis=1)
+    # the spinning drones really took the exact path: more than 1 rad in this sub-step
+    assert (np.linalg.norm(b.rpy_rates[spin, 0], axis=1) / 480.0 > 1.0).all()
+    o = core.obs12.cpu().numpy().astype(np.float64)
+    lock = np.concatenate([gimbal_up, gimbal_dn])
+    ang = np.abs((o[lock, 3:6] - obs[lock, 0, 3:6] + np.pi) % (2 * np.pi) - np.pi)
+    assert ang.max() < 1e-5, ang.max(axis=0)
+    assert np.allclose(np.abs(o[lock, 4]), np.pi / 2) and (o[lock, 3] == 0).all()     # Bullet's convention on the branch
+    # ... and a rollout through the same states is bitwise the K single steps (the rare blocks are shared code)
+    core.set_state(kin=kin0, step_counter=np.zeros(E, dtype=np.int32))
+    core2 = _core("cf2x", E, 1, 0, 1, "rpm", "hover", xyz, rpy, gpu_device, target=b.TARGET_POS)
+    core2.set_state(kin=kin0, step_counter=np.zeros(E, dtype=np.int32))
+    acts = torch.as_tensor(np.stack([a, a, a]), device=gpu_device)
+    singles = []
+    for k in range(3):
+        o1, *_ = core.step(acts[k])
+        singles.append(o1.clone())
+    o3, *_ = core2.rollout(acts)
+    assert torch.equal(torch.stack(singles), o3) and torch.equal(core.kin, core2.kin)
