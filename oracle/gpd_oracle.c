@@ -185,6 +185,16 @@ static void substep(const OrcParams* P, const OrcCfg* C, const double* rpm, cons
     for (int k = 0; k < 3; ++k) ang_v[k] = R[3 * k] * w[0] + R[3 * k + 1] * w[1] + R[3 * k + 2] * w[2];
 }
 
+static int g_threads = 1;
+#ifdef _OPENMP
+#include <omp.h>
+int orc_max_threads(void) { return omp_get_max_threads(); }
+#else
+int orc_max_threads(void) { return 1; }
+#endif
+/* threads orc_step spreads the aviaries over (the timed multi-core CPU baseline of bench.py); returns the value set */
+int orc_set_threads(int n) { g_threads = n < 1 ? 1 : (n > orc_max_threads() ? orc_max_threads() : n); return g_threads; }
+
 int orc_struct_sizes(int32_t out[2]) { out[0] = (int32_t)sizeof(OrcParams); out[1] = (int32_t)sizeof(OrcCfg); return 0; }
 
 /*
@@ -201,9 +211,13 @@ int orc_step(const OrcParams* P, const OrcCfg* C, double* pos, double* quat, dou
     static const int ADIM[7] = {4, 3, 4, 1, 1, 4, 4};
     const int A = ADIM[C->act_type];
     if (D > 256) return -2;
-    double snap[3 * 256], rpm_env[4 * 256];
     const double zero3[3] = {0, 0, 0};
+    /* aviaries are independent: one per iteration, any number of threads (orc_set_threads; 1 by default) */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+#endif
     for (int e = 0; e < E; ++e) {
+        double snap[3 * 256], rpm_env[4 * 256];
         /* ---- action -> RPM from the cached state */
         for (int d = 0; d < D; ++d) {
             const int n = e * D + d;
