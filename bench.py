@@ -124,10 +124,10 @@ def cpu_baseline(w, budget_s=12.0):
         c = CAviary(urdf, "cf2x", Ec, D, physics_flags=w["phys"], pyb_freq=240, ctrl_freq=w["ctrl"], act=w["act"],
                     task=w["task"] if w["task"] != "hover" or D == 1 else "multihover")
         ac = rng.uniform(-1, 1, size=(8, Ec, D, A))
-        c.step(ac[0])
+        c.step_in_place(ac[0])
         m, t0 = 0, time.perf_counter()
         while time.perf_counter() - t0 < 3.0:
-            c.step(ac[m % 8])
+            c.step_in_place(ac[m % 8])
             m += 1
         dtc = time.perf_counter() - t0
         out["c_port"] = {"value": m * Ec * D * S / dtc, "unit": "drone-steps/s", "cores": 1,
@@ -140,10 +140,10 @@ def cpu_baseline(w, budget_s=12.0):
             ca = CAviary(urdf, "cf2x", Ea, D, physics_flags=w["phys"], pyb_freq=240, ctrl_freq=w["ctrl"], act=w["act"],
                          task=w["task"] if w["task"] != "hover" or D == 1 else "multihover")
             aa = rng.uniform(-1, 1, size=(4, Ea, D, A))
-            ca.step(aa[0])
+            ca.step_in_place(aa[0])
             m, t0 = 0, time.perf_counter()
             while time.perf_counter() - t0 < 3.0:
-                ca.step(aa[m % 4])
+                ca.step_in_place(aa[m % 4])
                 m += 1
             dta = time.perf_counter() - t0
             out["c_port_all_cores"] = {"value": m * Ea * D * S / dta, "unit": "drone-steps/s", "cores": threads,

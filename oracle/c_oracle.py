@@ -149,6 +149,12 @@ class CAviary:
         return np.concatenate([self.pos, self.quat, self.rpy, self.vel, self.ang_v, self.last_rpm], axis=-1)
 
     def step(self, action):
+        self.step_in_place(action)
+        return (self.obs.copy(), self.reward.copy(), self.terminated.astype(bool), self.truncated.astype(bool),
+                self.term_obs.copy() if self.cfg.auto_reset else None)
+
+    def step_in_place(self, action):
+        """One step; results stay in self.obs / reward / terminated / truncated / term_obs (no copies: for timing)."""
         a = np.ascontiguousarray(np.asarray(action, dtype=np.float64).reshape(self.E, self.D, ACT_DIM.get(self.ACT, 4)))
         rc = self.L.orc_step(ctypes.byref(self.params), ctypes.byref(self.cfg), _ptr(self.pos), _ptr(self.quat),
                              _ptr(self.vel), _ptr(self.rpy_rates), _ptr(self.ang_v), _ptr(self.rpy), _ptr(self.last_rpm),
@@ -156,5 +162,3 @@ class CAviary:
                              _ptr(self.INIT_XYZS), _ptr(self.INIT_QUAT), _ptr(self.obs), _ptr(self.reward),
                              _ptr(self.terminated), _ptr(self.truncated), _ptr(self.term_obs))
         assert rc == 0
-        return (self.obs.copy(), self.reward.copy(), self.terminated.astype(bool), self.truncated.astype(bool),
-                self.term_obs.copy() if self.cfg.auto_reset else None)
