@@ -12,8 +12,9 @@ for w in ("hover65536_30hz", "hover65536_pid_240hz", "stack8x8192_ext_240hz", "m
     if os.path.exists(f"gpurun_out/bench_{w}.json"):
         shutil.copy(f"gpurun_out/bench_{w}.json", f"profiles/r01_bench_{w}.json")
 for src, dst in (("gpurun_out/sq_counters.txt", "profiles/r01_sq_counters.txt"), ("gpurun_out/issue_microbench.txt", "profiles/r01_issue_microbench.txt")):
-    if os.path.exists(src):
-        shutil.copy(src, dst)
+    if os.path.exists(src):   # keep the explanatory headers ('#' lines) of the committed file, replace the data
+        hdr = "".join(l for l in open(dst) if l.startswith("#")) if os.path.exists(dst) else ""
+        open(dst, "w").write(hdr + "".join(l for l in open(src) if not l.startswith("#")))
 d = json.load(open("profiles/r01_summary.json"))
 def kern(tag, name):
     for r in d[tag]:
