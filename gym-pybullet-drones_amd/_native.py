@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(CSRC, "libgpd.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # -mllvm -amdgpu-sched-strategy=max-ilp: interleaves independent dependency chains, which fills the one-wait-state hazard
 # behind every packed-fp32 result with useful work instead of s_nops (13 of 287 issue slots of a rollout step)
@@ -77,7 +77,7 @@ _SIGNATURES = {
                                     ctypes.c_int64, _P, ctypes.c_int64, _P, _P, ctypes.c_int64, _P]),
     "gpd_downwash_global": (ctypes.c_int, [ctypes.POINTER(GpdParams), _P, ctypes.c_int64, ctypes.c_int32, ctypes.c_float,
                                            ctypes.c_float, ctypes.c_float, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P, _P,
-                                           _P]),
+                                           _P, _P]),
     "gpd_reset": (ctypes.c_int, [ctypes.POINTER(GpdState), _P, ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_int32,
                                  ctypes.c_int32, _P, _P]),
     "gpd_pid": (ctypes.c_int, [ctypes.POINTER(GpdParams), _P, ctypes.c_int64, ctypes.c_float, _P, _P, _P, _P, _P, _P,

@@ -1402,11 +1402,33 @@ __device__ __forceinline__ int cell_of(float x, float y, float inv_cell, float x
     return cy * nx + cx;
 }
 
+// The sort's two passes visit the drones in `visit` order (NULL: 0, 1, 2 ...).  Handing in the previous call's `order`
+// makes consecutive lanes fall into the same cell (drones move centimetres per sub-step), and the lanes of a wave that
+// share a cell then issue ONE atomic for their whole run instead of one each: ~64 same-address atomics per cell
+// become a handful.  run_of(): this lane's run among the wave's consecutive equal cells -> (first lane, length).
+__device__ __forceinline__ void run_of(int c, int lane, int& head_lane, int& len) {
+    const int prev_c = __shfl_up(c, 1);
+    const bool head = lane == 0 || c != prev_c;
+    const uint64_t heads = __builtin_amdgcn_ballot_w64(head);
+    const uint64_t upto = heads & (((lane == 63) ? 0ull : (2ull << lane)) - 1ull);      // heads at or below this lane
+    head_lane = 63 - __builtin_clzll(upto);
+    const uint64_t above = heads & ~(((head_lane == 63) ? 0ull : (2ull << head_lane)) - 1ull);   // heads above the run's first lane
+    len = (above ? __builtin_ctzll(above) : 64) - head_lane;
+}
+
 __global__ __launch_bounds__(kBlock) void dwg_count_kernel(const float* __restrict__ kin, int64_t ld, int n, float inv_cell,
-                                                           float x0, float y0, int nx, int ny, int* __restrict__ count) {
+                                                           float x0, float y0, int nx, int ny, const int* __restrict__ visit,
+                                                           int* __restrict__ count) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    atomicAdd(&count[cell_of(kin[i], kin[ld + i], inv_cell, x0, y0, nx, ny)], 1);
+    const int lane = threadIdx.x & 63;
+    int c = -1 - lane;                                      // (no drone: a run of its own, no atomic)
+    if (i < n) {
+        const int d = visit ? visit[i] : i;
+        c = cell_of(kin[d], kin[ld + d], inv_cell, x0, y0, nx, ny);
+    }
+    int head_lane, len;
+    run_of(c, lane, head_lane, len);
+    if (lane == head_lane && c >= 0) atomicAdd(&count[c], len);
 }
 
 // exclusive scan of count[0..cells) into start[0..cells], one workgroup; count is zeroed for the scatter's cursors
@@ -1431,16 +1453,28 @@ __global__ __launch_bounds__(1024) void dwg_scan_kernel(int* __restrict__ count,
 }
 
 __global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const float* __restrict__ kin, int64_t ld, int n, float inv_cell,
-                                                             float x0, float y0, int nx, int ny, int* __restrict__ cursor,
-                                                             const int* __restrict__ start, int* __restrict__ order,
-                                                             float4* __restrict__ sorted) {
+                                                             float x0, float y0, int nx, int ny, const int* __restrict__ visit,
+                                                             int* __restrict__ cursor, const int* __restrict__ start,
+                                                             int* __restrict__ order, float4* __restrict__ sorted) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float x = kin[i], y = kin[ld + i], z = kin[2 * ld + i];
-    const int c = cell_of(x, y, inv_cell, x0, y0, nx, ny);
-    const int slot = start[c] + atomicAdd(&cursor[c], 1);
-    order[slot] = i;
-    sorted[slot] = make_float4(x, y, z, __int_as_float(c));
+    const int lane = threadIdx.x & 63;
+    int c = -1 - lane, d = 0;
+    float x = 0.0f, y = 0.0f, z = 0.0f;
+    if (i < n) {
+        d = visit ? visit[i] : i;
+        x = kin[d]; y = kin[ld + d]; z = kin[2 * ld + d];
+        c = cell_of(x, y, inv_cell, x0, y0, nx, ny);
+    }
+    int head_lane, len;
+    run_of(c, lane, head_lane, len);
+    int base = 0;
+    if (lane == head_lane && c >= 0) base = start[c] + atomicAdd(&cursor[c], len);   // one atomic per run of equal cells
+    base = __shfl(base, head_lane);
+    if (c >= 0) {
+        const int slot = base + (lane - head_lane);
+        order[slot] = d;
+        sorted[slot] = make_float4(x, y, z, __int_as_float(c));
+    }
 }
 
 // One workgroup per grid cell; every drone of the cell sweeps the candidates of the cell's 3x3 neighbourhood, staged
@@ -1751,11 +1785,12 @@ int gpd_full_obs(int32_t num_steps, int32_t n_drones, int32_t act_dim, int32_t h
 }
 
 int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, int32_t n, float cell, float x0,
-                        float y0, int32_t nx, int32_t ny, int32_t* cell_count, int32_t* cell_start, int32_t* order,
-                        float* sorted_xyzc, float* dw_out, void* stream) {
+                        float y0, int32_t nx, int32_t ny, const int32_t* visit_order, int32_t* cell_count,
+                        int32_t* cell_start, int32_t* order, float* sorted_xyzc, float* dw_out, void* stream) {
     if (!params || !kin || !cell_count || !cell_start || !order || !sorted_xyzc || !dw_out)
         return fail(GPD_EINVAL, "gpd_downwash_global: NULL argument");
     if (n <= 0 || ld < n) return fail(GPD_EINVAL, "gpd_downwash_global: need 0 < n <= ld");
+    if (visit_order == order) return fail(GPD_EINVAL, "gpd_downwash_global: visit_order must not alias order (ping-pong two buffers)");
     if (!(cell >= 10.0f)) return fail(GPD_EINVAL, "gpd_downwash_global: cell must be >= 10 m (the model's lateral cut-off)");
     if (nx < 3 || ny < 3 || static_cast<int64_t>(nx) * ny > 65536)
         return fail(GPD_ERANGE, "gpd_downwash_global: need nx, ny >= 3 (periodic 3x3 search) and nx*ny <= 65536");
@@ -1765,10 +1800,10 @@ int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, i
     hipError_t e = hipMemsetAsync(cell_count, 0, sizeof(int32_t) * (cells + 1), st);
     if (e != hipSuccess) return hip_fail(e, "gpd_downwash_global memset");
     const dim3 grid(static_cast<unsigned>((n + kBlock - 1) / kBlock));
-    hipLaunchKernelGGL(dwg_count_kernel, grid, dim3(kBlock), 0, st, kin, ld, n, inv_cell, x0, y0, nx, ny, cell_count);
+    hipLaunchKernelGGL(dwg_count_kernel, grid, dim3(kBlock), 0, st, kin, ld, n, inv_cell, x0, y0, nx, ny, visit_order, cell_count);
     hipLaunchKernelGGL(dwg_scan_kernel, dim3(1), dim3(1024), 0, st, cell_count, cell_start, cells);
-    hipLaunchKernelGGL(dwg_scatter_kernel, grid, dim3(kBlock), 0, st, kin, ld, n, inv_cell, x0, y0, nx, ny, cell_count,
-                       cell_start, order, reinterpret_cast<float4*>(sorted_xyzc));
+    hipLaunchKernelGGL(dwg_scatter_kernel, grid, dim3(kBlock), 0, st, kin, ld, n, inv_cell, x0, y0, nx, ny, visit_order,
+                       cell_count, cell_start, order, reinterpret_cast<float4*>(sorted_xyzc));
     hipLaunchKernelGGL(dwg_force_kernel, dim3(static_cast<unsigned>(cells)), dim3(kBlock), 0, st, *params, nx, ny, cell_start,
                        order, reinterpret_cast<const float4*>(sorted_xyzc), dw_out);
     e = hipGetLastError();

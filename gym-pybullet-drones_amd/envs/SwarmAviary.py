@@ -71,7 +71,9 @@ class SwarmAviary:
         cells = self.nx * self.ny
         i32 = dict(dtype=torch.int32, device=dev)
         self._count, self._start = torch.zeros(cells + 1, **i32), torch.zeros(cells + 1, **i32)
-        self._order = torch.zeros(N, **i32)
+        self._order = torch.zeros(N, **i32)          # sorted slot -> drone, filled by every call ...
+        self._visit = torch.zeros(N, **i32)          # ... and the previous call's, which the next sort visits the drones in
+        self._have_visit = False
         self._sorted = torch.zeros((N, 4), dtype=torch.float32, device=dev)
         self.dw_force = torch.zeros(self.core.ld, dtype=torch.float32, device=dev)
         if self.flags & PHYS_DW:
@@ -83,10 +85,13 @@ class SwarmAviary:
         """Body-z downwash force of every drone for the current positions (`gpd_downwash_global`) -> [N] view."""
         c = self.core
         with torch.cuda.device(self.device):
+            self._order, self._visit = self._visit, self._order      # ping-pong: last call's order is this call's visit order
             rc = c.lib.gpd_downwash_global(ctypes.byref(c._params), _ptr(c.kin), c.ld, self.NUM_DRONES, self.cell, self.x0,
-                                           self.y0, self.nx, self.ny, _ptr(self._count), _ptr(self._start), _ptr(self._order),
-                                           _ptr(self._sorted), _ptr(self.dw_force), c._stream())
+                                           self.y0, self.nx, self.ny, _ptr(self._visit) if self._have_visit else None,
+                                           _ptr(self._count), _ptr(self._start), _ptr(self._order), _ptr(self._sorted),
+                                           _ptr(self.dw_force), c._stream())
         _native.check(rc, "gpd_downwash_global")
+        self._have_visit = True
         return self.dw_force[:self.NUM_DRONES]
 
     def reset(self, seed=None, options=None):

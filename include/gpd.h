@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GPD_ABI_VERSION 2
+#define GPD_ABI_VERSION 3
 
 /* DroneModel (utils/enums.py:3-8) */
 enum { GPD_MODEL_CF2X = 0, GPD_MODEL_CF2P = 1, GPD_MODEL_RACE = 2 };
@@ -251,16 +251,20 @@ int gpd_full_obs(int32_t num_steps, int32_t n_drones, int32_t act_dim, int32_t h
  *
  *   kin, ld       the state block of gpd_step (rows 0..2 = positions are read)
  *   cell, x0, y0, nx, ny   grid: cell size [m] (>= 10), lower-left corner, cells per side (nx, ny >= 3, nx*ny <= 65536)
+ *   visit_order   [n] int32 permutation of 0..n-1 or NULL (= 0, 1, 2 ...): the order the sort visits the drones in.
+ *                 Any permutation gives the same forces bit for bit; handing in the `order` buffer the PREVIOUS call
+ *                 filled (two buffers, ping-pong: it must not alias `order`) makes neighbouring lanes share a cell, and
+ *                 the sort then issues one atomic per run of equal cells instead of one per drone.
  *   cell_count    [nx*ny + 1] int32 scratch       cell_start  [nx*ny + 1] int32 scratch
- *   order         [n] int32 scratch (drone index of sorted slot)
+ *   order         [n] int32 out (drone index of sorted slot: a permutation of 0..n-1)
  *   sorted_xyzc   [n][4] float scratch (x, y, z, cell id as int bits), sorted by cell
  *   dw_out        [n] out: the force of drone i at dw_out[i]  (pass it to gpd_step as state.dw_force)
  * Call it once per physics sub-step, before the gpd_step launch of that sub-step (positions are the snapshot every
  * drone sees, envs/BaseAviary.py:346-347).
  */
 int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, int32_t n, float cell, float x0,
-                        float y0, int32_t nx, int32_t ny, int32_t* cell_count, int32_t* cell_start, int32_t* order,
-                        float* sorted_xyzc, float* dw_out, void* stream);
+                        float y0, int32_t nx, int32_t ny, const int32_t* visit_order, int32_t* cell_count,
+                        int32_t* cell_start, int32_t* order, float* sorted_xyzc, float* dw_out, void* stream);
 
 /*
  * Masked reset.  Replaces BaseAviary.reset/_housekeeping (envs/BaseAviary.py:220-255, 451-477)

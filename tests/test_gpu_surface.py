@@ -165,6 +165,11 @@ def test_swarm_downwash_is_order_independent_and_matches_the_workgroup_path(gpu_
     b = SwarmAviary(N, initial_xyzs=xyz[perm], physics=Physics.PYB_DW, world_min=(-30, -30), world_max=(30, 30), device=gpu_device)
     fa, fb = a.downwash().clone(), b.downwash().clone()
     assert torch.equal(fa[torch.as_tensor(perm, device=gpu_device)], fb)
+    # the first call visits the drones as 0, 1, 2 ..., every later one in the previous call's cell order (one atomic per run
+    # of equal cells): same forces, and `order` stays a permutation
+    for _ in range(3):
+        assert torch.equal(a.downwash(), fa)
+        assert torch.equal(torch.sort(a._order.long()).values, torch.arange(N, device=gpu_device))
     v = VectorCtrlAviary(1, N, initial_xyzs=xyz, physics=Physics.PYB_DW, ctrl_freq=240, device=gpu_device)
     rpm = torch.full((N, 4), float(a.HOVER_RPM), device=gpu_device)
     for _ in range(5):
