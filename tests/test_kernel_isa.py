@@ -1,0 +1,73 @@
+"""The headline kernel's instruction stream, checked on the cross-compiled ISA (no GPU needed).
+
+DESIGN.md §3 argues from issue slots: at one wave per SIMD every instruction of the rollout step costs ~5.4 cycles and a
+taken branch ~60, and the wait for the prefetched action rows has to be an exact `vmcnt(18)`.  None of that is visible to
+a numerical test -- a compiler update or an innocent-looking edit can put a `vmcnt(0)` or a skip-branch back into the
+loop and cost 10-40 % without changing a bit of the results.  This test pins the properties on the assembly hipcc
+produces for gfx950."""
+import os
+import re
+import subprocess
+import tempfile
+from collections import Counter
+
+import pytest
+
+from conftest import REPO
+
+HEADLINE = "gpd_rollout1_kernelILb0ELb0ELi4ELi0ELb1ELb0E"      # <PID=0, EXT=0, AW=4, ACT=RPM, S1=1, MULTI=0>
+
+
+@pytest.fixture(scope="module")
+def headline_isa():
+    from gym_pybullet_drones_amd import _native
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    flags = [f for f in _native.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "gpd.s")
+        subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", "-I", os.path.join(REPO, "include"),
+                                          os.path.join(REPO, "gym-pybullet-drones_amd", "csrc", "gpd.hip"), "-o", out],
+                       check=True, capture_output=True)
+        lines = open(out).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*" + HEADLINE + r"\w*:", l))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    meta = "\n".join(lines[end:end + 80])
+    return lines[start:end], meta
+
+
+def _ops(lines):
+    for l in lines:
+        s = l.strip()
+        if s and not s.startswith((";", ".")) and not s.endswith(":"):
+            yield s.split()[0], s
+
+
+def test_rollout_step_is_straight_line_and_within_its_slot_budget(headline_isa):
+    body, meta = headline_isa
+    assert re.search(r"ScratchSize: 0\b", meta), "the kernel spills to scratch"
+    # the loop holds three copies of the step; a copy starts at the first of its three ds_write_b128 (the row patch)
+    writes = [i for i, l in enumerate(body) if "ds_write_b128" in l]
+    assert len(writes) == 9
+    hot = list(_ops(body[writes[3]:writes[6]]))            # the second copy, row write to row write (the rare blocks are
+                                                           # laid out behind the loop, not inside this range)
+    kinds = Counter("branch" if op.startswith(("s_cbranch", "s_branch")) else "nop" if op == "s_nop" else
+                    "packed" if op.startswith("v_pk_") else "other" for op, _ in hot)
+    assert len(hot) <= 285, f"{len(hot)} issue slots in a rollout step (272 when this test was written)"
+    assert kinds["branch"] <= 4 and kinds["nop"] <= 3 and kinds["packed"] >= 40, kinds
+    # the branches of the hot path are the rare-case tests and the step count: none of them is an exec-mask skip
+    assert not [s for op, s in hot if op in ("s_cbranch_execz", "s_cbranch_execnz")]
+
+
+def test_action_rows_are_claimed_with_an_exact_count(headline_isa):
+    body, _ = headline_isa
+    writes = [i for i, l in enumerate(body) if "ds_write_b128" in l]
+    loop = body[writes[0]:]
+    waits = [s for op, s in _ops(loop) if op == "s_waitcnt" and "vmcnt" in s]
+    assert any("vmcnt(18)" in s for s in waits), waits      # everything but this iteration's 3 x 6 stores
+    first = next(i for i, l in enumerate(loop) if "vmcnt(18)" in l)
+    assert not [l for l in loop[:first] if "s_waitcnt" in l and "vmcnt" in l], "a memory wait inside the three steps"
+    # stores of the loop use <uniform base in SGPRs> + <32-bit lane offset>
+    stores = [s for op, s in _ops(loop[:first]) if op.startswith("global_store")]
+    assert len(stores) == 18 and all(re.search(r"s\[\d+:\d+\]", s) for s in stores), stores[:3]
