@@ -12,19 +12,28 @@ each), Physics.DYN, ActionType.RPM, pyb_freq = ctrl_freq = 240 Hz (one physics s
 drone-steps); actions are pre-generated on the device and different every step.
 
 Launch modes:
-  rollout  (default, the headline `value`) `gpd_rollout`: 64 consecutive env steps per kernel launch -- the 64 action
-           blocks are staged in HBM, every step's outputs are written, the drone state stays in registers;
-  graph    one `gpd_step` launch per env step, 64 launches captured in a hipGraph (the pattern of an RL loop that
-           runs a policy between steps); measured as well in the default run and reported under
-           `one_launch_per_step`;
+  rollout  (default, the headline `value`) `gpd_rollout`: up to 64 consecutive env steps per kernel launch -- the
+           action blocks are staged in HBM, every step's outputs are written, the drone state stays in registers;
+  graph    one `gpd_step` launch per env step, up to 64 launches captured in a hipGraph (the pattern of an RL loop
+           that runs a policy between steps); measured as well in the default run and reported under
+           `one_launch_per_step`;  `--split C` steps C sub-batches of E/C aviaries on C streams inside the graph;
   eager    one host launch per step.
-Weak scaling: every rank owns its own 65 536 aviaries; no data-path collective unless `--allgather` asks for the
-optional RCCL all-gather of the observation shards.
 
-Rank 0 prints ONE JSON line (metric/value/unit + roofline + cpu_baseline).
+What is timed.  The K steps of `--steps` form one SCHEDULE (K // 64 groups of 64 steps + one group of K % 64).  A run of
+K = 20 steps of the headline workload lasts ~20 us, far below what an event pair or a wall clock resolves, so the
+schedule is repeated back to back `repeats` times until the timed region lasts >= 0.25 s (`--min-time`); `steps` echoes
+K, `timed_steps` = K x repeats is what the clock saw, and `ms_per_step` / `value` / `roofline.achieved` all come from
+ONE clock: HIP events on the launch stream (max over ranks).  The host wall clock around the same region (barrier +
+synchronize on both sides, max over ranks) is printed beside it as `wall_ms_per_step` / `value_wall`.
+Weak scaling: every rank owns its own aviaries; no data-path collective unless `--allgather` (or a workload that names
+it) asks for the optional RCCL all-gather of the observation shards.
+
+Rank 0 prints ONE JSON line (metric/value/unit + roofline + roofline_valu_issue + cpu_baseline).
 """
 import argparse
+import ctypes
 import json
+import math
 import os
 import sys
 import time
@@ -36,9 +45,12 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+PEAK_CLOCK_GHZ = 2.4       # MI355X peak engine clock
+NUM_SIMDS = 256 * 4        # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 4 cycles
+BASELINE_METRIC = "env steps/sec (whole node), HoverAviary N=65536 drones @240Hz"
 
 WORKLOADS = {
-    # name: (envs/GPU, drones/env, physics flags, ctrl_freq, act, task)
+    # name: envs/GPU, drones/env, physics flags, ctrl_freq, act, task
     "hover65536_240hz": dict(E=65536, D=1, phys=0, ctrl=240, act="rpm", task="hover"),
     "hover65536_30hz": dict(E=65536, D=1, phys=0, ctrl=30, act="rpm", task="hover"),
     "hover4096_240hz": dict(E=4096, D=1, phys=0, ctrl=240, act="rpm", task="hover"),
@@ -46,17 +58,25 @@ WORKLOADS = {
     "stack8x8192_ext_240hz": dict(E=8192, D=8, phys=7, ctrl=240, act="rpm", task="multihover"),
     "multihover2x16384_240hz": dict(E=16384, D=2, phys=4, ctrl=240, act="rpm", task="multihover"),
     "hover65536_pid_240hz": dict(E=65536, D=1, phys=0, ctrl=240, act="pid", task="hover"),
+    "hover65536_240hz_fullobs": dict(E=65536, D=1, phys=0, ctrl=240, act="rpm", task="hover", full_obs=True),
+    "hover65536_30hz_fullobs": dict(E=65536, D=1, phys=0, ctrl=30, act="rpm", task="hover", full_obs=True),
     "hover4m_240hz": dict(E=4194304, D=1, phys=0, ctrl=240, act="rpm", task="hover"),
     "hover16m_240hz": dict(E=16777216, D=1, phys=0, ctrl=240, act="rpm", task="hover"),
+    # BASELINE.json configs 4 and 5, per GPU, verbatim (launch with --gpus 8 under torch.distributed.run)
+    "hover65536x8_allgather": dict(E=65536, D=1, phys=0, ctrl=240, act="rpm", task="hover", allgather=True),
+    # (config 5's two drones are stacked 0.3 m apart like every multi-drone workload here: from MultiHoverAviary's DEFAULT
+    # poses -- both drones at z = 0.1125 -- the reference's downwash model, alpha ~ 1/dz^2, returns ~1e10 N as soon as
+    # rounding separates the heights; no trajectory from that start means anything, in any precision)
+    "multihover2x16384x8": dict(E=16384, D=2, phys=4, ctrl=240, act="rpm", task="multihover"),
     # ONE aviary of 65 536 drones, pairwise downwash over the whole swarm (gpd_downwash_global + gpd_step per sub-step)
     "swarm65536_ext_240hz": dict(E=1, D=65536, phys=7, ctrl=240, act="raw_rpm", task="none", swarm=True),
 }
 
 
-def make_env(w, device, seed):
+def make_env(w, device, seed, E=None):
     from gym_pybullet_drones_amd.envs import SwarmAviary, VectorAviary
     from gym_pybullet_drones_amd.utils.enums import ActionType, Physics
-    E, D = w["E"], w["D"]
+    E, D = E or w["E"], w["D"]
     rng = np.random.default_rng(seed)
     if w.get("swarm"):
         # 12 layers 1 m apart, a 4 m lattice per layer (74 x 74 sites) with +-0.3 m jitter: ~300 m x 300 m, 32 x 32 grid cells
@@ -77,7 +97,7 @@ def make_env(w, device, seed):
     rpy = rng.uniform(-0.1, 0.1, size=(E, D, 3))
     env = VectorAviary(E, D, initial_xyzs=xyz, initial_rpys=rpy, physics=w["phys"], pyb_freq=240,
                        ctrl_freq=w["ctrl"], act=ActionType(w["act"]), task=w["task"], auto_reset=True,
-                       track_rpm=bool(w["phys"] & 2), device=device)
+                       track_rpm=bool(w["phys"] & 2), full_obs=bool(w.get("full_obs")), device=device)
     return env
 
 
@@ -93,14 +113,27 @@ def make_actions(w, env, device, seed, pool):
     return a.contiguous()
 
 
+def host_threads():
+    """Threads this process may really use: the affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(math.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(w, budget_s=12.0):
     """Time the loop-structured float64 oracle (the CPU 'port' of the reference's per-drone Python/numpy
     path; PyBullet itself is not installable here) on ONE host core, on a bounded sample of the workload."""
     from oracle.aviary_oracle import OracleAviary
     urdf = os.path.join(REPO, "gym-pybullet-drones_amd", "assets", "cf2x.urdf")
     D = w["D"]
+    task = w["task"] if w["task"] != "hover" or D == 1 else "multihover"
     env = OracleAviary(urdf, "cf2x", num_drones=D, physics_flags=w["phys"], pyb_freq=240, ctrl_freq=w["ctrl"],
-                       act=w["act"], task=w["task"] if w["task"] != "hover" or D == 1 else "multihover")
+                       act=w["act"], task=task)
     rng = np.random.default_rng(0)
     A = env.action_buffer[0].shape[1]
     acts = rng.uniform(-1, 1, size=(64, D, A))
@@ -119,90 +152,151 @@ def cpu_baseline(w, budget_s=12.0):
                      f"(float64 per-drone numpy loop restating BaseAviary._dynamics + BaseRLAviary + task) in {dt:.1f}s "
                      f"on 1 host core; PyBullet (Physics.PYB) is not installable in this image"}
     try:    # second figure: the same arithmetic compiled (oracle/gpd_oracle.c, scalar float64, one core)
-        from oracle.c_oracle import CAviary
-        Ec = 2048
-        c = CAviary(urdf, "cf2x", Ec, D, physics_flags=w["phys"], pyb_freq=240, ctrl_freq=w["ctrl"], act=w["act"],
-                    task=w["task"] if w["task"] != "hover" or D == 1 else "multihover")
-        ac = rng.uniform(-1, 1, size=(8, Ec, D, A))
-        c.step_in_place(ac[0])
-        m, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < 3.0:
-            c.step_in_place(ac[m % 8])
-            m += 1
-        dtc = time.perf_counter() - t0
-        out["c_port"] = {"value": m * Ec * D * S / dtc, "unit": "drone-steps/s", "cores": 1,
-                         "sample": f"{m} steps of {Ec} aviaries through oracle/gpd_oracle.c (gcc -O2, scalar float64) in {dtc:.1f}s"}
-        # third figure: the same C restatement with the aviaries spread over every host core (OpenMP)
         from oracle import c_oracle
-        threads = c_oracle.lib().orc_set_threads(os.cpu_count() or 1)
-        try:
-            Ea = 2048 * max(1, min(threads, 64) // 2)
-            ca = CAviary(urdf, "cf2x", Ea, D, physics_flags=w["phys"], pyb_freq=240, ctrl_freq=w["ctrl"], act=w["act"],
-                         task=w["task"] if w["task"] != "hover" or D == 1 else "multihover")
-            aa = rng.uniform(-1, 1, size=(4, Ea, D, A))
-            ca.step_in_place(aa[0])
+        from oracle.c_oracle import CAviary
+
+        def timed(E, threads, secs):
+            c_oracle.lib().orc_set_threads(threads)
+            c = CAviary(urdf, "cf2x", E, D, physics_flags=w["phys"], pyb_freq=240, ctrl_freq=w["ctrl"], act=w["act"], task=task)
+            ac = rng.uniform(-1, 1, size=(4, E, D, A))
+            c.step_in_place(ac[0])          # (first touch of every array by the threads that will own its pages)
+            c.step_in_place(ac[1])
             m, t0 = 0, time.perf_counter()
-            while time.perf_counter() - t0 < 3.0:
-                ca.step_in_place(aa[m % 4])
+            while time.perf_counter() - t0 < secs:
+                c.step_in_place(ac[m % 4])
                 m += 1
-            dta = time.perf_counter() - t0
-            out["c_port_all_cores"] = {"value": m * Ea * D * S / dta, "unit": "drone-steps/s", "cores": threads,
-                                       "sample": f"{m} steps of {Ea} aviaries, OpenMP over aviaries, {threads} threads, in {dta:.1f}s"}
+            return m, time.perf_counter() - t0
+
+        m, dtc = timed(2048, 1, 3.0)
+        out["c_port"] = {"value": m * 2048 * D * S / dtc, "unit": "drone-steps/s", "cores": 1,
+                         "sample": f"{m} steps of 2048 aviaries through oracle/gpd_oracle.c (gcc -O2, scalar float64) in {dtc:.1f}s"}
+        # third figure: the same C restatement with the aviaries spread over the host's threads (OpenMP, static chunks).
+        # Thread counts: all usable threads (affinity mask / cgroup quota, not os.cpu_count()), half and a quarter of
+        # them (SMT siblings and oversubscribed containers make "all" slower than fewer); the best is reported.
+        try:
+            usable = min(host_threads(), c_oracle.lib().orc_max_threads())
+            best = None
+            for th in sorted({usable, max(1, usable // 2), max(1, usable // 4)}, reverse=True):
+                Ea = 2048 * th
+                m, dta = timed(Ea, th, 1.5)
+                rate = m * Ea * D * S / dta
+                if best is None or rate > best[0]:
+                    best = (rate, th, m, Ea, dta)
+            rate, th, m, Ea, dta = best
+            out["c_port_all_cores"] = {"value": rate, "unit": "drone-steps/s", "cores": th,
+                                       "sample": f"{m} steps of {Ea} aviaries, OpenMP over aviaries, best of "
+                                                 f"{{1, 1/2, 1/4}} x {usable} usable threads: {th}, in {dta:.1f}s"}
         finally:
             c_oracle.lib().orc_set_threads(1)
     except Exception as e:   # the C restatement is optional test infrastructure
-        out["c_port"] = {"error": str(e)[:200]}
+        out.setdefault("c_port", {"error": str(e)[:200]})
+    out["pybullet"] = pybullet_baseline()
     return out
 
 
-def measure(mode, args, env, actions, gather, device, world, POOL):
-    """Time K env steps of every aviary on this rank.  mode 'graph': one kernel launch per env step, 64
-    steps captured in a hipGraph; 'eager': one host launch per step; 'rollout': `gpd_rollout`, POOL steps
-    per launch (actions of the POOL steps pre-staged, every step's obs/reward/flags written)."""
+def pybullet_baseline(budget_s=8.0):
+    """The reference's REAL CPU path (BASELINE config 1: `HoverAviary()` defaults, Physics.PYB through Bullet's own
+    integrator, envs/BaseAviary.py:679-711), timed when a box has `pybullet` + the reference package installed.  This
+    image has neither (no network): the leg then reports why."""
+    try:
+        import pybullet  # noqa: F401
+        from gym_pybullet_drones.envs.HoverAviary import HoverAviary as RefHover
+    except Exception as e:
+        return {"available": False, "why": f"{type(e).__name__}: {e}"[:160]}
+    env = RefHover(gui=False)
+    env.reset(seed=0)
+    rng = np.random.default_rng(0)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        _, _, term, trunc, _ = env.step(rng.uniform(-1, 1, size=env.action_space.shape).astype(np.float32))
+        if term or trunc:
+            env.reset()
+        n += 1
+    dt = time.perf_counter() - t0
+    env.close()
+    return {"available": True, "value": n * env.PYB_STEPS_PER_CTRL / dt, "unit": "drone-steps/s", "cores": 1, "kind": "reference",
+            "sample": f"{n} env.step() of the reference's HoverAviary() (Physics.PYB, 30 Hz control / 240 Hz physics) in {dt:.1f}s"}
+
+
+def groups_of(k, pool):
+    return [pool] * (k // pool) + ([k % pool] if k % pool else [])
+
+
+def measure(mode, args, envs, actions, gather, device, world, POOL):
+    """Time `repeats` x K env steps of every aviary on this rank.  mode 'graph': one kernel launch per env step (per
+    sub-batch), up to POOL steps captured in a hipGraph; 'eager': one host launch per step; 'rollout': `gpd_rollout`,
+    up to POOL steps per launch (actions pre-staged, every step's obs/reward/flags written)."""
     from gym_pybullet_drones_amd import dist as gdist
-    core = env.core
+    cores = [e.core for e in envs]
+    core = cores[0]
+    K, W = args.steps, args.warmup
+    main = torch.cuda.current_stream(device)
+    side = [torch.cuda.Stream(device) for _ in envs[1:]]
 
     def one_step(i):
-        env.step(actions[i % POOL])
-        if gather is not None:
-            gather(core.obs12)
+        """step i of every sub-batch: sub-batch 0 on the current stream, the others on their own streams"""
+        if len(envs) == 1:
+            envs[0].step(actions[0][i % POOL])
+            if gather is not None:
+                gather(core.obs12)
+            return
+        cur = torch.cuda.current_stream(device)
+        for s in side:
+            s.wait_stream(cur)
+        envs[0].step(actions[0][i % POOL])
+        for e, a, s in zip(envs[1:], actions[1:], side):
+            with torch.cuda.stream(s):
+                e.step(a[i % POOL])
+        for s in side:
+            cur.wait_stream(s)
 
-    # exactly K timed steps: K // POOL full groups (a POOL-step rollout / a replay of the POOL-step graph) plus one
-    # group of K % POOL steps (a shorter rollout / a second, shorter graph)
-    K, W = args.steps, args.warmup
-    rem = K % POOL if mode != "eager" else 0
-    if mode != "eager":
-        W = (W + POOL - 1) // POOL * POOL          # (untimed warm-up: whole groups only, reported as run)
+    def chain_steps(n):
+        """n steps of every sub-batch, each sub-batch as an independent chain on its own stream"""
+        if len(envs) == 1:
+            for i in range(n):
+                one_step(i)
+            return
+        cur = torch.cuda.current_stream(device)
+        for s in side:
+            s.wait_stream(cur)
+        for i in range(n):
+            envs[0].step(actions[0][i % POOL])
+        for e, a, s in zip(envs[1:], actions[1:], side):
+            with torch.cuda.stream(s):
+                for i in range(n):
+                    e.step(a[i % POOL])
+        for s in side:
+            cur.wait_stream(s)
 
+    sizes = set(groups_of(K, POOL)) | set(groups_of(W, POOL))
     gathers = {}
     if mode == "rollout" and gather is not None:
-        for n in {POOL, rem} - {0}:
-            gathers[n] = gdist.ObsAllGather(n * core.N, 12, device=device)   # one larger collective per rollout
+        for n in sorted(sizes):                                            # (same order on every rank: collective inits)
+            gathers[n] = type(gather)(n * core.N, 12, device=device)       # one larger collective per rollout
 
     def one_rollout(n):
-        obs = core.rollout(actions[:n], update_latest=False)[0]
-        if n in gathers:
-            gathers[n](obs.view(-1, 12))
+        for e, a in zip(envs, actions):
+            out = e.rollout(a[:n]) if getattr(e, "full_obs", False) else e.core.rollout(a[:n], update_latest=False)
+            if n in gathers:
+                gathers[n](out[0].reshape(-1, 12))
 
     graphs = {}
     if mode == "rollout":
-        one_rollout(POOL)
-        if rem:
-            one_rollout(rem)
+        for n in sorted(sizes, reverse=True):
+            one_rollout(n)                          # (allocates the per-length output buffers outside the timed region)
     else:
-        for i in range(min(max(W, 1), 64)):
+        for i in range(min(max(W, 1), 8)):
             one_step(i)
     torch.cuda.synchronize()
     if mode == "graph":
-        for n in {POOL, rem} - {0}:
+        for n in set(groups_of(K, POOL)):
             stream = torch.cuda.Stream(device)
-            stream.wait_stream(torch.cuda.current_stream(device))
+            stream.wait_stream(main)
             with torch.cuda.stream(stream):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=stream):
-                    for i in range(n):
-                        one_step(i)
-            torch.cuda.current_stream(device).wait_stream(stream)
+                    chain_steps(n)
+            main.wait_stream(stream)
             graphs[n] = g
 
     def run(k):
@@ -210,7 +304,7 @@ def measure(mode, args, env, actions, gather, device, world, POOL):
             for i in range(k):
                 one_step(i)
             return
-        for n in [POOL] * (k // POOL) + ([k % POOL] if k % POOL else []):
+        for n in groups_of(k, POOL):
             if mode == "rollout":
                 one_rollout(n)
             elif n in graphs:
@@ -219,63 +313,124 @@ def measure(mode, args, env, actions, gather, device, world, POOL):
                 for i in range(n):
                     one_step(i)
 
-    run(W)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record()          # on the current stream = the stream every gpd_* launch above goes to
-    run(K)
-    ev1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    t1 = time.perf_counter()
-    wall = gdist.max_over_ranks(t1 - t0, device=device)
-    ev_ms = ev0.elapsed_time(ev1)
+    def timed(reps):
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record()          # on the current stream = the stream every gpd_* launch above goes to
+        for _ in range(reps):
+            run(K)
+        ev1.record()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        t1 = time.perf_counter()
+        return (gdist.max_over_ranks(ev0.elapsed_time(ev1) * 1e-3, device=device),
+                gdist.max_over_ranks(t1 - t0, device=device))
+
+    run(W)                                          # W untimed warm-up steps, as requested
+    run(K)                                          # + one untimed pass of the schedule itself
+    cal, _ = timed(1)                               # calibration pass (untimed in the result): how long is one schedule?
+    repeats = int(min(max(1, math.ceil(args.min_time / max(cal, 1e-7))), 1 << 20))
+    ev_s, wall_s = timed(repeats)
+    timed_steps = K * repeats
     # roofline of the dominant kernel: algorithmic bytes of all launches of the timed region / its HIP-event time
     if mode == "rollout":
-        launches = K // POOL + (1 if rem else 0)
-        bytes_total = (K // POOL) * core.bytes_per_rollout(POOL) + (core.bytes_per_rollout(rem) if rem else 0)
+        per_pass = sum(c.bytes_per_rollout(n) for n in groups_of(K, POOL) for c in cores)
+        launches_pass = len(groups_of(K, POOL))
     else:
-        launches, bytes_total = K, K * core.bytes_per_step()
-    bytes_launch = bytes_total / launches
-    launch_us = ev_ms * 1e3 / launches
-    achieved = bytes_total / (ev_ms * 1e-3) / 1e9
-    n_total = core.N * world
-    steps_per_launch = K / launches
+        per_pass = K * sum(c.bytes_per_step() for c in cores)
+        launches_pass = K
+    launches = launches_pass * repeats
+    bytes_total = per_pass * repeats
+    n_rank = sum(c.N for c in cores)
+    n_total = n_rank * world
+    achieved = bytes_total / ev_s / 1e9
+    steps_per_launch = K / launches_pass
+    kernel = "gpd_step_kernel" if mode != "rollout" else \
+        ("gpd_rollout1_kernel" if core.D & (core.D - 1) == 0 and core.D <= 64 else "gpd_rollout_kernel")
     return {
-        "K": K, "W": W, "wall": wall, "value": n_total * core.S * K / wall, "env_steps_per_s": n_total * K / wall,
+        "K": K, "W": W, "repeats": repeats, "timed_steps": timed_steps, "ev_s": ev_s, "wall_s": wall_s,
+        "value": n_total * core.S * timed_steps / ev_s, "value_wall": n_total * core.S * timed_steps / wall_s,
+        "env_steps_per_s": n_total * timed_steps / ev_s, "us_per_step": ev_s * 1e6 / timed_steps,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": ("gpd_rollout1_kernel" if core.D == 1 else "gpd_rollout_kernel") if mode == "rollout"
-                     else "gpd_step_kernel",
-                     "env_steps_per_launch": steps_per_launch, "bytes_per_launch": bytes_launch,
-                     "bytes_per_drone_per_env_step": bytes_launch / (core.N * steps_per_launch),
-                     "launch_us_hip_events": launch_us},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel,
+                     "env_steps_per_launch": steps_per_launch, "bytes_per_launch": bytes_total / launches,
+                     "bytes_per_drone_per_env_step": per_pass / (n_rank * K),
+                     "launch_us_hip_events": ev_s * 1e6 / launches, "launches_timed": launches,
+                     "clock": "HIP events on the launch stream, max over ranks"},
     }
+
+
+def attach_counters(roof, key, m, core, clock_ghz):
+    """Offline-measured per-kernel figures (separate rocprofv3 passes, profiles/*.json) next to the live numbers:
+    HBM traffic from the FETCH_SIZE / WRITE_SIZE counters, scaled to this launch's step count, and the instruction
+    counts behind the VALU-issue roofline."""
+    issue = None
+    tfile = os.path.join(REPO, "profiles", "hbm_traffic.json")
+    if os.path.exists(tfile):
+        rec = json.load(open(tfile)).get(key)
+        if rec and rec.get("traffic_bytes"):
+            prof_steps = rec.get("env_steps_per_launch", 64 if "rollout" in key else 1)
+            spl = roof["env_steps_per_launch"]
+            if spl == prof_steps:
+                roof["traffic"] = rec["traffic_bytes"]
+                roof["traffic_note"] = "per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (profiles/hbm_traffic.json)"
+            elif rec.get("algorithmic_bytes"):
+                # same kernel, other step count: the counters scale with the algorithmic bytes (ratio measured 1.00-1.02)
+                roof["traffic"] = rec["traffic_bytes"] / rec["algorithmic_bytes"] * roof["bytes_per_launch"]
+                roof["traffic_note"] = (f"counters of the {prof_steps}-step profile launch scaled by the algorithmic bytes to this "
+                                        f"launch's {spl:g} steps (profiles/hbm_traffic.json)")
+            roof["rocprof_kernel_avg_us"] = rec.get("rocprof_kernel_avg_ns", 0) / 1e3 if spl == prof_steps else None
+    cfile = os.path.join(REPO, "profiles", "kernel_counters.json")
+    if os.path.exists(cfile):
+        rec = json.load(open(cfile)).get(key)
+        if rec and rec.get("slots_per_wave_env_step"):
+            waves_per_simd = math.ceil(core.N / 64 / NUM_SIMDS)
+            slots, valu = rec["slots_per_wave_env_step"], rec.get("valu_per_wave_env_step")
+            floor_peak = waves_per_simd * slots * 4 / (PEAK_CLOCK_GHZ * 1e3)            # us per env step at 2.4 GHz
+            issue = {"bound": "valu_issue", "unit": "us/env-step", "slots_per_wave_env_step": slots,
+                     "valu_per_wave_env_step": valu, "waves_per_simd": waves_per_simd, "cycles_per_slot": 4,
+                     "peak_clock_ghz": PEAK_CLOCK_GHZ, "floor_us": floor_peak, "measured_us": m["us_per_step"],
+                     "frac": floor_peak / m["us_per_step"], "source": "profiles/kernel_counters.json (rocprofv3 --pmc SQ_INSTS_*)"}
+            if clock_ghz:
+                issue["measured_clock_ghz"] = clock_ghz
+                issue["frac_at_measured_clock"] = waves_per_simd * slots * 4 / (clock_ghz * 1e3) / m["us_per_step"]
+    hbm_floor = roof["bytes_per_launch"] / roof["env_steps_per_launch"] / (HBM_PEAK_GBS * 1e3)     # us per env step
+    roof["floor_us"] = hbm_floor
+    if issue is not None:
+        roof["binding"] = "valu_issue" if issue["floor_us"] > hbm_floor else "hbm"
+    return issue
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32768)
-    ap.add_argument("--warmup", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=4096)
+    ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--workload", default="hover65536_240hz", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="rollout", choices=["rollout", "graph", "eager"],
-                    help="rollout: gpd_rollout, 64 env steps per launch (state in registers, actions pre-staged); "
-                         "graph: one launch per env step, hipGraph of 64 steps; eager: one host launch per step")
+                    help="rollout: gpd_rollout, up to 64 env steps per launch (state in registers, actions pre-staged); "
+                         "graph: one launch per env step, hipGraph of up to 64 steps; eager: one host launch per step")
+    ap.add_argument("--min-time", type=float, default=0.25, help="repeat the K-step schedule until the timed region lasts this long [s]")
+    ap.add_argument("--split", type=int, default=1, help="graph/eager: step C sub-batches of E/C aviaries as C independent chains on C streams")
     ap.add_argument("--allgather", action="store_true", help="all-gather the obs shards over RCCL")
+    ap.add_argument("--allgather-impl", default="auto", choices=["auto", "native", "torch"],
+                    help="native: the C-ABI's gpd_allgather_obs (ncclAllGather); torch: torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-leg", action="store_true",
                     help="skip the extra one-launch-per-step measurement reported next to the rollout headline")
     args = ap.parse_args()
+    if args.steps < 1 or args.warmup < 0:
+        ap.error("--steps must be >= 1 and --warmup >= 0")
 
     from gym_pybullet_drones_amd import dist as gdist
     # (GPD_DIST_BACKEND / GPD_BENCH_SINGLE_DEVICE: test hooks -- run the multi-rank code path with gloo on one GPU)
-    rank, world, local = gdist.init_from_env(os.environ.get("GPD_DIST_BACKEND", "nccl") if args.gpus > 1 else None)
+    backend = os.environ.get("GPD_DIST_BACKEND", "nccl")
+    rank, world, local = gdist.init_from_env(backend if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
     if args.gpus != world:
         if rank == 0:
             print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run", file=sys.stderr)
@@ -285,49 +440,84 @@ def main():
     torch.cuda.set_device(device)
 
     w = WORKLOADS[args.workload]
-    env = make_env(w, device, seed=1000 + rank)
+    want_gather = bool(args.allgather or w.get("allgather"))
     POOL = 64      # env steps per rollout launch / per captured hipGraph
-    actions = make_actions(w, env, device, seed=2000 + rank, pool=POOL)
-    core = env.core
-    gather = gdist.ObsAllGather(core.N, 12, device=device) if args.allgather else None
-
     if w.get("swarm") and args.mode == "rollout":
         args.mode = "graph"          # a single world needs the downwash of every sub-step's snapshot: one step per launch group
+
+    def build(split):
+        if split > 1 and (w.get("swarm") or w["E"] % split):
+            raise SystemExit(f"--split {split} does not divide {w['E']} aviaries")
+        envs = [make_env(w, device, seed=1000 + rank * 16 + c, E=w["E"] // split) for c in range(split)]
+        acts = [make_actions(w, e, device, seed=2000 + rank * 16 + c, pool=POOL) for c, e in enumerate(envs)]
+        return envs, acts
+
+    envs, actions = build(1)
+    core = envs[0].core
+    gather, impl = None, None
+    if want_gather:
+        impl = args.allgather_impl
+        if impl == "auto":
+            impl = "native" if (world == 1 or backend == "nccl") else "torch"
+        gather = (gdist.NativeObsAllGather if impl == "native" else gdist.ObsAllGather)(core.N, 12, device=device)
+
     second = None
     if args.mode == "rollout" and not args.no_second_leg:
-        second = measure("graph", args, env, actions, gather, device, world, POOL)
-        env.reset()
-    m = measure(args.mode, args, env, actions, gather, device, world, POOL)
+        senvs, sacts = (envs, actions) if args.split == 1 else build(args.split)
+        second = measure("graph", args, senvs, sacts, gather if args.split == 1 else None, device, world, POOL)
+        for e in envs:
+            e.reset()
+    if args.mode != "rollout" and args.split > 1:
+        envs, actions = build(args.split)
+    m = measure(args.mode, args, envs, actions, gather if len(envs) == 1 else None, device, world, POOL)
+
+    clock_ghz = None
+    try:        # the shader clock a one-wave-per-SIMD FMA chain runs at right after the timed region (diagnostics)
+        ghz, nsf = ctypes.c_double(), ctypes.c_double()
+        if core.lib.gpd_clock_probe(ctypes.byref(ghz), ctypes.byref(nsf), ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)) == 0:
+            clock_ghz = ghz.value
+    except Exception:
+        pass
 
     if rank == 0:
-        n_total = core.N * world
-        launch = {"rollout": f"rollout{POOL}", "graph": "graph", "eager": "eager"}[args.mode]
+        n_total = sum(e.core.N for e in envs) * world
+        spl = m["roofline"]["env_steps_per_launch"]
+        launch = {"rollout": f"rollout{int(spl) if spl == int(spl) else spl:g}", "graph": "graph", "eager": "eager"}[args.mode]
+        D, S = core.D, core.S
+        metric = BASELINE_METRIC if args.workload == "hover65536_240hz" else \
+            (f"env steps/sec (whole node), {args.workload}: {w['E']} aviaries x {D} drone(s) per GPU, "
+             f"{w['ctrl']} Hz control / 240 Hz physics")
         out = {
-            "metric": "env steps/sec (whole node), HoverAviary N=65536 drones @240Hz",
+            "metric": metric,
             "value": m["value"], "unit": "drone-steps/s", "n_gpus": world, "steps": m["K"], "warmup": m["W"],
-            "ms_per_step": m["wall"] * 1e3 / m["K"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": m["ev_s"] * 1e3 / m["timed_steps"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "envs_per_gpu": core.E, "drones_per_env": core.D,
+            "repeats": m["repeats"], "timed_steps": m["timed_steps"], "timed_region_ms": m["ev_s"] * 1e3,
+            "wall_ms_per_step": m["wall_s"] * 1e3 / m["timed_steps"], "value_wall": m["value_wall"],
+            "config": {"workload": args.workload, "envs_per_gpu": w["E"], "drones_per_env": D,
                        "total_drones": n_total, "physics": "DYN" + "".join(n for b, n in ((1, "+GND"), (2, "+DRAG"), (4, "+DW")) if w["phys"] & b),
-                       "pyb_freq": 240, "ctrl_freq": w["ctrl"], "substeps_per_step": core.S, "action": w["act"],
-                       "task": w["task"], "auto_reset": True, "launch": launch,
-                       "obs_allgather": bool(args.allgather), "env_steps_per_s": m["env_steps_per_s"]},
+                       "pyb_freq": 240, "ctrl_freq": w["ctrl"], "substeps_per_step": S, "action": w["act"],
+                       "task": w["task"], "auto_reset": True, "mode": args.mode, "launch": launch, "split": len(envs),
+                       "full_obs": bool(w.get("full_obs")), "obs_allgather": want_gather, "allgather_impl": impl,
+                       "env_steps_per_s": m["env_steps_per_s"]},
             "roofline": m["roofline"],
         }
+        key_launch = "rollout64" if args.mode == "rollout" else args.mode
+        issue = attach_counters(out["roofline"], f"{args.workload}:{key_launch}", m, core, clock_ghz)
+        if issue is not None:
+            out["roofline_valu_issue"] = issue
+        if clock_ghz:
+            out["shader_clock_ghz_probe"] = clock_ghz
         if second is not None:
-            out["one_launch_per_step"] = {"value": second["value"], "unit": "drone-steps/s", "steps": second["K"],
-                                          "launch": "graph (hipGraph of 64 single-step launches)",
-                                          "roofline": second["roofline"]}
-        tfile = os.path.join(REPO, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile):   # measured offline in separate --pmc passes (see the file's _comment)
-            table = json.load(open(tfile))
-            for key, roof in ((f"{args.workload}:{launch}", out["roofline"]),
-                              (f"{args.workload}:graph", second["roofline"] if second else None)):
-                rec = table.get(key)
-                if rec and roof is not None and rec.get("traffic_bytes"):
-                    roof["traffic"] = rec["traffic_bytes"]
-                    roof["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
-                    roof["rocprof_kernel_avg_us"] = rec["rocprof_kernel_avg_ns"] / 1e3
+            sec = {"value": second["value"], "unit": "drone-steps/s", "steps": second["K"], "repeats": second["repeats"],
+                   "timed_steps": second["timed_steps"], "us_per_step": second["us_per_step"], "split": args.split,
+                   "launch": f"graph (hipGraph of {min(second['K'], POOL)} single-step launches" +
+                             (f", {args.split} sub-batches on {args.split} streams)" if args.split > 1 else ")"),
+                   "roofline": second["roofline"]}
+            si = attach_counters(sec["roofline"], f"{args.workload}:graph", second, core, clock_ghz)
+            if si is not None:
+                sec["roofline_valu_issue"] = si
+            out["one_launch_per_step"] = sec
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(CSRC, "libgpd.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # -mllvm -amdgpu-sched-strategy=max-ilp: interleaves independent dependency chains, which fills the one-wait-state hazard
 # behind every packed-fp32 result with useful work instead of s_nops (13 of 287 issue slots of a rollout step)
@@ -83,7 +83,14 @@ _SIGNATURES = {
     "gpd_pid": (ctypes.c_int, [ctypes.POINTER(GpdParams), _P, ctypes.c_int64, ctypes.c_float, _P, _P, _P, _P, _P, _P,
                                _P, _P, _P, _P, ctypes.c_int32, _P]),
     "gpd_state_vectors": (ctypes.c_int, [ctypes.POINTER(GpdState), _P, _P, ctypes.c_int32, _P]),
+    "gpd_comm_unique_id": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint8)]),
+    "gpd_comm_init": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32,
+                                     ctypes.c_int32]),
+    "gpd_comm_destroy": (ctypes.c_int, [_P]),
+    "gpd_allgather_obs": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, _P]),
+    "gpd_clock_probe": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _P]),
 }
+COMM_ID_BYTES = 128
 
 
 def lib() -> ctypes.CDLL:

@@ -39,6 +39,8 @@
 //   rotor thrusts          carried as deviations from the hover thrust (no cancellation near hover)
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-ilp -fPIC -shared
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types and enums only: the library itself is resolved at run time (dlopen), see Rccl below
+#include <dlfcn.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -308,7 +310,8 @@ __device__ __forceinline__ float thrust_dev_norm(const GpdParams& P, float e) {
 // Forces are assembled from the deviations: total thrust T = GRAVITY + sum(g) (+ ground effect, downwash), so
 //   F_z = R22*T - GRAVITY = R22*(T - GRAVITY) - GRAVITY*(1 - R22)      (1 - R22 computed directly)
 // and the torques only see differences of the g_i (F_h cancels analytically: every torque row sums to zero).
-template <bool EXT>
+//   AV          also produce the world angular velocity (only the LAST sub-step of an env step is observed)
+template <bool EXT, bool AV = true>
 __device__ __forceinline__ void substep(const GpdParams& P, float h, uint32_t flags, const float g[4],
                                         float drag_rpm_sum, float dw_force, Kin& k,
                                         float& avx, float& avy, float& avz) {
@@ -404,9 +407,11 @@ __device__ __forceinline__ void substep(const GpdParams& P, float h, uint32_t fl
         k.qz = turn ? nzw.x : k.qz; k.qw = turn ? nzw.y : k.qw;
     }
     // world angular velocity handed to the state store: PRE-update rotation, post-update rates (:873)
-    const fp2 axy = fma2(fp2{R.r02, R.r12}, splat(k.wz), fma2(fp2{R.r01, R.r11}, splat(k.wy), fp2{R.r00, R.r10} * splat(k.wx)));
-    avx = axy.x; avy = axy.y;
-    avz = fmaf(R.r22, k.wz, fmaf(R.r21, k.wy, R.r20 * k.wx));
+    if (AV) {
+        const fp2 axy = fma2(fp2{R.r02, R.r12}, splat(k.wz), fma2(fp2{R.r01, R.r11}, splat(k.wy), fp2{R.r00, R.r10} * splat(k.wx)));
+        avx = axy.x; avy = axy.y;
+        avz = fmaf(R.r22, k.wz, fmaf(R.r21, k.wy, R.r20 * k.wx));
+    }
 }
 
 // SoA row access as  <uniform 64-bit row base in SGPRs> + <32-bit per-lane byte offset>: this is the
@@ -563,15 +568,21 @@ __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C
         // ctrl_freq == pyb_freq, known at compile time: straight-line, no loop branches (two taken branches per step)
         substep<EXT>(P, C.pyb_dt, flags, g, drag_sum, EXT ? c.dw_in : 0.0f, k, avx, avy, avz);
     } else if (!MULTI) {
-        // two sub-steps per iteration: half the loop branches (HoverAviary's default 30 Hz control is 8 sub-steps)
+        // two sub-steps per iteration: half the loop branches (HoverAviary's default 30 Hz control is 8 sub-steps).  Only
+        // the LAST sub-step's world angular velocity is observed (BaseAviary.py:873 overwrites it every sub-step), so the
+        // loop covers all but the last one or two sub-steps without computing it.
         const float dw = EXT ? c.dw_in : 0.0f;
-        int ss = 0;
-        for (; ss + 1 < C.substeps; ss += 2) {
-            substep<EXT>(P, C.pyb_dt, flags, g, drag_sum, dw, k, avx, avy, avz);
-            substep<EXT>(P, C.pyb_dt, flags, g, cur_sum, dw, k, avx, avy, avz);
+        int left = C.substeps;
+        for (; left > 2; left -= 2) {
+            substep<EXT, false>(P, C.pyb_dt, flags, g, drag_sum, dw, k, avx, avy, avz);
+            substep<EXT, false>(P, C.pyb_dt, flags, g, cur_sum, dw, k, avx, avy, avz);
             drag_sum = cur_sum;
         }
-        if (ss < C.substeps) substep<EXT>(P, C.pyb_dt, flags, g, drag_sum, dw, k, avx, avy, avz);
+        if (left == 2) {
+            substep<EXT, false>(P, C.pyb_dt, flags, g, drag_sum, dw, k, avx, avy, avz);
+            drag_sum = cur_sum;
+        }
+        substep<EXT, true>(P, C.pyb_dt, flags, g, drag_sum, dw, k, avx, avy, avz);
     } else
     for (int ss = 0; ss < C.substeps; ++ss) {
         float dw = (EXT && !MULTI) ? c.dw_in : 0.0f;
@@ -1197,15 +1208,15 @@ struct RollOut {
 // loads and stores on one in-order counter, and only with a fixed number of operations per step can the wait for
 // "the row requested two steps ago" be an exact `vmcnt(14)` (the two younger loads and the twelve stores of the two
 // steps in between may still be in flight) instead of a wait for every store issued so far (a store takes > 1 us
-// to be acknowledged).  Lanes without a drone (ragged last workgroup) are exact CLONES of drone 0 -- same state,
-// same action row, same arithmetic, hence the same bits -- and store to drone 0's addresses: a benign duplicate
-// write instead of a branch around the stores.  (Calls that ask for terminal observations -- conditional stores -- use
+// to be acknowledged).  Lanes without a drone (ragged last workgroup) are exact CLONES of the first drone of their
+// own workgroup -- same state, same action row, same arithmetic, hence the same bits -- and store to that drone's
+// addresses: a benign duplicate write instead of a branch around the stores.  (Calls that ask for terminal observations -- conditional stores -- use
 // the compute-wave + store-wave kernel above.)
 // ------------------------------------------------------------------------------------------------
 // MULTI: aviaries of D = 2, 4, ..., 64 drones (a power of two: D aligned lanes of one wave, wave-local exchange inside
 // env_step, no workgroup barrier).  Every lane of an aviary ends a step with the aviary's reward and flags and stores
-// them to the aviary's slot -- D identical writes instead of a branch; a lane without a drone is a clone of the drone of
-// aviary 0 with the same index d, so whole clone aviaries replay aviary 0 bit for bit.
+// them to the aviary's slot -- D identical writes instead of a branch; a lane without a drone is a clone of the drone with
+// the same index d in its workgroup's first aviary, so whole clone aviaries replay that aviary bit for bit.
 template <bool PID, bool EXT, int AW, int ACT, bool S1, bool MULTI>
 __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     const GpdParams P, const GpdState S, const GpdStepCfg C, const Span T, const float* __restrict__ action,
@@ -1224,8 +1235,12 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     L.le = MULTI ? tid / D : tid;
     L.d = MULTI ? static_cast<int>(tid & dmask) : 0;
     L.active = n_raw < N;
-    L.n = L.active ? n_raw : (tid & dmask);
-    L.env = MULTI ? (L.active ? n_raw / static_cast<uint32_t>(D) : 0u) : L.n;
+    // a lane without a drone (ragged last workgroup) clones a drone of ITS OWN workgroup -- the one with the same index d
+    // in the workgroup's first aviary (which exists: the grid covers N, and N and 256 are multiples of D).  Owner and
+    // clone are co-resident, and the barrier behind load_carry orders the clone's loads before the owner's store_carry.
+    const uint32_t block_base = blockIdx.x * static_cast<uint32_t>(kBlock);
+    L.n = L.active ? n_raw : block_base + (tid & dmask);
+    L.env = MULTI ? L.n / static_cast<uint32_t>(D) : L.n;
 
     __shared__ __attribute__((aligned(16))) float sh_rows[kBlock * 12];
     __shared__ __attribute__((aligned(16))) float sh_pos[MULTI ? 4 * kBlock : 4];   // downwash: positions of the aviary's drones
@@ -1240,7 +1255,7 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const uint32_t cidx = static_cast<uint32_t>(j * 64 + lane), r = cidx / 3u, part = cidx - 3u * r;
-        goff[j] = (r < rows ? (n0 + r) * 48u : (r & dmask) * 48u) + part * 16u;   // a clone's row goes to the row of its original
+        goff[j] = (r < rows ? (n0 + r) : block_base + (r & dmask)) * 48u + part * 16u;   // a clone's row goes to the row of its original
     }
     const uint32_t eoff4 = L.env * 4u;
 
@@ -1255,6 +1270,9 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
                        "v"(c.counter), "v"(ip[0]), "v"(ip[1]), "v"(ip[2]), "v"(ip[3]), "v"(ip[4]), "v"(ip[5]), "v"(ip[6])
                  : "memory");
     __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0): the loop starts with nothing pending
+    // The ONLY workgroup barrier of the launch: every wave has its state in registers before any wave can reach its
+    // store_carry, so a clone lane (above) has read its original's state of step 0, not of step K.
+    __builtin_amdgcn_s_barrier();
     c.roll = c.pitch = c.yaw = 0.0f;
     if (PID) quat_to_rpy(c.k.qx, c.k.qy, c.k.qz, c.k.qw, c.roll, c.pitch, c.yaw);
 
@@ -1611,6 +1629,80 @@ __global__ __launch_bounds__(kBlock) void gpd_state20_kernel(const GpdState S, c
     w[4] = make_float4(l0, l1, l2, l3);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Shader-clock probe (diagnostics for bench.py's issue roofline): 256 workgroups x 4 waves = one wave per SIMD, like the
+// headline launch, each running a dependent v_fma_f32 chain; lane 0 of workgroup 0 reports the shader-clock cycles
+// (s_memtime) and the constant-rate wall-clock ticks (s_memrealtime) the chain took.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void gpd_clock_probe_kernel(unsigned long long* __restrict__ out, int iters) {
+    float r = threadIdx.x * 1e-3f;
+    const float b = 1.0001f, c = 1e-4f;
+    const unsigned long long c0 = __builtin_readcyclecounter(), t0 = wall_clock64();
+    for (int i = 0; i < iters; ++i) {
+#define GPD_FMA4 "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+#define GPD_FMA16 GPD_FMA4 GPD_FMA4 GPD_FMA4 GPD_FMA4
+        asm volatile(GPD_FMA16 GPD_FMA16 GPD_FMA16 GPD_FMA16 : "+v"(r) : "v"(b), "v"(c));
+#undef GPD_FMA16
+#undef GPD_FMA4
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter(), t1 = wall_clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = c1 - c0; out[1] = t1 - t0; }
+    if (r == 12345.678f) out[2] = 1;                       // (keeps the chain alive)
+}
+
+// ------------------------------------------------------------------------------------------------
+// RCCL, resolved at run time: libgpd.so has no link-time dependency on it (a single-GPU consumer never loads it), and
+// inside a PyTorch process dlopen() by SONAME returns the copy torch already mapped instead of a second one.
+// ------------------------------------------------------------------------------------------------
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+
+Rccl& rccl() {
+    static Rccl R = [] {
+        Rccl r;
+        const char* env = getenv("GPD_RCCL_LIB");
+        const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            if (!n || !*n) continue;
+            r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (r.handle) break;
+            r.why = dlerror();
+        }
+        if (!r.handle) return r;
+        auto sym = [&](const char* n) { void* p = dlsym(r.handle, n); if (!p) r.why = std::string("missing symbol ") + n; return p; };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.CommCount || !r.AllGather || !r.GetErrorString) {
+            dlclose(r.handle);
+            r.handle = nullptr;
+        }
+        return r;
+    }();
+    return R;
+}
+
+int rccl_fail(ncclResult_t e, const char* where) {
+    g_last_error = std::string(where) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(e) : "RCCL error");
+    return 1000 + static_cast<int>(e);          // (positive, outside hipError_t's range)
+}
+
+int need_rccl(const char* who) {
+    if (rccl().handle) return 0;
+    return fail(GPD_ENOTSUP, (std::string(who) + ": RCCL is not available (" + rccl().why + ")").c_str());
+}
+
 template <bool PID, bool EXT, int AW, int ACT>
 hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const GpdState& S, const GpdStepCfg& C,
                        const Span& T, const float* action, const float* target_pos, const float* init_pose,
@@ -1854,5 +1946,75 @@ int gpd_state_vectors(const GpdState* state, const float* obs12, float* state20,
     if (e != hipSuccess) return hip_fail(e, "gpd_state_vectors launch");
     return 0;
 }
+
+int gpd_comm_unique_id(uint8_t id[GPD_COMM_ID_BYTES]) {
+    if (!id) return fail(GPD_EINVAL, "gpd_comm_unique_id: NULL id");
+    if (int rc = need_rccl("gpd_comm_unique_id")) return rc;
+    static_assert(GPD_COMM_ID_BYTES == sizeof(ncclUniqueId), "GPD_COMM_ID_BYTES must match ncclUniqueId");
+    ncclUniqueId u;
+    ncclResult_t e = rccl().GetUniqueId(&u);
+    if (e != ncclSuccess) return rccl_fail(e, "ncclGetUniqueId");
+    memcpy(id, &u, sizeof(u));
+    return 0;
+}
+
+int gpd_comm_init(void** comm, const uint8_t id[GPD_COMM_ID_BYTES], int32_t rank, int32_t world_size) {
+    if (!comm || !id) return fail(GPD_EINVAL, "gpd_comm_init: NULL comm/id");
+    if (world_size < 1 || rank < 0 || rank >= world_size) return fail(GPD_EINVAL, "gpd_comm_init: need 0 <= rank < world_size");
+    if (int rc = need_rccl("gpd_comm_init")) return rc;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    ncclComm_t c = nullptr;
+    ncclResult_t e = rccl().CommInitRank(&c, world_size, u, rank);
+    if (e != ncclSuccess) return rccl_fail(e, "ncclCommInitRank");
+    *comm = c;
+    return 0;
+}
+
+int gpd_comm_destroy(void* comm) {
+    if (!comm) return 0;
+    if (int rc = need_rccl("gpd_comm_destroy")) return rc;
+    ncclResult_t e = rccl().CommDestroy(static_cast<ncclComm_t>(comm));
+    if (e != ncclSuccess) return rccl_fail(e, "ncclCommDestroy");
+    return 0;
+}
+
+int gpd_allgather_obs(void* comm, const float* shard, float* full, size_t count, void* stream) {
+    if (!comm || !shard || !full) return fail(GPD_EINVAL, "gpd_allgather_obs: NULL comm/shard/full");
+    if (count == 0) return fail(GPD_EINVAL, "gpd_allgather_obs: count must be positive");
+    if (int rc = need_rccl("gpd_allgather_obs")) return rc;
+    ncclResult_t e = rccl().AllGather(shard, full, count, ncclFloat32, static_cast<ncclComm_t>(comm),
+                                      static_cast<hipStream_t>(stream));
+    if (e != ncclSuccess) return rccl_fail(e, "ncclAllGather");
+    return 0;
+}
+
+int gpd_clock_probe(double* shader_ghz, double* ns_per_fma, void* stream) {
+    if (!shader_ghz) return fail(GPD_EINVAL, "gpd_clock_probe: NULL shader_ghz");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int dev = 0, wall_khz = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, dev);
+    if (e != hipSuccess || wall_khz <= 0) return hip_fail(e, "gpd_clock_probe: wall clock rate");
+    unsigned long long* d = nullptr;
+    e = hipMalloc(&d, 3 * sizeof(unsigned long long));
+    if (e != hipSuccess) return hip_fail(e, "gpd_clock_probe: hipMalloc");
+    const int iters = 4000;                                  // x 64 dependent FMAs: ~0.6 ms
+    unsigned long long h[2] = {0, 0};
+    for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {   // (the second pass runs at the ramped-up clock)
+        hipLaunchKernelGGL(gpd_clock_probe_kernel, dim3(256), dim3(kBlock), 0, st, d, iters);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    hipFree(d);
+    if (e != hipSuccess) return hip_fail(e, "gpd_clock_probe");
+    if (h[1] == 0) return fail(GPD_ENOTSUP, "gpd_clock_probe: the wall clock did not advance");
+    const double secs = static_cast<double>(h[1]) / (static_cast<double>(wall_khz) * 1e3);
+    *shader_ghz = static_cast<double>(h[0]) / secs * 1e-9;
+    if (ns_per_fma) *ns_per_fma = secs * 1e9 / (static_cast<double>(iters) * 64.0);
+    return 0;
+}
+
 
 }  // extern "C"

@@ -4,9 +4,16 @@ Aviaries are independent (the only cross-drone coupling, downwash and the MultiH
 is inside one aviary), so the physics needs NO collective: rank r owns a contiguous block of envs
 and runs the same kernel on its own device.  The one optional exchange step is an all-gather of
 the `(E_local*D, 12)` observation shards into the concatenated `(E*D, 12)` tensor a centralised
-learner would consume — `torch.distributed.all_gather_into_tensor`, which is RCCL over xGMI with
-the "nccl" backend on ROCm (gloo on CPU for tests).
+learner would consume.  Two implementations of that one collective:
+
+* `NativeObsAllGather` -- the C-ABI entry `gpd_allgather_obs` (`ncclAllGather` of RCCL over xGMI on the
+  caller's stream, capturable in one hipGraph with the `gpd_step` launch that produced the shard, no torch
+  in the data path); `torch.distributed` is only used once, to hand rank 0's communicator id to the others;
+* `ObsAllGather` -- `torch.distributed.all_gather_into_tensor` (RCCL with the "nccl" backend on ROCm; with
+  the gloo backend -- CPU tests, or the single-device test hook of bench.py -- device shards are staged
+  through host memory).
 """
+import ctypes
 import os
 
 import torch
@@ -14,10 +21,17 @@ import torch.distributed as dist
 
 
 def env_shard(total_envs: int, rank: int, world_size: int):
-    """Contiguous block [start, stop) of envs owned by `rank` (sizes differ by at most one)."""
+    """Contiguous block [start, stop) of envs owned by `rank` (sizes differ by at most one; hand
+    `shard_rows_per_rank()` to `ObsAllGather` when `total_envs % world_size != 0`)."""
     base, rem = divmod(total_envs, world_size)
     start = rank * base + min(rank, rem)
     return start, start + base + (1 if rank < rem else 0)
+
+
+def shard_rows_per_rank(total_envs: int, world_size: int, rows_per_env: int = 1):
+    """Observation rows each rank contributes under `env_shard` (rows_per_env = drones per aviary)."""
+    return [(env_shard(total_envs, r, world_size)[1] - env_shard(total_envs, r, world_size)[0]) * rows_per_env
+            for r in range(world_size)]
 
 
 def init_from_env(backend: str = None):
@@ -34,28 +48,110 @@ def init_from_env(backend: str = None):
     return rank, world, local
 
 
-class ObsAllGather:
-    """Pre-allocated all-gather of equally sized observation shards."""
+def _backend(group=None) -> str:
+    return dist.get_backend(group) if dist.is_initialized() else "none"
 
-    def __init__(self, shard_rows: int, cols: int = 12, device=None, dtype=torch.float32, group=None):
+
+class ObsAllGather:
+    """Pre-allocated all-gather of observation shards through `torch.distributed`.
+
+    `shard_rows`: rows of THIS rank's shard.  Equal shards on every rank (the default, weak scaling) use ONE
+    `all_gather_into_tensor`; `rows_per_rank` (e.g. `shard_rows_per_rank(E, world, D)` for an `env_shard` split
+    of a total that the world size does not divide) pads every shard to the largest one for the collective and
+    compacts the result, so that `full` is always the plain concatenation of the shards in rank order."""
+
+    def __init__(self, shard_rows: int, cols: int = 12, device=None, dtype=torch.float32, group=None,
+                 rows_per_rank=None):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.group = group
-        self.full = torch.empty((self.world * shard_rows, cols), dtype=dtype, device=device)
+        self.rows = [int(shard_rows)] * self.world if rows_per_rank is None else [int(r) for r in rows_per_rank]
+        if len(self.rows) != self.world or self.rows[self.rank] != int(shard_rows):
+            raise ValueError(f"rows_per_rank {self.rows} does not describe a world of {self.world} ranks in which "
+                             f"rank {self.rank} owns {shard_rows} rows")
+        self.uniform = len(set(self.rows)) == 1
+        self.cols = cols
+        self.full = torch.empty((sum(self.rows), cols), dtype=dtype, device=device)
+        self._pad = None if self.uniform else torch.zeros((self.world, max(self.rows), cols), dtype=dtype, device=device)
+        # gloo moves host memory only: device shards are staged (tests / bench.py's single-device hook)
+        self._stage = self.world > 1 and _backend(group) == "gloo" and self.full.is_cuda
 
     def __call__(self, shard: torch.Tensor, async_op: bool = False):
-        """Gather `shard` (rows, cols) from every rank into `self.full` (world*rows, cols)."""
+        """Gather `shard` (rows, cols) from every rank into `self.full` (sum of rows, cols)."""
+        shard = shard.reshape(-1, self.cols)
         if self.world == 1:
-            self.full.copy_(shard.reshape(self.full.shape))
+            self.full.copy_(shard)
             return self.full if not async_op else (self.full, None)
-        work = dist.all_gather_into_tensor(self.full, shard.reshape(-1, self.full.shape[1]).contiguous(),
-                                           group=self.group, async_op=async_op)
+        if self._stage or not self.uniform:
+            mine = shard if self.uniform else self._pad[self.rank]
+            if not self.uniform:
+                mine[:shard.shape[0]].copy_(shard)
+            out = self.full if self.uniform else self._pad
+            if self._stage:
+                host = torch.empty(out.shape, dtype=out.dtype)
+                dist.all_gather_into_tensor(host.view(-1, self.cols), mine.reshape(-1, self.cols).cpu().contiguous(),
+                                            group=self.group)
+                out.copy_(host)
+            else:
+                dist.all_gather_into_tensor(out.view(-1, self.cols), mine.reshape(-1, self.cols).contiguous(), group=self.group)
+            if not self.uniform:
+                torch.cat([self._pad[r, :n] for r, n in enumerate(self.rows)], out=self.full)
+            return (self.full, None) if async_op else self.full
+        work = dist.all_gather_into_tensor(self.full, shard.contiguous(), group=self.group, async_op=async_op)
         return (self.full, work) if async_op else self.full
+
+
+class NativeObsAllGather:
+    """The same collective through the C-ABI (`gpd_comm_*`, `gpd_allgather_obs`): `ncclAllGather` of RCCL on the
+    current stream.  Equal shards only (what `ncclAllGather` offers).  `torch.distributed` (any backend) carries the
+    128-byte communicator id from rank 0 to the other ranks, once."""
+
+    def __init__(self, shard_rows: int, cols: int = 12, device=None, group=None):
+        from . import _native
+        self._native = _native
+        self.lib = _native.lib()
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.count = int(shard_rows) * cols
+        self.full = torch.empty((self.world * int(shard_rows), cols), dtype=torch.float32, device=self.device)
+        ident = (ctypes.c_uint8 * _native.COMM_ID_BYTES)()
+        blob = [None]
+        with torch.cuda.device(self.device):
+            if self.rank == 0:
+                _native.check(self.lib.gpd_comm_unique_id(ident), "gpd_comm_unique_id")
+                blob[0] = bytes(ident)
+            if self.world > 1:
+                dist.broadcast_object_list(blob, src=0, group=group)
+                ident = (ctypes.c_uint8 * _native.COMM_ID_BYTES).from_buffer_copy(blob[0])
+            self.comm = ctypes.c_void_p()
+            _native.check(self.lib.gpd_comm_init(ctypes.byref(self.comm), ident, self.rank, self.world), "gpd_comm_init")
+
+    def __call__(self, shard: torch.Tensor):
+        if shard.numel() != self.count or shard.dtype != torch.float32 or not shard.is_contiguous():
+            raise ValueError(f"shard must be a contiguous float32 tensor of {self.count} elements")
+        with torch.cuda.device(self.device):
+            rc = self.lib.gpd_allgather_obs(self.comm, ctypes.c_void_p(shard.data_ptr()), ctypes.c_void_p(self.full.data_ptr()),
+                                            self.count, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        self._native.check(rc, "gpd_allgather_obs")
+        return self.full
+
+    def close(self):
+        if getattr(self, "comm", None):
+            self.lib.gpd_comm_destroy(self.comm)
+            self.comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def max_over_ranks(value: float, device=None) -> float:
     """MAX-reduce a python float over all ranks (timing)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=device if _backend() != "gloo" else None)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -61,7 +61,7 @@ class SimCore:
                  task: int = TASK_NONE, initial_xyzs=None, initial_rpys=None, target_pos=None,
                  episode_len_sec: float = 8.0, xy_bound: float = 1.5, z_bound: float = 2.0, tilt_bound: float = 0.4,
                  term_dist: float = 1e-4, auto_reset: bool = False, track_rpm: bool = True,
-                 keep_terminal_obs: bool = False, device=None, gains: PIDGains = None):
+                 keep_terminal_obs: bool = False, device=None, gains: PIDGains = None, force_pid: bool = False):
         if pyb_freq % ctrl_freq != 0:
             raise ValueError("[ERROR] pyb_freq is not divisible by ctrl_freq.")
         self.lib = _native.lib()                      # raises if the HIP extension is missing
@@ -93,7 +93,8 @@ class SimCore:
         self.kin = torch.zeros((13, self.ld), dtype=f32, device=dev)
         need_rpm = track_rpm or bool(self.physics_flags & PHYS_DRAG)
         self.last_rpm = torch.zeros((4, self.ld), dtype=f32, device=dev) if need_rpm else None
-        self.pid = torch.zeros((9, self.ld), dtype=f32, device=dev) if self.uses_pid else None
+        # (force_pid: the controller state exists although the kernel is fed RPMs -- a host-side caller runs gpd_pid on it)
+        self.pid = torch.zeros((9, self.ld), dtype=f32, device=dev) if (self.uses_pid or force_pid) else None
         self.step_counter = torch.zeros((self.E,), dtype=torch.int32, device=dev)
         self.obs12 = torch.zeros((self.N, 12), dtype=f32, device=dev)
         self.reward = torch.zeros((self.E,), dtype=f32, device=dev)
@@ -268,7 +269,7 @@ class SimCore:
         return out
 
     def _rollout_buffers(self, K: int):
-        """Persistent output buffers of a K-step rollout (kept per K: the two most recent lengths stay allocated)."""
+        """Persistent output buffers of a K-step rollout (kept per K: the four most recent lengths stay allocated)."""
         cache = self.__dict__.setdefault("_rollout_cache", {})
         buf = cache.get(K)
         if buf is None:
@@ -278,7 +279,7 @@ class SimCore:
                    torch.zeros((K, self.E), dtype=torch.bool, device=dev),
                    torch.zeros((K, self.E), dtype=torch.bool, device=dev),
                    torch.zeros((K, self.N, 12), dtype=torch.float32, device=dev) if self.term_obs12 is not None else None)
-            while len(cache) >= 2:
+            while len(cache) >= 4:
                 cache.pop(next(iter(cache)))
             cache[K] = buf
         self._rollout_buf = buf

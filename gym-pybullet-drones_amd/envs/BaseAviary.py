@@ -24,7 +24,7 @@ import torch
 from .. import engine
 from .._gym_shim import Env
 from ..params import DroneParams
-from ..utils.enums import ACT_DIRECT_RPM, DroneModel, Physics
+from ..utils.enums import ACT_DIRECT_RPM, DroneModel, Physics, warn_if_pyb
 
 
 class BaseAviary(Env):
@@ -67,6 +67,7 @@ class BaseAviary(Env):
         self.DRONE_MODEL = drone_model
         self.GUI, self.RECORD = False, False
         self.PHYSICS = physics
+        warn_if_pyb(physics)                  # Physics.PYB* runs the explicit integrator here: say so, once
         self.OBSTACLES = obstacles
         self.USER_DEBUG = user_debug_gui
         self.URDF = self.DRONE_MODEL.value + ".urdf"
@@ -103,7 +104,10 @@ class BaseAviary(Env):
                                     physics=physics, pyb_freq=pyb_freq, ctrl_freq=ctrl_freq,
                                     act_code=fused if self._fused_action else ACT_DIRECT_RPM,
                                     task=self._TASK, initial_xyzs=self.INIT_XYZS, initial_rpys=self.INIT_RPYS,
-                                    auto_reset=False, track_rpm=True, device=device, **task_kw)
+                                    auto_reset=False, track_rpm=True, device=device,
+                                    # a subclass that overrides _preprocessAction and calls super()'s for a PID action type
+                                    # still needs the embedded controllers' state (BaseRLAviary.py:75-76)
+                                    force_pid=bool(getattr(getattr(self, "ACT_TYPE", None), "uses_pid", False)), **task_kw)
         self.DRONE_IDS = np.arange(1, self.NUM_DRONES + 1)
         self._housekeeping()
         self._updateAndStoreKinematicInformation()

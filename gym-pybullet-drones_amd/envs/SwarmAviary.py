@@ -22,7 +22,7 @@ import torch
 from .. import _native, engine
 from ..control.DSLPIDControl import DSLPIDControlBatch
 from ..params import DroneParams
-from ..utils.enums import ACT_DIRECT_RPM, ActionType, DroneModel, PHYS_DW, Physics
+from ..utils.enums import ACT_DIRECT_RPM, ACT_RAW_RPM, ActionType, DroneModel, PHYS_DW, Physics, warn_if_pyb
 
 
 def _ptr(t):
@@ -41,6 +41,7 @@ class SwarmAviary:
             raise ValueError("SwarmAviary supports act = 'raw_rpm', ActionType.RPM or ActionType.PID")
         self.NUM_DRONES = N = int(num_drones)
         self.DRONE_MODEL, self.PHYSICS, self.ACT_TYPE = drone_model, physics, act
+        warn_if_pyb(physics)
         self.PYB_FREQ, self.CTRL_FREQ = pyb_freq, ctrl_freq
         self.PYB_STEPS_PER_CTRL = pyb_freq // ctrl_freq
         self.CTRL_TIMESTEP, self.PYB_TIMESTEP = 1. / ctrl_freq, 1. / pyb_freq
@@ -51,9 +52,12 @@ class SwarmAviary:
         xyz = np.asarray(initial_xyzs, dtype=np.float64).reshape(N, 1, 3)
         rpy = np.zeros((N, 1, 3)) if initial_rpys is None else np.asarray(initial_rpys, dtype=np.float64).reshape(N, 1, 3)
         self.INIT_XYZS, self.INIT_RPYS = xyz[:, 0], rpy[:, 0]
-        # the kernel runs N single-drone lanes, one physics sub-step per launch; actions arrive as RPMs
+        # the kernel runs N single-drone lanes, one physics sub-step per launch.  The action -> RPM mapping is the kernel's own
+        # (GPD_ACT_RAW_RPM: clip to [0, MAX_RPM], envs/CtrlAviary.py:140; GPD_ACT_RPM: HOVER_RPM (1 + 0.05 a),
+        # envs/BaseRLAviary.py:191-192); waypoint actions go through the batched DSLPID kernel and arrive as RPMs.
+        act_code = {"raw_rpm": ACT_RAW_RPM, ActionType.RPM: ActionType.RPM.code, ActionType.PID: ACT_DIRECT_RPM}[act]
         self.core = engine.SimCore(drone_model=drone_model, num_envs=N, drones_per_env=1, physics=physics, pyb_freq=pyb_freq,
-                                   ctrl_freq=pyb_freq, act_code=ACT_DIRECT_RPM, task=engine.TASK_NONE, initial_xyzs=xyz,
+                                   ctrl_freq=pyb_freq, act_code=act_code, task=engine.TASK_NONE, initial_xyzs=xyz,
                                    initial_rpys=rpy, auto_reset=False, track_rpm=True, device=device)
         self.device = dev = self.core.device
         self.flags = self.core.physics_flags
@@ -101,20 +105,20 @@ class SwarmAviary:
         self.step_counter = 0
         return self.state_vectors(), {"answer": 42}
 
-    def _rpm(self, action: torch.Tensor) -> torch.Tensor:
+    def _kernel_action(self, action) -> torch.Tensor:
+        """What the step kernel is fed: the raw action itself (the kernel maps it to RPMs), or -- waypoint actions -- the
+        RPMs of the N embedded DSLPID controllers (`gpd_pid`, one launch)."""
         N = self.NUM_DRONES
         a = torch.as_tensor(action, dtype=torch.float32, device=self.device)
-        if self.ACT_TYPE == "raw_rpm":
-            return a.reshape(N, 4).clamp(0.0, float(self.MAX_RPM))
-        if self.ACT_TYPE == ActionType.RPM:
-            return float(self.HOVER_RPM) * (1.0 + 0.05 * a.reshape(N, 4))
+        if self.ctrl is None:
+            return a.reshape(N, 4)
         k = self.core.kin[:, :N]
         rpm, _, _ = self.ctrl.computeControl(self.CTRL_TIMESTEP, k[0:3].t(), k[3:7].t(), k[7:10].t(), None, a.reshape(N, 3))
         return rpm
 
     def step(self, action):
         """One control step = PYB_STEPS_PER_CTRL × { downwash of the snapshot, one physics sub-step }."""
-        rpm = self._rpm(action).contiguous()
+        rpm = self._kernel_action(action).contiguous()
         for _ in range(self.PYB_STEPS_PER_CTRL):
             if self.flags & PHYS_DW:
                 self.downwash()

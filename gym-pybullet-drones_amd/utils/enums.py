@@ -75,6 +75,26 @@ class ObservationType(Enum):
     RGB = "rgb"
 
 
+_warned_pyb = False
+
+
+def warn_if_pyb(physics) -> None:
+    """One `UserWarning` per process when a `Physics.PYB*` member is requested: this package has no Bullet -- the
+    explicit `Physics.DYN` integrator runs instead (with the selected add-on force models inside it), so there is
+    no Featherstone integrator, no collision shapes and no Bullet damping; the ground is the contact model of
+    `GPD_PHYS_GROUND` (a plane at z = 0 the airframe's collision cylinder rests on), not Bullet's solver."""
+    global _warned_pyb
+    if _warned_pyb or not isinstance(physics, Physics) or physics == Physics.DYN:
+        return
+    _warned_pyb = True
+    import warnings
+    warnings.warn(f"Physics.{physics.name} was requested, but PyBullet's integrator does not exist in this package: the "
+                  f"explicit Physics.DYN integrator (envs/BaseAviary.py:815-877 of the reference) is used instead"
+                  + (", with the " + "/".join(n for b, n in ((1, "ground-effect"), (2, "drag"), (4, "downwash")) if physics.flags & b)
+                     + " model(s) evaluated inside it" if physics.flags else "")
+                  + ".  Trajectories follow the reference's Physics.DYN, not its Physics.PYB.", UserWarning, stacklevel=3)
+
+
 #: physics add-on bits, mirrored in include/gpd.h
 PHYS_GND, PHYS_DRAG, PHYS_DW = 1, 2, 4
 #: raw-RPM action clipped to [0, MAX_RPM] (CtrlAviary, `CtrlAviary.py:140`); kernel-only code

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GPD_ABI_VERSION 3
+#define GPD_ABI_VERSION 4
 
 /* DroneModel (utils/enums.py:3-8) */
 enum { GPD_MODEL_CF2X = 0, GPD_MODEL_CF2P = 1, GPD_MODEL_RACE = 2 };
@@ -296,6 +296,37 @@ int gpd_pid(const GpdParams* params, float* pid, int64_t ld, float ctrl_dt,
  */
 int gpd_state_vectors(const GpdState* state, const float* obs12, float* state20, int32_t n,
                       void* stream);
+
+/*
+ * The one optional exchange step of the multi-GPU layout: all-gather of the observation shards over RCCL (xGMI).
+ * The aviaries shard across ranks with no data-path collective (one process per GPU, rank r owns a contiguous block of
+ * envs); a centralised learner that wants the concatenated (E_total*D, 12) observation tensor -- what the reference's
+ * single process holds in `obs` after `env.step()` (envs/BaseAviary.py:375, envs/BaseRLAviary.py:307-320; consumed by
+ * examples/learn.py:157-192) -- gathers it with ONE collective per step (or per rollout: fewer, larger collectives).
+ * RCCL is resolved at run time (dlopen of librccl.so.1; GPD_RCCL_LIB overrides): a single-GPU consumer needs no RCCL,
+ * and GPD_ENOTSUP is returned when it cannot be found.
+ *
+ *   gpd_comm_unique_id   rank 0: ncclGetUniqueId; the caller distributes the GPD_COMM_ID_BYTES to the other ranks
+ *                        (torch.distributed broadcast, MPI, a file ...)
+ *   gpd_comm_init        every rank, after hipSetDevice: ncclCommInitRank (collective, blocks until all ranks joined)
+ *   gpd_allgather_obs    ncclAllGather of `count` floats per rank: shard [count] -> full [world_size*count], rank r's
+ *                        shard at full + r*count.  Asynchronous on `stream`, capturable in a hipGraph together with the
+ *                        gpd_step / gpd_rollout launch that produced the shard.
+ *   gpd_comm_destroy     ncclCommDestroy (NULL is a no-op)
+ * RCCL errors are returned as 1000 + ncclResult_t.
+ */
+#define GPD_COMM_ID_BYTES 128
+int gpd_comm_unique_id(uint8_t id[GPD_COMM_ID_BYTES]);
+int gpd_comm_init(void** comm, const uint8_t id[GPD_COMM_ID_BYTES], int32_t rank, int32_t world_size);
+int gpd_comm_destroy(void* comm);
+int gpd_allgather_obs(void* comm, const float* shard, float* full, size_t count, void* stream);
+
+/*
+ * Diagnostics for the measurement harness (bench.py's issue roofline): runs a dependent v_fma_f32 chain at one wave per
+ * SIMD and reports the shader clock it ran at [GHz] (shader-clock cycles / constant-rate wall-clock time) and, optionally,
+ * the time per dependent FMA [ns].  Synchronous (it waits for `stream`).
+ */
+int gpd_clock_probe(double* shader_ghz, double* ns_per_fma, void* stream);
 
 #ifdef __cplusplus
 }

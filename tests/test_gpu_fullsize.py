@@ -73,6 +73,113 @@ def test_config3_stacks_of_8_all_force_terms(gpu_device):
     np.testing.assert_allclose(core.reward.cpu().numpy(), orc.reward, rtol=1e-3, atol=1e-3)
 
 
+def _all_threads():
+    """the C oracle on every usable host thread (the aviaries are independent: static OpenMP chunks)"""
+    import os
+    from oracle import c_oracle
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return c_oracle.lib().orc_set_threads(max(1, min(n, 64)))
+
+
+def test_config5_16384x2_pairwise_downwash_240_steps(gpu_device):
+    """BASELINE config 5 at its per-GPU size: 16 384 two-drone MultiHover aviaries, pairwise downwash ON (the D == 2 pair
+    path of the wave-local exchange), RPM actions, 240 steps -- HIP vs the float64 C oracle.
+
+    Scene: the two drones 0.3 m above each other, 5 cm apart laterally.  (MultiHoverAviary's DEFAULT initial poses put
+    both drones at the same height, z = 0.1125: the reference's downwash model is singular there -- alpha = DW1
+    (r / 4 dz)^2 with dz -> 0+ gives ~1e10 N as soon as rounding separates the heights -- so no finite-precision
+    trajectory, float64 included, is meaningful from that start)  The upper drone pushes the lower
+    one down with ~2x its weight; it falls away, dz only grows, the comparison stays well-conditioned."""
+    rng = np.random.default_rng(16384)
+    E, D, S = 16384, 2, 1
+    xyz = rng.uniform(-0.02, 0.02, size=(E, D, 3)) + np.arange(D)[None, :, None] * np.array([0.05, 0.0, 0.3]) + \
+        np.array([0, 0, 0.6])
+    rpy = rng.uniform(-0.05, 0.05, size=(E, D, 3))
+    _all_threads()
+    try:
+        orc = CAviary(urdf("cf2x"), "cf2x", E, D, initial_xyzs=xyz, initial_rpys=rpy, physics_flags=4, pyb_freq=240,
+                      ctrl_freq=240, act="rpm", task="multihover")
+        core = _core("cf2x", E, D, 4, S, "rpm", "multihover", xyz, rpy, gpu_device, target=orc.TARGET_POS)
+        _sync_c(core, orc)
+        acts = (0.02 * rng.uniform(-1, 1, size=(240, E, D, 4))).astype(np.float32)
+        errs = _run(core, orc, acts, gpu_device, {1, 24, 120, 240})
+    finally:
+        from oracle import c_oracle
+        c_oracle.lib().orc_set_threads(1)
+    for t, e in sorted(errs.items()):
+        print(f"t={t:5d} " + " ".join(f"{g}={v:.2e}" for g, v in e.items()))
+        assert max(e.values()) < 1e-4, (t, e)
+    # the downwash really acted: the lower drones fell well below the upper ones' free trajectory
+    z = core.kin[2, :E * D].view(E, D)
+    assert float((z[:, 1] - z[:, 0]).min()) > 0.5
+    np.testing.assert_allclose(core.reward.cpu().numpy(), orc.reward, rtol=1e-3, atol=1e-3)
+    assert (core.truncated.cpu().numpy() != orc.truncated.astype(bool)).mean() < 0.002
+
+
+def test_config3i_65536_all_force_terms_single_drone_aviaries(gpu_device):
+    """BASELINE config 3 (i): 65 536 single-drone aviaries with GND|DRAG|DW compiled in and enabled (no neighbours, so the
+    downwash term is exercised as "present and zero"), start heights in [0.05, 1] m so that the ground effect is active,
+    240 steps, against the float64 C oracle."""
+    rng = np.random.default_rng(3)
+    E, D, S = 65536, 1, 1
+    xyz = rng.uniform(-0.5, 0.5, size=(E, D, 3)) * np.array([1, 1, 0]) + np.array([0, 0, 1]) * rng.uniform(0.05, 1.0, size=(E, D, 1))
+    rpy = rng.uniform(-0.1, 0.1, size=(E, D, 3))
+    _all_threads()
+    try:
+        orc = CAviary(urdf("cf2x"), "cf2x", E, D, initial_xyzs=xyz, initial_rpys=rpy, physics_flags=7, pyb_freq=240,
+                      ctrl_freq=240, act="rpm", task="hover")
+        core = _core("cf2x", E, D, 7, S, "rpm", "hover", xyz, rpy, gpu_device, target=orc.TARGET_POS)
+        _sync_c(core, orc)
+        acts = (0.01 * rng.uniform(-1, 1, size=(1, E, D, 4)) + 0.01 * rng.uniform(-1, 1, size=(240, E, D, 4))).astype(np.float32)
+        errs = _run(core, orc, acts, gpu_device, {1, 24, 120, 240})
+    finally:
+        from oracle import c_oracle
+        c_oracle.lib().orc_set_threads(1)
+    for t, e in sorted(errs.items()):
+        print(f"t={t:5d} " + " ".join(f"{g}={v:.2e}" for g, v in e.items()))
+        assert max(e.values()) < 1e-4, (t, e)
+    np.testing.assert_allclose(core.reward.cpu().numpy(), orc.reward, rtol=1e-3, atol=1e-3)
+
+
+def test_config4_524288_drones_240_steps_against_the_c_oracle(gpu_device):
+    """BASELINE config 4's whole-node size (8 x 65 536 = 524 288 HoverAviaries) on ONE GPU: an oracle trajectory, not
+    only size-independent properties -- 240 steps at 240 Hz, RPM actions, through gpd_rollout (4 launches of 60 steps:
+    also the launch mode the scaling bench uses)."""
+    rng = np.random.default_rng(524288)
+    E, D, S, K = 524288, 1, 1, 60
+    xyz = np.array([0, 0, 0.1125]) + rng.uniform(-0.5, 0.5, size=(E, D, 3)) * np.array([1, 1, 0])
+    rpy = rng.uniform(-0.1, 0.1, size=(E, D, 3))
+    _all_threads()
+    try:
+        orc = CAviary(urdf("cf2x"), "cf2x", E, D, initial_xyzs=xyz, initial_rpys=rpy, pyb_freq=240, ctrl_freq=240, act="rpm",
+                      task="hover")
+        core = _core("cf2x", E, D, 0, S, "rpm", "hover", xyz, rpy, gpu_device, target=orc.TARGET_POS)
+        _sync_c(core, orc)
+        bias = 0.01 * rng.uniform(-1, 1, size=(1, E, D, 4))
+        maxima = {g: fl for g, (_, fl) in GROUPS.items()}
+        for r in range(4):
+            acts = (bias + 0.01 * rng.uniform(-1, 1, size=(K, E, D, 4))).astype(np.float32)
+            obs, rew, te, tr = core.rollout(torch.as_tensor(acts, device=gpu_device))
+            for k in range(K):
+                orc.step_in_place(acts[k].astype(np.float64))
+            ref = _oracle_kin(orc)
+            for g, (sl, _) in GROUPS.items():
+                maxima[g] = max(maxima[g], float(np.abs(ref[sl]).max()))
+            kin = core.kin[:, :E].cpu().numpy().astype(np.float64)
+            e = {g: float(np.abs(kin[sl] - ref[sl]).max() / maxima[g]) for g, (sl, _) in GROUPS.items()}
+            print(f"t={(r + 1) * K:5d} " + " ".join(f"{g}={v:.2e}" for g, v in e.items()))
+            assert max(e.values()) < 1e-4, (r, e)
+            # the last step's observation rows and rewards of the rollout block
+            o64 = orc.obs.reshape(E, 12)
+            oerr = np.abs(obs[K - 1].cpu().numpy().astype(np.float64) - o64)
+            oerr[:, 3:6] = np.abs((oerr[:, 3:6] + np.pi) % (2 * np.pi) - np.pi)
+            assert oerr.max() < 1e-4
+            np.testing.assert_allclose(rew[K - 1].cpu().numpy(), orc.reward, rtol=1e-3, atol=1e-3)
+    finally:
+        from oracle import c_oracle
+        c_oracle.lib().orc_set_threads(1)
+
+
 def _sync_c(core, orc):
     """CAviary has the same state attributes as BatchedAviary (the PID block aside, unused here)."""
     assert core.pid is None

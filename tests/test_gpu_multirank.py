@@ -1,0 +1,78 @@
+"""The multi-rank paths on ONE GPU box: bench.py under torch.distributed.run with two ranks (gloo rendezvous, both ranks
+on device 0 -- the test hook; RCCL itself refuses two ranks on one device), and the C-ABI's RCCL all-gather with a
+one-rank communicator, alone and captured in one hipGraph together with the step that produces the shard."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _bench(args, world, port, timeout=900):
+    env = dict(os.environ, GPD_DIST_BACKEND="gloo", GPD_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", str(world)] + args
+    res = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]          # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_with_obs_allgather(gpu_device):
+    j = _bench(["--steps", "64", "--warmup", "8", "--allgather", "--min-time", "0.02", "--no-second-leg", "--no-cpu-baseline"], 2, 29541)
+    assert j["n_gpus"] == 2 and j["config"]["total_drones"] == 2 * 65536 and j["config"]["obs_allgather"] is True
+    assert j["steps"] == 64 and j["warmup"] == 8 and j["timed_steps"] == 64 * j["repeats"] and j["scaling"] == "weak"
+    assert j["metric"].startswith("env steps/sec") and j["unit"] == "drone-steps/s" and j["value"] > 1e8
+    assert j["ms_per_step"] == pytest.approx(j["timed_region_ms"] / j["timed_steps"])
+    assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1.5 and "cpu_baseline" not in j
+
+
+def test_bench_two_ranks_named_config5_workload(gpu_device):
+    """BASELINE config 5 per GPU (16 384 two-drone aviaries, pairwise downwash) through the same two-rank path, both legs."""
+    j = _bench(["--steps", "20", "--warmup", "5", "--workload", "multihover2x16384x8", "--min-time", "0.05", "--no-cpu-baseline"], 2, 29542)
+    assert j["n_gpus"] == 2 and j["config"]["total_drones"] == 2 * 2 * 16384 and j["config"]["drones_per_env"] == 2
+    assert "DW" in j["config"]["physics"] and j["steps"] == 20 and j["warmup"] == 5
+    assert j["one_launch_per_step"]["value"] > 0 and j["one_launch_per_step"]["roofline"]["kernel"] == "gpd_step_kernel"
+
+
+def test_native_allgather_one_rank_and_inside_a_graph(gpu_device):
+    from gym_pybullet_drones_amd import dist as gdist
+    from gym_pybullet_drones_amd.envs import VectorHoverAviary
+    from gym_pybullet_drones_amd.utils.enums import ActionType
+    E = 4096
+    env = VectorHoverAviary(E, act=ActionType.RPM, ctrl_freq=240, device=gpu_device)
+    ag = gdist.NativeObsAllGather(env.core.N, 12, device=gpu_device)
+    rng = np.random.default_rng(0)
+    acts = torch.as_tensor(rng.uniform(-1, 1, size=(4, E, 1, 4)).astype(np.float32), device=gpu_device)
+    env.step(acts[0])
+    full = ag(env.core.obs12)
+    torch.cuda.synchronize()
+    assert full.shape == (E, 12) and torch.equal(full, env.core.obs12)
+    # step + gather captured together: one graph launch = env.step() of every aviary + the collective, no torch op inside
+    stream = torch.cuda.Stream(gpu_device)
+    stream.wait_stream(torch.cuda.current_stream(gpu_device))
+    with torch.cuda.stream(stream):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            for k in range(1, 4):
+                env.step(acts[k])
+                ag(env.core.obs12)
+    torch.cuda.current_stream(gpu_device).wait_stream(stream)
+    ref = VectorHoverAviary(E, act=ActionType.RPM, ctrl_freq=240, device=gpu_device)
+    for k in range(4):
+        ref.step(acts[k])
+    ag.full.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(ag.full, ref.core.obs12)
+    with pytest.raises(ValueError):
+        ag(env.core.obs12[:10])
+    ag.close()

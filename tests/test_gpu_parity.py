@@ -90,7 +90,10 @@ def _actions(rng, act, shape, hover_rpm):
 @pytest.mark.parametrize("model", ["cf2x", "cf2p", "racer"])
 @pytest.mark.parametrize("act", ["rpm", "one_d_rpm", "pid", "vel", "one_d_pid", "raw_rpm"])
 @pytest.mark.parametrize("flags,D,S", [(0, 1, 1), (0, 1, 8), (7, 1, 2), (7, 3, 2), (2, 2, 8), (5, 8, 1), (1, 5, 4),
-                                       (7, 1, 3), (2, 1, 5)])   # (odd sub-step counts: the remainder of the 2x unrolled loop)
+                                       (7, 1, 3), (2, 1, 5),    # (odd sub-step counts: the remainder of the 2x unrolled loop)
+                                       # the pair path of the wave-local downwash exchange (D == 2: `mate(0); mate(1)`),
+                                       # BASELINE config 5's shape, alone and with every term, and config 3(i)'s shape
+                                       (4, 2, 1), (7, 2, 8), (7, 1, 1)])
 def test_one_step_parity(gpu_device, model, act, flags, D, S):
     if model == "racer" and act in ("pid", "vel", "one_d_pid"):
         pytest.skip("no DSLPID controller for the racer")
@@ -229,9 +232,61 @@ def test_closed_loop_pid_240hz(gpu_device):
     errs = _traj_errors(core, b, acts, gpu_device, {1, 24, 240, 480})
     for t, e in sorted(errs.items()):
         print(f"t={t:5d} " + " ".join(f"{g}={v:.2e}" for g, v in e.items()))
-    # closed loop with gains up to 7e4: the bound is looser than the open-loop 1e-4 and is stated here
+    # closed loop with gains up to 7e4; bounds = ~3x what the MI355X measures (pos 5.8e-7, quat 2.9e-6, vel 2.4e-6,
+    # rates 1.2e-6 at t = 480): a 10x regression fails
     for t, e in errs.items():
-        assert e["pos"] < 1e-4 and e["vel"] < 1e-3 and e["quat"] < 1e-3 and e["rates"] < 2e-2, (t, e)
+        assert e["pos"] < 2e-6 and e["vel"] < 8e-6 and e["quat"] < 1e-5 and e["rates"] < 5e-6, (t, e)
+
+
+@pytest.mark.parametrize("ctrl", [30, 48])
+def test_closed_loop_pid_low_rate_stays_inside_the_float64_envelope(gpu_device, ctrl):
+    """DSLPID at the reference's default 30 Hz (HoverAviary) and at 48 Hz (examples/pid.py): the attitude loop rides
+    its +-3200 torque clip and chatters, so ANY rounding-level difference grows ~10x per 4 control steps until it
+    saturates at the chatter amplitude -- two float64 runs do that too.  This test quantifies it: run the float64
+    oracle twice, the second time with its state nudged by half an fp32 ulp (relative 2^-24, random sign) after every
+    control step -- a float64 run that suffers exactly the input rounding the fp32 state array imposes -- and demand
+    that the fp32 HIP run stays within a small factor of that envelope at every checkpoint, per field group, on the
+    95th percentile and the median over 1024 drones."""
+    rng = np.random.default_rng(100 + ctrl)
+    E, D, S, T = 1024, 1, 240 // ctrl, 48
+    xyz, rpy = _random_scene(rng, E, D)
+    mk = lambda: BatchedAviary(urdf("cf2x"), "cf2x", E, D, initial_xyzs=xyz, initial_rpys=rpy * 0.3, pyb_freq=240,  # noqa: E731
+                               ctrl_freq=ctrl, act="pid", task="hover")
+    b, bp = mk(), mk()
+    core = _core("cf2x", E, D, 0, S, "pid", "hover", xyz, rpy * 0.3, gpu_device, target=b.TARGET_POS)
+    _sync_from_oracle(core, b)
+    for name in ("pos", "quat", "vel", "rpy_rates", "rpy", "last_rpm"):
+        setattr(bp, name, getattr(b, name).copy())
+    bp.pid.integral_pos_e, bp.pid.last_rpy, bp.pid.integral_rpy_e = (b.pid.integral_pos_e.copy(), b.pid.last_rpy.copy(),
+                                                                    b.pid.integral_rpy_e.copy())
+    wp = (xyz + rng.uniform(-0.3, 0.3, size=(E, D, 3))).astype(np.float32)
+    eps = 2.0 ** -24
+    from oracle import bullet_math as bm
+    rows = []
+    for k in range(T):
+        b.step(wp.astype(np.float64))
+        bp.step(wp.astype(np.float64))
+        for name in ("pos", "quat", "vel", "rpy_rates"):
+            arr = getattr(bp, name)
+            arr *= 1.0 + eps * rng.choice([-1.0, 1.0], size=arr.shape)
+        bp.rpy = bm.euler_from_quaternion_b(bp.quat)
+        core.step(torch.as_tensor(wp, device=gpu_device))
+        if (k + 1) in (2, 4, 8, 12, 16, 24, 32, 48):
+            ref, per = _oracle_kin(b), _oracle_kin(bp)
+            k32 = core.kin[:, :E].cpu().numpy().astype(np.float64)
+            for g, (sl, _) in GROUPS.items():
+                e32 = np.abs(k32[sl] - ref[sl]).max(axis=0)
+                env = np.abs(per[sl] - ref[sl]).max(axis=0)
+                rows.append((k + 1, g, np.percentile(e32, 50), np.percentile(env, 50), np.percentile(e32, 95),
+                             np.percentile(env, 95), e32.max(), env.max()))
+    for r in rows:
+        print("t=%3d %-5s median fp32 %.2e envelope %.2e | p95 fp32 %.2e envelope %.2e | max fp32 %.2e envelope %.2e" % r)
+    for t, g, m32, menv, p32, penv, x32, xenv in rows:
+        floor = 5e-7                     # one-step fp32 rounding of O(1) quantities
+        assert m32 <= 10.0 * menv + floor, (t, g, "median", m32, menv)
+        assert p32 <= 10.0 * penv + floor, (t, g, "p95", p32, penv)
+    # the divergence saturates at the chatter amplitude on both sides (bounded, not a blow-up)
+    assert rows[-4][6] < 0.1 and rows[-4][7] < 0.1
 
 
 # ---- against the reference's own fixtures -------------------------------------------------------------

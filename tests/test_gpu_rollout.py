@@ -34,6 +34,9 @@ RAGGED = [  # act, flags, D, S, model, E, K: ragged last workgroups, whole-aviar
     ("one_d_rpm", 0, 1, 1, "cf2x", 5, 4), ("raw_rpm", 2, 7, 2, "cf2p", 37, 6), ("rpm", 0, 1, 1, "cf2x", 140001, 10),
     ("vel", 7, 2, 1, "cf2x", 70001, 5), ("rpm", 0, 1, 1, "cf2x", 1, 2),
     ("rpm", 2, 1, 3, "cf2x", 300, 7), ("pid", 7, 1, 5, "cf2p", 200, 4),       # odd sub-step counts
+    # more workgroups than the chip holds at once (256 CUs x 8) AND a ragged tail: the clone lanes of the last workgroup
+    # start long after workgroup 0 has finished and rewritten its state (round-1 advisor finding)
+    ("rpm", 0, 1, 1, "cf2x", 1200001, 6), ("rpm", 4, 2, 1, "cf2x", 600001, 5),
 ]
 
 
@@ -44,7 +47,7 @@ def test_rollout_is_bitwise_k_steps(gpu_device, act, flags, D, S, model, E, K, k
     same-step auto-reset (short episodes so that resets happen inside the rollout), the terminal observations,
     the DSLPID members, last RPMs and step counters.  `keep_term` selects the kernel: single-drone aviaries without
     terminal observations and without DSLPID run `gpd_rollout1_kernel` (no helper wave; lanes of a ragged last
-    workgroup are clones of drone 0), everything else the compute-wave + store-wave kernel."""
+    workgroup are clones of the first drone of that workgroup), everything else the compute-wave + store-wave kernel."""
     rng = np.random.default_rng(zlib.crc32(repr((act, flags, D, S, model)).encode()))
     a, b = _pair(act, flags, D, S, model, gpu_device, E, rng, keep_term=keep_term)
     for c in (a, b):   # episodes of 10 physics steps -> several resets within K steps

@@ -159,6 +159,21 @@ assert torch.equal(full[5:], torch.arange(60, dtype=torch.float32).reshape(5, 12
 full2, work = ag(shard, async_op=True); work.wait()
 assert torch.equal(full2, full)
 assert gdist.max_over_ranks(float(rank)) == 1.0
+# a total the world size does not divide: env_shard hands out 6 + 5 aviaries of 2 drones, the gather pads and compacts
+a, b = gdist.env_shard(11, rank, world)
+rows = gdist.shard_rows_per_rank(11, world, rows_per_env=2)
+assert rows == [12, 10] and rows[rank] == (b - a) * 2
+shard = (torch.arange(rows[rank] * 12, dtype=torch.float32).reshape(rows[rank], 12) + 1000 * rank)
+ag2 = gdist.ObsAllGather(rows[rank], 12, device="cpu", rows_per_rank=rows)
+full = ag2(shard)
+assert full.shape == (22, 12)
+assert torch.equal(full[:12], torch.arange(144, dtype=torch.float32).reshape(12, 12))
+assert torch.equal(full[12:], torch.arange(120, dtype=torch.float32).reshape(10, 12) + 1000)
+try:
+    gdist.ObsAllGather(rows[rank] + 1, 12, device="cpu", rows_per_rank=rows)
+    raise SystemExit("a rows_per_rank list that contradicts this rank's shard must be refused")
+except ValueError:
+    pass
 dist.barrier(); dist.destroy_process_group()
 open({str(tmp_path)!r} + f"/ok{{rank}}", "w").write("ok")
 """)
