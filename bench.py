@@ -44,7 +44,8 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6300.0    # ... and what a streaming kernel reaches on it (same guide)
 PEAK_CLOCK_GHZ = 2.4       # MI355X peak engine clock
 NUM_SIMDS = 256 * 4        # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 4 cycles
 BASELINE_METRIC = "env steps/sec (whole node), HoverAviary N=65536 drones @240Hz"
@@ -60,6 +61,9 @@ WORKLOADS = {
     "hover65536_pid_240hz": dict(E=65536, D=1, phys=0, ctrl=240, act="pid", task="hover"),
     "hover65536_240hz_fullobs": dict(E=65536, D=1, phys=0, ctrl=240, act="rpm", task="hover", full_obs=True),
     "hover65536_30hz_fullobs": dict(E=65536, D=1, phys=0, ctrl=30, act="rpm", task="hover", full_obs=True),
+    # ... and with the action ring only ("lazy": the history tail stays a strided view of the ring the step kernel pushes into)
+    "hover65536_240hz_history": dict(E=65536, D=1, phys=0, ctrl=240, act="rpm", task="hover", full_obs="lazy"),
+    "hover65536_30hz_history": dict(E=65536, D=1, phys=0, ctrl=30, act="rpm", task="hover", full_obs="lazy"),
     "hover4m_240hz": dict(E=4194304, D=1, phys=0, ctrl=240, act="rpm", task="hover"),
     "hover16m_240hz": dict(E=16777216, D=1, phys=0, ctrl=240, act="rpm", task="hover"),
     # BASELINE.json configs 4 and 5, per GPU, verbatim (launch with --gpus 8 under torch.distributed.run)
@@ -97,7 +101,7 @@ def make_env(w, device, seed, E=None):
     rpy = rng.uniform(-0.1, 0.1, size=(E, D, 3))
     env = VectorAviary(E, D, initial_xyzs=xyz, initial_rpys=rpy, physics=w["phys"], pyb_freq=240,
                        ctrl_freq=w["ctrl"], act=ActionType(w["act"]), task=w["task"], auto_reset=True,
-                       track_rpm=bool(w["phys"] & 2), full_obs=bool(w.get("full_obs")), device=device)
+                       track_rpm=bool(w["phys"] & 2), full_obs=w.get("full_obs", False), device=device)
     return env
 
 
@@ -276,7 +280,8 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
 
     def one_rollout(n):
         for e, a in zip(envs, actions):
-            out = e.rollout(a[:n]) if getattr(e, "full_obs", False) else e.core.rollout(a[:n], update_latest=False)
+            hist = getattr(e, "full_obs", False) or getattr(e, "lazy_history", False)
+            out = e.rollout(a[:n]) if hist else e.core.rollout(a[:n], update_latest=False)
             if n in gathers:
                 gathers[n](out[0].reshape(-1, 12))
 
@@ -338,11 +343,19 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
     ev_s, wall_s = timed(repeats)
     timed_steps = K * repeats
     # roofline of the dominant kernel: algorithmic bytes of all launches of the timed region / its HIP-event time
+    def extra(e, n, rollout):          # materialised (12 + H*A)-float rows / the ring update behind a rollout
+        c = e.core
+        if getattr(e, "full_obs", False):
+            return c.bytes_full_rows(n, push=rollout)
+        if getattr(e, "lazy_history", False) and rollout:
+            return c.bytes_full_rows(n, push=True) - c.bytes_full_rows(n)
+        return 0
+
     if mode == "rollout":
-        per_pass = sum(c.bytes_per_rollout(n) for n in groups_of(K, POOL) for c in cores)
+        per_pass = sum(e.core.bytes_per_rollout(n) + extra(e, n, True) for n in groups_of(K, POOL) for e in envs)
         launches_pass = len(groups_of(K, POOL))
     else:
-        per_pass = K * sum(c.bytes_per_step() for c in cores)
+        per_pass = K * sum(e.core.bytes_per_step() + extra(e, 1, False) for e in envs)
         launches_pass = K
     launches = launches_pass * repeats
     bytes_total = per_pass * repeats
@@ -357,7 +370,8 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
         "value": n_total * core.S * timed_steps / ev_s, "value_wall": n_total * core.S * timed_steps / wall_s,
         "env_steps_per_s": n_total * timed_steps / ev_s, "us_per_step": ev_s * 1e6 / timed_steps,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel,
+                     "frac": achieved / HBM_PEAK_GBS, "achievable": HBM_ACHIEVABLE_GBS,
+                     "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS, "traffic": None, "kernel": kernel,
                      "env_steps_per_launch": steps_per_launch, "bytes_per_launch": bytes_total / launches,
                      "bytes_per_drone_per_env_step": per_pass / (n_rank * K),
                      "launch_us_hip_events": ev_s * 1e6 / launches, "launches_timed": launches,
@@ -498,7 +512,7 @@ def main():
                        "total_drones": n_total, "physics": "DYN" + "".join(n for b, n in ((1, "+GND"), (2, "+DRAG"), (4, "+DW")) if w["phys"] & b),
                        "pyb_freq": 240, "ctrl_freq": w["ctrl"], "substeps_per_step": S, "action": w["act"],
                        "task": w["task"], "auto_reset": True, "mode": args.mode, "launch": launch, "split": len(envs),
-                       "full_obs": bool(w.get("full_obs")), "obs_allgather": want_gather, "allgather_impl": impl,
+                       "full_obs": w.get("full_obs", False), "obs_allgather": want_gather, "allgather_impl": impl,
                        "env_steps_per_s": m["env_steps_per_s"]},
             "roofline": m["roofline"],
         }

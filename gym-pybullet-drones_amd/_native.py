@@ -29,7 +29,9 @@ class GpdError(RuntimeError):
 class GpdState(ctypes.Structure):
     """mirror of `struct GpdState`"""
     _fields_ = [("kin", ctypes.c_void_p), ("last_rpm", ctypes.c_void_p), ("pid", ctypes.c_void_p),
-                ("step_counter", ctypes.c_void_p), ("ld", ctypes.c_int64), ("dw_force", ctypes.c_void_p)]
+                ("step_counter", ctypes.c_void_p), ("ld", ctypes.c_int64), ("dw_force", ctypes.c_void_p),
+                ("act_ring", ctypes.c_void_p), ("ring_pos", ctypes.c_void_p), ("hist_len", ctypes.c_int32),
+                ("pad_", ctypes.c_int32)]
 
 
 class GpdStepCfg(ctypes.Structure):
@@ -73,8 +75,9 @@ _SIGNATURES = {
     "gpd_rollout": (ctypes.c_int, [ctypes.POINTER(GpdParams), ctypes.POINTER(GpdState), ctypes.POINTER(GpdStepCfg),
                                    ctypes.c_int32, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_int64, _P, _P, _P,
                                    ctypes.c_int64, _P, _P]),
-    "gpd_full_obs": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P,
-                                    ctypes.c_int64, _P, ctypes.c_int64, _P, _P, ctypes.c_int64, _P]),
+    "gpd_hist_rows": (ctypes.c_int, [ctypes.POINTER(GpdState), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P]),
+    "gpd_full_obs": (ctypes.c_int, [ctypes.POINTER(GpdState), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P,
+                                    ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_int64, _P]),
     "gpd_downwash_global": (ctypes.c_int, [ctypes.POINTER(GpdParams), _P, ctypes.c_int64, ctypes.c_int32, ctypes.c_float,
                                            ctypes.c_float, ctypes.c_float, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P, _P,
                                            _P, _P]),

@@ -373,6 +373,15 @@ __device__ __forceinline__ void substep(const GpdParams& P, float h, uint32_t fl
     k.wx = wxy.x; k.wy = wxy.y; k.wz = fmaf(h, P.J_INV[2] * tzz, k.wz);
     const fp2 pxy = fma2(hh, vxy, fp2{k.px, k.py});
     k.px = pxy.x; k.py = pxy.y; k.pz = fmaf(h, k.vz, k.pz);
+    if (EXT && (flags & GPD_PHYS_GROUND)) {
+        // the ground plane (NOT in the reference's Physics.DYN, see gpd.h): a drone whose collision cylinder would sink
+        // below z = 0 is put back on the plane, loses its downward velocity (restitution 0) and sticks laterally
+        const bool hit = k.pz < P.ground_z;
+        k.pz = hit ? P.ground_z : k.pz;
+        k.vz = hit ? fmaxf(k.vz, 0.0f) : k.vz;
+        k.vx = hit ? 0.0f : k.vx;
+        k.vy = hit ? 0.0f : k.vy;
+    }
     // exact exponential quaternion update q <- q (x) exp(w h / 2)  (:879-892)
     //   q' = cos(t) q + (sin(t)/|w|) (q (x) [w,0]),  t = |w| h / 2.  cos(t) and sin(t)/t are even functions
     //   of t, evaluated as minimax polynomials in u = t^2 (abs err 7e-8 / 5e-8 for t <= 1 rad, i.e. body
@@ -827,6 +836,9 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     Carry c;
     float tgx, tgy, tgz, ip[7];
     const float4 act = load_action<AW>(action, L.n);
+    // action history: the slot this aviary's action goes to (read with the other loads, from a readable dummy when there is
+    // no ring: the load section stays branch-free)
+    const int ring_q = (S.act_ring ? S.ring_pos : S.step_counter)[L.env];
     // a single step reads its reset pose only if it resets (in env_step); the slots `ip` are filled from a cached row
     const float* ipose = reinterpret_cast<const float*>(reinterpret_cast<const char*>(init_pose) +
                                                         (C.init_per_env ? L.n * 28u : static_cast<uint32_t>(L.d) * 28u));
@@ -876,6 +888,21 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
         reward[L.env] = out.rew;
         terminated[L.env] = out.term ? 1 : 0;
         truncated[L.env] = out.trunc ? 1 : 0;
+    }
+    if (S.act_ring) {
+        // push the raw action into the double ring (slots q and q + H: the H most recent actions stay H consecutive slots);
+        // a slot is a contiguous [N][A] block, so this is the coalesced mirror image of the action load
+        const size_t slot = static_cast<size_t>(N) * AW, at = static_cast<size_t>(ring_q) * slot + static_cast<size_t>(L.n) * AW;
+        float* r0 = S.act_ring + at;
+        float* r1 = r0 + static_cast<size_t>(S.hist_len) * slot;
+        if (AW == 4) {
+            *reinterpret_cast<float4*>(r0) = act;
+            *reinterpret_cast<float4*>(r1) = act;
+        } else {
+            r0[0] = act.x; r1[0] = act.x;
+            if (AW == 3) { r0[1] = act.y; r0[2] = act.z; r1[1] = act.y; r1[2] = act.z; }
+        }
+        if (L.d == 0) S.ring_pos[L.env] = ring_q + 1 == S.hist_len ? 0 : ring_q + 1;
     }
     if (out.reset && term_obs12)
         store_obs12(term_obs12, L.n, out.to[0], out.to[1], out.to[2], out.to[3], out.to[4], out.to[5], out.to[6], out.to[7],
@@ -1361,14 +1388,35 @@ __global__ __launch_bounds__(kBlock) void gpd_reset_kernel(const GpdState S, con
 
 // ------------------------------------------------------------------------------------------------
 // Full KIN observation rows: [ pos | rpy | vel | ang_v | the H most recent actions, oldest first ]
-// (envs/BaseRLAviary.py:307-320).  Pure data movement: one lane per output float, so that a wave writes 256
-// contiguous bytes; the source of a float is the obs12 row, an action row of this call, or -- for steps before
-// the call -- the per-drone action ring.
+// (envs/BaseRLAviary.py:307-320), materialised on request from the action ring (GpdState: a double ring [2H][N][A],
+// slot-major; the H most recent actions of an aviary are the H consecutive slots starting at its ring_pos).  Pure data
+// movement: one lane per output float, so that a wave writes 256 contiguous bytes.
 // ------------------------------------------------------------------------------------------------
+// rows of the CURRENT state (after gpd_step, which pushed its action itself)
+__global__ __launch_bounds__(kBlock) void gpd_hist_rows_kernel(uint32_t N, int D, int A, int H, const float* __restrict__ ring,
+                                                               const int32_t* __restrict__ ring_pos,
+                                                               const float* __restrict__ obs12, float* __restrict__ out) {
+    const uint32_t W = 12u + static_cast<uint32_t>(H * A);
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= N * W) return;
+    const uint32_t n = j / W, col = j - n * W;
+    float v;
+    if (col < 12u) {
+        v = obs12[static_cast<size_t>(n) * 12 + col];
+    } else {
+        const uint32_t i = (col - 12u) / static_cast<uint32_t>(A), a = (col - 12u) - i * static_cast<uint32_t>(A);
+        const int p = ring_pos[n / static_cast<uint32_t>(D)];
+        v = ring[(static_cast<size_t>(p + static_cast<int>(i)) * N + n) * A + a];
+    }
+    out[j] = v;
+}
+
+// rows of the K steps of a rollout: the source of a float is the obs12 row of its step, an action block of this call, or --
+// for steps before the call -- the ring as the rollout found it
 __global__ __launch_bounds__(kBlock) void gpd_full_obs_kernel(
-    int K, uint32_t N, int A, int H, int pos, const float* __restrict__ obs12, int64_t obs_stride,
-    const float* __restrict__ actions, int64_t act_stride, const float* __restrict__ hist, float* __restrict__ out,
-    int64_t out_stride) {
+    int K, uint32_t N, int D, int A, int H, const float* __restrict__ ring, const int32_t* __restrict__ ring_pos,
+    const float* __restrict__ obs12, int64_t obs_stride, const float* __restrict__ actions, int64_t act_stride,
+    float* __restrict__ out, int64_t out_stride) {
     const uint32_t W = 12u + static_cast<uint32_t>(H * A);
     const uint32_t per_step = N * W;                        // floats per step (< 2^32 by the host-side check)
     const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
@@ -1383,27 +1431,33 @@ __global__ __launch_bounds__(kBlock) void gpd_full_obs_kernel(
         const int s = t - (H - 1) + static_cast<int>(i);    // step of this call the action belongs to (< 0: earlier)
         if (s >= 0) {
             v = actions[s * act_stride + static_cast<int64_t>(n) * A + a];
-        } else {
-            int q = (pos + 1 + s) % H;                      // ring slot of global step (last + 1 + s)
-            if (q < 0) q += H;
-            v = hist[(static_cast<int64_t>(n) * H + q) * A + a];
+        } else {                                            // s = -1 is the newest action before the call: slot p + H - 1
+            const int p = ring_pos[n / static_cast<uint32_t>(D)];
+            v = ring[(static_cast<size_t>(p + H + s) * N + n) * A + a];
         }
     }
     out[t * out_stride + j] = v;
 }
 
-// pushes the actions of the K steps of a call into the per-drone ring [N][H][A] (the last H of them survive)
-__global__ __launch_bounds__(kBlock) void gpd_hist_push_kernel(int K, uint32_t N, int A, int H, int pos,
+// pushes the actions of the K steps of a call into the ring (the last H of them survive): blockIdx.y = 0 is the newest step
+__global__ __launch_bounds__(kBlock) void gpd_hist_push_kernel(int K, uint32_t N, int D, int A, int H,
                                                                const float* __restrict__ actions, int64_t act_stride,
-                                                               float* __restrict__ hist) {
+                                                               float* __restrict__ ring, const int32_t* __restrict__ ring_pos) {
     const uint32_t NA = N * static_cast<uint32_t>(A);
     const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
-    const int back = blockIdx.y;                            // 0 = the newest step of the call, 1 = the one before ...
-    const int s = K - 1 - back;
+    const int s = K - 1 - static_cast<int>(blockIdx.y);
     if (j >= NA || s < 0) return;
-    const uint32_t n = j / static_cast<uint32_t>(A), a = j - n * static_cast<uint32_t>(A);
-    const int q = (pos + 1 + s) % H;
-    hist[(static_cast<int64_t>(n) * H + q) * A + a] = actions[s * act_stride + j];
+    const uint32_t n = j / static_cast<uint32_t>(A);
+    const int q = (ring_pos[n / static_cast<uint32_t>(D)] + s) % H;
+    const float v = actions[s * act_stride + j];
+    ring[static_cast<size_t>(q) * NA + j] = v;
+    ring[static_cast<size_t>(q + H) * NA + j] = v;
+}
+
+// ... and then, in a launch of its own (every lane of the push has read the old value), the aviaries' ring positions advance
+__global__ __launch_bounds__(kBlock) void gpd_hist_advance_kernel(int K, int E, int H, int32_t* __restrict__ ring_pos) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e < E) ring_pos[e] = (ring_pos[e] + K) % H;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1761,7 +1815,7 @@ int step_impl(const char* who, const GpdParams* params, const GpdState* state, c
     if (cfg->drones_per_env > kBlock) return bad(GPD_ERANGE, "drones_per_env > 256 is not supported");
     if (cfg->act_type < GPD_ACT_RPM || cfg->act_type > GPD_ACT_DIRECT_RPM) return bad(GPD_EINVAL, "unknown act_type");
     if (cfg->task < GPD_TASK_NONE || cfg->task > GPD_TASK_MULTIHOVER) return bad(GPD_EINVAL, "unknown task");
-    if (cfg->physics_flags & ~7u) return bad(GPD_EINVAL, "unknown physics flag");
+    if (cfg->physics_flags & ~15u) return bad(GPD_EINVAL, "unknown physics flag");
     const int64_t N = static_cast<int64_t>(cfg->num_envs) * cfg->drones_per_env;
     if (state->ld < N) return bad(GPD_EINVAL, "state.ld < num_envs*drones_per_env");
     if (N > (1LL << 26)) return bad(GPD_ERANGE, "more than 2^26 drones per launch (32-bit byte offsets)");
@@ -1838,39 +1892,67 @@ int gpd_rollout(const GpdParams* params, const GpdState* state, const GpdStepCfg
     if (action_step_stride < 0 || obs_step_stride < 0 || env_step_stride < 0)
         return fail(GPD_EINVAL, "gpd_rollout: strides must be non-negative");
     const Span T{num_steps, action_step_stride, obs_step_stride, env_step_stride, 2};
-    return step_impl("gpd_rollout", params, state, cfg, T, actions, target_pos, init_pose, obs12, reward, terminated,
-                     truncated, term_obs12, stream);
+    // a rollout never pushes into the action ring itself (gpd_full_obs does, after the call) -- also not when a one-step
+    // rollout is routed to the single-step kernel
+    GpdState no_ring;
+    if (state) { no_ring = *state; no_ring.act_ring = nullptr; }
+    return step_impl("gpd_rollout", params, state ? &no_ring : nullptr, cfg, T, actions, target_pos, init_pose, obs12, reward,
+                     terminated, truncated, term_obs12, stream);
 }
 
-int gpd_full_obs(int32_t num_steps, int32_t n_drones, int32_t act_dim, int32_t hist_len, int32_t hist_pos,
+static int hist_args(const char* who, const GpdState* st, int32_t n_drones, int32_t D, int32_t A) {
+    auto bad = [&](int code, const char* msg) { return fail(code, (std::string(who) + ": " + msg).c_str()); };
+    if (!st || !st->act_ring || !st->ring_pos || st->hist_len <= 0) return bad(GPD_EINVAL, "state has no action ring (act_ring / ring_pos / hist_len)");
+    if (n_drones <= 0 || D <= 0 || n_drones % D != 0 || A <= 0 || A > 4)
+        return bad(GPD_EINVAL, "n_drones must be a positive multiple of drones_per_env and act_dim in 1..4");
+    const int64_t W = 12 + static_cast<int64_t>(st->hist_len) * A;
+    if (static_cast<int64_t>(n_drones) * W >= (1LL << 32)) return bad(GPD_ERANGE, "n_drones*(12+hist_len*act_dim) must be < 2^32");
+    return 0;
+}
+
+int gpd_hist_rows(const GpdState* state, int32_t n_drones, int32_t drones_per_env, int32_t act_dim, const float* obs12,
+                  float* obs_full, void* stream) {
+    if (int rc = hist_args("gpd_hist_rows", state, n_drones, drones_per_env, act_dim)) return rc;
+    if (!obs12 || !obs_full) return fail(GPD_EINVAL, "gpd_hist_rows: NULL obs12/obs_full");
+    const int64_t total = static_cast<int64_t>(n_drones) * (12 + static_cast<int64_t>(state->hist_len) * act_dim);
+    hipLaunchKernelGGL(gpd_hist_rows_kernel, dim3(static_cast<unsigned>((total + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), static_cast<uint32_t>(n_drones), drones_per_env, act_dim, state->hist_len,
+                       state->act_ring, state->ring_pos, obs12, obs_full);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gpd_hist_rows launch");
+    return 0;
+}
+
+int gpd_full_obs(const GpdState* state, int32_t num_steps, int32_t n_drones, int32_t drones_per_env, int32_t act_dim,
                  const float* obs12, int64_t obs_step_stride, const float* actions, int64_t action_step_stride,
-                 float* act_hist, float* obs_full, int64_t full_step_stride, void* stream) {
-    if (!actions || !act_hist) return fail(GPD_EINVAL, "gpd_full_obs: NULL actions/act_hist");
+                 float* obs_full, int64_t full_step_stride, void* stream) {
+    if (int rc = hist_args("gpd_full_obs", state, n_drones, drones_per_env, act_dim)) return rc;
+    if (!actions) return fail(GPD_EINVAL, "gpd_full_obs: NULL actions");
     if (obs_full && !obs12) return fail(GPD_EINVAL, "gpd_full_obs: obs_full needs obs12");
-    if (num_steps <= 0 || n_drones <= 0 || hist_len <= 0 || act_dim <= 0 || act_dim > 4)
-        return fail(GPD_EINVAL, "gpd_full_obs: num_steps, n_drones, hist_len must be positive and act_dim in 1..4");
-    if (hist_pos < 0 || hist_pos >= hist_len) return fail(GPD_EINVAL, "gpd_full_obs: hist_pos outside [0, hist_len)");
+    if (num_steps <= 0 || num_steps > 65535) return fail(GPD_EINVAL, "gpd_full_obs: num_steps must be in 1..65535");
     if (obs_step_stride < 0 || action_step_stride < 0 || full_step_stride < 0)
         return fail(GPD_EINVAL, "gpd_full_obs: strides must be non-negative");
-    const int64_t W = 12 + static_cast<int64_t>(hist_len) * act_dim;
-    if (static_cast<int64_t>(n_drones) * W >= (1LL << 32) || num_steps > 65535)
-        return fail(GPD_ERANGE, "gpd_full_obs: n_drones*(12+hist_len*act_dim) must be < 2^32 and num_steps <= 65535");
+    const int H = state->hist_len;
+    const int64_t W = 12 + static_cast<int64_t>(H) * act_dim;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (obs_full) {
         const int64_t per_step = static_cast<int64_t>(n_drones) * W;
         const dim3 grid(static_cast<unsigned>((per_step + kBlock - 1) / kBlock), static_cast<unsigned>(num_steps));
         hipLaunchKernelGGL(gpd_full_obs_kernel, grid, dim3(kBlock), 0, st, num_steps, static_cast<uint32_t>(n_drones),
-                           act_dim, hist_len, hist_pos, obs12, obs_step_stride, actions, action_step_stride, act_hist,
-                           obs_full, full_step_stride);
+                           drones_per_env, act_dim, H, state->act_ring, state->ring_pos, obs12, obs_step_stride, actions,
+                           action_step_stride, obs_full, full_step_stride);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "gpd_full_obs launch");
     }
-    // the ring is read by the kernel above and updated by the next one: same stream, in order
-    const int keep = num_steps < hist_len ? num_steps : hist_len;
+    // the ring is read by the kernel above and updated by the next two: same stream, in order
+    const int keep = num_steps < H ? num_steps : H;
     const int64_t NA = static_cast<int64_t>(n_drones) * act_dim;
     const dim3 grid2(static_cast<unsigned>((NA + kBlock - 1) / kBlock), static_cast<unsigned>(keep));
-    hipLaunchKernelGGL(gpd_hist_push_kernel, grid2, dim3(kBlock), 0, st, num_steps, static_cast<uint32_t>(n_drones), act_dim,
-                       hist_len, hist_pos, actions, action_step_stride, act_hist);
+    hipLaunchKernelGGL(gpd_hist_push_kernel, grid2, dim3(kBlock), 0, st, num_steps, static_cast<uint32_t>(n_drones),
+                       drones_per_env, act_dim, H, actions, action_step_stride, state->act_ring, state->ring_pos);
+    const int E = n_drones / drones_per_env;
+    hipLaunchKernelGGL(gpd_hist_advance_kernel, dim3(static_cast<unsigned>((E + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                       num_steps, E, H, state->ring_pos);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gpd_full_obs (ring update) launch");
     return 0;

@@ -20,7 +20,7 @@ import torch
 
 from . import _native
 from .params import DroneParams, PIDGains, euler_to_quat, trunc_counter
-from .utils.enums import ACT_RAW_RPM, ActionType, DroneModel, PHYS_DRAG, Physics
+from .utils.enums import ACT_RAW_RPM, ActionType, DroneModel, PHYS_DRAG, PHYS_GROUND, Physics
 
 TASK_NONE, TASK_HOVER, TASK_MULTIHOVER = 0, 1, 2
 _ACT_DIM = {0: 4, 1: 3, 2: 4, 3: 1, 4: 1, 5: 4, 6: 4}
@@ -77,7 +77,8 @@ class SimCore:
             raise ValueError("drones_per_env must be in 1..256")
         self.ld = (self.N + 63) // 64 * 64
         self.P = DroneParams(drone_model)
-        self.physics_flags = physics.flags if isinstance(physics, Physics) else int(physics)
+        # a `Physics` member selects the add-on force models and, for PYB*, the ground plane; an int is the raw GPD_PHYS_* mask
+        self.physics_flags = (physics.flags | (PHYS_GROUND if physics.ground else 0)) if isinstance(physics, Physics) else int(physics)
         self.act_code = int(act_code)
         self.A = _ACT_DIM[self.act_code]
         self.uses_pid = self.act_code in _PID_ACTS
@@ -230,18 +231,39 @@ class SimCore:
 
     # ---- action history / full KIN observation rows (envs/BaseRLAviary.py:65-67, 153-154, 187, 307-320) ----
     def enable_history(self, hist_len: int):
-        """Allocate the per-drone action ring [N, H, A] (zeros, like the reference's pre-filled deque; never cleared
-        by a reset, App. B.2)."""
+        """Allocate the action ring: a DOUBLE ring `[2H][N][A]` (zeros, like the reference's pre-filled deque; never
+        cleared by a reset, App. B.2) + the per-aviary ring positions, and hand them to the kernels through `GpdState`:
+        from now on `step()` pushes its action into the ring inside the step kernel."""
         self.H = int(hist_len)
-        self.act_hist = torch.zeros((self.N, self.H, self.A), dtype=torch.float32, device=self.device)
-        self.hist_pos = self.H - 1
-        self.obs_full = torch.zeros((self.N, 12 + self.H * self.A), dtype=torch.float32, device=self.device)
+        self.act_ring = torch.zeros((2 * self.H, self.N, self.A), dtype=torch.float32, device=self.device)
+        self.ring_pos = torch.zeros((self.E,), dtype=torch.int32, device=self.device)
+        self.obs_full = None            # materialised rows, allocated on first request
         self._full_buf = None
+        self._state.act_ring = self.act_ring.data_ptr()
+        self._state.ring_pos = self.ring_pos.data_ptr()
+        self._state.hist_len = self.H
+
+    def history_view(self) -> torch.Tensor:
+        """`[N, H, A]` STRIDED VIEW of the ring: the H most recent actions of every drone, oldest first (what the
+        reference appends to the observation row, BaseRLAviary.py:317-318).  No copy; valid until the next step.  Reads
+        the ring position from the device (one 4-byte copy): the aviaries of a core advance in lock-step."""
+        p = int(self.ring_pos[0].item())
+        return self.act_ring[p:p + self.H].permute(1, 0, 2)
+
+    def history_rows(self, obs12: torch.Tensor = None) -> torch.Tensor:
+        """Materialise the current full rows `[N, 12 + H*A]` (`gpd_hist_rows`: one gather kernel, no host sync)."""
+        if self.obs_full is None:
+            self.obs_full = torch.zeros((self.N, 12 + self.H * self.A), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.gpd_hist_rows(ctypes.byref(self._state), self.N, self.D, self.A,
+                                        _ptr(self.obs12 if obs12 is None else obs12), _ptr(self.obs_full), self._stream())
+        _native.check(rc, "gpd_hist_rows")
+        return self.obs_full
 
     def full_obs(self, actions: torch.Tensor, obs12: torch.Tensor = None, num_steps: int = 1, want_rows: bool = True):
-        """After `step(action)` / `rollout(actions)`: push the action(s) into the ring and (want_rows) assemble the
-        full observation rows `[K, N, 12 + H*A]` (K = 1: the persistent `obs_full` [N, 12 + H*A]) in one kernel.
-        `actions`: what was passed to step/rollout; `obs12`: its observation output (default: the latest)."""
+        """After `rollout(actions)`: (want_rows) assemble the full observation rows `[K, N, 12 + H*A]` of the K steps,
+        then push the K actions into the ring (`gpd_full_obs`).  `actions`: what was passed to the rollout; `obs12`: its
+        observation output (default: the latest rollout buffer)."""
         K = int(num_steps)
         per = self.N * self.A
         if action_needs_fix(actions, self.device):
@@ -252,20 +274,16 @@ class SimCore:
         W = 12 + self.H * self.A
         out = None
         if want_rows:
-            if K == 1:
-                out = self.obs_full
-            else:
-                if self._full_buf is None or self._full_buf.shape[0] != K:
-                    self._full_buf = torch.zeros((K, self.N, W), dtype=torch.float32, device=self.device)
-                out = self._full_buf
+            if self._full_buf is None or self._full_buf.shape[0] != K:
+                self._full_buf = torch.zeros((K, self.N, W), dtype=torch.float32, device=self.device)
+            out = self._full_buf
             if obs12 is None:
-                obs12 = self.obs12 if K == 1 else self._rollout_buf[0]
+                obs12 = self._rollout_buf[0]
         with torch.cuda.device(self.device):
-            rc = self.lib.gpd_full_obs(K, self.N, self.A, self.H, self.hist_pos, _ptr(obs12) if want_rows else _ptr(None),
-                                       self.N * 12, _ptr(actions), a_stride, _ptr(self.act_hist), _ptr(out), self.N * W,
-                                       self._stream())
+            rc = self.lib.gpd_full_obs(ctypes.byref(self._state), K, self.N, self.D, self.A,
+                                       _ptr(obs12) if want_rows else _ptr(None), self.N * 12, _ptr(actions), a_stride,
+                                       _ptr(out), self.N * W, self._stream())
         _native.check(rc, "gpd_full_obs")
-        self.hist_pos = (self.hist_pos + K) % self.H
         return out
 
     def _rollout_buffers(self, K: int):
@@ -300,6 +318,16 @@ class SimCore:
         per_drone = state + ka * self.A * 4 + ko * 12 * 4
         per_env = 2 * 4 + ko * (4 + 2)
         return per_drone * self.N + per_env * self.E
+
+    def bytes_full_rows(self, K: int = 1, push: bool = False) -> int:
+        """Algorithmic HBM bytes of materialising the full observation rows of K steps (`history_rows` / `full_obs`): every
+        row float is read once (obs12 row, ring slot or action block) and written once; `push`: plus the ring update of a
+        rollout's post-pass (min(K, H) action blocks read and written twice)."""
+        W = 12 + self.H * self.A
+        b = 2 * K * self.N * W * 4
+        if push:
+            b += 3 * min(K, self.H) * self.N * self.A * 4 + 2 * 4 * self.E
+        return b
 
     def state_vectors(self) -> torch.Tensor:
         """[N,20] state vectors in `_getDroneStateVector` order (BaseAviary.py:559-561)."""
@@ -341,4 +369,7 @@ class SimCore:
         if self.last_rpm is not None:
             per_drone += 4 * 4
         per_env = 4 + 2 + 2 * 4                                   # reward + 2 flags + counter r/w
+        if getattr(self, "act_ring", None) is not None:           # action pushed into both halves of the double ring
+            per_drone += 2 * self.A * 4
+            per_env += 2 * 4                                      # ring position r/w
         return per_drone * self.N + per_env * self.E

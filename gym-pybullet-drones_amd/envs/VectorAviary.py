@@ -74,9 +74,17 @@ class VectorAviary:
         self.device = self.core.device
         self.ACT_DIM = self.core.A
         self.INIT_XYZS, self.INIT_RPYS, self.TARGET_POS = self.core.INIT_XYZS, self.core.INIT_RPYS, self.core.TARGET_POS
-        self.full_obs = bool(full_obs)
+        # full_obs: False -> (E, D, 12) rows only, no action history kept;
+        #           True  -> the reference's (E, D, 12 + H*A) rows, materialised after every step (one gather kernel);
+        #           "lazy" -> the action ring is kept (pushed inside the step kernel, +2 x 16 B per drone and step) and
+        #                     step() returns the (E, D, 12) rows; `history()` is a zero-copy strided view of the ring,
+        #                     `full_rows()` materialises the reference's rows when a consumer wants them
+        if full_obs not in (False, True, "lazy"):
+            raise ValueError("full_obs must be False, True or 'lazy'")
+        self.lazy_history = full_obs == "lazy"
+        self.full_obs = full_obs is True
         self.ACTION_BUFFER_SIZE = int(ctrl_freq // 2)
-        self.OBS_DIM = 12 + (self.ACTION_BUFFER_SIZE * self.ACT_DIM if full_obs else 0)
+        self.OBS_DIM = 12 + (self.ACTION_BUFFER_SIZE * self.ACT_DIM if self.full_obs else 0)
         if full_obs:
             self.core.enable_history(self.ACTION_BUFFER_SIZE)
 
@@ -91,29 +99,33 @@ class VectorAviary:
             return self.core.obs12.view(E, D, 12)
         return self.core.obs_full.view(E, D, self.OBS_DIM)
 
+    def history(self) -> torch.Tensor:
+        """(E, D, H, A) zero-copy strided VIEW of the action ring: the last H actions of every drone, oldest first
+        (the tail the reference appends to the observation row, BaseRLAviary.py:317-318).  Valid until the next step."""
+        H = self.ACTION_BUFFER_SIZE
+        return self.core.history_view().unflatten(0, (self.NUM_ENVS, self.NUM_DRONES))
+
     def action_history(self) -> torch.Tensor:
         """(E*D, H, A) copy of the last H actions, oldest first."""
-        H, p = self.ACTION_BUFFER_SIZE, self.core.hist_pos
-        return torch.roll(self.core.act_hist, shifts=-(p + 1), dims=1)
+        return self.core.history_view().contiguous()
+
+    def full_rows(self) -> torch.Tensor:
+        """(E, D, 12 + H*A): the reference's observation rows for the current state, materialised now."""
+        return self.core.history_rows().view(self.NUM_ENVS, self.NUM_DRONES, -1)
 
     def reset(self, seed=None, options=None, mask=None):
         """Reset all aviaries (or those selected by the boolean/uint8 tensor `mask` [E]).  As in the reference the
         action history (and the embedded PID state) survives a reset."""
         self.core.reset(mask=mask)
         if self.full_obs:      # rows of the reset poses with the unchanged history tail (ring not advanced)
-            self._refresh_full_obs()
+            self.core.history_rows()
         return self._obs(), {}
-
-    def _refresh_full_obs(self):
-        c = self.core
-        c.obs_full[:, :12].copy_(c.obs12)
-        c.obs_full[:, 12:].copy_(self.action_history().reshape(c.N, -1))
 
     def step(self, action: torch.Tensor):
         """action: float32 tensor (E, D, A) on `self.device` -> (obs, reward[E], terminated[E], truncated[E], info)."""
-        _, reward, terminated, truncated = self.core.step(action)
+        _, reward, terminated, truncated = self.core.step(action)      # (pushes the action into the ring, if there is one)
         if self.full_obs:
-            self.core.full_obs(action)                       # ring push + row assembly, one more launch
+            self.core.history_rows()                         # row assembly: one more launch
         info = {}
         if self.core.term_obs12 is not None:
             info["terminal_observation"] = self.core.term_obs12.view(self.NUM_ENVS, self.NUM_DRONES, 12)
@@ -126,8 +138,11 @@ class VectorAviary:
         obs, reward, terminated, truncated = self.core.rollout(actions)
         if self.full_obs:
             obs = self.core.full_obs(actions, obs12=obs, num_steps=K)
-            if K > 1:
-                self.core.obs_full.copy_(obs[K - 1])
+            if self.core.obs_full is None:
+                self.core.history_rows()
+            self.core.obs_full.copy_(obs[K - 1])
+        elif self.lazy_history:
+            self.core.full_obs(actions, num_steps=K, want_rows=False)      # ring update only
         return obs.view(K, self.NUM_ENVS, self.NUM_DRONES, -1), reward, terminated, truncated
 
     def state_vectors(self) -> torch.Tensor:
@@ -262,3 +277,69 @@ class VecEnvAdapter:
 
     def seed(self, seed=None):
         return [seed] * self.num_envs          # the simulator is deterministic: nothing draws random numbers
+
+
+class GymVectorEnvAdapter:
+    """`gymnasium.vector.VectorEnv`-shaped front end of a `VectorAviary` (duck-typed: gymnasium is optional here).
+
+    The gymnasium >= 1.0 vector API (what `gymnasium.make_vec` / `SyncVectorEnv` give a learner that does not go through
+    SB3's `make_vec_env`, `examples/learn.py:54-58`): `reset(seed=, options=) -> (obs, infos)`, `step(actions) ->
+    (obs, rewards, terminations, truncations, infos)` with batched numpy arrays, `num_envs`, `single_observation_space`
+    / `single_action_space` and their batched versions, and an explicit autoreset mode.  The kernel resets an aviary in
+    the SAME step it ends in (`AutoresetMode.SAME_STEP`): the returned observation is the first one of the new episode
+    and the last one of the finished episode is `infos["final_obs"][i]` (with the mask `infos["_final_obs"]`), as
+    gymnasium's own same-step vector envs report it.  `last` keeps the device tensors of the latest step for a
+    GPU-resident learner."""
+
+    metadata = {"autoreset_mode": "SameStep", "render_modes": []}
+
+    def __init__(self, env: "VectorAviary"):
+        if not env.core.auto_reset:
+            raise ValueError("GymVectorEnvAdapter needs a VectorAviary built with auto_reset=True")
+        self.env = env
+        self.num_envs = env.NUM_ENVS
+        from .._gym_shim import spaces
+        D, W, A = env.NUM_DRONES, env.OBS_DIM, env.ACT_DIM
+        box = lambda shape, lo, hi: spaces.Box(low=np.full(shape, lo), high=np.full(shape, hi), dtype=np.float32)  # noqa: E731
+        self.single_observation_space = box((D, W), -np.inf, np.inf)
+        self.single_action_space = box((D, A), -1.0, 1.0)
+        self.observation_space = box((self.num_envs, D, W), -np.inf, np.inf)
+        self.action_space = box((self.num_envs, D, A), -1.0, 1.0)
+        self.last = None
+        self.closed = False
+        if env.core.term_obs12 is None:
+            env.core.term_obs12 = torch.zeros((env.core.N, 12), dtype=torch.float32, device=env.device)
+
+    def reset(self, *, seed=None, options=None):
+        mask = None if not options or "reset_mask" not in options else torch.as_tensor(options["reset_mask"], device=self.env.device)
+        obs, _ = self.env.reset(seed=seed, mask=mask)
+        return obs.cpu().numpy(), {}
+
+    def step(self, actions):
+        env = self.env
+        a = torch.as_tensor(np.asarray(actions, dtype=np.float32), device=env.device).reshape(self.num_envs, env.NUM_DRONES, env.ACT_DIM)
+        obs, reward, terminated, truncated, _ = env.step(a)
+        self.last = (obs, reward, terminated, truncated)
+        packed = torch.stack([reward, terminated.to(torch.float32), truncated.to(torch.float32)]).cpu().numpy()
+        rew, term, trunc = packed[0], packed[1] != 0, packed[2] != 0
+        obs_np = obs.cpu().numpy()
+        infos = {}
+        done = term | trunc
+        if done.any():
+            final = np.zeros_like(obs_np)
+            tob = env.core.term_obs12.view(self.num_envs, env.NUM_DRONES, 12).cpu().numpy()
+            final[done, :, :12] = tob[done]
+            final[done, :, 12:] = obs_np[done, :, 12:]       # the history tail is not cleared by a reset (App. B.2)
+            infos["final_obs"], infos["_final_obs"] = final, done
+        return obs_np, rew, term, trunc, infos
+
+    def close(self, **kwargs):
+        self.closed = True
+        self.env.close()
+
+    def render(self):
+        return None
+
+    @property
+    def unwrapped(self):
+        return self

@@ -5,8 +5,8 @@ from .HoverAviary import HoverAviary
 from .MultiHoverAviary import MultiHoverAviary
 from .SwarmAviary import SwarmAviary
 from .VelocityAviary import VelocityAviary
-from .VectorAviary import (VecEnvAdapter, VectorAviary, VectorCtrlAviary, VectorHoverAviary, VectorMultiHoverAviary,
+from .VectorAviary import (GymVectorEnvAdapter, VecEnvAdapter, VectorAviary, VectorCtrlAviary, VectorHoverAviary, VectorMultiHoverAviary,
                            VectorVelocityAviary)
 
 __all__ = ["BaseAviary", "BaseRLAviary", "CtrlAviary", "HoverAviary", "MultiHoverAviary", "VelocityAviary", "VectorAviary",
-           "VectorCtrlAviary", "VectorHoverAviary", "VectorMultiHoverAviary", "VectorVelocityAviary", "VecEnvAdapter", "SwarmAviary"]
+           "VectorCtrlAviary", "VectorHoverAviary", "VectorMultiHoverAviary", "VectorVelocityAviary", "VecEnvAdapter", "GymVectorEnvAdapter", "SwarmAviary"]

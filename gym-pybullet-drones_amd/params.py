@@ -76,7 +76,7 @@ class GpdParams(ctypes.Structure):
         ("mixer", ctypes.c_float * 12),
         ("pwm2rpm_scale", ctypes.c_float), ("inv_pwm2rpm_scale", ctypes.c_float), ("pwm2rpm_const", ctypes.c_float),
         ("min_pwm", ctypes.c_float), ("max_pwm", ctypes.c_float),
-        ("speed_limit", ctypes.c_float),
+        ("speed_limit", ctypes.c_float), ("ground_z", ctypes.c_float),
     ]
 
 
@@ -187,6 +187,7 @@ class DroneParams:
             s.inv_pwm2rpm_scale = 1.0 / gains.PWM2RPM_SCALE
             s.min_pwm, s.max_pwm = gains.MIN_PWM, gains.MAX_PWM
         s.speed_limit = self.SPEED_LIMIT
+        s.ground_z = self.COLLISION_H / 2 - self.COLLISION_Z_OFFSET      # base-link height with the cylinder on the plane
         return s
 
 

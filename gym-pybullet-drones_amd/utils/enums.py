@@ -40,6 +40,14 @@ class Physics(Enum):
         return {"pyb": 0, "dyn": 0, "pyb_gnd": 1, "pyb_drag": 2, "pyb_dw": 4,
                 "pyb_gnd_drag_dw": 7}[self.value]
 
+    @property
+    def ground(self) -> bool:
+        """Whether the ground plane acts (`GPD_PHYS_GROUND`).  In the reference every `PYB*` member resolves contact with
+        the plane loaded at `BaseAviary.py:479` through Bullet's solver, while `DYN` overwrites the pose every step
+        (`:865-875`) and a drone falls through z = 0.  Here: `PYB*` -> plane on (the minimal contact model of
+        include/gpd.h), `DYN` -> off, exactly the reference's `DYN`."""
+        return self != Physics.DYN
+
 
 class ImageType(Enum):
     RGB = 0
@@ -96,7 +104,7 @@ def warn_if_pyb(physics) -> None:
 
 
 #: physics add-on bits, mirrored in include/gpd.h
-PHYS_GND, PHYS_DRAG, PHYS_DW = 1, 2, 4
+PHYS_GND, PHYS_DRAG, PHYS_DW, PHYS_GROUND = 1, 2, 4, 8
 #: raw-RPM action clipped to [0, MAX_RPM] (CtrlAviary, `CtrlAviary.py:140`); kernel-only code
 ACT_RAW_RPM = 5
 #: RPMs taken as they are (output of a user subclass's own `_preprocessAction`); kernel-only code

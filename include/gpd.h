@@ -56,8 +56,15 @@ enum {
 };
 
 /* Aerodynamic add-on terms evaluated inside the explicit integrator
- * (envs/BaseAviary.py:354-367 dispatch; formulas :715-811) */
-enum { GPD_PHYS_GND = 1, GPD_PHYS_DRAG = 2, GPD_PHYS_DW = 4 };
+ * (envs/BaseAviary.py:354-367 dispatch; formulas :715-811), and the ground plane.
+ *
+ * GPD_PHYS_GROUND is NOT part of the reference's Physics.DYN (there the drone's pose is overwritten every step,
+ * envs/BaseAviary.py:865-875, so the plane loaded at :479 never acts and a drone falls through z = 0).  It stands in
+ * for what Bullet's solver does for Physics.PYB* with that plane: after every physics sub-step a drone whose collision
+ * cylinder (URDF: COLLISION_H, COLLISION_Z_OFFSET) would sink below z = 0 is put back ON the plane
+ * (z = params.ground_z), its downward velocity is removed (restitution 0) and it sticks laterally (vx = vy = 0); body
+ * rates and attitude are left to the rigid-body equations.  The Python classes enable it for Physics.PYB* only. */
+enum { GPD_PHYS_GND = 1, GPD_PHYS_DRAG = 2, GPD_PHYS_DW = 4, GPD_PHYS_GROUND = 8 };
 
 /* Which task's reward / termination / truncation is evaluated in the step kernel */
 enum {
@@ -105,6 +112,9 @@ typedef struct GpdParams {
     float mixer[12];           /* row-major 4x3, control/DSLPIDControl.py:47-60 */
     float pwm2rpm_scale, inv_pwm2rpm_scale, pwm2rpm_const, min_pwm, max_pwm;
     float speed_limit;         /* ActionType.VEL, envs/BaseRLAviary.py:94-95 */
+    float ground_z;            /* GPD_PHYS_GROUND: height of the base link when the collision cylinder rests on the
+                                  plane, COLLISION_H/2 - COLLISION_Z_OFFSET (the 0.1 m the default INIT_XYZS adds on
+                                  top of it, envs/BaseAviary.py:194-197) */
 } GpdParams;
 
 /*
@@ -124,6 +134,19 @@ typedef struct GpdState {
     float* dw_force;       /* [ld] or NULL: body-z downwash force per drone computed OUTSIDE the step kernel
                               (gpd_downwash_global, for one aviary of more than 256 drones); used with
                               GPD_PHYS_DW when drones_per_env == 1, added in every sub-step of the call */
+    /* Action history (the reference's action_buffer deque, envs/BaseRLAviary.py:65-67, 153-154, 187): a DOUBLE ring
+     * of the raw actions, [2*hist_len][N][A] floats, slot-major -- every action is written to slots q and q + hist_len,
+     * so that the hist_len most recent actions are always hist_len CONSECUTIVE slots, oldest first, starting at
+     * ring_pos: the history tail of the observation row (:317-318) is a strided VIEW of the ring ([N][hist_len][A]
+     * with strides A, N*A, 1), no copy.  A slot is one contiguous [N][A] block, the shape of an action input: the
+     * push is a coalesced 16-byte store per lane.  Zero-filled at start (:153-154), never cleared by a reset
+     * (SURVEY.md App. B.2).  gpd_step pushes its action itself when act_ring != NULL; after a gpd_rollout call
+     * gpd_full_obs pushes the K actions of the call. */
+    float* act_ring;       /* [2*hist_len][N][A] or NULL */
+    int32_t* ring_pos;     /* [num_envs]: slot (0 .. hist_len-1) the NEXT action of the aviary goes to = where its oldest
+                              one sits.  Kept on the device so that a captured hipGraph of steps replays correctly */
+    int32_t hist_len;      /* H = ctrl_freq // 2 (envs/BaseRLAviary.py:65); 0 with act_ring == NULL */
+    int32_t pad_;
 } GpdState;
 
 /* Per-call configuration of gpd_step */
@@ -219,24 +242,30 @@ int gpd_rollout(const GpdParams* params, const GpdState* state, const GpdStepCfg
                 float* term_obs12, void* stream);
 
 /*
- * Full KIN observation rows with the action-history tail, and the action ring behind them.  Replaces the
- * action buffer of BaseRLAviary (envs/BaseRLAviary.py:65-67 deque, :153-154 zero pre-fill, :187 append; never
- * cleared by reset()) and the row assembly of BaseRLAviary._computeObs (:307-320):
+ * Full KIN observation rows with the action-history tail.  Replaces the row assembly of BaseRLAviary._computeObs
+ * (envs/BaseRLAviary.py:307-320) on top of the action ring of GpdState (which replaces the deque, :65-67, 153-154, 187):
  *     row = [ pos | rpy | vel | ang_v | a(t-H+1) ... a(t) ]      H = ctrl_freq // 2, oldest action first
- * for the num_steps steps of a gpd_step / gpd_rollout call (call it after the step call, same stream).
+ * The rows are MATERIALISED only on request -- at 240 Hz control a row is 12 + 120*4 floats, ten times the bytes of the
+ * whole physics step; a consumer that can take (obs12, history view) separately never needs them.
  *
- *   act_hist      [n_drones][hist_len][act_dim] in/out: per-drone ring of the raw actions; slot hist_pos holds
- *                 the most recent action BEFORE this call (a zeroed ring with hist_pos = hist_len-1 is the
- *                 reference's initial state).  On return it also holds the actions of this call; the caller
- *                 advances its hist_pos by num_steps modulo hist_len.
- *   obs12         the step call's observation blocks, step t at obs12 + t*obs_step_stride
- *   actions       the step call's action blocks,      step t at actions + t*action_step_stride (0: held action)
+ * gpd_hist_rows: the current rows, after a gpd_step call (which pushed its action into the ring itself):
+ *   state       act_ring / ring_pos / hist_len are read (ring_pos of aviary n / drones_per_env)
+ *   obs12       [n_drones][12] of the latest step
+ *   obs_full    [n_drones][12 + hist_len*act_dim] out
+ *
+ * gpd_full_obs: the rows of the num_steps steps of a gpd_rollout call (call it after the rollout, same stream), built
+ * from the ring as the rollout found it plus the call's own action blocks; then the K actions are pushed into the ring
+ * and ring_pos advances by num_steps (mod hist_len).
+ *   obs12         the rollout's observation blocks, step t at obs12 + t*obs_step_stride
+ *   actions       the rollout's action blocks,      step t at actions + t*action_step_stride (0: held action)
  *   obs_full      [num_steps][n_drones][12 + hist_len*act_dim] out, step t at obs_full + t*full_step_stride;
  *                 NULL: only update the ring
  */
-int gpd_full_obs(int32_t num_steps, int32_t n_drones, int32_t act_dim, int32_t hist_len, int32_t hist_pos,
+int gpd_hist_rows(const GpdState* state, int32_t n_drones, int32_t drones_per_env, int32_t act_dim, const float* obs12,
+                  float* obs_full, void* stream);
+int gpd_full_obs(const GpdState* state, int32_t num_steps, int32_t n_drones, int32_t drones_per_env, int32_t act_dim,
                  const float* obs12, int64_t obs_step_stride, const float* actions, int64_t action_step_stride,
-                 float* act_hist, float* obs_full, int64_t full_step_stride, void* stream);
+                 float* obs_full, int64_t full_step_stride, void* stream);
 
 /*
  * Downwash forces inside ONE aviary of n drones, any n (the step kernel itself handles aviaries of up to 256

@@ -28,6 +28,11 @@ from scipy.spatial.transform import Rotation
 from . import bullet_math as bm
 
 PHYS_GND, PHYS_DRAG, PHYS_DW = 1, 2, 4
+#: EXTENSION, not in the reference's Physics.DYN (include/gpd.h, GPD_PHYS_GROUND): the plane at z = 0.  A drone whose
+#: collision cylinder would sink below it is put back on it (base-link height COLLISION_H/2 - COLLISION_Z_OFFSET), loses
+#: its downward velocity and sticks laterally.  UNPINNED by construction: the reference resolves ground contact only
+#: through Bullet's solver (Physics.PYB*), which is not available; this restates the kernel's definition in float64.
+PHYS_GROUND = 8
 ACT_DIM = {"rpm": 4, "pid": 3, "vel": 4, "one_d_rpm": 1, "one_d_pid": 1, "raw_rpm": 4}
 
 
@@ -289,6 +294,11 @@ class OracleAviary:
         v = v + h * a                                     # semi-implicit Euler: x uses the NEW v
         w = w + h * w_dot
         x = x + h * v
+        if self.PHYS & PHYS_GROUND:                       # extension (see PHYS_GROUND): the plane at z = 0
+            z_rest = C.COLLISION_H / 2 - C.COLLISION_Z_OFFSET
+            if x[2] < z_rest:
+                x = np.array([x[0], x[1], z_rest])
+                v = np.array([0.0, 0.0, max(v[2], 0.0)])
         q = self._integrateQ(q, w, h)
         self._s_pos[i], self._s_quat[i] = x, q            # not renormalised
         self._s_vel[i], self._s_ang_v[i] = v, R @ w       # world rates use the PRE-update rotation

@@ -10,7 +10,7 @@ auto-reset of SB3's DummyVecEnv (examples/learn.py:54-58 is the calling pattern;
 import numpy as np
 
 from . import bullet_math as bm
-from .aviary_oracle import ACT_DIM, PHYS_DRAG, PHYS_DW, PHYS_GND, UrdfConstants
+from .aviary_oracle import ACT_DIM, PHYS_DRAG, PHYS_DW, PHYS_GND, PHYS_GROUND, UrdfConstants
 
 
 def _cross(a, b):
@@ -213,6 +213,11 @@ class BatchedAviary:
         w = w + h * (tau * np.diag(C.J_INV))
         v = self.vel + h * (F / C.M)
         x = self.pos + h * v
+        if self.PHYS & PHYS_GROUND:                       # extension (aviary_oracle.PHYS_GROUND): the plane at z = 0
+            z_rest = C.COLLISION_H / 2 - C.COLLISION_Z_OFFSET
+            hit = x[..., 2] < z_rest
+            x = np.where(hit[..., None], np.stack([x[..., 0], x[..., 1], np.full_like(x[..., 2], z_rest)], axis=-1), x)
+            v = np.where(hit[..., None], np.stack([np.zeros_like(v[..., 0]), np.zeros_like(v[..., 1]), np.maximum(v[..., 2], 0.0)], axis=-1), v)
         n = _norm(w)
         th = n * h / 2
         qx, qy, qz, qw = (self.quat[..., k] for k in range(4))

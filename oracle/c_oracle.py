@@ -30,7 +30,8 @@ class OrcParams(ctypes.Structure):
                 ("pid_gravity", ctypes.c_double), ("pid_kf", ctypes.c_double),
                 ("p_for", _d3), ("i_for", _d3), ("d_for", _d3), ("p_tor", _d3), ("i_tor", _d3), ("d_tor", _d3),
                 ("mixer", _d12), ("pwm2rpm_scale", ctypes.c_double), ("pwm2rpm_const", ctypes.c_double),
-                ("min_pwm", ctypes.c_double), ("max_pwm", ctypes.c_double), ("speed_limit", ctypes.c_double)]
+                ("min_pwm", ctypes.c_double), ("max_pwm", ctypes.c_double), ("speed_limit", ctypes.c_double),
+                ("ground_z", ctypes.c_double)]
 
 
 class OrcCfg(ctypes.Structure):
@@ -72,6 +73,7 @@ def make_params(C: UrdfConstants, pid_consts: UrdfConstants = None, pid_model="c
     p.gnd_eff_coeff, p.prop_radius, p.gnd_eff_h_clip = C.GND_EFF_COEFF, C.PROP_RADIUS, C.GND_EFF_H_CLIP
     p.dw_coeff[0], p.dw_coeff[1], p.dw_coeff[2] = C.DW_COEFF_1, C.DW_COEFF_2, C.DW_COEFF_3
     p.hover_rpm, p.max_rpm, p.speed_limit = C.HOVER_RPM, C.MAX_RPM, C.SPEED_LIMIT
+    p.ground_z = C.COLLISION_H / 2 - C.COLLISION_Z_OFFSET
     pc = pid_consts or C
     p.pid_gravity, p.pid_kf = 9.8 * pc.M, pc.KF
     gains = dict(p_for=[.4, .4, 1.25], i_for=[.05, .05, .05], d_for=[.2, .2, .5], p_tor=[70000., 70000., 60000.],

@@ -35,6 +35,7 @@ typedef struct OrcParams {
     double mixer[12];
     double pwm2rpm_scale, pwm2rpm_const, min_pwm, max_pwm;
     double speed_limit;
+    double ground_z;           /* PHYS_GROUND: COLLISION_H/2 - COLLISION_Z_OFFSET */
 } OrcParams;
 
 typedef struct OrcCfg {
@@ -45,7 +46,8 @@ typedef struct OrcCfg {
 } OrcCfg;
 
 enum { ACT_RPM = 0, ACT_PID = 1, ACT_VEL = 2, ACT_ONE_D_RPM = 3, ACT_ONE_D_PID = 4, ACT_RAW_RPM = 5, ACT_DIRECT_RPM = 6 };
-enum { PHYS_GND = 1, PHYS_DRAG = 2, PHYS_DW = 4 };
+/* PHYS_GROUND: EXTENSION, not in the reference's Physics.DYN (see oracle/aviary_oracle.py, include/gpd.h) */
+enum { PHYS_GND = 1, PHYS_DRAG = 2, PHYS_DW = 4, PHYS_GROUND = 8 };
 
 static double clip(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -173,6 +175,11 @@ static void substep(const OrcParams* P, const OrcCfg* C, const double* rpm, cons
         vel[k] += h * (F[k] / P->M);
         w[k] += h * (P->J_INV[k] * tau[k]);
         pos[k] += h * vel[k];
+    }
+    if ((C->physics_flags & PHYS_GROUND) && pos[2] < P->ground_z) {   /* the plane at z = 0 */
+        pos[2] = P->ground_z;
+        vel[0] = 0; vel[1] = 0;
+        if (vel[2] < 0) vel[2] = 0;
     }
     const double n = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
     if (!(fabs(n) <= 1e-8)) {                     /* !np.isclose(n, 0) */

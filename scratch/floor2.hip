@@ -1,0 +1,103 @@
+// Micro-benchmark, round 2: what could one dependent launch per env step cost at N = 65536 if the state block were laid out /
+// stored differently?  Same method as floor.hip (hipGraph of 64 launches, HIP events): the in-place "like step" mover with
+//   (a) plain stores (round-1 baseline)         (b) non-temporal stores (write-through instead of an end-of-kernel flush)
+//   (c) the 13 state floats packed into 4 x float4 per drone ([4][ld] float4: 4 loads + 4 stores per lane instead of 13 + 13)
+//   (d) c + non-temporal                          (e) a 600-byte by-value kernel argument (GpdParams-sized) on top of (a)
+// Run twice: HIP_FORCE_DEV_KERNARG=0 and =1 (where the kernel-argument segment lives).
+//   hipcc --offload-arch=gfx950 -O3 floor2.hip -o floor2
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+typedef float f4v __attribute__((ext_vector_type(4)));
+struct Big { float v[150]; };
+
+__global__ void k_empty(float* p) { if (p == nullptr) p[0] = 1; }
+
+template <bool NT>
+__global__ __launch_bounds__(256) void k_like(float* __restrict__ kin, const float4* __restrict__ act, f4v* __restrict__ obs, int ld, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v[13];
+#pragma unroll
+    for (int r = 0; r < 13; ++r) v[r] = kin[(size_t)r * ld + i];
+    float4 a = act[i];
+    float acc = a.x + a.y + a.z + a.w;
+#pragma unroll
+    for (int r = 0; r < 13; ++r) {
+        v[r] = v[r] * 0.999f + acc * 1e-6f;
+        if (NT) __builtin_nontemporal_store(v[r], &kin[(size_t)r * ld + i]); else kin[(size_t)r * ld + i] = v[r];
+    }
+    f4v o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]}, o2 = {v[8], v[9], v[10], v[11]};
+    if (NT) { __builtin_nontemporal_store(o0, &obs[i * 3]); __builtin_nontemporal_store(o1, &obs[i * 3 + 1]); __builtin_nontemporal_store(o2, &obs[i * 3 + 2]); }
+    else { obs[i * 3] = o0; obs[i * 3 + 1] = o1; obs[i * 3 + 2] = o2; }
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256) void k_like4(f4v* __restrict__ kin, const float4* __restrict__ act, f4v* __restrict__ obs, int ld, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f4v s[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] = kin[(size_t)r * ld + i];
+    float4 a = act[i];
+    float acc = (a.x + a.y + a.z + a.w) * 1e-6f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        s[r] = s[r] * 0.999f + acc;
+        if (NT) __builtin_nontemporal_store(s[r], &kin[(size_t)r * ld + i]); else kin[(size_t)r * ld + i] = s[r];
+    }
+    if (NT) { __builtin_nontemporal_store(s[0], &obs[i * 3]); __builtin_nontemporal_store(s[1], &obs[i * 3 + 1]); __builtin_nontemporal_store(s[2], &obs[i * 3 + 2]); }
+    else { obs[i * 3] = s[0]; obs[i * 3 + 1] = s[1]; obs[i * 3 + 2] = s[2]; }
+}
+
+__global__ __launch_bounds__(256) void k_like_big(const Big P, float* __restrict__ kin, const float4* __restrict__ act, f4v* __restrict__ obs, int ld, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v[13];
+#pragma unroll
+    for (int r = 0; r < 13; ++r) v[r] = kin[(size_t)r * ld + i];
+    float4 a = act[i];
+    float acc = a.x + a.y + a.z + a.w + P.v[149] + P.v[75] + P.v[3];
+#pragma unroll
+    for (int r = 0; r < 13; ++r) { v[r] = v[r] * P.v[r * 7] + acc * 1e-6f; kin[(size_t)r * ld + i] = v[r]; }
+    f4v o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]}, o2 = {v[8], v[9], v[10], v[11]};
+    obs[i * 3] = o0; obs[i * 3 + 1] = o1; obs[i * 3 + 2] = o2;
+}
+
+int main() {
+    const int n = 65536, ld = 65536;
+    float* a; f4v* a4; float4* act; f4v* obs;
+    CK(hipMalloc(&a, (size_t)16 * ld * 4)); CK(hipMalloc(&a4, (size_t)4 * ld * 16));
+    CK(hipMalloc(&act, (size_t)n * 16)); CK(hipMalloc(&obs, (size_t)n * 48));
+    CK(hipMemset(a, 0, (size_t)16 * ld * 4)); CK(hipMemset(a4, 0, (size_t)4 * ld * 16)); CK(hipMemset(act, 0, (size_t)n * 16));
+    hipStream_t st; CK(hipStreamCreate(&st));
+    const int K = 64, REP = 200;
+    Big P; for (int i = 0; i < 150; ++i) P.v[i] = 0.999f;
+    const char* env = getenv("HIP_FORCE_DEV_KERNARG");
+    printf("# HIP_FORCE_DEV_KERNARG=%s\n", env ? env : "(unset)");
+    auto bench = [&](const char* name, auto launch) -> int {
+        hipGraph_t g; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+        for (int i = 0; i < K; ++i) launch(i);
+        CK(hipStreamEndCapture(st, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        for (int i = 0; i < 20; ++i) CK(hipGraphLaunch(ge, st));
+        CK(hipStreamSynchronize(st));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < REP; ++i) CK(hipGraphLaunch(ge, st));
+        CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-58s %.3f us per launch\n", name, ms * 1e3 / (K * REP));
+        return 0;
+    };
+    bench("empty 256x256", [&](int) { hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, st, a); });
+    bench("in-place like step: 13 SoA rows + act + obs (r01 baseline)", [&](int) { hipLaunchKernelGGL((k_like<false>), dim3(256), dim3(256), 0, st, a, act, obs, ld, n); });
+    bench("  ... non-temporal stores", [&](int) { hipLaunchKernelGGL((k_like<true>), dim3(256), dim3(256), 0, st, a, act, obs, ld, n); });
+    bench("  ... state packed as 4 x float4 per drone", [&](int) { hipLaunchKernelGGL((k_like4<false>), dim3(256), dim3(256), 0, st, a4, act, obs, ld, n); });
+    bench("  ... packed + non-temporal", [&](int) { hipLaunchKernelGGL((k_like4<true>), dim3(256), dim3(256), 0, st, a4, act, obs, ld, n); });
+    bench("  ... SoA + a 600-byte by-value argument", [&](int) { hipLaunchKernelGGL(k_like_big, dim3(256), dim3(256), 0, st, P, a, act, obs, ld, n); });
+    bench("  ... packed, 1024 x 64 threads", [&](int) { hipLaunchKernelGGL((k_like4<false>), dim3(1024), dim3(64), 0, st, a4, act, obs, ld, n); });
+    return 0;
+}

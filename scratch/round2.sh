@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 for what in "$@"; do
 case $what in
 tests)
-  timeout 1500 python -m pytest tests -m gpu -x -q -s > gpurun_out/pytest_r02.log 2>&1; echo "pytest rc $?"; tail -5 gpurun_out/pytest_r02.log | cut -c1-300 ;;
+  timeout 1500 python -m pytest tests -m gpu -q -s > gpurun_out/pytest_r02.log 2>&1; echo "pytest rc $?"; grep -E "^(FAILED|ERROR)" gpurun_out/pytest_r02.log | head -20; tail -3 gpurun_out/pytest_r02.log | cut -c1-300 ;;
 bench)
   timeout 300 python bench.py --steps 20 --warmup 5 2>gpurun_out/r02_bench_driver_cmd.err | tail -1 > gpurun_out/r02_bench_driver_cmd.json
   timeout 300 python bench.py --no-cpu-baseline 2>gpurun_out/r02_bench_default.err | tail -1 > gpurun_out/r02_bench_default.json
@@ -28,9 +28,20 @@ split)
     python -c "
 import json; d=json.load(open('gpurun_out/r02_bench_split$c.json')); print('split $c', 'us/step %.3f'%(d['ms_per_step']*1e3), 'frac %.3f'%d['roofline']['frac'])"
   done ;;
-workloads)
-  for w in hover65536_30hz hover65536_pid_240hz stack8x8192_ext_240hz multihover2x16384_240hz hover65536_240hz_fullobs hover65536_30hz_fullobs swarm65536_ext_240hz hover4m_240hz; do
-    timeout 300 python bench.py --workload $w --no-cpu-baseline 2>gpurun_out/r02_bench_$w.err | tail -1 > gpurun_out/r02_bench_$w.json
+floor)
+  for k in 0 1; do HIP_FORCE_DEV_KERNARG=$k timeout 120 ./scratch/floor2; done > gpurun_out/r02_launch_floor_microbench.txt 2>&1; cat gpurun_out/r02_launch_floor_microbench.txt ;;
+kernarg)
+  for k in 0 1; do
+    HIP_FORCE_DEV_KERNARG=$k timeout 200 python bench.py --mode graph --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r02_bench_kernarg$k.json
+    python -c "
+import json; d=json.load(open('gpurun_out/r02_bench_kernarg$k.json')); print('HIP_FORCE_DEV_KERNARG=$k graph', 'us/step %.3f'%(d['ms_per_step']*1e3), 'frac %.3f'%d['roofline']['frac'])"
+  done ;;
+workloads|workloads2)
+  if [ $what = workloads ]; then list="hover65536_30hz hover65536_pid_240hz stack8x8192_ext_240hz multihover2x16384_240hz hover65536_240hz_fullobs hover65536_30hz_fullobs hover65536_240hz_history hover65536_30hz_history swarm65536_ext_240hz hover4m_240hz"
+  else list="hover65536_240hz_fullobs hover65536_30hz_fullobs hover65536_240hz_history hover65536_30hz_history swarm65536_ext_240hz"; fi
+  for w in $list; do
+    timeout 300 python -X faulthandler bench.py --workload $w --no-cpu-baseline > gpurun_out/r02_bench_$w.out 2>gpurun_out/r02_bench_$w.err; echo "$w rc $?"
+    tail -1 gpurun_out/r02_bench_$w.out > gpurun_out/r02_bench_$w.json
     python - <<PY
 import json
 try:

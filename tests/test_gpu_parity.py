@@ -93,7 +93,10 @@ def _actions(rng, act, shape, hover_rpm):
                                        (7, 1, 3), (2, 1, 5),    # (odd sub-step counts: the remainder of the 2x unrolled loop)
                                        # the pair path of the wave-local downwash exchange (D == 2: `mate(0); mate(1)`),
                                        # BASELINE config 5's shape, alone and with every term, and config 3(i)'s shape
-                                       (4, 2, 1), (7, 2, 8), (7, 1, 1)])
+                                       (4, 2, 1), (7, 2, 8), (7, 1, 1),
+                                       # GPD_PHYS_GROUND (8), the plane at z = 0 (an extension, see include/gpd.h): alone, with
+                                       # the ground effect it belongs with, and with every term in a multi-drone aviary
+                                       (8, 1, 1), (9, 1, 8), (15, 2, 2)])
 def test_one_step_parity(gpu_device, model, act, flags, D, S):
     if model == "racer" and act in ("pid", "vel", "one_d_pid"):
         pytest.skip("no DSLPID controller for the racer")
@@ -101,6 +104,8 @@ def test_one_step_parity(gpu_device, model, act, flags, D, S):
     E = 2048 // D
     task = "none" if act == "raw_rpm" else ("hover" if D == 1 else "multihover")
     xyz, rpy = _random_scene(rng, E, D)
+    if flags & 8:      # a third of the aviaries start within centimetres of the plane: contact happens within the 4 passes
+        xyz[::3, :, 2] = rng.uniform(0.0, 0.04, size=xyz[::3, :, 2].shape) + (0.3 * np.arange(D) if D > 1 else 0.0)
     kw = dict(physics_flags=flags, pyb_freq=240, ctrl_freq=240 // S, act=act, task=task, pid_urdf_path=urdf("cf2x"))
     b = BatchedAviary(urdf(model), model, num_envs=E, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, **kw)
     core = _core(model, E, D, flags, S, act, task, xyz, rpy, gpu_device,
@@ -122,6 +127,14 @@ def test_one_step_parity(gpu_device, model, act, flags, D, S):
         ref = _oracle_kin(b)
         scale = np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1.0)
         err = np.abs(kin - ref) / scale
+        if flags & 8:
+            # contact is a threshold: a drone that touches down within rounding of the plane may do so on one side only (its
+            # velocity is then zeroed on that side only) -- at most a handful among 2048, excluded like the flag mismatches
+            touched32, touched64 = kin[2] == np.float32(b.C.COLLISION_H / 2 - b.C.COLLISION_Z_OFFSET), ref[2] == b.C.COLLISION_H / 2 - b.C.COLLISION_Z_OFFSET
+            assert (touched32 != touched64).mean() <= 0.002
+            err[:, touched32 != touched64] = 0.0
+            if k == 3:
+                assert touched64.mean() > 0.02, "the scene must exercise the contact"
         assert err.max() < 2e-5, f"kin rows max err {err.max(axis=1)} at pass {k}"
         o = core.obs12.cpu().numpy().astype(np.float64).reshape(E, D, 12)
         oscale = np.maximum(np.abs(obs).reshape(-1, 12).max(axis=0), 1.0)
@@ -129,6 +142,8 @@ def test_one_step_parity(gpu_device, model, act, flags, D, S):
         # yaw/roll near +-pi may wrap: compare angles modulo 2*pi
         ang = np.abs((o[..., 3:6] - obs[..., 3:6] + np.pi) % (2 * np.pi) - np.pi)
         oerr[..., 3:6] = ang
+        if flags & 8:
+            oerr[(touched32 != touched64).reshape(E, D)] = 0.0
         assert oerr.max() < 2e-5, f"obs12 col max err {oerr.reshape(-1, 12).max(axis=0)}"
         np.testing.assert_allclose(core.last_rpm[:, :E * D].cpu().numpy().T, b.last_rpm.reshape(-1, 4),
                                    rtol=2e-5, atol=0.5)

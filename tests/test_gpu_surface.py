@@ -76,6 +76,123 @@ def test_vecenv_adapter_follows_dummyvecenv(gpu_device):
     assert venv.env_is_wrapped(object) == [False] * E and venv.get_attr("CTRL_FREQ")[0] == 30
 
 
+def test_gymnasium_vector_env_adapter(gpu_device):
+    """gymnasium >= 1.0 vector API: batched (obs, rewards, terminations, truncations, infos), SAME_STEP autoreset with
+    infos["final_obs"] / infos["_final_obs"], single_* and batched spaces."""
+    from gym_pybullet_drones_amd.envs import GymVectorEnvAdapter, VectorMultiHoverAviary
+    from gym_pybullet_drones_amd.utils.enums import ActionType
+    E, D = 32, 2
+    base = VectorMultiHoverAviary(E, D, act=ActionType.RPM, ctrl_freq=30, full_obs=True, episode_len_sec=0.2, device=gpu_device)
+    venv = GymVectorEnvAdapter(base)
+    W = 12 + 15 * 4
+    assert venv.num_envs == E and venv.metadata["autoreset_mode"] == "SameStep"
+    assert venv.single_observation_space.shape == (D, W) and venv.observation_space.shape == (E, D, W)
+    assert venv.single_action_space.shape == (D, 4) and venv.action_space.shape == (E, D, 4)
+    obs, infos = venv.reset(seed=1)
+    assert obs.shape == (E, D, W) and obs.dtype == np.float32 and infos == {}
+    rng = np.random.default_rng(0)
+    saw = False
+    for k in range(10):
+        a = rng.uniform(-1, 1, size=(E, D, 4)).astype(np.float32)
+        prev = obs
+        obs, rew, term, trunc, infos = venv.step(a)
+        assert obs.shape == (E, D, W) and rew.shape == (E,) and term.dtype == bool and trunc.dtype == bool
+        np.testing.assert_array_equal(obs[..., -4:], a)
+        if (term | trunc).any():
+            saw = True
+            m = infos["_final_obs"]
+            np.testing.assert_array_equal(m, term | trunc)
+            assert infos["final_obs"].shape == obs.shape
+            # the returned row is the first observation of the new episode, the final one is the finished episode's last
+            np.testing.assert_allclose(obs[m][..., 2], 0.1125, atol=1e-6)
+            assert (np.abs(infos["final_obs"][m][..., 2] - 0.1125) > 1e-6).any()
+            assert not infos["final_obs"][~m].any()
+        else:
+            assert infos == {}
+    assert saw                                   # 0.2 s episodes at 30 Hz: time truncation on step 8
+    assert venv.last[0].is_cuda
+    venv.close()
+    assert venv.closed
+
+
+def test_lazy_history_is_a_view_and_survives_graph_replay(gpu_device):
+    """`full_obs="lazy"`: the step kernel pushes the action into the device ring itself, `history()` is a zero-copy strided
+    view of it, `full_rows()` materialises the reference's rows on request -- identical to the eagerly materialised rows
+    (`full_obs=True`); and because the ring position lives on the device, a captured hipGraph of steps can be replayed any
+    number of times (here across the wrap of the 15-deep ring)."""
+    from gym_pybullet_drones_amd.envs import VectorHoverAviary
+    from gym_pybullet_drones_amd.utils.enums import ActionType
+    E, H, A = 300, 15, 4
+    mk = lambda mode: VectorHoverAviary(E, act=ActionType.RPM, ctrl_freq=30, full_obs=mode, auto_reset=True,  # noqa: E731
+                                        episode_len_sec=0.3, device=gpu_device)
+    eager, lazy, graphed = mk(True), mk("lazy"), mk("lazy")
+    rng = np.random.default_rng(4)
+    acts = torch.as_tensor(rng.uniform(-1, 1, size=(5, E, 1, A)).astype(np.float32), device=gpu_device)
+    for k in range(7):
+        o_e, *_ = eager.step(acts[k % 5])
+        o_l, *_ = lazy.step(acts[k % 5])
+        assert o_l.shape == (E, 1, 12) and o_e.shape == (E, 1, 12 + H * A)
+        assert torch.equal(o_e[..., :12], o_l)
+    hist = lazy.history()
+    assert hist.shape == (E, 1, H, A) and hist.data_ptr() >= lazy.core.act_ring.data_ptr() and not hist.is_contiguous()
+    assert hist.untyped_storage().data_ptr() == lazy.core.act_ring.untyped_storage().data_ptr()      # a view, not a copy
+    assert torch.equal(hist.reshape(E, 1, H * A), o_e[..., 12:])
+    assert torch.equal(lazy.full_rows(), o_e)
+    # 3 replays of a 5-step graph after 2 eager steps == 17 eager steps (the ring wraps at 15)
+    for k in range(2):
+        graphed.step(acts[k])
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream(gpu_device)
+    stream.wait_stream(torch.cuda.current_stream(gpu_device))
+    with torch.cuda.stream(stream):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            for k in range(5):
+                graphed.step(acts[(2 + k) % 5])
+    torch.cuda.current_stream(gpu_device).wait_stream(stream)
+    for _ in range(3):
+        g.replay()
+    for k in range(7, 17):
+        o_e, *_ = eager.step(acts[k % 5])
+    torch.cuda.synchronize()
+    assert torch.equal(graphed.full_rows(), o_e)
+    assert int(graphed.core.ring_pos[0]) == 17 % H and torch.equal(graphed.core.ring_pos, eager.core.ring_pos)
+    # rollouts keep the same ring: 6 more steps as one launch on the lazy env, singly on the eager one
+    lazy_acts = torch.stack([acts[k % 5] for k in range(7, 13)])
+    lazy.rollout(lazy_acts)
+    e2 = mk(True)
+    for k in range(13):
+        o2, *_ = e2.step(acts[k % 5])
+    assert torch.equal(lazy.full_rows(), o2)
+
+
+def test_default_physics_warns_and_rests_on_the_ground(gpu_device):
+    """`HoverAviary()` with the reference's defaults asks for Physics.PYB: the explicit integrator runs instead -- said once,
+    as a warning -- with the ground plane on, so a drone that does not fly ends up ON the plane (z = COLLISION_H/2), not
+    falling through it, and the observation stays inside the advertised observation_space (z >= 0).  Physics.DYN keeps the
+    reference's DYN behaviour: no plane."""
+    import warnings
+    from gym_pybullet_drones_amd.envs import HoverAviary
+    from gym_pybullet_drones_amd.utils import enums
+    from gym_pybullet_drones_amd.utils.enums import ActionType, Physics
+    enums._warned_pyb = False
+    with pytest.warns(UserWarning, match="explicit Physics.DYN integrator"):
+        env = HoverAviary(act=ActionType.ONE_D_RPM, device=gpu_device)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")          # ... once per process
+        HoverAviary(act=ActionType.ONE_D_RPM, device=gpu_device)
+    obs, _ = env.reset()
+    for _ in range(40):                          # 95 % of the hover RPM: sinks 0.1 m in ~0.45 s (30 Hz control)
+        obs, rew, term, trunc, _ = env.step(np.array([[-1.0]], dtype=np.float32))
+    assert env.pos[0, 2] == pytest.approx(env.COLLISION_H / 2 - env.COLLISION_Z_OFFSET, abs=1e-7)
+    assert np.all(env.vel[0] == 0) and env.observation_space.contains(obs)
+    dyn = HoverAviary(physics=Physics.DYN, act=ActionType.ONE_D_RPM, device=gpu_device)
+    dyn.reset()
+    for _ in range(40):
+        dyn.step(np.array([[-1.0]], dtype=np.float32))
+    assert dyn.pos[0, 2] < 0                     # the reference's DYN: nothing holds the drone
+
+
 def test_logger_export_of_device_states(gpu_device, tmp_path):
     """Logger.log_batch on (N,20) state vectors from the device == N x Logger.log on the rows; CSV/npz files load."""
     from gym_pybullet_drones_amd.envs import VectorCtrlAviary
