@@ -92,6 +92,10 @@ def make_env(w, device, seed, E=None):
         env = SwarmAviary(D, initial_xyzs=xyz, initial_rpys=rng.uniform(-0.05, 0.05, size=(D, 3)), physics=Physics.PYB_GND_DRAG_DW,
                           pyb_freq=240, ctrl_freq=w["ctrl"], act="raw_rpm", device=device)
         env.NUM_ENVS, env.ACT_DIM = 1, 4
+        # a single world has no task and no auto-reset: every pass of the schedule starts from the initial lattice (one reset
+        # launch per pass), otherwise thousands of open-loop steps let drones pass each other vertically, where the
+        # reference's downwash model (alpha ~ 1/dz^2) diverges
+        env.reset_each_pass = True
         return env
     if D == 1:
         xyz = np.array([0, 0, 0.1125]) + rng.uniform(-0.5, 0.5, size=(E, D, 3)) * np.array([1, 1, 0])
@@ -110,7 +114,7 @@ def make_actions(w, env, device, seed, pool):
     g.manual_seed(seed)
     a = torch.rand((pool, env.NUM_ENVS, env.NUM_DRONES, env.ACT_DIM), generator=g, device=device) * 2 - 1
     if w["act"] == "raw_rpm":
-        a = float(env.HOVER_RPM) * (1 + 0.05 * a)
+        a = float(env.HOVER_RPM) * (1 + 0.005 * a)
     if w["act"] == "pid":
         a = a * 0.5
         a[..., 2] += 1.0
@@ -305,6 +309,9 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
             graphs[n] = g
 
     def run(k):
+        for e in envs:
+            if getattr(e, "reset_each_pass", False):
+                e.reset()
         if mode == "eager":
             for i in range(k):
                 one_step(i)

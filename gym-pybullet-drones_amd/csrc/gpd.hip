@@ -1392,23 +1392,48 @@ __global__ __launch_bounds__(kBlock) void gpd_reset_kernel(const GpdState S, con
 // slot-major; the H most recent actions of an aviary are the H consecutive slots starting at its ring_pos).  Pure data
 // movement: one lane per output float, so that a wave writes 256 contiguous bytes.
 // ------------------------------------------------------------------------------------------------
-// rows of the CURRENT state (after gpd_step, which pushed its action itself)
+// rows of the CURRENT state (after gpd_step, which pushed its action itself).  A workgroup owns 64 consecutive drones and
+// (blockIdx.y) one chunk of 16 history slots; it is a transpose through LDS, coalesced on both sides:
+//   in : slot i of the ring is a contiguous [N][A] block -> wave w reads the 64 drones' A floats of slot i (lane = drone:
+//        one 16-byte load for A = 4), four slots in flight per workgroup;
+//   out: a drone's 16*A history floats of the chunk are contiguous in its row -> one wave writes them as one 256-byte
+//        segment (A = 4), sixteen drones per wave.
+// Chunk 0 also copies the twelve kinematic floats.  (The lane-per-output-float form this replaces fetched sixteen 16-byte
+// pieces from sixteen different 1 MB-apart slots per wave: 2.2 TB/s at N = 65 536.)
+constexpr int kHistSlots = 16;                               // history slots per chunk
 __global__ __launch_bounds__(kBlock) void gpd_hist_rows_kernel(uint32_t N, int D, int A, int H, const float* __restrict__ ring,
                                                                const int32_t* __restrict__ ring_pos,
                                                                const float* __restrict__ obs12, float* __restrict__ out) {
-    const uint32_t W = 12u + static_cast<uint32_t>(H * A);
-    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
-    if (j >= N * W) return;
-    const uint32_t n = j / W, col = j - n * W;
-    float v;
-    if (col < 12u) {
-        v = obs12[static_cast<size_t>(n) * 12 + col];
-    } else {
-        const uint32_t i = (col - 12u) / static_cast<uint32_t>(A), a = (col - 12u) - i * static_cast<uint32_t>(A);
-        const int p = ring_pos[n / static_cast<uint32_t>(D)];
-        v = ring[(static_cast<size_t>(p + static_cast<int>(i)) * N + n) * A + a];
+    __shared__ float tile[64 * (kHistSlots * 4 + 1)];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t n0 = blockIdx.x * 64u;
+    const int i0 = blockIdx.y * kHistSlots;                  // first history slot of this chunk
+    const int cnt = min(kHistSlots, H - i0);                 // slots in this chunk
+    const size_t W = 12u + static_cast<size_t>(H) * A;
+    const int pitch = kHistSlots * A + 1;                    // odd: lane-strided LDS writes are conflict-free
+    const uint32_t n = n0 + lane;
+    const bool have = n < N;
+    const int p = have ? ring_pos[n / static_cast<uint32_t>(D)] : 0;
+    for (int s = wave; s < cnt; s += 4) {                    // this wave's slots: lane = drone
+        const float* src = ring + (static_cast<size_t>(p + i0 + s) * N + n) * A;
+        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (have) {
+            if (A == 4) { const float4 q = *reinterpret_cast<const float4*>(src); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+            else for (int a = 0; a < A; ++a) v[a] = src[a];
+        }
+        for (int a = 0; a < A; ++a) tile[lane * pitch + s * A + a] = v[a];
     }
-    out[j] = v;
+    __syncthreads();
+    const int width = cnt * A;                               // floats of this chunk per drone (<= 64)
+    const uint32_t rows = N - n0 < 64u ? N - n0 : 64u;
+    for (uint32_t r = wave; r < rows; r += 4)                // one drone per wave and iteration: lane = float of its chunk
+        if (lane < width) out[(n0 + r) * W + 12 + static_cast<size_t>(i0) * A + lane] = tile[r * pitch + lane];
+    if (blockIdx.y == 0) {                                   // the kinematic part: 64 rows x 12 floats, contiguous in obs12
+        for (uint32_t j = tid; j < rows * 12u; j += kBlock) {
+            const uint32_t r = j / 12u, c = j - r * 12u;
+            out[(n0 + r) * W + c] = obs12[static_cast<size_t>(n0) * 12 + j];
+        }
+    }
 }
 
 // rows of the K steps of a rollout: the source of a float is the obs12 row of its step, an action block of this call, or --
@@ -1496,7 +1521,10 @@ __global__ __launch_bounds__(kBlock) void dwg_count_kernel(const float* __restri
     int c = -1 - lane;                                      // (no drone: a run of its own, no atomic)
     if (i < n) {
         const int d = visit ? visit[i] : i;
-        c = cell_of(kin[d], kin[ld + d], inv_cell, x0, y0, nx, ny);
+        const float x = kin[d], y = kin[ld + d], z = kin[2 * ld + d];
+        // a drone whose position is no longer finite (the downwash model diverges when two drones pass each other
+        // vertically, dz -> 0+) takes no part: it would otherwise alias into cell 0 together with every other such drone
+        if (isfinite(x) && isfinite(y) && isfinite(z)) c = cell_of(x, y, inv_cell, x0, y0, nx, ny);
     }
     int head_lane, len;
     run_of(c, lane, head_lane, len);
@@ -1527,7 +1555,8 @@ __global__ __launch_bounds__(1024) void dwg_scan_kernel(int* __restrict__ count,
 __global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const float* __restrict__ kin, int64_t ld, int n, float inv_cell,
                                                              float x0, float y0, int nx, int ny, const int* __restrict__ visit,
                                                              int* __restrict__ cursor, const int* __restrict__ start,
-                                                             int* __restrict__ order, float4* __restrict__ sorted) {
+                                                             int* __restrict__ order, float4* __restrict__ sorted,
+                                                             float* __restrict__ dw_out) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int c = -1 - lane, d = 0;
@@ -1535,7 +1564,14 @@ __global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const float* __rest
     if (i < n) {
         d = visit ? visit[i] : i;
         x = kin[d]; y = kin[ld + d]; z = kin[2 * ld + d];
-        c = cell_of(x, y, inv_cell, x0, y0, nx, ny);
+        if (isfinite(x) && isfinite(y) && isfinite(z)) {
+            c = cell_of(x, y, inv_cell, x0, y0, nx, ny);
+        } else {
+            // (see dwg_count_kernel) no force on it, none from it; it keeps a slot behind the sorted drones so that `order`
+            // stays a permutation (the next call visits the drones in this order)
+            dw_out[d] = 0.0f;
+            order[start[nx * ny] + atomicAdd(&cursor[nx * ny], 1)] = d;
+        }
     }
     int head_lane, len;
     run_of(c, lane, head_lane, len);
@@ -1914,8 +1950,8 @@ int gpd_hist_rows(const GpdState* state, int32_t n_drones, int32_t drones_per_en
                   float* obs_full, void* stream) {
     if (int rc = hist_args("gpd_hist_rows", state, n_drones, drones_per_env, act_dim)) return rc;
     if (!obs12 || !obs_full) return fail(GPD_EINVAL, "gpd_hist_rows: NULL obs12/obs_full");
-    const int64_t total = static_cast<int64_t>(n_drones) * (12 + static_cast<int64_t>(state->hist_len) * act_dim);
-    hipLaunchKernelGGL(gpd_hist_rows_kernel, dim3(static_cast<unsigned>((total + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+    const dim3 grid(static_cast<unsigned>((n_drones + 63) / 64), static_cast<unsigned>((state->hist_len + kHistSlots - 1) / kHistSlots));
+    hipLaunchKernelGGL(gpd_hist_rows_kernel, grid, dim3(kBlock), 0,
                        static_cast<hipStream_t>(stream), static_cast<uint32_t>(n_drones), drones_per_env, act_dim, state->hist_len,
                        state->act_ring, state->ring_pos, obs12, obs_full);
     hipError_t e = hipGetLastError();
@@ -1977,7 +2013,7 @@ int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, i
     hipLaunchKernelGGL(dwg_count_kernel, grid, dim3(kBlock), 0, st, kin, ld, n, inv_cell, x0, y0, nx, ny, visit_order, cell_count);
     hipLaunchKernelGGL(dwg_scan_kernel, dim3(1), dim3(1024), 0, st, cell_count, cell_start, cells);
     hipLaunchKernelGGL(dwg_scatter_kernel, grid, dim3(kBlock), 0, st, kin, ld, n, inv_cell, x0, y0, nx, ny, visit_order,
-                       cell_count, cell_start, order, reinterpret_cast<float4*>(sorted_xyzc));
+                       cell_count, cell_start, order, reinterpret_cast<float4*>(sorted_xyzc), dw_out);
     hipLaunchKernelGGL(dwg_force_kernel, dim3(static_cast<unsigned>(cells)), dim3(kBlock), 0, st, *params, nx, ny, cell_start,
                        order, reinterpret_cast<const float4*>(sorted_xyzc), dw_out);
     e = hipGetLastError();

@@ -111,6 +111,7 @@ def test_one_step_parity(gpu_device, model, act, flags, D, S):
     core = _core(model, E, D, flags, S, act, task, xyz, rpy, gpu_device,
                  target=None if task == "none" else b.TARGET_POS)
     # a few free-running steps to get non-trivial velocities, rates and PID memories, re-syncing each time
+    most_touched = 0.0
     for k in range(4):
         # random velocities / rates on the first pass so every term of the integrator is exercised
         if k == 0:
@@ -133,8 +134,9 @@ def test_one_step_parity(gpu_device, model, act, flags, D, S):
             touched32, touched64 = kin[2] == np.float32(b.C.COLLISION_H / 2 - b.C.COLLISION_Z_OFFSET), ref[2] == b.C.COLLISION_H / 2 - b.C.COLLISION_Z_OFFSET
             assert (touched32 != touched64).mean() <= 0.002
             err[:, touched32 != touched64] = 0.0
+            most_touched = max(most_touched, float(touched64.mean()))
             if k == 3:
-                assert touched64.mean() > 0.02, "the scene must exercise the contact"
+                assert most_touched > 0.02, "the scene must exercise the contact"
         assert err.max() < 2e-5, f"kin rows max err {err.max(axis=1)} at pass {k}"
         o = core.obs12.cpu().numpy().astype(np.float64).reshape(E, D, 12)
         oscale = np.maximum(np.abs(obs).reshape(-1, 12).max(axis=0), 1.0)
