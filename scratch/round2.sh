@@ -28,6 +28,9 @@ split)
     python -c "
 import json; d=json.load(open('gpurun_out/r02_bench_split$c.json')); print('split $c', 'us/step %.3f'%(d['ms_per_step']*1e3), 'frac %.3f'%d['roofline']['frac'])"
   done ;;
+debug-swarm)
+  timeout 200 python scratch/debug_swarm.py eager 3000 > gpurun_out/debug_swarm_eager.log 2>&1; echo "eager rc $?"; tail -8 gpurun_out/debug_swarm_eager.log | cut -c1-250
+  timeout 200 python scratch/debug_swarm.py graph 8192 > gpurun_out/debug_swarm_graph.log 2>&1; echo "graph rc $?"; tail -8 gpurun_out/debug_swarm_graph.log | cut -c1-250 ;;
 floor)
   for k in 0 1; do HIP_FORCE_DEV_KERNARG=$k timeout 120 ./scratch/floor2; done > gpurun_out/r02_launch_floor_microbench.txt 2>&1; cat gpurun_out/r02_launch_floor_microbench.txt ;;
 kernarg)

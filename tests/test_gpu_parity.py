@@ -136,7 +136,9 @@ def test_one_step_parity(gpu_device, model, act, flags, D, S):
             err[:, touched32 != touched64] = 0.0
             most_touched = max(most_touched, float(touched64.mean()))
             if k == 3:
-                assert most_touched > 0.02, "the scene must exercise the contact"
+                # (drones ON the plane at the end of a step, i.e. those that touched down and were not lifted off again by
+                # their thrust -- with the ground effect a drone on the plane has ~3x its hover thrust -- a few per mille)
+                assert most_touched > 0.001, "the scene must exercise the contact"
         assert err.max() < 2e-5, f"kin rows max err {err.max(axis=1)} at pass {k}"
         o = core.obs12.cpu().numpy().astype(np.float64).reshape(E, D, 12)
         oscale = np.maximum(np.abs(obs).reshape(-1, 12).max(axis=0), 1.0)
