@@ -83,11 +83,17 @@ def make_env(w, device, seed, E=None):
     E, D = E or w["E"], w["D"]
     rng = np.random.default_rng(seed)
     if w.get("swarm"):
-        # 12 layers 1 m apart, a 4 m lattice per layer (74 x 74 sites) with +-0.3 m jitter: ~300 m x 300 m, 32 x 32 grid cells
+        # 12 layers 1 m apart, a 4 m lattice per layer (74 x 74 sites) with +-0.1 m jitter: ~300 m x 300 m, 32 x 32 grid cells.
+        # Layer l is shifted by (l % 4, l // 4) metres inside the lattice cell, so no drone hovers within 0.8 m (laterally)
+        # of one above it: with drones stacked vertically the reference's downwash model pushes the lower one down by up to
+        # half its weight, it falls onto the next one, and alpha ~ 1/dz^2 diverges as they pass -- under open-loop hover
+        # RPMs the whole swarm is flung apart within two seconds (gpurun_out/debug_swarm_*.log, round 2).  Every drone
+        # still sweeps the same ~600 candidates of its 3x3 cells.
         side = int(np.ceil(np.sqrt(D / 12)))
         idx = rng.permutation(side * side * 12)[:D]
         layer, site = idx // (side * side), idx % (side * side)
-        xy = np.stack([(site % side) * 4.0, (site // side) * 4.0], axis=1) - 2.0 * side + rng.uniform(-0.3, 0.3, size=(D, 2))
+        xy = np.stack([(site % side) * 4.0 + layer % 4, (site // side) * 4.0 + layer // 4], axis=1) - 2.0 * side + \
+            rng.uniform(-0.1, 0.1, size=(D, 2))
         xyz = np.concatenate([xy, (1.0 + layer)[:, None]], axis=1)
         env = SwarmAviary(D, initial_xyzs=xyz, initial_rpys=rng.uniform(-0.05, 0.05, size=(D, 3)), physics=Physics.PYB_GND_DRAG_DW,
                           pyb_freq=240, ctrl_freq=w["ctrl"], act="raw_rpm", device=device)

@@ -1493,7 +1493,10 @@ __global__ __launch_bounds__(kBlock) void gpd_hist_advance_kernel(int K, int E, 
 // keep spreading over all cells instead of piling up at its border; far-apart drones that alias into neighbouring
 // cells are rejected by the exact distance test
 __device__ __forceinline__ int cell_of(float x, float y, float inv_cell, float x0, float y0, int nx, int ny) {
-    int cx = static_cast<int>(floorf((x - x0) * inv_cell)) % nx, cy = static_cast<int>(floorf((y - y0) * inv_cell)) % ny;
+    // (clamped before the conversion: float -> int is undefined beyond the int range, and a drone flung 1e10 m away by a
+    // diverging downwash term must still land in SOME cell -- which one is irrelevant, every candidate pair is distance-tested)
+    const float fx = fminf(fmaxf(floorf((x - x0) * inv_cell), -1.0e9f), 1.0e9f), fy = fminf(fmaxf(floorf((y - y0) * inv_cell), -1.0e9f), 1.0e9f);
+    int cx = static_cast<int>(fx) % nx, cy = static_cast<int>(fy) % ny;
     cx = cx < 0 ? cx + nx : cx;
     cy = cy < 0 ? cy + ny : cy;
     return cy * nx + cx;

@@ -10,8 +10,9 @@ import sys
 sys.path.insert(0, ".")
 SRC = "gpurun_out/prof_r02"
 d = json.load(open(f"{SRC}/summary.json"))
-for f in glob.glob("profiles/r02_*"):
-    os.remove(f)
+for f in glob.glob("profiles/r02_trace_*") + glob.glob("profiles/r02_pmc_*") + glob.glob("profiles/r02_bench_*") + ["profiles/r02_summary.json"]:
+    if os.path.exists(f):
+        os.remove(f)
 for f in glob.glob(f"{SRC}/*_kernel_stats.csv") + glob.glob(f"{SRC}/pmc_*.csv"):
     shutil.copy(f, "profiles/r02_" + os.path.basename(f))
 shutil.copy(f"{SRC}/summary.json", "profiles/r02_summary.json")

@@ -302,8 +302,9 @@ def test_closed_loop_pid_low_rate_stays_inside_the_float64_envelope(gpu_device, 
         print("t=%3d %-5s median fp32 %.2e envelope %.2e | p95 fp32 %.2e envelope %.2e | max fp32 %.2e envelope %.2e" % r)
     for t, g, m32, menv, p32, penv, x32, xenv in rows:
         floor = 5e-7                     # one-step fp32 rounding of O(1) quantities
-        assert m32 <= 10.0 * menv + floor, (t, g, "median", m32, menv)
-        assert p32 <= 10.0 * penv + floor, (t, g, "p95", p32, penv)
+        # measured on the MI355X: the fp32 run sits 1.0-3.3x above the envelope at every checkpoint (profiles/r02_pid_envelope.txt)
+        assert m32 <= 4.0 * menv + floor, (t, g, "median", m32, menv)
+        assert p32 <= 4.0 * penv + floor, (t, g, "p95", p32, penv)
     # the divergence saturates at the chatter amplitude on both sides (bounded, not a blow-up)
     assert rows[-4][6] < 0.1 and rows[-4][7] < 0.1
 
@@ -334,7 +335,7 @@ def test_reference_fixture_hover_240(gpu_device):
         if k < 230:   # later the tumbling drone sits near the truncation thresholds
             assert trunc == bool(g["truncated"][k])
     print("worst relative state error over 300 steps:", worst)
-    assert worst < 1e-3      # this fixture tumbles (|rpy| up to 0.6 rad, open loop) — looser than hover
+    assert worst < 1e-5      # measured 2.9e-6 (this fixture tumbles, |rpy| up to 0.6 rad, open loop)
 
 
 def test_reference_fixture_time_truncation(gpu_device):
