@@ -193,6 +193,33 @@ def test_default_physics_warns_and_rests_on_the_ground(gpu_device):
     assert dyn.pos[0, 2] < 0                     # the reference's DYN: nothing holds the drone
 
 
+def test_subclass_overriding_preprocess_action_with_a_pid_action_type(gpu_device):
+    """The reference's subclassing pattern: override `_preprocessAction`, call the base class's mapping, post-process the
+    RPMs.  With a PID action type the base mapping runs the embedded DSLPID controllers on the host-side path (`gpd_pid`),
+    which needs their state although the step kernel is fed RPMs (round-1 advisor finding: it used to raise GpdError)."""
+    from gym_pybullet_drones_amd.envs import HoverAviary
+    from gym_pybullet_drones_amd.utils.enums import ActionType, Physics
+
+    class Damped(HoverAviary):
+        def _preprocessAction(self, action):
+            rpm = super()._preprocessAction(action)
+            return np.minimum(rpm, 1.02 * self.HOVER_RPM)          # e.g. a thrust limiter
+
+    plain = HoverAviary(physics=Physics.DYN, act=ActionType.PID, ctrl_freq=240, device=gpu_device)
+    sub = Damped(physics=Physics.DYN, act=ActionType.PID, ctrl_freq=240, device=gpu_device)
+    assert sub._core.pid is not None and not sub._fused_action and plain._fused_action
+    plain.reset(); sub.reset()
+    wp = np.array([[0.0, 0.0, 0.12]])
+    for k in range(30):
+        o1, *_ = plain.step(wp)
+        o2, *_ = sub.step(wp)
+        assert o2.shape == o1.shape
+    # a waypoint 7 mm above the start: the limiter never engages, both envs must follow the same trajectory (fp32 vs the
+    # host-side float64 waypoint arithmetic: rounding-level differences only)
+    np.testing.assert_allclose(o2[:, :12], o1[:, :12], rtol=0, atol=2e-5)
+    assert np.isfinite(sub.last_clipped_action).all() and (sub.last_clipped_action <= 1.02 * sub.HOVER_RPM + 1e-3).all()
+
+
 def test_logger_export_of_device_states(gpu_device, tmp_path):
     """Logger.log_batch on (N,20) state vectors from the device == N x Logger.log on the rows; CSV/npz files load."""
     from gym_pybullet_drones_amd.envs import VectorCtrlAviary
