@@ -64,6 +64,11 @@ WORKLOADS = {
     # ... and with the action ring only ("lazy": the history tail stays a strided view of the ring the step kernel pushes into)
     "hover65536_240hz_history": dict(E=65536, D=1, phys=0, ctrl=240, act="rpm", task="hover", full_obs="lazy"),
     "hover65536_30hz_history": dict(E=65536, D=1, phys=0, ctrl=30, act="rpm", task="hover", full_obs="lazy"),
+    # the loop of examples/learn.py:157-192 with the policy IN the kernel (gpd_rollout_policy: SB3's default 2 x 64 tanh actor on
+    # the matrix cores, the policy sees the reference's full 72-float row); second leg: the same policy as torch operations between
+    # two gpd_step launches (rows gathered for it every step), one hipGraph
+    "hover65536_30hz_policy": dict(E=65536, D=1, phys=0, ctrl=30, act="rpm", task="hover", full_obs="lazy", policy=True),
+    "hover65536_240hz_policy12": dict(E=65536, D=1, phys=0, ctrl=240, act="rpm", task="hover", policy=True),
     "hover4m_240hz": dict(E=4194304, D=1, phys=0, ctrl=240, act="rpm", task="hover"),
     "hover16m_240hz": dict(E=16777216, D=1, phys=0, ctrl=240, act="rpm", task="hover"),
     # BASELINE.json configs 4 and 5, per GPU, verbatim (launch with --gpus 8 under torch.distributed.run)
@@ -112,6 +117,10 @@ def make_env(w, device, seed, E=None):
     env = VectorAviary(E, D, initial_xyzs=xyz, initial_rpys=rpy, physics=w["phys"], pyb_freq=240,
                        ctrl_freq=w["ctrl"], act=ActionType(w["act"]), task=w["task"], auto_reset=True,
                        track_rpm=bool(w["phys"] & 2), full_obs=w.get("full_obs", False), device=device)
+    if w.get("policy"):
+        from gym_pybullet_drones_amd.policy import MlpPolicy
+        hist = env.ACTION_BUFFER_SIZE * env.ACT_DIM if w.get("full_obs") else 0
+        env.bench_policy = MlpPolicy.random(12 + hist, env.ACT_DIM, seed=seed, gain=1.0, device=device)
     return env
 
 
@@ -250,7 +259,12 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
     def one_step(i):
         """step i of every sub-batch: sub-batch 0 on the current stream, the others on their own streams"""
         if len(envs) == 1:
-            envs[0].step(actions[0][i % POOL])
+            pol = getattr(envs[0], "bench_policy", None)
+            if pol is not None:         # the policy between two steps, as torch operations on the rows gathered for it
+                row = envs[0].full_rows() if pol.in_dim > 12 else envs[0].core.obs12.view(-1, 1, 12)
+                envs[0].step(pol(row))
+            else:
+                envs[0].step(actions[0][i % POOL])
             if gather is not None:
                 gather(core.obs12)
             return
@@ -291,7 +305,10 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
     def one_rollout(n):
         for e, a in zip(envs, actions):
             hist = getattr(e, "full_obs", False) or getattr(e, "lazy_history", False)
-            out = e.rollout(a[:n]) if hist else e.core.rollout(a[:n], update_latest=False)
+            if getattr(e, "bench_policy", None) is not None:
+                out = e.core.rollout_policy(e.bench_policy, n, want_actions=True)
+            else:
+                out = e.rollout(a[:n]) if hist else e.core.rollout(a[:n], update_latest=False)
             if n in gathers:
                 gathers[n](out[0].reshape(-1, 12))
 
@@ -358,6 +375,10 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
     # roofline of the dominant kernel: algorithmic bytes of all launches of the timed region / its HIP-event time
     def extra(e, n, rollout):          # materialised (12 + H*A)-float rows / the ring update behind a rollout
         c = e.core
+        pol = getattr(e, "bench_policy", None)
+        if pol is not None:             # in the kernel: the ring push; between steps: the gathered rows (+ the MLP's own traffic, not counted)
+            ring = 2 * n * c.N * c.A * 4 if getattr(e, "lazy_history", False) else 0
+            return ring if rollout else (c.bytes_full_rows(n) if pol.in_dim > 12 else 0)
         if getattr(e, "full_obs", False):
             return c.bytes_full_rows(n, push=rollout)
         if getattr(e, "lazy_history", False) and rollout:
@@ -376,7 +397,8 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
     n_total = n_rank * world
     achieved = bytes_total / ev_s / 1e9
     steps_per_launch = K / launches_pass
-    kernel = "gpd_step_kernel" if mode != "rollout" else \
+    kernel = "gpd_rollout_policy_kernel" if (mode == "rollout" and getattr(envs[0], "bench_policy", None) is not None) else \
+        "gpd_step_kernel" if mode != "rollout" else \
         ("gpd_rollout1_kernel" if core.D & (core.D - 1) == 0 and core.D <= 64 else "gpd_rollout_kernel")
     return {
         "K": K, "W": W, "repeats": repeats, "timed_steps": timed_steps, "ev_s": ev_s, "wall_s": wall_s,
@@ -525,7 +547,8 @@ def main():
                        "total_drones": n_total, "physics": "DYN" + "".join(n for b, n in ((1, "+GND"), (2, "+DRAG"), (4, "+DW")) if w["phys"] & b),
                        "pyb_freq": 240, "ctrl_freq": w["ctrl"], "substeps_per_step": S, "action": w["act"],
                        "task": w["task"], "auto_reset": True, "mode": args.mode, "launch": launch, "split": len(envs),
-                       "full_obs": w.get("full_obs", False), "obs_allgather": want_gather, "allgather_impl": impl,
+                       "full_obs": w.get("full_obs", False), "policy": "MlpPolicy 64x64 tanh, in the kernel (rollout) / torch between steps (graph)" if w.get("policy") else None,
+                       "obs_allgather": want_gather, "allgather_impl": impl,
                        "env_steps_per_s": m["env_steps_per_s"]},
             "roofline": m["roofline"],
         }

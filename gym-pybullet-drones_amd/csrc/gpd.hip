@@ -1351,6 +1351,308 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// gpd_rollout_policy: K env steps per launch with an MLP policy IN the loop (the actor of SB3's default MlpPolicy:
+// in_dim -> 64 -> 64 -> A, tanh or ReLU; examples/learn.py:157-192).  One drone per lane, state in registers like the rollout
+// kernels; per step the 64 drones of a wavefront are the COLUMNS of the matrix-core tiles:
+//     H1^T [64 x 64 drones] = W1 [64 x in] . X^T [in x 64 drones]     (A operand = weights, from LDS; B = features, registers)
+// with v_mfma_f32_32x32x16_bf16: 2 row tiles (hidden units) x 2 column tiles (drones) x in/16 K-steps.
+//   * Precision: every operand is split into bf16 hi + lo (x = hi + lo to ~16 bits) and a tile takes three MFMAs
+//     (hi.hi + hi.lo + lo.hi, fp32 accumulate): plain bf16 would resolve a position of 1.0 m to 4 mm.
+//   * B operand of layer 1: lane l holds drone l's features; the tile of drones 0..31 wants K-slots 0..7 from lanes 0..31 and
+//     K-slots 8..15 OF THE SAME DRONES from lanes 32..63 -- one v_permlane32_swap per register pair hands both column tiles
+//     their operand (x' = [x.lo | y.lo], y' = [x.hi | y.hi]).
+//   * Chaining: the C/D layout puts hidden unit (r&3) + 8(r>>2) + 4(lane>>5) of drone lane&31 in register r -- exactly "eight
+//     values per lane and K-step" if the NEXT layer's K index is permuted accordingly.  The permutation is applied to the
+//     weight matrices when they are staged in LDS, so activations never leave registers between layers.
+//   * The action history (the tail of the reference's observation row) lives in registers as packed bf16 hi/lo pairs and
+//     shifts by one action per step; its capacity is 16*NK1 - 12 features, a shorter history sits at the end of it and
+//     the unused features in front meet zero weight columns (whatever shifts into them is multiplied by zero).
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// two floats -> packed bf16 hi parts (round to nearest even) and packed bf16 lo parts (bf16 of the remainders)
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const bf16x2 h = __builtin_convertvector(f32x2{a, b}, bf16x2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    const f32x2 r = f32x2{a, b} - f32x2{__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};      // (exact: v_pk_add_f32)
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+}
+__device__ __forceinline__ bf16x8 as_frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    return __builtin_bit_cast(bf16x8, u32x4{a, b, c, d});
+}
+// tanh(x) = 2 / (1 + exp(-2x)) - 1: v_exp_f32 + v_rcp_f32 (1 ulp each) and three plain operations, no sign handling (x -> -inf:
+// exp -> inf, rcp -> 0, result -1; x -> +inf: exp -> 0, result 1); absolute error ~1.5e-7
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float t = __builtin_amdgcn_exp2f(x * -2.88539008177792681472f);            // exp(-2x) = 2^(-2 log2(e) x)
+    return fmaf(2.0f, fast_rcp(1.0f + t), -1.0f);
+}
+
+// K index (unit of the previous layer) that K-step s, lane half h, element j of an operand stands for, layers 2 and 3
+__device__ __forceinline__ int chained_k(int s, int h, int j) {
+    const int r = 8 * (s & 1) + j;
+    return 32 * (s >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
+}
+
+constexpr int kPolHidden = 64;
+template <int NK1> struct PolLds {     // weights as A operands: [block][hi|lo][64 lanes] x 16 bytes; biases per (tile, lane half)
+    uint4 w1[2 * NK1][2][64];
+    uint4 w2[2 * 4][2][64];
+    uint4 w3[1 * 4][2][64];
+    float b1[2][2][16], b2[2][2][16], b3[2][16];
+};
+
+template <bool EXT, int AW, int ACT, int NK1, bool RELU>
+__global__ __launch_bounds__(kBlock) void gpd_rollout_policy_kernel(
+    const GpdParams P, const GpdState S, const GpdStepCfg C, const Span T, const GpdPolicy Pol,
+    const float* __restrict__ obs12_in, const float* __restrict__ target_pos, const float* __restrict__ init_pose,
+    float* __restrict__ actions_out, float* __restrict__ obs12, float* __restrict__ reward, uint8_t* __restrict__ terminated,
+    uint8_t* __restrict__ truncated) {
+    constexpr int CAP = 16 * NK1 - 12;                       // history capacity in features
+    constexpr int NP = 8 * NK1;                              // packed feature registers (two bf16 features each)
+    constexpr bool HIST = NK1 > 1;
+    __shared__ PolLds<NK1> W;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const uint32_t N = static_cast<uint32_t>(C.num_envs);
+    const uint32_t n_raw = blockIdx.x * static_cast<uint32_t>(kBlock) + tid;
+    const int K = T.num_steps;
+    const uint32_t flags = EXT ? C.physics_flags : 0u;
+    Lane L;
+    L.tid = tid; L.shfl = false; L.le = tid; L.d = 0;
+    L.active = n_raw < N;
+    L.n = L.active ? n_raw : blockIdx.x * static_cast<uint32_t>(kBlock);     // (a lane without a drone replays its workgroup's first one, stores nothing)
+    L.env = L.n;
+    const int HA = HIST ? S.hist_len * AW : 0;               // history features in use (<= CAP, checked by the host)
+    const int pad = CAP - HA;                                // unused features in front of the history
+
+    // ---- stage the weights in LDS as A operands (bf16 hi / lo), K permuted for the chained layers -------------------------
+    auto stage = [&](uint4 (*dst)[2][64], const float* __restrict__ w, int rows, int ld, int blocks_k, int tiles_m, bool first) {
+        for (int e = tid; e < tiles_m * blocks_k * 64; e += kBlock) {
+            const int l = e & 63, blk = e >> 6, m = blk / blocks_k, s = blk - m * blocks_k, h = l >> 5, row = 32 * m + (l & 31);
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int k;
+                if (first) {                                 // layer 1: feature f = 16 s + 8 h + j -> column of w1 (or none)
+                    const int f = 16 * s + 8 * h + j;
+                    k = f < 12 ? f : (f - 12 < pad ? -1 : f - pad);
+                    if (k >= Pol.in_dim) k = -1;
+                } else {
+                    k = chained_k(s, h, j);
+                }
+                v[j] = (row < rows && k >= 0) ? w[row * ld + k] : 0.0f;
+            }
+            uint32_t hi[4], lo[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) split_pair(v[2 * i], v[2 * i + 1], hi[i], lo[i]);
+            dst[blk][0][l] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            dst[blk][1][l] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+    };
+    stage(W.w1, Pol.w1, kPolHidden, Pol.in_dim, NK1, 2, true);
+    stage(W.w2, Pol.w2, kPolHidden, kPolHidden, 4, 2, false);
+    stage(W.w3, Pol.w3, AW, kPolHidden, 4, 1, false);
+    if (tid < 64) {                                          // biases in C/D order: element r of (tile m, lane half h) = unit 32 m + (r&3) + 8 (r>>2) + 4 h
+        const int m = tid >> 5, h = (tid >> 4) & 1, r = tid & 15, u = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+        W.b1[m][h][r] = Pol.b1[u];
+        W.b2[m][h][r] = Pol.b2[u];
+        if (m == 0) W.b3[h][r] = u < AW ? Pol.b3[u] : 0.0f;
+    }
+
+    // ---- the drone: state, latest observation, action history ------------------------------------------------------------
+    Carry c;
+    float tgx, tgy, tgz, ip[7];
+    const float* ipose = reinterpret_cast<const float*>(reinterpret_cast<const char*>(init_pose) + (C.init_per_env ? L.n * 28u : 0u));
+    load_carry<false, EXT>(S, C, flags, L, target_pos, C.auto_reset ? ipose : S.kin, c, tgx, tgy, tgz, ip);
+    c.roll = c.pitch = c.yaw = 0.0f;
+    float o[12];
+    {
+        const float4* op = reinterpret_cast<const float4*>(obs12_in + static_cast<size_t>(L.n) * 12);
+        const float4 o0 = op[0], o1 = op[1], o2 = op[2];
+        o[0] = o0.x; o[1] = o0.y; o[2] = o0.z; o[3] = o0.w; o[4] = o1.x; o[5] = o1.y; o[6] = o1.z; o[7] = o1.w;
+        o[8] = o2.x; o[9] = o2.y; o[10] = o2.z; o[11] = o2.w;
+    }
+    uint32_t Fhi[NP], Flo[NP];                               // packed features: [0..5] observation, [6..] history
+#pragma unroll
+    for (int i = 0; i < NP; ++i) Fhi[i] = Flo[i] = 0u;
+    const bool ring = S.act_ring != nullptr;                 // the action ring is kept current (one push per step, like gpd_step)
+    const size_t slot = static_cast<size_t>(N) * AW;
+    int ring_q = (ring ? S.ring_pos : S.step_counter)[L.env];
+    if (HIST) {
+        const int p = ring_q;
+#pragma unroll
+        for (int i = 0; i < CAP / 2; ++i) {                  // features 12 + 2i, 12 + 2i + 1 <- history elements (oldest first)
+            float v[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = 2 * i + q - pad;               // element of the HA-long history, < 0: unused
+                v[q] = e >= 0 ? S.act_ring[static_cast<size_t>(p + e / AW) * slot + static_cast<size_t>(L.n) * AW + e % AW] : 0.0f;
+            }
+            split_pair(v[0], v[1], Fhi[6 + i], Flo[6 + i]);
+        }
+    }
+    __syncthreads();                                         // weights staged
+
+    const uint4* w1 = &W.w1[0][0][lane];                     // this lane's 16 bytes of every A block: + (blk * 2 + part) * 64
+    const uint4* w2 = &W.w2[0][0][lane];
+    const uint4* w3 = &W.w3[0][0][lane];
+    auto a_frag = [](const uint4* base, int blk, int part) {
+        const uint4 q = base[(blk * 2 + part) * 64];
+        return as_frag(q.x, q.y, q.z, q.w);
+    };
+    auto bias16 = [&](const float* b) {
+        f32x16 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 q = reinterpret_cast<const float4*>(b)[i];
+            v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+        }
+        return v;
+    };
+    auto mfma3 = [](bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x16 acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);      // (small terms first)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    };
+    // activation of one output tile -> the next layer's B operands (two K-steps: registers 0..7 and 8..15), hi and lo
+    auto activate = [&](const f32x16& acc, bf16x8 bh[2], bf16x8 bl[2]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint32_t hi[4], lo[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float x0 = acc[8 * s + 2 * i], x1 = acc[8 * s + 2 * i + 1];
+                float y0, y1;
+                if (RELU) { y0 = fmaxf(x0, 0.0f); y1 = fmaxf(x1, 0.0f); }
+                else {                                       // fast_tanh on a pair: the three plain operations as packed instructions
+                    const fp2 e = fp2{x0, x1} * splat(-2.88539008177792681472f);
+                    const fp2 u = fp2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} + splat(1.0f);
+                    const fp2 y = fma2(splat(2.0f), fp2{fast_rcp(u.x), fast_rcp(u.y)}, splat(-1.0f));
+                    y0 = y.x; y1 = y.y;
+                }
+                split_pair(y0, y1, hi[i], lo[i]);
+            }
+            bh[s] = as_frag(hi[0], hi[1], hi[2], hi[3]);
+            bl[s] = as_frag(lo[0], lo[1], lo[2], lo[3]);
+        }
+    };
+
+    const size_t obs_step = static_cast<size_t>(T.obs_stride), env_stride = static_cast<size_t>(T.env_stride);
+    for (int t = 0; t < K; ++t) {
+        // ---- features of this step: the observation row (the history registers are current) ------------------------------
+#pragma unroll
+        for (int i = 0; i < 6; ++i) split_pair(o[2 * i], o[2 * i + 1], Fhi[i], Flo[i]);
+        // ---- layer 1: B operands of both column tiles by one lane-half swap per register pair ------------------------------
+        bf16x8 b1h[2][NK1], b1l[2][NK1];
+#pragma unroll
+        for (int s = 0; s < NK1; ++s) {
+            uint32_t h0[4], h1[4], l0[4], l1[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const auto sh = __builtin_amdgcn_permlane32_swap(Fhi[8 * s + i], Fhi[8 * s + 4 + i], false, false);
+                const auto sl = __builtin_amdgcn_permlane32_swap(Flo[8 * s + i], Flo[8 * s + 4 + i], false, false);
+                h0[i] = sh[0]; h1[i] = sh[1]; l0[i] = sl[0]; l1[i] = sl[1];
+            }
+            b1h[0][s] = as_frag(h0[0], h0[1], h0[2], h0[3]); b1h[1][s] = as_frag(h1[0], h1[1], h1[2], h1[3]);
+            b1l[0][s] = as_frag(l0[0], l0[1], l0[2], l0[3]); b1l[1][s] = as_frag(l1[0], l1[1], l1[2], l1[3]);
+        }
+        bf16x8 b2h[2][4], b2l[2][4];                         // [column tile][K-step] for layer 2
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            f32x16 acc0 = bias16(W.b1[m][half]), acc1 = acc0;
+#pragma unroll
+            for (int s = 0; s < NK1; ++s) {
+                const bf16x8 ah = a_frag(w1, m * NK1 + s, 0), al = a_frag(w1, m * NK1 + s, 1);
+                acc0 = mfma3(ah, al, b1h[0][s], b1l[0][s], acc0);
+                acc1 = mfma3(ah, al, b1h[1][s], b1l[1][s], acc1);
+            }
+            activate(acc0, &b2h[0][2 * m], &b2l[0][2 * m]);
+            activate(acc1, &b2h[1][2 * m], &b2l[1][2 * m]);
+        }
+        // ---- layer 2 ----------------------------------------------------------------------------------------------------------
+        bf16x8 b3h[2][4], b3l[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            f32x16 acc0 = bias16(W.b2[m][half]), acc1 = acc0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 ah = a_frag(w2, m * 4 + s, 0), al = a_frag(w2, m * 4 + s, 1);
+                acc0 = mfma3(ah, al, b2h[0][s], b2l[0][s], acc0);
+                acc1 = mfma3(ah, al, b2h[1][s], b2l[1][s], acc1);
+            }
+            activate(acc0, &b3h[0][2 * m], &b3l[0][2 * m]);
+            activate(acc1, &b3h[1][2 * m], &b3l[1][2 * m]);
+        }
+        // ---- layer 3: rows 0 .. AW-1 of one row tile are the action; clip to the action space (SB3 predict()) ---------------
+        f32x16 y0 = bias16(W.b3[half]), y1 = y0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 ah = a_frag(w3, s, 0), al = a_frag(w3, s, 1);
+            y0 = mfma3(ah, al, b3h[0][s], b3l[0][s], y0);
+            y1 = mfma3(ah, al, b3h[1][s], b3l[1][s], y1);
+        }
+        float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < AW; ++k) {                       // unit k sits in register k of lanes 0..31: drones 0..31 keep y0, drones 32..63 fetch y1
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(y0[k]), __float_as_uint(y1[k]), false, false);
+            a[k] = clampf(__uint_as_float(sw[0]), -1.0f, 1.0f);
+        }
+        // ---- the env step ---------------------------------------------------------------------------------------------------------
+        StepOut out;
+        env_step<false, EXT, false, AW, ACT, false>(P, C, flags, 1, L, make_float4(a[0], a[1], a[2], a[3]), tgx, tgy, tgz, true, ipose,
+                                                    ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], ip[6], nullptr, nullptr, c, out);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) o[i] = out.o[i];
+        if (HIST) {                                          // the history moves up by one action, the new one goes to its end
+            uint32_t nh[2] = {0u, 0u}, nl[2] = {0u, 0u};
+            if (AW == 4) {
+                split_pair(a[0], a[1], nh[0], nl[0]);
+                split_pair(a[2], a[3], nh[1], nl[1]);
+#pragma unroll
+                for (int i = 6; i < NP - 2; ++i) { Fhi[i] = Fhi[i + 2]; Flo[i] = Flo[i + 2]; }
+                Fhi[NP - 2] = nh[0]; Flo[NP - 2] = nl[0]; Fhi[NP - 1] = nh[1]; Flo[NP - 1] = nl[1];
+            } else {                                         // AW == 1: one bf16 element per step
+                split_pair(0.0f, a[0], nh[0], nl[0]);         // the new action in the upper half
+#pragma unroll
+                for (int i = 6; i < NP - 1; ++i) {
+                    Fhi[i] = __builtin_amdgcn_alignbit(Fhi[i + 1], Fhi[i], 16);
+                    Flo[i] = __builtin_amdgcn_alignbit(Flo[i + 1], Flo[i], 16);
+                }
+                Fhi[NP - 1] = (Fhi[NP - 1] >> 16) | nh[0];
+                Flo[NP - 1] = (Flo[NP - 1] >> 16) | nl[0];
+            }
+        }
+        if (L.active) {
+            float4* orow = reinterpret_cast<float4*>(obs12 + t * obs_step + static_cast<size_t>(L.n) * 12);
+            orow[0] = make_float4(o[0], o[1], o[2], o[3]);
+            orow[1] = make_float4(o[4], o[5], o[6], o[7]);
+            orow[2] = make_float4(o[8], o[9], o[10], o[11]);
+            reward[t * env_stride + L.env] = out.rew;
+            terminated[t * env_stride + L.env] = out.term ? 1 : 0;
+            truncated[t * env_stride + L.env] = out.trunc ? 1 : 0;
+            if (actions_out) {
+                float* ar = actions_out + (static_cast<size_t>(t) * N + L.n) * AW;
+                if (AW == 4) *reinterpret_cast<float4*>(ar) = make_float4(a[0], a[1], a[2], a[3]);
+                else ar[0] = a[0];
+            }
+            if (ring) {                                      // exact fp32 action into both halves of the double ring
+                float* r0 = S.act_ring + static_cast<size_t>(ring_q) * slot + static_cast<size_t>(L.n) * AW;
+                float* r1 = r0 + static_cast<size_t>(S.hist_len) * slot;
+                if (AW == 4) { *reinterpret_cast<float4*>(r0) = make_float4(a[0], a[1], a[2], a[3]); *reinterpret_cast<float4*>(r1) = make_float4(a[0], a[1], a[2], a[3]); }
+                else { r0[0] = a[0]; r1[0] = a[0]; }
+            }
+        }
+        ring_q = ring_q + 1 == S.hist_len ? 0 : ring_q + 1;
+    }
+    if (!L.active) return;
+    store_carry<false>(S, L, c);
+    if (ring) S.ring_pos[L.env] = ring_q;
+}
+
+// ------------------------------------------------------------------------------------------------
 // masked reset (envs/BaseAviary.py:451-477)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void gpd_reset_kernel(const GpdState S, const float* __restrict__ init_pose,
@@ -1937,6 +2239,64 @@ int gpd_rollout(const GpdParams* params, const GpdState* state, const GpdStepCfg
     if (state) { no_ring = *state; no_ring.act_ring = nullptr; }
     return step_impl("gpd_rollout", params, state ? &no_ring : nullptr, cfg, T, actions, target_pos, init_pose, obs12, reward,
                      terminated, truncated, term_obs12, stream);
+}
+
+int gpd_rollout_policy(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, const GpdPolicy* policy,
+                       int32_t num_steps, const float* obs12_in, const float* target_pos, const float* init_pose,
+                       float* actions_out, float* obs12, int64_t obs_step_stride, float* reward, uint8_t* terminated,
+                       uint8_t* truncated, int64_t env_step_stride, void* stream) {
+    auto bad = [&](int code, const char* msg) { return fail(code, (std::string("gpd_rollout_policy: ") + msg).c_str()); };
+    if (!params || !state || !cfg || !policy) return bad(GPD_EINVAL, "NULL params/state/cfg/policy");
+    if (!state->kin || !state->step_counter) return bad(GPD_EINVAL, "NULL state.kin/step_counter");
+    if (!obs12_in || !obs12 || !reward || !terminated || !truncated) return bad(GPD_EINVAL, "NULL obs12_in/obs12/reward/terminated/truncated");
+    if (!policy->w1 || !policy->b1 || !policy->w2 || !policy->b2 || !policy->w3 || !policy->b3) return bad(GPD_EINVAL, "NULL policy weights");
+    if (num_steps <= 0 || obs_step_stride < 0 || env_step_stride < 0) return bad(GPD_EINVAL, "num_steps must be positive, strides non-negative");
+    if (cfg->num_envs <= 0 || cfg->substeps <= 0) return bad(GPD_EINVAL, "num_envs and substeps must be positive");
+    if (cfg->drones_per_env != 1) return bad(GPD_ENOTSUP, "single-drone aviaries only (drones_per_env == 1)");
+    if (cfg->act_type != GPD_ACT_RPM && cfg->act_type != GPD_ACT_ONE_D_RPM) return bad(GPD_ENOTSUP, "ActionType.RPM or ONE_D_RPM only");
+    if (cfg->task < GPD_TASK_NONE || cfg->task > GPD_TASK_MULTIHOVER) return bad(GPD_EINVAL, "unknown task");
+    if (cfg->physics_flags & ~15u) return bad(GPD_EINVAL, "unknown physics flag");
+    if (policy->hidden != kPolHidden) return bad(GPD_ENOTSUP, "hidden must be 64");
+    if (policy->activation != 0 && policy->activation != 1) return bad(GPD_EINVAL, "activation must be 0 (tanh) or 1 (relu)");
+    const int64_t N = cfg->num_envs;
+    if (state->ld < N) return bad(GPD_EINVAL, "state.ld < num_envs");
+    if (N > (1LL << 26)) return bad(GPD_ERANGE, "more than 2^26 drones per launch");
+    if ((cfg->physics_flags & GPD_PHYS_DRAG) && !state->last_rpm) return bad(GPD_EINVAL, "GPD_PHYS_DRAG needs state.last_rpm");
+    if (cfg->task != GPD_TASK_NONE && !target_pos) return bad(GPD_EINVAL, "task needs target_pos");
+    if (cfg->auto_reset && !init_pose) return bad(GPD_EINVAL, "auto_reset needs init_pose");
+    const int A = cfg->act_type == GPD_ACT_RPM ? 4 : 1;
+    const bool hist = policy->in_dim != 12;
+    if (hist) {
+        if (!state->act_ring || !state->ring_pos || state->hist_len <= 0) return bad(GPD_EINVAL, "in_dim > 12 needs the action ring of state");
+        if (policy->in_dim != 12 + state->hist_len * A) return bad(GPD_ENOTSUP, "in_dim must be 12 or 12 + hist_len*act_dim");
+        if (state->hist_len * A > (A == 4 ? 68 : 20)) return bad(GPD_ENOTSUP, "history too long for the in-kernel policy (RPM: 17 actions, ONE_D_RPM: 20)");
+    } else if (state->act_ring && (!state->ring_pos || state->hist_len <= 0)) {
+        return bad(GPD_EINVAL, "state.act_ring without ring_pos / hist_len");
+    }
+    GpdStepCfg c = *cfg;
+    if (cfg->task == GPD_TASK_NONE) { target_pos = state->kin; c.target_per_env = 0; }
+    const Span T{num_steps, 0, obs_step_stride, env_step_stride, 2};
+    const dim3 grid(static_cast<unsigned>((N + kBlock - 1) / kBlock));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // (one physics variant: the add-on terms are wave-uniform run-time tests there, a handful of slots next to the policy's ~3000)
+#define GPD_POL(AW_, ACT_, NK1_)                                                                                                    \
+    do {                                                                                                                            \
+        if (policy->activation == 1)                                                                                                \
+            hipLaunchKernelGGL((gpd_rollout_policy_kernel<true, AW_, ACT_, NK1_, true>), grid, dim3(kBlock), 0, st, *params, *state, c, T, \
+                               *policy, obs12_in, target_pos, init_pose, actions_out, obs12, reward, terminated, truncated);        \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((gpd_rollout_policy_kernel<true, AW_, ACT_, NK1_, false>), grid, dim3(kBlock), 0, st, *params, *state, c, T, \
+                               *policy, obs12_in, target_pos, init_pose, actions_out, obs12, reward, terminated, truncated);        \
+    } while (0)
+    if (A == 4) {
+        if (hist) GPD_POL(4, GPD_ACT_RPM, 5); else GPD_POL(4, GPD_ACT_RPM, 1);
+    } else {
+        if (hist) GPD_POL(1, GPD_ACT_ONE_D_RPM, 2); else GPD_POL(1, GPD_ACT_ONE_D_RPM, 1);
+    }
+#undef GPD_POL
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gpd_rollout_policy launch");
+    return 0;
 }
 
 static int hist_args(const char* who, const GpdState* st, int32_t n_drones, int32_t D, int32_t A) {

@@ -229,6 +229,35 @@ class SimCore:
             self.truncated.copy_(trunc[K - 1])
         return obs, rew, term, trunc
 
+    def rollout_policy(self, policy, num_steps: int, want_actions: bool = True):
+        """K env steps in ONE launch with `policy` (a `policy.MlpPolicy`) evaluated inside the kernel
+        (`gpd_rollout_policy`): a_t = policy(o_t), o_{t+1}, r_t, ... = step(a_t), starting from the latest observation.
+        Returns `(obs12 [K,N,12], reward [K,E], terminated [K,E], truncated [K,E], actions [K,N,A] or None)` -- the same
+        persistent buffers `rollout()` uses; the latest-step tensors (`obs12`, `reward`, ...) are updated as well."""
+        K = int(num_steps)
+        if K < 1:
+            raise ValueError("num_steps must be >= 1")
+        obs, rew, term, trunc, _ = self._rollout_buffers(K)
+        cache = self.__dict__.setdefault("_policy_actions", {})
+        acts = None
+        if want_actions:
+            acts = cache.get(K)
+            if acts is None:
+                cache.clear()
+                acts = cache[K] = torch.zeros((K, self.N, self.A), dtype=torch.float32, device=self.device)
+        ps = policy.struct()
+        with torch.cuda.device(self.device):
+            rc = self.lib.gpd_rollout_policy(ctypes.byref(self._params), ctypes.byref(self._state), ctypes.byref(self._cfg),
+                                             ctypes.byref(ps), K, _ptr(self.obs12), _ptr(self.target), _ptr(self.init_pose),
+                                             _ptr(acts), _ptr(obs), self.N * 12, _ptr(rew), _ptr(term), _ptr(trunc), self.E,
+                                             self._stream())
+        _native.check(rc, "gpd_rollout_policy")
+        self.obs12.copy_(obs[K - 1])
+        self.reward.copy_(rew[K - 1])
+        self.terminated.copy_(term[K - 1])
+        self.truncated.copy_(trunc[K - 1])
+        return obs, rew, term, trunc, acts
+
     # ---- action history / full KIN observation rows (envs/BaseRLAviary.py:65-67, 153-154, 187, 307-320) ----
     def enable_history(self, hist_len: int):
         """Allocate the action ring: a DOUBLE ring `[2H][N][A]` (zeros, like the reference's pre-filled deque; never

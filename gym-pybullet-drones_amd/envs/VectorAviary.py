@@ -145,6 +145,17 @@ class VectorAviary:
             self.core.full_obs(actions, num_steps=K, want_rows=False)      # ring update only
         return obs.view(K, self.NUM_ENVS, self.NUM_DRONES, -1), reward, terminated, truncated
 
+    def rollout_policy(self, policy, num_steps: int):
+        """K env steps in ONE launch with the policy in the loop (`policy.MlpPolicy`; the loop of
+        `examples/learn.py:157-192`).  The policy's input is the (12,) kinematic row, or -- `full_obs` True / "lazy" and
+        `policy.in_dim == 12 + H*A` -- the reference's full row with the action history.  Returns
+        `(obs (K,E,1,12), reward (K,E), terminated (K,E), truncated (K,E), actions (K,E,1,A))`."""
+        obs, reward, terminated, truncated, acts = self.core.rollout_policy(policy, num_steps)
+        if self.full_obs:
+            self.core.history_rows()
+        E, D = self.NUM_ENVS, self.NUM_DRONES
+        return obs.view(-1, E, D, 12), reward, terminated, truncated, acts.view(-1, E, D, self.ACT_DIM)
+
     def state_vectors(self) -> torch.Tensor:
         """(E, D, 20) `_getDroneStateVector`-ordered states (needs `track_rpm=True` for the RPM columns)."""
         return self.core.state_vectors().view(self.NUM_ENVS, self.NUM_DRONES, 20)

@@ -242,6 +242,50 @@ int gpd_rollout(const GpdParams* params, const GpdState* state, const GpdStepCfg
                 float* term_obs12, void* stream);
 
 /*
+ * A deterministic MLP policy evaluated INSIDE the rollout kernel: the actor of Stable-Baselines3's default `MlpPolicy`
+ * (features -> Linear(in_dim, 64) -> tanh -> Linear(64, 64) -> tanh -> Linear(64, act_dim), `model.predict(obs,
+ * deterministic=True)` incl. its clip to the action space [-1, 1]) -- what examples/learn.py:157-192 evaluates between two
+ * env.step() calls.  Weights are float32 device arrays in torch's Linear layout (weight [out][in] row-major, bias [out]).
+ *   in_dim = 12                       the policy sees the kinematic observation only
+ *   in_dim = 12 + hist_len*act_dim    the policy sees the reference's full row (BaseRLAviary._computeObs): kinematics, then the
+ *                                     hist_len most recent actions, oldest first (state->act_ring must be set)
+ * activation: 0 = tanh (SB3's default), 1 = ReLU.
+ */
+typedef struct GpdPolicy {
+    const float* w1; const float* b1;   /* [64][in_dim], [64] */
+    const float* w2; const float* b2;   /* [64][64], [64] */
+    const float* w3; const float* b3;   /* [act_dim][64], [act_dim] */
+    int32_t in_dim;
+    int32_t hidden;                     /* 64 */
+    int32_t activation;                 /* 0 tanh, 1 relu */
+    int32_t pad_;
+} GpdPolicy;
+
+/*
+ * K consecutive env.step() calls in ONE launch with the policy IN the loop.  Replaces the evaluation / sampling loop of
+ * examples/learn.py:157-192 (`action, _ = model.predict(obs, deterministic=True); obs, reward, terminated, truncated, info =
+ * env.step(action)`), for single-drone aviaries (HoverAviary) with ActionType.RPM or ONE_D_RPM:
+ *     a_t = clip(W3 act(W2 act(W1 o_t + b1) + b2) + b3, -1, 1);   o_{t+1}, r_t, ... = step(a_t)
+ * where o_t is the latest observation row -- of the reset pose when the aviary was reset in step t-1 (same-step auto-reset, the
+ * history tail survives resets like the reference's action buffer).  The drone state stays in registers for all K steps like in
+ * gpd_rollout; the two 64-unit layers run on the matrix cores: the 64 drones of a wavefront are the columns of
+ * v_mfma_f32_32x32x16_bf16 tiles, every operand split into bf16 hi + lo parts (three products per tile: hi*hi + hi*lo + lo*hi,
+ * fp32 accumulate), which keeps ~16 mantissa bits of the float32 weights and observations (actions agree with a float64
+ * evaluation to ~1e-5); a layer's output tile is the next layer's B operand without leaving registers.
+ *
+ *   obs12_in     [E][12] the latest observation rows (the obs12 output of the previous step / reset / rollout)
+ *   actions_out  [K][E][A] out or NULL: the actions the policy chose, step t at actions_out + t*E*A
+ *   obs12 / reward / terminated / truncated and the strides: as in gpd_rollout
+ * With in_dim > 12 the action ring of `state` is read at the start and rewritten (with ring_pos = 0) at the end.
+ * GPD_ENOTSUP: drones_per_env > 1, a DSLPID action type, hidden != 64, in_dim not one of the two forms, or a history longer
+ * than 16 (RPM) / 20 (ONE_D_RPM) actions.
+ */
+int gpd_rollout_policy(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, const GpdPolicy* policy,
+                       int32_t num_steps, const float* obs12_in, const float* target_pos, const float* init_pose,
+                       float* actions_out, float* obs12, int64_t obs_step_stride, float* reward, uint8_t* terminated,
+                       uint8_t* truncated, int64_t env_step_stride, void* stream);
+
+/*
  * Full KIN observation rows with the action-history tail.  Replaces the row assembly of BaseRLAviary._computeObs
  * (envs/BaseRLAviary.py:307-320) on top of the action ring of GpdState (which replaces the deque, :65-67, 153-154, 187):
  *     row = [ pos | rpy | vel | ang_v | a(t-H+1) ... a(t) ]      H = ctrl_freq // 2, oldest action first

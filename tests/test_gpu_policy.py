@@ -1,0 +1,126 @@
+"""`gpd_rollout_policy`: K env steps per launch with an MLP policy evaluated inside the kernel (matrix cores, bf16 hi/lo
+operands) -- against the float64 actor of oracle/policy_oracle.py, against stepping the same actions through `gpd_step`
+(bitwise), and closed loop against the float64 oracle aviary."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import urdf
+from oracle.batched_oracle import BatchedAviary
+from oracle.policy_oracle import mlp_actor, policy_loop
+
+pytestmark = pytest.mark.gpu
+
+
+def _weights(p):
+    return [x.cpu().numpy().astype(np.float64) for x in (p.w1, p.b1, p.w2, p.b2, p.w3, p.b3)]
+
+
+def _env(act, ctrl, mode, E, dev, **kw):
+    from gym_pybullet_drones_amd.envs import VectorHoverAviary
+    from gym_pybullet_drones_amd.utils.enums import ActionType
+    rng = np.random.default_rng(E)
+    xyz = np.array([0, 0, 0.5]) + rng.uniform(-0.4, 0.4, size=(E, 1, 3))
+    rpy = rng.uniform(-0.2, 0.2, size=(E, 1, 3))
+    return VectorHoverAviary(E, initial_xyzs=xyz, initial_rpys=rpy, act=ActionType(act), ctrl_freq=ctrl, full_obs=mode, device=dev, **kw)
+
+
+CASES = [  # act, ctrl_freq (H = ctrl // 2), policy sees the history, activation
+    ("rpm", 30, True, "tanh"), ("rpm", 30, False, "tanh"), ("one_d_rpm", 30, True, "tanh"), ("one_d_rpm", 240, False, "relu"),
+    ("rpm", 24, True, "relu"), ("one_d_rpm", 40, True, "tanh"),
+]
+
+
+@pytest.mark.parametrize("act,ctrl,hist,activation", CASES)
+def test_policy_actions_match_the_float64_actor_every_step(gpu_device, act, ctrl, hist, activation):
+    """Every action the kernel chose equals the float64 actor evaluated on the kernel's OWN previous observation row (and
+    action history): checks the feature staging, the lane-half swaps, the K permutation of the chained layers, the history
+    shift and the reset handling at every step, independent of how the trajectories evolve.  Ragged batch, short episodes."""
+    from gym_pybullet_drones_amd.policy import MlpPolicy
+    E, K = 1000, 40
+    env = _env(act, ctrl, "lazy" if hist else False, E, gpu_device, episode_len_sec=12.0 / ctrl)
+    A, H = env.ACT_DIM, ctrl // 2
+    pol = MlpPolicy.random(12 + (H * A if hist else 0), A, seed=ctrl + A, gain=1.5, activation=activation, device=gpu_device)
+    rng = np.random.default_rng(0)
+    for _ in range(5):                           # some history and motion first
+        env.step(torch.as_tensor(rng.uniform(-1, 1, size=(E, 1, A)).astype(np.float32), device=gpu_device))
+    obs0 = env.core.obs12.clone()
+    hist0 = env.history().clone() if hist else None
+    obs, rew, term, trunc, acts = env.rollout_policy(pol, K)
+    torch.cuda.synchronize()
+    assert obs.shape == (K, E, 1, 12) and acts.shape == (K, E, 1, A) and float(acts.abs().max()) <= 1.0
+    assert (term | trunc).any(), "the test must exercise resets inside the rollout"
+    w = _weights(pol)
+    o_prev = obs0.cpu().numpy().astype(np.float64).reshape(E, 12)
+    h = hist0.cpu().numpy().astype(np.float64).reshape(E, H, A) if hist else None
+    worst = 0.0
+    for t in range(K):
+        row = o_prev if h is None else np.concatenate([o_prev, h.reshape(E, -1)], axis=1)
+        want = mlp_actor(row, *w, activation=activation)
+        got = acts[t].cpu().numpy().astype(np.float64).reshape(E, A)
+        worst = max(worst, float(np.abs(got - want).max()))
+        if h is not None:
+            h = np.concatenate([h[:, 1:], got[:, None, :]], axis=1)
+        o_prev = obs[t].cpu().numpy().astype(np.float64).reshape(E, 12)
+    print(f"{act} ctrl={ctrl} hist={hist} {activation}: max |kernel action - float64 actor| over {K} steps = {worst:.2e}")
+    assert worst < 5e-5
+    if hist:   # the ring holds the exact actions, oldest first
+        np.testing.assert_array_equal(env.history().cpu().numpy().reshape(E, H, A)[:, -min(H, K):], acts[-min(H, K):].cpu().numpy().reshape(-1, E, A).transpose(1, 0, 2))
+
+
+@pytest.mark.parametrize("act,ctrl,hist", [("rpm", 30, True), ("one_d_rpm", 240, False), ("rpm", 48, False)])
+def test_policy_rollout_is_bitwise_stepping_its_actions(gpu_device, act, ctrl, hist):
+    """The physics inside the policy kernel is the shared `env_step`: feeding the actions it chose to `gpd_step` one at a time
+    reproduces its observations, rewards, flags, state and action ring bit for bit."""
+    from gym_pybullet_drones_amd.policy import MlpPolicy
+    E, K = 777, 25
+    mode = "lazy" if hist else False
+    a, b = (_env(act, ctrl, mode, E, gpu_device, episode_len_sec=10.0 / ctrl) for _ in range(2))
+    A, H = a.ACT_DIM, ctrl // 2
+    pol = MlpPolicy.random(12 + (H * A if hist else 0), A, seed=3, gain=1.2, device=gpu_device)
+    obs, rew, term, trunc, acts = a.rollout_policy(pol, K)
+    for t in range(K):
+        o, r, te, tr, _ = b.step(acts[t])
+        assert torch.equal(o, obs[t]) and torch.equal(r, rew[t]) and torch.equal(te, term[t]) and torch.equal(tr, trunc[t]), t
+    for name in ("kin", "step_counter", "obs12", "reward", "terminated", "truncated"):
+        assert torch.equal(getattr(a.core, name), getattr(b.core, name)), name
+    if hist:
+        assert torch.equal(a.history(), b.history())
+
+
+def test_policy_closed_loop_against_the_float64_oracle(gpu_device):
+    """`examples/learn.py:157-192` end to end: HoverAviary at the reference's 30 Hz, RPM actions, the policy sees the full
+    row; fp32 HIP kernel vs float64 oracle aviary + float64 actor, 45 control steps (1.5 s)."""
+    from gym_pybullet_drones_amd.policy import MlpPolicy
+    E, K, ctrl, A, H = 512, 45, 30, 4, 15
+    env = _env("rpm", ctrl, "lazy", E, gpu_device, auto_reset=False)
+    orc = BatchedAviary(urdf("cf2x"), "cf2x", E, 1, initial_xyzs=env.INIT_XYZS, initial_rpys=env.INIT_RPYS, pyb_freq=240,
+                        ctrl_freq=ctrl, act="rpm", task="hover")
+    pol = MlpPolicy.random(12 + H * A, A, seed=11, gain=1.0, device=gpu_device)
+    obs0, _ = env.reset()
+    ref = policy_loop(orc, _weights(pol), K, obs0.cpu().numpy().astype(np.float64), history=np.zeros((E, 1, H, A)))
+    obs, rew, term, trunc, acts = env.rollout_policy(pol, K)
+    o32 = obs.cpu().numpy().astype(np.float64)
+    for t in (0, 4, 14, 29, 44):
+        eo = np.abs(o32[t] - ref["obs"][t]).max(axis=(0, 1))
+        ea = np.abs(acts[t].cpu().numpy() - ref["actions"][t]).max()
+        print(f"t={t + 1:3d} obs err pos {eo[:3].max():.2e} rpy {eo[3:6].max():.2e} vel {eo[6:9].max():.2e} ang_v {eo[9:].max():.2e} | action err {ea:.2e}")
+    scale = np.maximum(np.abs(ref["obs"]).max(axis=(0, 1, 2)), 1.0)
+    assert (np.abs(o32 - ref["obs"]) / scale).max() < 1e-4
+    assert np.abs(acts.cpu().numpy() - ref["actions"]).max() < 2e-4
+    np.testing.assert_allclose(rew.cpu().numpy(), ref["reward"], rtol=1e-3, atol=1e-3)
+
+
+def test_policy_argument_errors(gpu_device):
+    from gym_pybullet_drones_amd import _native
+    from gym_pybullet_drones_amd.envs import VectorMultiHoverAviary
+    from gym_pybullet_drones_amd.policy import MlpPolicy
+    env = _env("rpm", 30, False, 64, gpu_device)
+    with pytest.raises(_native.GpdError, match="in_dim"):
+        env.rollout_policy(MlpPolicy.random(72, 4, device=gpu_device), 4)          # wants the history, the env keeps none
+    with pytest.raises(_native.GpdError, match="single-drone"):
+        VectorMultiHoverAviary(8, 2, device=gpu_device).rollout_policy(MlpPolicy.random(12, 4, device=gpu_device), 4)
+    with pytest.raises(_native.GpdError, match="history too long"):
+        _env("rpm", 240, "lazy", 64, gpu_device).rollout_policy(MlpPolicy.random(12 + 120 * 4, 4, device=gpu_device), 4)
+    with pytest.raises(ValueError):
+        MlpPolicy(np.zeros((32, 12)), np.zeros(32), np.zeros((32, 32)), np.zeros(32), np.zeros((4, 32)), np.zeros(4), device=gpu_device)
