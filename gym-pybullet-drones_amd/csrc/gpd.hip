@@ -1895,7 +1895,8 @@ __global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const float* __rest
 constexpr int kDwTile = 1024;     // candidates staged in LDS at a time (16 KiB)
 __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, int nx, int ny,
                                                            const int* __restrict__ start, const int* __restrict__ order,
-                                                           const float4* __restrict__ sorted, float* __restrict__ dw_out) {
+                                                           const float4* __restrict__ sorted, float* __restrict__ dw_out,
+                                                           int* __restrict__ cursor) {
     // The drones of the cell are taken 64 at a time, and ALL FOUR waves hold the same 64 (lane i of every wave = drone
     // base + i): the waves split the CANDIDATES of a tile four ways instead of the drones -- a cell holds ~64 drones, so
     // splitting the drones would leave three of the four waves sweeping for nobody.  The partial sums are 64-bit fixed
@@ -1905,6 +1906,8 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, in
     const int c = blockIdx.x;
     const int cy = c / nx, cx = c - cy * nx;
     const int m0 = start[c], m1 = start[c + 1];            // the drones of this cell
+    // the sort's per-cell counters / cursors are done with: leave them zeroed for the next call (no memset node per call)
+    if (threadIdx.x == 0) { cursor[c] = 0; if (c == 0) cursor[nx * ny] = 0; }
     if (m0 == m1) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float kr = 0.25f * P.prop_radius;
@@ -2370,15 +2373,14 @@ int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, i
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int cells = nx * ny;
     const float inv_cell = 1.0f / cell;
-    hipError_t e = hipMemsetAsync(cell_count, 0, sizeof(int32_t) * (cells + 1), st);
-    if (e != hipSuccess) return hip_fail(e, "gpd_downwash_global memset");
+    hipError_t e;
     const dim3 grid(static_cast<unsigned>((n + kBlock - 1) / kBlock));
     hipLaunchKernelGGL(dwg_count_kernel, grid, dim3(kBlock), 0, st, kin, ld, n, inv_cell, x0, y0, nx, ny, visit_order, cell_count);
     hipLaunchKernelGGL(dwg_scan_kernel, dim3(1), dim3(1024), 0, st, cell_count, cell_start, cells);
     hipLaunchKernelGGL(dwg_scatter_kernel, grid, dim3(kBlock), 0, st, kin, ld, n, inv_cell, x0, y0, nx, ny, visit_order,
                        cell_count, cell_start, order, reinterpret_cast<float4*>(sorted_xyzc), dw_out);
     hipLaunchKernelGGL(dwg_force_kernel, dim3(static_cast<unsigned>(cells)), dim3(kBlock), 0, st, *params, nx, ny, cell_start,
-                       order, reinterpret_cast<const float4*>(sorted_xyzc), dw_out);
+                       order, reinterpret_cast<const float4*>(sorted_xyzc), dw_out, cell_count);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gpd_downwash_global launch");
     return 0;

@@ -328,7 +328,8 @@ int gpd_full_obs(const GpdState* state, int32_t num_steps, int32_t n_drones, int
  *                 Any permutation gives the same forces bit for bit; handing in the `order` buffer the PREVIOUS call
  *                 filled (two buffers, ping-pong: it must not alias `order`) makes neighbouring lanes share a cell, and
  *                 the sort then issues one atomic per run of equal cells instead of one per drone.
- *   cell_count    [nx*ny + 1] int32 scratch       cell_start  [nx*ny + 1] int32 scratch
+ *   cell_count    [nx*ny + 1] int32: ZERO before the first call; every call leaves it zeroed again (the last kernel
+ *                 clears what the sort counted: no memset per call)          cell_start  [nx*ny + 1] int32 scratch
  *   order         [n] int32 out (drone index of sorted slot: a permutation of 0..n-1)
  *   sorted_xyzc   [n][4] float scratch (x, y, z, cell id as int bits), sorted by cell
  *   dw_out        [n] out: the force of drone i at dw_out[i]  (pass it to gpd_step as state.dw_force)
