@@ -534,7 +534,7 @@ def main():
         launch = {"rollout": f"rollout{int(spl) if spl == int(spl) else spl:g}", "graph": "graph", "eager": "eager"}[args.mode]
         D, S = core.D, core.S
         metric = BASELINE_METRIC if args.workload == "hover65536_240hz" else \
-            (f"env steps/sec (whole node), {args.workload}: {w['E']} aviaries x {D} drone(s) per GPU, "
+            (f"env steps/sec (whole node), {args.workload}: {w['E']} aviaries x {w['D']} drone(s) per GPU, "
              f"{w['ctrl']} Hz control / 240 Hz physics")
         out = {
             "metric": metric,

@@ -18,8 +18,11 @@ from conftest import REPO
 HEADLINE = "gpd_rollout1_kernelILb0ELb0ELi4ELi0ELb1ELb0E"      # <PID=0, EXT=0, AW=4, ACT=RPM, S1=1, MULTI=0>
 
 
+POLICY = "gpd_rollout_policy_kernelILb1ELi4ELi0ELi5ELb0E"  # <EXT=1, AW=4, ACT=RPM, NK1=5 (72-float rows), tanh>
+
+
 @pytest.fixture(scope="module")
-def headline_isa():
+def gpd_asm():
     from gym_pybullet_drones_amd import _native
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
@@ -30,11 +33,18 @@ def headline_isa():
         subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", "-I", os.path.join(REPO, "include"),
                                           os.path.join(REPO, "gym-pybullet-drones_amd", "csrc", "gpd.hip"), "-o", out],
                        check=True, capture_output=True)
-        lines = open(out).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*" + HEADLINE + r"\w*:", l))
+        return open(out).read().split("\n")
+
+
+def _kernel(lines, name):
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*" + name + r"\w*:", l))
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
-    meta = "\n".join(lines[end:end + 80])
-    return lines[start:end], meta
+    return lines[start:end], "\n".join(lines[end:end + 80])
+
+
+@pytest.fixture(scope="module")
+def headline_isa(gpd_asm):
+    return _kernel(gpd_asm, HEADLINE)
 
 
 def _ops(lines):
@@ -71,3 +81,14 @@ def test_action_rows_are_claimed_with_an_exact_count(headline_isa):
     # stores of the loop use <uniform base in SGPRs> + <32-bit lane offset>
     stores = [s for op, s in _ops(loop[:first]) if op.startswith("global_store")]
     assert len(stores) == 18 and all(re.search(r"s\[\d+:\d+\]", s) for s in stores), stores[:3]
+
+
+def test_policy_kernel_runs_its_layers_on_the_matrix_cores(gpd_asm):
+    """gpd_rollout_policy for the reference's 72-float rows: 44 operand tiles x 3 bf16 hi/lo products = 132 MFMAs per step, both
+    column tiles' layer-1 operands from lane-half swaps (no LDS round trip for activations), no scratch."""
+    body, meta = _kernel(gpd_asm, POLICY)
+    assert re.search(r"ScratchSize: 0\b", meta), "the policy kernel spills to scratch"
+    ops = Counter(op for op, _ in _ops(body))
+    assert ops["v_mfma_f32_32x32x16_bf16"] == 132, ops["v_mfma_f32_32x32x16_bf16"]
+    assert ops["v_permlane32_swap_b32_e32"] >= 40 and ops["v_exp_f32_e32"] == 128 and ops["v_cvt_pk_bf16_f32"] >= 140
+    assert not [op for op in ops if op.startswith("scratch_")]
