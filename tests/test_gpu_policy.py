@@ -68,22 +68,25 @@ def test_policy_actions_match_the_float64_actor_every_step(gpu_device, act, ctrl
         np.testing.assert_array_equal(env.history().cpu().numpy().reshape(E, H, A)[:, -min(H, K):], acts[-min(H, K):].cpu().numpy().reshape(-1, E, A).transpose(1, 0, 2))
 
 
-@pytest.mark.parametrize("act,ctrl,hist", [("rpm", 30, True), ("one_d_rpm", 240, False), ("rpm", 48, False)])
-def test_policy_rollout_is_bitwise_stepping_its_actions(gpu_device, act, ctrl, hist):
+@pytest.mark.parametrize("act,ctrl,hist,phys", [("rpm", 30, True, "dyn"), ("one_d_rpm", 240, False, "dyn"), ("rpm", 48, False, "dyn"),
+                                                ("rpm", 30, True, "pyb_gnd_drag_dw"), ("one_d_rpm", 30, True, "pyb_drag")])
+def test_policy_rollout_is_bitwise_stepping_its_actions(gpu_device, act, ctrl, hist, phys):
     """The physics inside the policy kernel is the shared `env_step`: feeding the actions it chose to `gpd_step` one at a time
     reproduces its observations, rewards, flags, state and action ring bit for bit."""
     from gym_pybullet_drones_amd.policy import MlpPolicy
     E, K = 777, 25
     mode = "lazy" if hist else False
-    a, b = (_env(act, ctrl, mode, E, gpu_device, episode_len_sec=10.0 / ctrl) for _ in range(2))
+    from gym_pybullet_drones_amd.utils.enums import Physics
+    a, b = (_env(act, ctrl, mode, E, gpu_device, episode_len_sec=10.0 / ctrl, physics=Physics(phys)) for _ in range(2))
     A, H = a.ACT_DIM, ctrl // 2
     pol = MlpPolicy.random(12 + (H * A if hist else 0), A, seed=3, gain=1.2, device=gpu_device)
     obs, rew, term, trunc, acts = a.rollout_policy(pol, K)
     for t in range(K):
         o, r, te, tr, _ = b.step(acts[t])
         assert torch.equal(o, obs[t]) and torch.equal(r, rew[t]) and torch.equal(te, term[t]) and torch.equal(tr, trunc[t]), t
-    for name in ("kin", "step_counter", "obs12", "reward", "terminated", "truncated"):
-        assert torch.equal(getattr(a.core, name), getattr(b.core, name)), name
+    for name in ("kin", "last_rpm", "step_counter", "obs12", "reward", "terminated", "truncated"):
+        if getattr(a.core, name) is not None:
+            assert torch.equal(getattr(a.core, name), getattr(b.core, name)), name
     if hist:
         assert torch.equal(a.history(), b.history())
 
