@@ -81,8 +81,8 @@ _SIGNATURES = {
     "gpd_full_obs": (ctypes.c_int, [ctypes.POINTER(GpdState), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P,
                                     ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_int64, _P]),
     "gpd_downwash_global": (ctypes.c_int, [ctypes.POINTER(GpdParams), _P, ctypes.c_int64, ctypes.c_int32, ctypes.c_float,
-                                           ctypes.c_float, ctypes.c_float, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P, _P,
-                                           _P, _P]),
+                                           ctypes.c_float, ctypes.c_float, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
+                                           ctypes.c_float, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "gpd_reset": (ctypes.c_int, [ctypes.POINTER(GpdState), _P, ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_int32,
                                  ctypes.c_int32, _P, _P]),
     "gpd_pid": (ctypes.c_int, [ctypes.POINTER(GpdParams), _P, ctypes.c_int64, ctypes.c_float, _P, _P, _P, _P, _P, _P,

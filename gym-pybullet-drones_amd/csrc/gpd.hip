@@ -1794,14 +1794,28 @@ __global__ __launch_bounds__(kBlock) void gpd_hist_advance_kernel(int K, int E, 
 // cell of a position: the grid is periodic (cells wrap around), so drones that leave the box the grid was laid over
 // keep spreading over all cells instead of piling up at its border; far-apart drones that alias into neighbouring
 // cells are rejected by the exact distance test
-__device__ __forceinline__ int cell_of(float x, float y, float inv_cell, float x0, float y0, int nx, int ny) {
+struct DwGrid {            // uniform periodic x-y grid of >= 10 m cells, each cell split into nz height bins (nz = 1: none)
+    float inv_cell, x0, y0;
+    int nx, ny;
+    float z0, inv_zbin;
+    int nz;
+};
+
+__device__ __forceinline__ int cell_of(float x, float y, const DwGrid& G) {
     // (clamped before the conversion: float -> int is undefined beyond the int range, and a drone flung 1e10 m away by a
     // diverging downwash term must still land in SOME cell -- which one is irrelevant, every candidate pair is distance-tested)
-    const float fx = fminf(fmaxf(floorf((x - x0) * inv_cell), -1.0e9f), 1.0e9f), fy = fminf(fmaxf(floorf((y - y0) * inv_cell), -1.0e9f), 1.0e9f);
-    int cx = static_cast<int>(fx) % nx, cy = static_cast<int>(fy) % ny;
-    cx = cx < 0 ? cx + nx : cx;
-    cy = cy < 0 ? cy + ny : cy;
-    return cy * nx + cx;
+    const float fx = fminf(fmaxf(floorf((x - G.x0) * G.inv_cell), -1.0e9f), 1.0e9f), fy = fminf(fmaxf(floorf((y - G.y0) * G.inv_cell), -1.0e9f), 1.0e9f);
+    int cx = static_cast<int>(fx) % G.nx, cy = static_cast<int>(fy) % G.ny;
+    cx = cx < 0 ? cx + G.nx : cx;
+    cy = cy < 0 ? cy + G.ny : cy;
+    return cy * G.nx + cx;
+}
+// sort key: cell * nz + height bin.  Bin b holds z0 + b/inv_zbin <= z < z0 + (b+1)/inv_zbin; bin 0 also everything below,
+// bin nz-1 everything above.  Inside a cell the drones are thereby ordered by height bin, and a group of drones whose lowest
+// bin is b can skip every candidate in a bin below b: such a candidate is below all of them (dz < 0), the model ignores it.
+__device__ __forceinline__ int key_of(float x, float y, float z, const DwGrid& G) {
+    const float fz = fminf(fmaxf(floorf((z - G.z0) * G.inv_zbin), 0.0f), static_cast<float>(G.nz - 1));
+    return cell_of(x, y, G) * G.nz + static_cast<int>(fz);
 }
 
 // The sort's two passes visit the drones in `visit` order (NULL: 0, 1, 2 ...).  Handing in the previous call's `order`
@@ -1818,9 +1832,8 @@ __device__ __forceinline__ void run_of(int c, int lane, int& head_lane, int& len
     len = (above ? __builtin_ctzll(above) : 64) - head_lane;
 }
 
-__global__ __launch_bounds__(kBlock) void dwg_count_kernel(const float* __restrict__ kin, int64_t ld, int n, float inv_cell,
-                                                           float x0, float y0, int nx, int ny, const int* __restrict__ visit,
-                                                           int* __restrict__ count) {
+__global__ __launch_bounds__(kBlock) void dwg_count_kernel(const float* __restrict__ kin, int64_t ld, int n, const DwGrid G,
+                                                           const int* __restrict__ visit, int* __restrict__ count) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int c = -1 - lane;                                      // (no drone: a run of its own, no atomic)
@@ -1829,7 +1842,7 @@ __global__ __launch_bounds__(kBlock) void dwg_count_kernel(const float* __restri
         const float x = kin[d], y = kin[ld + d], z = kin[2 * ld + d];
         // a drone whose position is no longer finite (the downwash model diverges when two drones pass each other
         // vertically, dz -> 0+) takes no part: it would otherwise alias into cell 0 together with every other such drone
-        if (isfinite(x) && isfinite(y) && isfinite(z)) c = cell_of(x, y, inv_cell, x0, y0, nx, ny);
+        if (isfinite(x) && isfinite(y) && isfinite(z)) c = key_of(x, y, z, G);
     }
     int head_lane, len;
     run_of(c, lane, head_lane, len);
@@ -1857,31 +1870,31 @@ __global__ __launch_bounds__(1024) void dwg_scan_kernel(int* __restrict__ count,
     if (t == 1023) start[cells] = part[1023];
 }
 
-__global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const float* __restrict__ kin, int64_t ld, int n, float inv_cell,
-                                                             float x0, float y0, int nx, int ny, const int* __restrict__ visit,
-                                                             int* __restrict__ cursor, const int* __restrict__ start,
-                                                             int* __restrict__ order, float4* __restrict__ sorted,
-                                                             float* __restrict__ dw_out) {
+__global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const float* __restrict__ kin, int64_t ld, int n, const DwGrid G,
+                                                             const int* __restrict__ visit, int* __restrict__ cursor,
+                                                             const int* __restrict__ start, int* __restrict__ order,
+                                                             float4* __restrict__ sorted, float* __restrict__ dw_out) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    const int keys = G.nx * G.ny * G.nz;
     int c = -1 - lane, d = 0;
     float x = 0.0f, y = 0.0f, z = 0.0f;
     if (i < n) {
         d = visit ? visit[i] : i;
         x = kin[d]; y = kin[ld + d]; z = kin[2 * ld + d];
         if (isfinite(x) && isfinite(y) && isfinite(z)) {
-            c = cell_of(x, y, inv_cell, x0, y0, nx, ny);
+            c = key_of(x, y, z, G);
         } else {
             // (see dwg_count_kernel) no force on it, none from it; it keeps a slot behind the sorted drones so that `order`
             // stays a permutation (the next call visits the drones in this order)
             dw_out[d] = 0.0f;
-            order[start[nx * ny] + atomicAdd(&cursor[nx * ny], 1)] = d;
+            order[start[keys] + atomicAdd(&cursor[keys], 1)] = d;
         }
     }
     int head_lane, len;
     run_of(c, lane, head_lane, len);
     int base = 0;
-    if (lane == head_lane && c >= 0) base = start[c] + atomicAdd(&cursor[c], len);   // one atomic per run of equal cells
+    if (lane == head_lane && c >= 0) base = start[c] + atomicAdd(&cursor[c], len);   // one atomic per run of equal keys
     base = __shfl(base, head_lane);
     if (c >= 0) {
         const int slot = base + (lane - head_lane);
@@ -1893,7 +1906,7 @@ __global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const float* __rest
 // One workgroup per grid cell; every drone of the cell sweeps the candidates of the cell's 3x3 neighbourhood, staged
 // through LDS (broadcast reads instead of a dependent global load per candidate).
 constexpr int kDwTile = 1024;     // candidates staged in LDS at a time (16 KiB)
-__global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, int nx, int ny,
+__global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, const DwGrid G,
                                                            const int* __restrict__ start, const int* __restrict__ order,
                                                            const float4* __restrict__ sorted, float* __restrict__ dw_out,
                                                            int* __restrict__ cursor) {
@@ -1903,30 +1916,37 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, in
     // point, hence the four-way split changes no bit of the result.
     __shared__ float4 tile[kDwTile];
     __shared__ long long part[kBlock];
+    const int nx = G.nx, ny = G.ny, nz = G.nz;
     const int c = blockIdx.x;
     const int cy = c / nx, cx = c - cy * nx;
-    const int m0 = start[c], m1 = start[c + 1];            // the drones of this cell
-    // the sort's per-cell counters / cursors are done with: leave them zeroed for the next call (no memset node per call)
-    if (threadIdx.x == 0) { cursor[c] = 0; if (c == 0) cursor[nx * ny] = 0; }
+    const int m0 = start[c * nz], m1 = start[(c + 1) * nz];   // the drones of this cell, ordered by height bin
+    // the sort's per-key counters / cursors are done with: leave them zeroed for the next call (no memset node per call)
+    if (threadIdx.x < nz) cursor[c * nz + threadIdx.x] = 0;
+    if (c == 0 && threadIdx.x == 0) cursor[nx * ny * nz] = 0;
     if (m0 == m1) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float kr = 0.25f * P.prop_radius;
     // The candidates of the 3x3 neighbourhood (periodic; nx, ny >= 3: nine distinct cells) are nine runs of the sorted
     // array.  They are staged as ONE concatenated list, kDwTile at a time: one pair of barriers and one round of global
     // loads per ~1000 candidates instead of per cell (the loads' latency sits between the two barriers).
-    int run0[9], pre[10];                                  // first element of each run; prefix sums of the run lengths
-    pre[0] = 0;
+    int nb_cell[9];
 #pragma unroll
-    for (int nb = 0; nb < 9; ++nb) {
-        const int yy = (cy + nb / 3 - 1 + ny) % ny, xx = (cx + nb % 3 - 1 + nx) % nx;
-        run0[nb] = start[yy * nx + xx];
-        pre[nb + 1] = pre[nb] + (start[yy * nx + xx + 1] - run0[nb]);
-    }
-    const int total = pre[9];
+    for (int nb = 0; nb < 9; ++nb) nb_cell[nb] = ((cy + nb / 3 - 1 + ny) % ny) * nx + (cx + nb % 3 - 1 + nx) % nx;
     for (int base = m0; base < m1; base += 64) {           // groups of 64 drones
         const int s = base + lane;
         const bool have = s < m1;
         const float4 me = have ? sorted[s] : make_float4(0.0f, 0.0f, 3.0e38f, 0.0f);   // (no drone: nothing is above it)
+        // the group's lowest height bin is its first drone's (the cell is ordered by bin): every neighbour cell's run starts
+        // at that bin -- candidates in lower bins are below all 64 drones and would only fail the dz > 0 test one by one
+        const int bmin = __float_as_int(sorted[base].w) % nz;
+        int run0[9], pre[10];                              // first element of each run; prefix sums of the run lengths
+        pre[0] = 0;
+#pragma unroll
+        for (int nb = 0; nb < 9; ++nb) {
+            run0[nb] = start[nb_cell[nb] * nz + bmin];
+            pre[nb + 1] = pre[nb] + (start[(nb_cell[nb] + 1) * nz] - run0[nb]);
+        }
+        const int total = pre[9];
         long long acc = 0;                                 // sum of contributions in units of 2^-30 N: order-independent
         for (int v0 = 0; v0 < total; v0 += kDwTile) {
             const int cnt = min(kDwTile, total - v0);
@@ -2361,25 +2381,27 @@ int gpd_full_obs(const GpdState* state, int32_t num_steps, int32_t n_drones, int
 }
 
 int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, int32_t n, float cell, float x0,
-                        float y0, int32_t nx, int32_t ny, const int32_t* visit_order, int32_t* cell_count,
-                        int32_t* cell_start, int32_t* order, float* sorted_xyzc, float* dw_out, void* stream) {
+                        float y0, int32_t nx, int32_t ny, float z0, float zbin, int32_t nz, const int32_t* visit_order,
+                        int32_t* cell_count, int32_t* cell_start, int32_t* order, float* sorted_xyzc, float* dw_out,
+                        void* stream) {
     if (!params || !kin || !cell_count || !cell_start || !order || !sorted_xyzc || !dw_out)
         return fail(GPD_EINVAL, "gpd_downwash_global: NULL argument");
     if (n <= 0 || ld < n) return fail(GPD_EINVAL, "gpd_downwash_global: need 0 < n <= ld");
     if (visit_order == order) return fail(GPD_EINVAL, "gpd_downwash_global: visit_order must not alias order (ping-pong two buffers)");
     if (!(cell >= 10.0f)) return fail(GPD_EINVAL, "gpd_downwash_global: cell must be >= 10 m (the model's lateral cut-off)");
-    if (nx < 3 || ny < 3 || static_cast<int64_t>(nx) * ny > 65536)
-        return fail(GPD_ERANGE, "gpd_downwash_global: need nx, ny >= 3 (periodic 3x3 search) and nx*ny <= 65536");
+    if (nz < 1 || nz > kBlock || (nz > 1 && !(zbin > 0.0f))) return fail(GPD_EINVAL, "gpd_downwash_global: need 1 <= nz <= 256 and zbin > 0");
+    if (nx < 3 || ny < 3 || static_cast<int64_t>(nx) * ny * nz > 65536)
+        return fail(GPD_ERANGE, "gpd_downwash_global: need nx, ny >= 3 (periodic 3x3 search) and nx*ny*nz <= 65536");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int cells = nx * ny;
-    const float inv_cell = 1.0f / cell;
+    const int cells = nx * ny, keys = cells * nz;
+    const DwGrid G{1.0f / cell, x0, y0, nx, ny, z0, nz > 1 ? 1.0f / zbin : 0.0f, nz};
     hipError_t e;
     const dim3 grid(static_cast<unsigned>((n + kBlock - 1) / kBlock));
-    hipLaunchKernelGGL(dwg_count_kernel, grid, dim3(kBlock), 0, st, kin, ld, n, inv_cell, x0, y0, nx, ny, visit_order, cell_count);
-    hipLaunchKernelGGL(dwg_scan_kernel, dim3(1), dim3(1024), 0, st, cell_count, cell_start, cells);
-    hipLaunchKernelGGL(dwg_scatter_kernel, grid, dim3(kBlock), 0, st, kin, ld, n, inv_cell, x0, y0, nx, ny, visit_order,
-                       cell_count, cell_start, order, reinterpret_cast<float4*>(sorted_xyzc), dw_out);
-    hipLaunchKernelGGL(dwg_force_kernel, dim3(static_cast<unsigned>(cells)), dim3(kBlock), 0, st, *params, nx, ny, cell_start,
+    hipLaunchKernelGGL(dwg_count_kernel, grid, dim3(kBlock), 0, st, kin, ld, n, G, visit_order, cell_count);
+    hipLaunchKernelGGL(dwg_scan_kernel, dim3(1), dim3(1024), 0, st, cell_count, cell_start, keys);
+    hipLaunchKernelGGL(dwg_scatter_kernel, grid, dim3(kBlock), 0, st, kin, ld, n, G, visit_order, cell_count, cell_start, order,
+                       reinterpret_cast<float4*>(sorted_xyzc), dw_out);
+    hipLaunchKernelGGL(dwg_force_kernel, dim3(static_cast<unsigned>(cells)), dim3(kBlock), 0, st, *params, G, cell_start,
                        order, reinterpret_cast<const float4*>(sorted_xyzc), dw_out, cell_count);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gpd_downwash_global launch");

@@ -34,7 +34,7 @@ class SwarmAviary:
 
     def __init__(self, num_drones: int, drone_model: DroneModel = DroneModel.CF2X, initial_xyzs=None, initial_rpys=None,
                  physics: Physics = Physics.PYB_DW, pyb_freq: int = 240, ctrl_freq: int = 240, act="raw_rpm",
-                 world_min=None, world_max=None, cell: float = 10.0, device=None):
+                 world_min=None, world_max=None, cell: float = 10.0, zbin: float = 1.0, nz: int = 16, device=None):
         if pyb_freq % ctrl_freq != 0:
             raise ValueError("[ERROR] in SwarmAviary.__init__(), pyb_freq is not divisible by ctrl_freq.")
         if act not in ("raw_rpm", ActionType.RPM, ActionType.PID):
@@ -73,8 +73,12 @@ class SwarmAviary:
             self.cell *= 2
             self.nx, self.ny = max(3, int(np.ceil((hi[0] - lo[0]) / self.cell))), max(3, int(np.ceil((hi[1] - lo[1]) / self.cell)))
         cells = self.nx * self.ny
+        # height bins inside every cell (sort key = cell * nz + bin): a drone only sweeps candidates from its own bin upwards
+        self.zbin = float(zbin)
+        self.z0 = float(xyz[:, 0, 2].min() - self.zbin)
+        self.nz = int(max(1, min(nz, 65536 // cells)))
         i32 = dict(dtype=torch.int32, device=dev)
-        self._count, self._start = torch.zeros(cells + 1, **i32), torch.zeros(cells + 1, **i32)
+        self._count, self._start = torch.zeros(cells * self.nz + 1, **i32), torch.zeros(cells * self.nz + 1, **i32)
         self._order = torch.zeros(N, **i32)          # sorted slot -> drone, filled by every call ...
         self._visit = torch.zeros(N, **i32)          # ... and the previous call's, which the next sort visits the drones in
         self._have_visit = False
@@ -91,7 +95,8 @@ class SwarmAviary:
         with torch.cuda.device(self.device):
             self._order, self._visit = self._visit, self._order      # ping-pong: last call's order is this call's visit order
             rc = c.lib.gpd_downwash_global(ctypes.byref(c._params), _ptr(c.kin), c.ld, self.NUM_DRONES, self.cell, self.x0,
-                                           self.y0, self.nx, self.ny, _ptr(self._visit) if self._have_visit else None,
+                                           self.y0, self.nx, self.ny, self.z0, self.zbin, self.nz,
+                                           _ptr(self._visit) if self._have_visit else None,
                                            _ptr(self._count), _ptr(self._start), _ptr(self._order), _ptr(self._sorted),
                                            _ptr(self.dw_force), c._stream())
         _native.check(rc, "gpd_downwash_global")

@@ -323,22 +323,28 @@ int gpd_full_obs(const GpdState* state, int32_t num_steps, int32_t n_drones, int
  * in 64-bit fixed point (2^-30 N), so the result does not depend on the order the sort leaves the neighbours in.
  *
  *   kin, ld       the state block of gpd_step (rows 0..2 = positions are read)
- *   cell, x0, y0, nx, ny   grid: cell size [m] (>= 10), lower-left corner, cells per side (nx, ny >= 3, nx*ny <= 65536)
+ *   cell, x0, y0, nx, ny   grid: cell size [m] (>= 10), lower-left corner, cells per side (nx, ny >= 3)
+ *   z0, zbin, nz  every cell is split into nz height bins of zbin metres starting at z0 (bin 0 also holds everything below z0,
+ *                 bin nz-1 everything above; nz = 1: no bins, z0/zbin ignored); nx*ny*nz <= 65536.  The sort key is
+ *                 cell*nz + bin, so inside a cell the drones are ordered by height bin and a group of 64 drones skips every
+ *                 candidate in a bin below its own lowest one (such a candidate is below all of them: the model ignores it).
+ *                 Pruning only: any (z0, zbin, nz) gives the same forces bit for bit.
  *   visit_order   [n] int32 permutation of 0..n-1 or NULL (= 0, 1, 2 ...): the order the sort visits the drones in.
  *                 Any permutation gives the same forces bit for bit; handing in the `order` buffer the PREVIOUS call
  *                 filled (two buffers, ping-pong: it must not alias `order`) makes neighbouring lanes share a cell, and
  *                 the sort then issues one atomic per run of equal cells instead of one per drone.
- *   cell_count    [nx*ny + 1] int32: ZERO before the first call; every call leaves it zeroed again (the last kernel
- *                 clears what the sort counted: no memset per call)          cell_start  [nx*ny + 1] int32 scratch
+ *   cell_count    [nx*ny*nz + 1] int32: ZERO before the first call; every call leaves it zeroed again (the last kernel
+ *                 clears what the sort counted: no memset per call)          cell_start  [nx*ny*nz + 1] int32 scratch
  *   order         [n] int32 out (drone index of sorted slot: a permutation of 0..n-1)
- *   sorted_xyzc   [n][4] float scratch (x, y, z, cell id as int bits), sorted by cell
+ *   sorted_xyzc   [n][4] float scratch (x, y, z, sort key as int bits), sorted by key
  *   dw_out        [n] out: the force of drone i at dw_out[i]  (pass it to gpd_step as state.dw_force)
  * Call it once per physics sub-step, before the gpd_step launch of that sub-step (positions are the snapshot every
  * drone sees, envs/BaseAviary.py:346-347).
  */
 int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, int32_t n, float cell, float x0,
-                        float y0, int32_t nx, int32_t ny, const int32_t* visit_order, int32_t* cell_count,
-                        int32_t* cell_start, int32_t* order, float* sorted_xyzc, float* dw_out, void* stream);
+                        float y0, int32_t nx, int32_t ny, float z0, float zbin, int32_t nz, const int32_t* visit_order,
+                        int32_t* cell_count, int32_t* cell_start, int32_t* order, float* sorted_xyzc, float* dw_out,
+                        void* stream);
 
 /*
  * Masked reset.  Replaces BaseAviary.reset/_housekeeping (envs/BaseAviary.py:220-255, 451-477)
