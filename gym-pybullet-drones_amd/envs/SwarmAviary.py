@@ -34,7 +34,7 @@ class SwarmAviary:
 
     def __init__(self, num_drones: int, drone_model: DroneModel = DroneModel.CF2X, initial_xyzs=None, initial_rpys=None,
                  physics: Physics = Physics.PYB_DW, pyb_freq: int = 240, ctrl_freq: int = 240, act="raw_rpm",
-                 world_min=None, world_max=None, cell: float = 10.0, zbin: float = 1.0, nz: int = 16, device=None):
+                 world_min=None, world_max=None, cell: float = 10.0, zbin: float = 1.0, nz: int = 1, device=None):
         if pyb_freq % ctrl_freq != 0:
             raise ValueError("[ERROR] in SwarmAviary.__init__(), pyb_freq is not divisible by ctrl_freq.")
         if act not in ("raw_rpm", ActionType.RPM, ActionType.PID):
@@ -73,7 +73,9 @@ class SwarmAviary:
             self.cell *= 2
             self.nx, self.ny = max(3, int(np.ceil((hi[0] - lo[0]) / self.cell))), max(3, int(np.ceil((hi[1] - lo[1]) / self.cell)))
         cells = self.nx * self.ny
-        # height bins inside every cell (sort key = cell * nz + bin): a drone only sweeps candidates from its own bin upwards
+        # optional height bins inside every cell (sort key = cell * nz + bin): a group of 64 drones sweeps the candidates from
+        # its lowest bin upwards.  Off by default (nz = 1): it pays only when the 64 drones of a group share a height band --
+        # with twelve layers mixed in every cell it prunes nothing and the 16x larger key space costs 20 us per step (measured)
         self.zbin = float(zbin)
         self.z0 = float(xyz[:, 0, 2].min() - self.zbin)
         self.nz = int(max(1, min(nz, 65536 // cells)))

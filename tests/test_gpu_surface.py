@@ -308,9 +308,9 @@ def test_swarm_downwash_is_order_independent_and_matches_the_workgroup_path(gpu_
     a = SwarmAviary(N, initial_xyzs=xyz, physics=Physics.PYB_DW, device=gpu_device)
     b = SwarmAviary(N, initial_xyzs=xyz[perm], physics=Physics.PYB_DW, world_min=(-30, -30), world_max=(30, 30), device=gpu_device)
     fa, fb = a.downwash().clone(), b.downwash().clone()
-    # (3) the height bins inside a cell only prune candidates that are below every drone of a group: no bins, the default
-    # sixteen 1 m bins and sixty-four 0.25 m bins (drones in the clamped bottom and top bins) give the same forces, bit for bit
-    for kw in (dict(nz=1), dict(zbin=0.25, nz=64), dict(zbin=0.4, nz=5)):
+    # (3) the height bins inside a cell only prune candidates that are below every drone of a group: no bins (the default),
+    # sixteen 1 m bins, sixty-four 0.25 m bins and five 0.4 m bins (drones in the clamped bottom and top bins) give the same forces, bit for bit
+    for kw in (dict(zbin=1.0, nz=16), dict(zbin=0.25, nz=64), dict(zbin=0.4, nz=5)):
         c = SwarmAviary(N, initial_xyzs=xyz, physics=Physics.PYB_DW, device=gpu_device, **kw)
         assert c.nz == kw["nz"] and torch.equal(c.downwash(), fa), kw
         assert torch.equal(c.downwash(), fa)                 # ... also on the second call (visit order = the previous call's order)
