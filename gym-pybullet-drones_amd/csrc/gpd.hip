@@ -1932,13 +1932,23 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
     int nb_cell[9];
 #pragma unroll
     for (int nb = 0; nb < 9; ++nb) nb_cell[nb] = ((cy + nb / 3 - 1 + ny) % ny) * nx + (cx + nb % 3 - 1 + nx) % nx;
-    for (int base = m0; base < m1; base += 64) {           // groups of 64 drones
+    // Groups of 64 drones (lane = drone).  One group: the four waves hold the SAME 64 drones and split the candidates four ways;
+    // two groups left: two waves per group, candidates split two ways; three or more: one group per wave.  A cell holds ~64 drones
+    // with a Poisson spread, so nearly half the cells have a second, mostly empty group -- it now rides along in the same pass
+    // over the candidates instead of costing a pass of its own.  (Fixed-point partial sums: the split changes no bit.)
+    const int ngroups = (m1 - m0 + 63) >> 6;
+    for (int g0 = 0; g0 < ngroups;) {
+        const int rem = ngroups - g0;
+        const int gp = rem >= 3 ? 4 : rem;                 // groups in this pass: 1, 2 or 4 (a fourth may be empty)
+        const int ways = 4 / gp;                           // waves per group
+        const int grp = wave % gp, split = wave / gp;
+        const int base = m0 + 64 * (g0 + grp);
         const int s = base + lane;
         const bool have = s < m1;
         const float4 me = have ? sorted[s] : make_float4(0.0f, 0.0f, 3.0e38f, 0.0f);   // (no drone: nothing is above it)
-        // the group's lowest height bin is its first drone's (the cell is ordered by bin): every neighbour cell's run starts
-        // at that bin -- candidates in lower bins are below all 64 drones and would only fail the dz > 0 test one by one
-        const int bmin = __float_as_int(sorted[base].w) % nz;
+        // the pass's lowest height bin is its first drone's (the cell is ordered by bin): every neighbour cell's run starts
+        // at that bin -- candidates in lower bins are below all drones of the pass and would only fail the dz > 0 test one by one
+        const int bmin = __float_as_int(sorted[m0 + 64 * g0].w) % nz;
         int run0[9], pre[10];                              // first element of each run; prefix sums of the run lengths
         pre[0] = 0;
 #pragma unroll
@@ -1960,7 +1970,7 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
             }
             __syncthreads();
 #pragma unroll 4
-            for (int j = wave; j < cnt; j += 4) {          // this wave's quarter of the candidates
+            for (int j = split; j < cnt; j += ways) {      // this wave's share of the candidates
                 const float4 o = tile[j];
                 const float dz = o.z - me.z;
                 const float ddx = o.x - me.x, ddy = o.y - me.y;
@@ -1977,13 +1987,15 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
                 }
             }
         }
-        __syncthreads();                                   // (all waves are done with `part` of the previous group)
+        __syncthreads();                                   // (all waves are done with `part` of the previous pass)
         part[threadIdx.x] = acc;
         __syncthreads();
-        if (wave == 0 && have) {
-            const long long sum = (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
+        if (split == 0 && have) {                          // the group's first wave adds up the shares of its `ways` waves
+            long long sum = 0;
+            for (int k = 0; k < ways; ++k) sum += part[(k * gp + grp) * 64 + lane];
             dw_out[order[s]] = -static_cast<float>(static_cast<double>(sum) * (1.0 / 1073741824.0));
         }
+        g0 += gp;
     }
 }
 
