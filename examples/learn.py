@@ -97,19 +97,46 @@ def run(num_envs=4096, iters=60, horizon=128, target=474.0, epochs=4, minibatche
                       f"({sim_steps / (time.time() - t0):.3g} env-steps/s incl. learning)")
             if mean_ret >= target:
                 break
-    # deterministic evaluation: one full episode of every aviary with the mean action
-    obs = env.reset()[0].view(E, obs_dim)
-    tot, alive = torch.zeros(E, device=dev), torch.ones(E, dtype=torch.bool, device=dev)
-    with torch.no_grad():
-        for _ in range(242):
-            obs_n, r, term, trunc, _ = env.step(net.pi(obs).clamp(-1, 1).view(E, 1, act_dim))
+    # Deterministic evaluation: one full episode of every aviary with the mean action -- the loop of the reference's
+    # examples/learn.py:157-192.  Twice: (a) the policy as torch operations between two env.step() launches, (b) the whole
+    # 242-step episode in ONE launch with the trained actor evaluated inside the kernel (gpd_rollout_policy).
+    def episode_return(step_fn):
+        tot, alive = torch.zeros(E, device=dev), torch.ones(E, dtype=torch.bool, device=dev)
+        for r, done in step_fn():
             tot += r * alive
-            alive &= ~(term | trunc)
-            obs = obs_n.view(E, obs_dim)
-    eval_ret = float(tot.mean())
+            alive &= ~done
+        return float(tot.mean())
+
+    def fresh_episode():        # every aviary at its initial pose with an empty (all-zero) action buffer
+        env.core.ring_pos.zero_()
+        env.core.act_ring.zero_()
+        return env.reset()[0].view(E, obs_dim)
+
+    def torch_loop():
+        obs = fresh_episode()
+        with torch.no_grad():
+            for _ in range(242):
+                obs_n, r, term, trunc, _ = env.step(net.pi(obs).clamp(-1, 1).view(E, 1, act_dim))
+                yield r, term | trunc
+                obs = obs_n.view(E, obs_dim)
+
+    def in_kernel():
+        from gym_pybullet_drones_amd.policy import MlpPolicy
+        pol = MlpPolicy(net.pi[0].weight.detach(), net.pi[0].bias.detach(), net.pi[2].weight.detach(), net.pi[2].bias.detach(),
+                        net.pi[4].weight.detach(), net.pi[4].bias.detach(), device=dev)
+        fresh_episode()
+        _, rew, term, trunc, _ = env.rollout_policy(pol, 242)
+        for t in range(242):
+            yield rew[t], term[t] | trunc[t]
+
+    t1 = time.time(); torch.cuda.synchronize()
+    eval_torch = episode_return(torch_loop); torch.cuda.synchronize(); t2 = time.time()
+    eval_ret = episode_return(in_kernel); torch.cuda.synchronize(); t3 = time.time()
     if verbose:
-        print(f"[learn.py] deterministic evaluation over {E} episodes: mean reward {eval_ret:.2f} (target {target}), "
+        print(f"[learn.py] deterministic evaluation over {E} episodes: mean reward {eval_ret:.2f} with the policy inside the kernel "
+              f"({(t3 - t2) * 1e3:.0f} ms), {eval_torch:.2f} with the policy between the steps ({(t2 - t1) * 1e3:.0f} ms); target {target}, "
               f"wall {time.time() - t0:.1f}s")
+    run.last_eval_torch = eval_torch
     return history, eval_ret
 
 

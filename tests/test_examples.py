@@ -56,3 +56,6 @@ def test_learn(gpu_device):
     history, eval_ret = m.run(num_envs=2048, iters=25, verbose=False, device=gpu_device)
     assert history[0] < 250                      # an untrained policy drifts away / times out low
     assert eval_ret > 440 and max(history) > 430
+    # the evaluation episode ran twice: 242 launches with the actor as torch operations in between, and ONE launch with the
+    # trained actor inside the kernel -- the same policy from the same start, the same return (fp32 torch vs bf16 hi/lo MFMA)
+    assert abs(m.run.last_eval_torch - eval_ret) < 0.1
