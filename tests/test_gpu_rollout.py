@@ -16,12 +16,15 @@ CASES = [  # act, flags, D, S, model
     ("rpm", 0, 1, 1, "cf2x"), ("rpm", 0, 1, 8, "cf2p"), ("one_d_rpm", 7, 1, 2, "racer"), ("pid", 0, 1, 1, "cf2x"),
     ("pid", 7, 3, 2, "cf2x"), ("vel", 2, 2, 4, "cf2p"), ("one_d_pid", 5, 8, 1, "cf2x"), ("raw_rpm", 7, 5, 2, "racer"),
     ("rpm", 4, 2, 8, "cf2x"),
+    ("rpm", 15, 1, 2, "cf2x"), ("one_d_rpm", 9, 4, 8, "cf2p"),      # the ground plane (GPD_PHYS_GROUND = 8) in both rollout kernels
 ]
 
 
 def _pair(act, flags, D, S, model, dev, E, rng, auto_reset=True, keep_term=True):
     task = "none" if act == "raw_rpm" else ("hover" if D == 1 else "multihover")
     xyz, rpy = _random_scene(rng, E, D)
+    if flags & 8:          # a third of the aviaries start on / within centimetres of the ground plane
+        xyz[::3, :, 2] = rng.uniform(0.0, 0.04, size=xyz[::3, :, 2].shape) + (0.3 * np.arange(D) if D > 1 else 0.0)
     tgt = None if task == "none" else xyz + np.array([0, 0, 0.3])
     mk = lambda: _core(model, E, D, flags, S, act, task, xyz, rpy, dev, auto_reset=auto_reset, target=tgt,  # noqa: E731
                        keep_term=keep_term)
