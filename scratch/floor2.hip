@@ -83,6 +83,19 @@ __global__ __launch_bounds__(256) void k_stream(const f4v* __restrict__ act, f4v
     }
 }
 
+// pure store stream: what the memory system takes when NOTHING is read (grid-stride, 16 bytes per lane and store, non-temporal)
+__global__ __launch_bounds__(256) void k_fill(f4v* __restrict__ out, size_t n16, float v) {
+    const f4v x = {v, v + 1.0f, v + 2.0f, v + 3.0f};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+        __builtin_nontemporal_store(x, &out[i]);
+}
+__global__ __launch_bounds__(256) void k_sum(const f4v* __restrict__ in, float* __restrict__ out, size_t n16) {
+    f4v acc = {0, 0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+        acc += __builtin_nontemporal_load(&in[i]);
+    if (acc.x + acc.y + acc.z + acc.w == 12345.0f) out[0] = 1.0f;
+}
+
 int main() {
     const int n = 65536, ld = 65536;
     float* a; f4v* a4; float4* act; f4v* obs;
@@ -117,6 +130,27 @@ int main() {
     bench("  ... packed + non-temporal", [&](int) { hipLaunchKernelGGL((k_like4<true>), dim3(256), dim3(256), 0, st, a4, act, obs, ld, n); });
     bench("  ... SoA + a 600-byte by-value argument", [&](int) { hipLaunchKernelGGL(k_like_big, dim3(256), dim3(256), 0, st, P, a, act, obs, ld, n); });
     bench("  ... packed, 1024 x 64 threads", [&](int) { hipLaunchKernelGGL((k_like4<false>), dim3(1024), dim3(64), 0, st, a4, act, obs, ld, n); });
+    {   // store-only and load-only streams over 1 GiB (far beyond the 256 MB Infinity Cache), at the headline's occupancy (256
+        // workgroups = one wave per SIMD) and with the chip full (4096 workgroups)
+        const size_t n16 = (size_t)1 << 26;               // 2^26 x 16 B = 1 GiB
+        f4v* big; float* flag; CK(hipMalloc(&big, n16 * 16)); CK(hipMalloc(&flag, 4));
+        CK(hipMemset(big, 0, n16 * 16));
+        for (int grid : {256, 1024, 4096}) {
+            for (int kind = 0; kind < 2; ++kind) {
+                hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+                auto go = [&]() { if (kind == 0) hipLaunchKernelGGL(k_fill, dim3(grid), dim3(256), 0, st, big, n16, 1.0f);
+                                  else hipLaunchKernelGGL(k_sum, dim3(grid), dim3(256), 0, st, big, flag, n16); };
+                go(); go(); CK(hipStreamSynchronize(st));
+                CK(hipEventRecord(e0, st));
+                for (int i = 0; i < 20; ++i) go();
+                CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("%-10s 1 GiB, %4d workgroups x 256                     %.0f GB/s\n", kind == 0 ? "store-only" : "load-only", grid,
+                       (double)n16 * 16 * 20 / (ms * 1e-3) / 1e9);
+            }
+        }
+        hipFree(big); hipFree(flag);
+    }
     {   // the write-heavy stream of a 64-step rollout at N = 65536: 70 B per drone and step, 77 % of it written
         const int steps = 64;
         f4v *sa, *so; float* sr; unsigned char* sf;
