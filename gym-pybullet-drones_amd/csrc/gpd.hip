@@ -1182,6 +1182,7 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
 //     the empty asm keeps the zero-extension of the offsets inside the loop (hoisted, it turns every store into a
 //     64-bit VALU add plus a flat-addressed store).
 // ------------------------------------------------------------------------------------------------
+template <bool NT_OBS = true>     // NT_OBS: the observation bursts are stored non-temporally (see launch_step for when not)
 struct RollOut {
     char* og_prev; char* og; char* rg; uint8_t* tg; uint8_t* ug;     // obs block of the previous / this step, reward, flags
     int64_t obs_step, env_step;                                     // bytes / elements between consecutive steps
@@ -1197,9 +1198,15 @@ struct RollOut {
     }
     __device__ __forceinline__ void bursts(char* base) {
         asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2));
-        __builtin_nontemporal_store(pend[0], reinterpret_cast<f4v*>(base + g0));   // written once, streamed out
-        __builtin_nontemporal_store(pend[1], reinterpret_cast<f4v*>(base + g1));
-        __builtin_nontemporal_store(pend[2], reinterpret_cast<f4v*>(base + g2));
+        if (NT_OBS) {
+            __builtin_nontemporal_store(pend[0], reinterpret_cast<f4v*>(base + g0));   // written once, streamed out
+            __builtin_nontemporal_store(pend[1], reinterpret_cast<f4v*>(base + g1));
+            __builtin_nontemporal_store(pend[2], reinterpret_cast<f4v*>(base + g2));
+        } else {
+            *reinterpret_cast<f4v*>(base + g0) = pend[0];
+            *reinterpret_cast<f4v*>(base + g1) = pend[1];
+            *reinterpret_cast<f4v*>(base + g2) = pend[2];
+        }
     }
     // `advance`: false on the first step of the launch (the pointers already address step 0)
     __device__ __forceinline__ void emit(const StepOut& out, bool advance) {
@@ -1244,7 +1251,7 @@ struct RollOut {
 // env_step, no workgroup barrier).  Every lane of an aviary ends a step with the aviary's reward and flags and stores
 // them to the aviary's slot -- D identical writes instead of a branch; a lane without a drone is a clone of the drone with
 // the same index d in its workgroup's first aviary, so whole clone aviaries replay that aviary bit for bit.
-template <bool PID, bool EXT, int AW, int ACT, bool S1, bool MULTI>
+template <bool PID, bool EXT, int AW, int ACT, bool S1, bool MULTI, bool NT_OBS = true>
 __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     const GpdParams P, const GpdState S, const GpdStepCfg C, const Span T, const float* __restrict__ action,
     const float* __restrict__ target_pos, const float* __restrict__ init_pose, float* __restrict__ obs12,
@@ -1305,7 +1312,7 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
 
     (void)term_obs12;   // (terminal observations: the host routes such calls to gpd_rollout_kernel -- a conditional
                         // store in this loop body would make the wait counts conservative again)
-    RollOut ro(obs12, reward, terminated, truncated, T, goff, eoff4, L.env, sh_rows + tid * 12, lsrc);
+    RollOut<NT_OBS> ro(obs12, reward, terminated, truncated, T, goff, eoff4, L.env, sh_rows + tid * 12, lsrc);
     auto do_step = [&](const int t, const float4 act) {
         StepOut out;
         env_step<PID, EXT, MULTI, AW, ACT, S1>(P, C, flags, D, L, act, tgx, tgy, tgz, true, ipose, ip[0], ip[1], ip[2], ip[3],
@@ -2163,7 +2170,15 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
             hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, true, AW>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
                                action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
         } else if (!store_wave_variant && term_obs12 == nullptr) {
-            if (C.substeps == 1)
+            // The headline shape -- plain DYN, RPM actions, one sub-step, a batch that leaves one wave per SIMD -- stores its
+            // observation bursts as ordinary stores: measured 3-4 % faster there (0.837 -> 0.803 us per step), while every other
+            // shape (larger batches, sub-step loops, multi-drone aviaries) is 1-3 % faster with non-temporal ones
+            // (A/B on one box, round 2: scratch/ab.sh, scratch/ab2.sh) -- and only for long rollouts: the ordinary stores leave
+            // their lines to the end-of-kernel write-back, which a 20-step launch does not amortise (1.14 vs 1.00 us per step).
+            if (C.substeps == 1 && !PID && !EXT && ACT == GPD_ACT_RPM && N <= (1 << 17) && T.num_steps >= 48)
+                hipLaunchKernelGGL((gpd_rollout1_kernel<false, false, 4, GPD_ACT_RPM, true, false, false>), grid, dim3(kBlock), 0, st, P, S, C, Tr,
+                                   action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+            else if (C.substeps == 1)
                 hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, true, false>), grid, dim3(kBlock), 0, st, P, S, C, Tr, action,
                                    target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
             else

@@ -1,9 +1,8 @@
 #!/bin/bash
-# usage: scratch/ab.sh "<workloads>" <lib1> <lib2> ...   -> us/launch for each lib x workload, 2 rounds interleaved
-WL=$1; shift
-for round in 1 2; do for lib in "$@"; do for w in $WL; do
-  GPD_LIB=$lib python bench.py --workload $w --no-cpu-baseline --steps 1920 --warmup 192 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$lib', d['config']['workload'], 'us/launch %.2f'%d['roofline']['launch_us_hip_events'], 'GB/s %.0f'%d['roofline']['achieved'])
-"; done; done; done
+# A/B of library builds on ONE box: scratch/ab.sh <lib.so> ... (the default in-tree build first)
+run() { GPD_LIB=$1 timeout 200 python bench.py --no-cpu-baseline --no-second-leg ${@:2} 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.load(sys.stdin); print('%-44s us/step %.4f  frac %.3f' % ('$1'[-44:], d['ms_per_step']*1e3, d['roofline']['frac']))"; }
+for rep in 1 2; do
+  run gym-pybullet-drones_amd/csrc/libgpd.so "${ARGS[@]}"
+  for l in "$@"; do run $l; done
+done
