@@ -805,7 +805,8 @@ __device__ __forceinline__ void store_carry(const GpdState& S, const Lane& L, co
 // observation row and the aviary's reward / flags itself (latency matters more than anything here: at
 // N = 65 536 a launch lasts ~5 us).
 // ------------------------------------------------------------------------------------------------
-template <bool PID, bool EXT, bool MULTI, int AW>
+// ACT / S1: the action type and "one sub-step per step" as compile-time constants (no action-type ladder, no sub-step loop)
+template <bool PID, bool EXT, bool MULTI, int AW, int ACT, bool S1>
 __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     const GpdParams P, const GpdState S, const GpdStepCfg C, const float* __restrict__ action,
     const float* __restrict__ target_pos, const float* __restrict__ init_pose, float* __restrict__ obs12,
@@ -847,13 +848,15 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     if (PID) quat_to_rpy(c.k.qx, c.k.qy, c.k.qz, c.k.qw, c.roll, c.pitch, c.yaw);
 
     StepOut out;
-    env_step<PID, EXT, MULTI, AW>(P, C, flags, D, L, act, tgx, tgy, tgz, false, ipose, ip[0], ip[1], ip[2], ip[3], ip[4], ip[5],
-                              ip[6], sh_pos, sh_red, c, out);
+    env_step<PID, EXT, MULTI, AW, ACT, S1>(P, C, flags, D, L, act, tgx, tgy, tgz, false, ipose, ip[0], ip[1], ip[2], ip[3], ip[4],
+                                           ip[5], ip[6], sh_pos, sh_red, c, out);
     // Observation rows.  A lane's row is 48 bytes, so a wave's direct stores are 48-byte-strided pieces of cache
     // lines; in the bandwidth-bound regime (large batches) the wave transposes its 64 rows through LDS and
-    // stores three fully coalesced 1 KiB bursts instead (the rows of a wave are contiguous in memory).  Small
-    // batches are latency-bound and store directly (one LDS round trip less on the critical path).
-    const bool big = C.lanes_per_wave == 64 && N >= (1u << 18);
+    // stores three fully coalesced 1 KiB bursts instead (the rows of a wave are contiguous in memory); narrower waves
+    // (lanes_per_wave < 64, a tuning knob) store directly.
+    // (round 1 kept direct 48-byte row stores below 2^18 drones; a round-2 A/B on one box has the transposed bursts ahead at
+    // every size: 4.74 -> 4.38 us per step at N = 65 536, -8..10 % with DSLPID / 8 sub-steps / 8-drone aviaries, equal at 4 096)
+    const bool big = C.lanes_per_wave == 64;
     if (big) {
         float4* mine = reinterpret_cast<float4*>(sh_rows + tid * 12);
         mine[0] = make_float4(out.o[0], out.o[1], out.o[2], out.o[3]);
@@ -885,9 +888,10 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
                     out.o[9], out.o[10], out.o[11]);
     }
     if (L.d == 0) {
-        reward[L.env] = out.rew;
-        terminated[L.env] = out.term ? 1 : 0;
-        truncated[L.env] = out.trunc ? 1 : 0;
+        // (written once, read by another kernel: non-temporal like the observation bursts -- 4.38 -> 4.30 us per step, A/B)
+        __builtin_nontemporal_store(out.rew, &reward[L.env]);
+        __builtin_nontemporal_store(static_cast<uint8_t>(out.term ? 1 : 0), &terminated[L.env]);
+        __builtin_nontemporal_store(static_cast<uint8_t>(out.trunc ? 1 : 0), &truncated[L.env]);
     }
     if (S.act_ring) {
         // push the raw action into the double ring (slots q and q + H: the H most recent actions stay H consecutive slots);
@@ -2152,10 +2156,13 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
         const int lanes = multi ? (kBlock / C.drones_per_env) * C.drones_per_env : (kBlock / 64) * C.lanes_per_wave;
         const dim3 grid(static_cast<unsigned>((N + lanes - 1) / lanes));
         if (multi) {
-            hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, true, AW>), grid, dim3(kBlock), 0, st, P, S, C, action,
+            hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, true, AW, ACT, false>), grid, dim3(kBlock), 0, st, P, S, C, action,
+                               target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+        } else if (C.substeps == 1) {
+            hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, false, AW, ACT, true>), grid, dim3(kBlock), 0, st, P, S, C, action,
                                target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
         } else {
-            hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, false, AW>), grid, dim3(kBlock), 0, st, P, S, C, action,
+            hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, false, AW, ACT, false>), grid, dim3(kBlock), 0, st, P, S, C, action,
                                target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
         }
     } else {

@@ -65,6 +65,22 @@ __global__ __launch_bounds__(256) void k_like_big(const Big P, float* __restrict
     obs[i * 3] = o0; obs[i * 3 + 1] = o1; obs[i * 3 + 2] = o2;
 }
 
+// ... the same 600 bytes behind a POINTER to device memory (scalar loads of the used fields) instead of by value
+__global__ __launch_bounds__(256) void k_like_bigptr(const Big* __restrict__ Pp, float* __restrict__ kin, const float4* __restrict__ act, f4v* __restrict__ obs, int ld, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Big& P = *Pp;
+    float v[13];
+#pragma unroll
+    for (int r = 0; r < 13; ++r) v[r] = kin[(size_t)r * ld + i];
+    float4 a = act[i];
+    float acc = a.x + a.y + a.z + a.w + P.v[149] + P.v[75] + P.v[3];
+#pragma unroll
+    for (int r = 0; r < 13; ++r) { v[r] = v[r] * P.v[r * 7] + acc * 1e-6f; kin[(size_t)r * ld + i] = v[r]; }
+    f4v o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]}, o2 = {v[8], v[9], v[10], v[11]};
+    obs[i * 3] = o0; obs[i * 3 + 1] = o1; obs[i * 3 + 2] = o2;
+}
+
 // The rollout kernel's memory pattern without its arithmetic: per "step" a lane reads one 16-byte action and writes a 48-byte
 // observation row (as three coalesced float4 planes), a reward float and two flag bytes -- 64 steps per launch, non-temporal.
 __global__ __launch_bounds__(256) void k_stream(const f4v* __restrict__ act, f4v* __restrict__ obs, float* __restrict__ rew,
@@ -129,6 +145,8 @@ int main() {
     bench("  ... state packed as 4 x float4 per drone", [&](int) { hipLaunchKernelGGL((k_like4<false>), dim3(256), dim3(256), 0, st, a4, act, obs, ld, n); });
     bench("  ... packed + non-temporal", [&](int) { hipLaunchKernelGGL((k_like4<true>), dim3(256), dim3(256), 0, st, a4, act, obs, ld, n); });
     bench("  ... SoA + a 600-byte by-value argument", [&](int) { hipLaunchKernelGGL(k_like_big, dim3(256), dim3(256), 0, st, P, a, act, obs, ld, n); });
+    Big* Pd; CK(hipMalloc(&Pd, sizeof(Big))); CK(hipMemcpy(Pd, &P, sizeof(Big), hipMemcpyHostToDevice));
+    bench("  ... SoA + the 600 bytes behind a device pointer", [&](int) { hipLaunchKernelGGL(k_like_bigptr, dim3(256), dim3(256), 0, st, Pd, a, act, obs, ld, n); });
     bench("  ... packed, 1024 x 64 threads", [&](int) { hipLaunchKernelGGL((k_like4<false>), dim3(1024), dim3(64), 0, st, a4, act, obs, ld, n); });
     {   // store-only and load-only streams over 1 GiB (far beyond the 256 MB Infinity Cache), at the headline's occupancy (256
         // workgroups = one wave per SIMD) and with the chip full (4096 workgroups)
