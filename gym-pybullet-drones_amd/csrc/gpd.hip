@@ -1640,13 +1640,13 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout_policy_kernel(
             }
         }
         if (L.active) {
-            float4* orow = reinterpret_cast<float4*>(obs12 + t * obs_step + static_cast<size_t>(L.n) * 12);
-            orow[0] = make_float4(o[0], o[1], o[2], o[3]);
-            orow[1] = make_float4(o[4], o[5], o[6], o[7]);
-            orow[2] = make_float4(o[8], o[9], o[10], o[11]);
-            reward[t * env_stride + L.env] = out.rew;
-            terminated[t * env_stride + L.env] = out.term ? 1 : 0;
-            truncated[t * env_stride + L.env] = out.trunc ? 1 : 0;
+            f4v* orow = reinterpret_cast<f4v*>(obs12 + t * obs_step + static_cast<size_t>(L.n) * 12);
+            __builtin_nontemporal_store(f4v{o[0], o[1], o[2], o[3]}, orow);          // (written once per step: streamed out)
+            __builtin_nontemporal_store(f4v{o[4], o[5], o[6], o[7]}, orow + 1);
+            __builtin_nontemporal_store(f4v{o[8], o[9], o[10], o[11]}, orow + 2);
+            __builtin_nontemporal_store(out.rew, &reward[t * env_stride + L.env]);
+            __builtin_nontemporal_store(static_cast<uint8_t>(out.term ? 1 : 0), &terminated[t * env_stride + L.env]);
+            __builtin_nontemporal_store(static_cast<uint8_t>(out.trunc ? 1 : 0), &truncated[t * env_stride + L.env]);
             if (actions_out) {
                 float* ar = actions_out + (static_cast<size_t>(t) * N + L.n) * AW;
                 if (AW == 4) *reinterpret_cast<float4*>(ar) = make_float4(a[0], a[1], a[2], a[3]);
