@@ -62,7 +62,20 @@ namespace {
 #endif
 constexpr int kBlock = GPD_BLOCK;   // 256 = 4 wavefronts; one workgroup per CU fills all 4 SIMDs
 
-thread_local std::string g_last_error;
+}  // namespace
+// The library is built from TWO translation units of this one source: gpd.hip itself, and gpd_policy.hip, which defines
+// GPD_POLICY_TU and includes this file to compile only gpd_rollout_policy -- its kernel wants another instruction scheduler
+// than the step / rollout kernels (-amdgpu-sched-strategy: max-ilp fills the packed-fp32 hazards of the physics; the default
+// strategy is 10 % faster on the MFMA / activation mix of the policy, A/B in round 2).  The last-error string is shared.
+std::string& gpd_detail_last_error();
+#ifndef GPD_POLICY_TU
+std::string& gpd_detail_last_error() {
+    thread_local std::string e;
+    return e;
+}
+#endif
+namespace {
+#define g_last_error gpd_detail_last_error()
 
 int fail(int code, const char* msg) {
     g_last_error = msg;
@@ -1666,6 +1679,7 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout_policy_kernel(
     if (ring) S.ring_pos[L.env] = ring_q;
 }
 
+#ifndef GPD_POLICY_TU
 // ------------------------------------------------------------------------------------------------
 // masked reset (envs/BaseAviary.py:451-477)
 // ------------------------------------------------------------------------------------------------
@@ -2260,12 +2274,16 @@ int step_impl(const char* who, const GpdParams* params, const GpdState* state, c
     return 0;
 }
 
+#endif  // !GPD_POLICY_TU
+
 }  // namespace
 
 // ==================================================================================================
 // C ABI
 // ==================================================================================================
 extern "C" {
+
+#ifndef GPD_POLICY_TU
 
 int gpd_abi_version(void) { return GPD_ABI_VERSION; }
 
@@ -2301,6 +2319,8 @@ int gpd_rollout(const GpdParams* params, const GpdState* state, const GpdStepCfg
                      terminated, truncated, term_obs12, stream);
 }
 
+#endif  // !GPD_POLICY_TU
+#ifdef GPD_POLICY_TU
 int gpd_rollout_policy(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, const GpdPolicy* policy,
                        int32_t num_steps, const float* obs12_in, const float* target_pos, const float* init_pose,
                        float* actions_out, float* obs12, int64_t obs_step_stride, float* reward, uint8_t* terminated,
@@ -2359,6 +2379,8 @@ int gpd_rollout_policy(const GpdParams* params, const GpdState* state, const Gpd
     return 0;
 }
 
+#endif  // GPD_POLICY_TU
+#ifndef GPD_POLICY_TU
 static int hist_args(const char* who, const GpdState* st, int32_t n_drones, int32_t D, int32_t A) {
     auto bad = [&](int code, const char* msg) { return fail(code, (std::string(who) + ": " + msg).c_str()); };
     if (!st || !st->act_ring || !st->ring_pos || st->hist_len <= 0) return bad(GPD_EINVAL, "state has no action ring (act_ring / ring_pos / hist_len)");
@@ -2558,5 +2580,7 @@ int gpd_clock_probe(double* shader_ghz, double* ns_per_fma, void* stream) {
     return 0;
 }
 
+
+#endif  // !GPD_POLICY_TU
 
 }  // extern "C"

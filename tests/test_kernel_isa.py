@@ -21,19 +21,30 @@ HEADLINE = "gpd_rollout1_kernelILb0ELb0ELi4ELi0ELb1ELb0ELb0E"  # <PID=0, EXT=0, 
 POLICY = "gpd_rollout_policy_kernelILb1ELi4ELi0ELi5ELb0E"  # <EXT=1, AW=4, ACT=RPM, NK1=5 (72-float rows), tanh>
 
 
-@pytest.fixture(scope="module")
-def gpd_asm():
+def _asm(unit, extra):
     from gym_pybullet_drones_amd import _native
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
-    flags = [f for f in _native.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    flags = [f for f in _native.COMMON_FLAGS if f != "-fPIC"] + extra
     with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "gpd.s")
+        out = os.path.join(d, "unit.s")
         subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", "-I", os.path.join(REPO, "include"),
-                                          os.path.join(REPO, "gym-pybullet-drones_amd", "csrc", "gpd.hip"), "-o", out],
+                                          os.path.join(REPO, "gym-pybullet-drones_amd", "csrc", unit), "-o", out],
                        check=True, capture_output=True)
         return open(out).read().split("\n")
+
+
+@pytest.fixture(scope="module")
+def gpd_asm():
+    from gym_pybullet_drones_amd import _native
+    return _asm(*_native.UNITS[0])
+
+
+@pytest.fixture(scope="module")
+def policy_asm():
+    from gym_pybullet_drones_amd import _native
+    return _asm(*_native.UNITS[1])
 
 
 def _kernel(lines, name):
@@ -83,10 +94,10 @@ def test_action_rows_are_claimed_with_an_exact_count(headline_isa):
     assert len(stores) == 18 and all(re.search(r"s\[\d+:\d+\]", s) for s in stores), stores[:3]
 
 
-def test_policy_kernel_runs_its_layers_on_the_matrix_cores(gpd_asm):
+def test_policy_kernel_runs_its_layers_on_the_matrix_cores(policy_asm):
     """gpd_rollout_policy for the reference's 72-float rows: 44 operand tiles x 3 bf16 hi/lo products = 132 MFMAs per step, both
     column tiles' layer-1 operands from lane-half swaps (no LDS round trip for activations), no scratch."""
-    body, meta = _kernel(gpd_asm, POLICY)
+    body, meta = _kernel(policy_asm, POLICY)
     assert re.search(r"ScratchSize: 0\b", meta), "the policy kernel spills to scratch"
     ops = Counter(op for op, _ in _ops(body))
     assert ops["v_mfma_f32_32x32x16_bf16"] == 132, ops["v_mfma_f32_32x32x16_bf16"]
