@@ -1432,7 +1432,9 @@ template <int NK1> struct PolLds {     // weights as A operands: [block][hi|lo][
     float b1[2][2][16], b2[2][2][16], b3[2][16];
 };
 
-template <bool EXT, int AW, int ACT, int NK1, bool RELU>
+// PID: a DSLPID action type (the policy's output is the controller's set-point); the add-on physics terms are always compiled in
+// (wave-uniform run-time tests: a handful of slots next to the policy's ~2 500)
+template <bool PID, int AW, int ACT, int NK1, bool RELU>
 __global__ __launch_bounds__(kBlock) void gpd_rollout_policy_kernel(
     const GpdParams P, const GpdState S, const GpdStepCfg C, const Span T, const GpdPolicy Pol,
     const float* __restrict__ obs12_in, const float* __restrict__ target_pos, const float* __restrict__ init_pose,
@@ -1446,7 +1448,8 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout_policy_kernel(
     const uint32_t N = static_cast<uint32_t>(C.num_envs);
     const uint32_t n_raw = blockIdx.x * static_cast<uint32_t>(kBlock) + tid;
     const int K = T.num_steps;
-    const uint32_t flags = EXT ? C.physics_flags : 0u;
+    constexpr bool EXT = true;
+    const uint32_t flags = C.physics_flags;
     Lane L;
     L.tid = tid; L.shfl = false; L.le = tid; L.d = 0;
     L.active = n_raw < N;
@@ -1493,8 +1496,9 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout_policy_kernel(
     Carry c;
     float tgx, tgy, tgz, ip[7];
     const float* ipose = reinterpret_cast<const float*>(reinterpret_cast<const char*>(init_pose) + (C.init_per_env ? L.n * 28u : 0u));
-    load_carry<false, EXT>(S, C, flags, L, target_pos, C.auto_reset ? ipose : S.kin, c, tgx, tgy, tgz, ip);
+    load_carry<PID, EXT>(S, C, flags, L, target_pos, C.auto_reset ? ipose : S.kin, c, tgx, tgy, tgz, ip);
     c.roll = c.pitch = c.yaw = 0.0f;
+    if (PID) quat_to_rpy(c.k.qx, c.k.qy, c.k.qz, c.k.qw, c.roll, c.pitch, c.yaw);
     float o[12];
     {
         const float4* op = reinterpret_cast<const float4*>(obs12_in + static_cast<size_t>(L.n) * 12);
@@ -1629,7 +1633,7 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout_policy_kernel(
         }
         // ---- the env step ---------------------------------------------------------------------------------------------------------
         StepOut out;
-        env_step<false, EXT, false, AW, ACT, false>(P, C, flags, 1, L, make_float4(a[0], a[1], a[2], a[3]), tgx, tgy, tgz, true, ipose,
+        env_step<PID, EXT, false, AW, ACT, false>(P, C, flags, 1, L, make_float4(a[0], a[1], a[2], a[3]), tgx, tgy, tgz, true, ipose,
                                                     ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], ip[6], nullptr, nullptr, c, out);
 #pragma unroll
         for (int i = 0; i < 12; ++i) o[i] = out.o[i];
@@ -1641,6 +1645,17 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout_policy_kernel(
 #pragma unroll
                 for (int i = 6; i < NP - 2; ++i) { Fhi[i] = Fhi[i + 2]; Flo[i] = Flo[i + 2]; }
                 Fhi[NP - 2] = nh[0]; Flo[NP - 2] = nl[0]; Fhi[NP - 1] = nh[1]; Flo[NP - 1] = nl[1];
+            } else if (AW == 3) {                            // three bf16 elements: every register takes the upper half of its
+                uint32_t xh[2], xl[2];                       // successor and the lower half of the one after (v_alignbit_b32)
+                split_pair(a[0], a[1], xh[0], xl[0]);
+                split_pair(a[2], 0.0f, xh[1], xl[1]);
+#pragma unroll
+                for (int i = 6; i < NP; ++i) {
+                    const uint32_t h1 = i + 1 < NP ? Fhi[i + 1] : xh[i + 1 - NP], h2 = i + 2 < NP ? Fhi[i + 2] : xh[i + 2 - NP];
+                    const uint32_t l1 = i + 1 < NP ? Flo[i + 1] : xl[i + 1 - NP], l2 = i + 2 < NP ? Flo[i + 2] : xl[i + 2 - NP];
+                    Fhi[i] = __builtin_amdgcn_alignbit(h2, h1, 16);
+                    Flo[i] = __builtin_amdgcn_alignbit(l2, l1, 16);
+                }
             } else {                                         // AW == 1: one bf16 element per step
                 split_pair(0.0f, a[0], nh[0], nl[0]);         // the new action in the upper half
 #pragma unroll
@@ -1663,19 +1678,19 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout_policy_kernel(
             if (actions_out) {
                 float* ar = actions_out + (static_cast<size_t>(t) * N + L.n) * AW;
                 if (AW == 4) *reinterpret_cast<float4*>(ar) = make_float4(a[0], a[1], a[2], a[3]);
-                else ar[0] = a[0];
+                else { ar[0] = a[0]; if (AW == 3) { ar[1] = a[1]; ar[2] = a[2]; } }
             }
             if (ring) {                                      // exact fp32 action into both halves of the double ring
                 float* r0 = S.act_ring + static_cast<size_t>(ring_q) * slot + static_cast<size_t>(L.n) * AW;
                 float* r1 = r0 + static_cast<size_t>(S.hist_len) * slot;
                 if (AW == 4) { *reinterpret_cast<float4*>(r0) = make_float4(a[0], a[1], a[2], a[3]); *reinterpret_cast<float4*>(r1) = make_float4(a[0], a[1], a[2], a[3]); }
-                else { r0[0] = a[0]; r1[0] = a[0]; }
+                else { r0[0] = a[0]; r1[0] = a[0]; if (AW == 3) { r0[1] = a[1]; r0[2] = a[2]; r1[1] = a[1]; r1[2] = a[2]; } }
             }
         }
         ring_q = ring_q + 1 == S.hist_len ? 0 : ring_q + 1;
     }
     if (!L.active) return;
-    store_carry<false>(S, L, c);
+    store_carry<PID>(S, L, c);
     if (ring) S.ring_pos[L.env] = ring_q;
 }
 
@@ -2333,7 +2348,10 @@ int gpd_rollout_policy(const GpdParams* params, const GpdState* state, const Gpd
     if (num_steps <= 0 || obs_step_stride < 0 || env_step_stride < 0) return bad(GPD_EINVAL, "num_steps must be positive, strides non-negative");
     if (cfg->num_envs <= 0 || cfg->substeps <= 0) return bad(GPD_EINVAL, "num_envs and substeps must be positive");
     if (cfg->drones_per_env != 1) return bad(GPD_ENOTSUP, "single-drone aviaries only (drones_per_env == 1)");
-    if (cfg->act_type != GPD_ACT_RPM && cfg->act_type != GPD_ACT_ONE_D_RPM) return bad(GPD_ENOTSUP, "ActionType.RPM or ONE_D_RPM only");
+    if (cfg->act_type < GPD_ACT_RPM || cfg->act_type > GPD_ACT_ONE_D_PID) return bad(GPD_ENOTSUP, "one of the five ActionTypes (RPM, PID, VEL, ONE_D_RPM, ONE_D_PID)");
+    const bool pid = cfg->act_type == GPD_ACT_PID || cfg->act_type == GPD_ACT_VEL || cfg->act_type == GPD_ACT_ONE_D_PID;
+    if (pid && !state->pid) return bad(GPD_EINVAL, "PID action type needs state.pid");
+    if (pid && params->pid_kf <= 0.0f) return bad(GPD_ENOTSUP, "no DSLPID controller for this airframe (CF2X/CF2P only)");
     if (cfg->task < GPD_TASK_NONE || cfg->task > GPD_TASK_MULTIHOVER) return bad(GPD_EINVAL, "unknown task");
     if (cfg->physics_flags & ~15u) return bad(GPD_EINVAL, "unknown physics flag");
     if (policy->hidden != kPolHidden) return bad(GPD_ENOTSUP, "hidden must be 64");
@@ -2344,12 +2362,13 @@ int gpd_rollout_policy(const GpdParams* params, const GpdState* state, const Gpd
     if ((cfg->physics_flags & GPD_PHYS_DRAG) && !state->last_rpm) return bad(GPD_EINVAL, "GPD_PHYS_DRAG needs state.last_rpm");
     if (cfg->task != GPD_TASK_NONE && !target_pos) return bad(GPD_EINVAL, "task needs target_pos");
     if (cfg->auto_reset && !init_pose) return bad(GPD_EINVAL, "auto_reset needs init_pose");
-    const int A = cfg->act_type == GPD_ACT_RPM ? 4 : 1;
+    const int A = (cfg->act_type == GPD_ACT_RPM || cfg->act_type == GPD_ACT_VEL) ? 4 : (cfg->act_type == GPD_ACT_PID ? 3 : 1);
+    const int cap = A == 4 ? 68 : (A == 3 ? 52 : 20);                 // history features the kernel's registers hold (16*NK1 - 12)
     const bool hist = policy->in_dim != 12;
     if (hist) {
         if (!state->act_ring || !state->ring_pos || state->hist_len <= 0) return bad(GPD_EINVAL, "in_dim > 12 needs the action ring of state");
         if (policy->in_dim != 12 + state->hist_len * A) return bad(GPD_ENOTSUP, "in_dim must be 12 or 12 + hist_len*act_dim");
-        if (state->hist_len * A > (A == 4 ? 68 : 20)) return bad(GPD_ENOTSUP, "history too long for the in-kernel policy (RPM: 17 actions, ONE_D_RPM: 20)");
+        if (state->hist_len * A > cap) return bad(GPD_ENOTSUP, "history too long for the in-kernel policy (17 actions of 4 or 3 floats, 20 of 1)");
     } else if (state->act_ring && (!state->ring_pos || state->hist_len <= 0)) {
         return bad(GPD_EINVAL, "state.act_ring without ring_pos / hist_len");
     }
@@ -2358,20 +2377,21 @@ int gpd_rollout_policy(const GpdParams* params, const GpdState* state, const Gpd
     const Span T{num_steps, 0, obs_step_stride, env_step_stride, 2};
     const dim3 grid(static_cast<unsigned>((N + kBlock - 1) / kBlock));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // (one physics variant: the add-on terms are wave-uniform run-time tests there, a handful of slots next to the policy's ~3000)
-#define GPD_POL(AW_, ACT_, NK1_)                                                                                                    \
+#define GPD_POL(PID_, AW_, ACT_, NK1_)                                                                                              \
     do {                                                                                                                            \
         if (policy->activation == 1)                                                                                                \
-            hipLaunchKernelGGL((gpd_rollout_policy_kernel<true, AW_, ACT_, NK1_, true>), grid, dim3(kBlock), 0, st, *params, *state, c, T, \
+            hipLaunchKernelGGL((gpd_rollout_policy_kernel<PID_, AW_, ACT_, NK1_, true>), grid, dim3(kBlock), 0, st, *params, *state, c, T, \
                                *policy, obs12_in, target_pos, init_pose, actions_out, obs12, reward, terminated, truncated);        \
         else                                                                                                                        \
-            hipLaunchKernelGGL((gpd_rollout_policy_kernel<true, AW_, ACT_, NK1_, false>), grid, dim3(kBlock), 0, st, *params, *state, c, T, \
+            hipLaunchKernelGGL((gpd_rollout_policy_kernel<PID_, AW_, ACT_, NK1_, false>), grid, dim3(kBlock), 0, st, *params, *state, c, T, \
                                *policy, obs12_in, target_pos, init_pose, actions_out, obs12, reward, terminated, truncated);        \
     } while (0)
-    if (A == 4) {
-        if (hist) GPD_POL(4, GPD_ACT_RPM, 5); else GPD_POL(4, GPD_ACT_RPM, 1);
-    } else {
-        if (hist) GPD_POL(1, GPD_ACT_ONE_D_RPM, 2); else GPD_POL(1, GPD_ACT_ONE_D_RPM, 1);
+    switch (cfg->act_type) {     // NK1 = K-steps of layer 1: 16*NK1 >= 12 + history features
+        case GPD_ACT_RPM: if (hist) GPD_POL(false, 4, GPD_ACT_RPM, 5); else GPD_POL(false, 4, GPD_ACT_RPM, 1); break;
+        case GPD_ACT_VEL: if (hist) GPD_POL(true, 4, GPD_ACT_VEL, 5); else GPD_POL(true, 4, GPD_ACT_VEL, 1); break;
+        case GPD_ACT_PID: if (hist) GPD_POL(true, 3, GPD_ACT_PID, 4); else GPD_POL(true, 3, GPD_ACT_PID, 1); break;
+        case GPD_ACT_ONE_D_PID: if (hist) GPD_POL(true, 1, GPD_ACT_ONE_D_PID, 2); else GPD_POL(true, 1, GPD_ACT_ONE_D_PID, 1); break;
+        default: if (hist) GPD_POL(false, 1, GPD_ACT_ONE_D_RPM, 2); else GPD_POL(false, 1, GPD_ACT_ONE_D_RPM, 1); break;
     }
 #undef GPD_POL
     hipError_t e = hipGetLastError();

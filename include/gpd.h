@@ -264,7 +264,8 @@ typedef struct GpdPolicy {
 /*
  * K consecutive env.step() calls in ONE launch with the policy IN the loop.  Replaces the evaluation / sampling loop of
  * examples/learn.py:157-192 (`action, _ = model.predict(obs, deterministic=True); obs, reward, terminated, truncated, info =
- * env.step(action)`), for single-drone aviaries (HoverAviary) with ActionType.RPM or ONE_D_RPM:
+ * env.step(action)`), for single-drone aviaries (HoverAviary) and all five ActionTypes (for PID / VEL / ONE_D_PID the policy's
+ * output is the set-point of the embedded DSLPID controller, which runs inside the same step):
  *     a_t = clip(W3 act(W2 act(W1 o_t + b1) + b2) + b3, -1, 1);   o_{t+1}, r_t, ... = step(a_t)
  * where o_t is the latest observation row -- of the reset pose when the aviary was reset in step t-1 (same-step auto-reset, the
  * history tail survives resets like the reference's action buffer).  The drone state stays in registers for all K steps like in
@@ -277,8 +278,8 @@ typedef struct GpdPolicy {
  *   actions_out  [K][E][A] out or NULL: the actions the policy chose, step t at actions_out + t*E*A
  *   obs12 / reward / terminated / truncated and the strides: as in gpd_rollout
  * With in_dim > 12 the action ring of `state` is read at the start and rewritten (with ring_pos = 0) at the end.
- * GPD_ENOTSUP: drones_per_env > 1, a DSLPID action type, hidden != 64, in_dim not one of the two forms, or a history longer
- * than 16 (RPM) / 20 (ONE_D_RPM) actions.
+ * GPD_ENOTSUP: drones_per_env > 1, hidden != 64, in_dim not one of the two forms, or a history longer than 17 actions of 4 or
+ * 3 floats / 20 actions of 1 float (the reference's 30 Hz control: 15).
  */
 int gpd_rollout_policy(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, const GpdPolicy* policy,
                        int32_t num_steps, const float* obs12_in, const float* target_pos, const float* init_pose,

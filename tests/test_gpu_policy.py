@@ -28,6 +28,8 @@ def _env(act, ctrl, mode, E, dev, **kw):
 CASES = [  # act, ctrl_freq (H = ctrl // 2), policy sees the history, activation
     ("rpm", 30, True, "tanh"), ("rpm", 30, False, "tanh"), ("one_d_rpm", 30, True, "tanh"), ("one_d_rpm", 240, False, "relu"),
     ("rpm", 24, True, "relu"), ("one_d_rpm", 40, True, "tanh"),
+    # DSLPID action types: the policy's output is the controller's set-point (A = 3: the history shifts by one and a half registers)
+    ("pid", 30, True, "tanh"), ("pid", 240, False, "tanh"), ("vel", 30, True, "tanh"), ("one_d_pid", 30, True, "relu"), ("pid", 24, True, "tanh"),
 ]
 
 
@@ -69,7 +71,8 @@ def test_policy_actions_match_the_float64_actor_every_step(gpu_device, act, ctrl
 
 
 @pytest.mark.parametrize("act,ctrl,hist,phys", [("rpm", 30, True, "dyn"), ("one_d_rpm", 240, False, "dyn"), ("rpm", 48, False, "dyn"),
-                                                ("rpm", 30, True, "pyb_gnd_drag_dw"), ("one_d_rpm", 30, True, "pyb_drag")])
+                                                ("rpm", 30, True, "pyb_gnd_drag_dw"), ("one_d_rpm", 30, True, "pyb_drag"),
+                                                ("pid", 30, True, "dyn"), ("vel", 48, False, "pyb_gnd_drag_dw"), ("one_d_pid", 30, True, "dyn")])
 def test_policy_rollout_is_bitwise_stepping_its_actions(gpu_device, act, ctrl, hist, phys):
     """The physics inside the policy kernel is the shared `env_step`: feeding the actions it chose to `gpd_step` one at a time
     reproduces its observations, rewards, flags, state and action ring bit for bit."""
@@ -84,7 +87,7 @@ def test_policy_rollout_is_bitwise_stepping_its_actions(gpu_device, act, ctrl, h
     for t in range(K):
         o, r, te, tr, _ = b.step(acts[t])
         assert torch.equal(o, obs[t]) and torch.equal(r, rew[t]) and torch.equal(te, term[t]) and torch.equal(tr, trunc[t]), t
-    for name in ("kin", "last_rpm", "step_counter", "obs12", "reward", "terminated", "truncated"):
+    for name in ("kin", "last_rpm", "pid", "step_counter", "obs12", "reward", "terminated", "truncated"):
         if getattr(a.core, name) is not None:
             assert torch.equal(getattr(a.core, name), getattr(b.core, name)), name
     if hist:
