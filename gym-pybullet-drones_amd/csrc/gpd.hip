@@ -68,6 +68,18 @@ constexpr int kBlock = GPD_BLOCK;   // 256 = 4 wavefronts; one workgroup per CU 
 // than the step / rollout kernels (-amdgpu-sched-strategy: max-ilp fills the packed-fp32 hazards of the physics; the default
 // strategy is 10 % faster on the MFMA / activation mix of the policy, A/B in round 2).  The last-error string is shared.
 std::string& gpd_detail_last_error();
+// The DSLPID variants of the policy kernel are instantiated in the MAIN unit (max-ilp scheduler): compiled with the default
+// scheduler, the VEL variant returns `truncated` = 1 and a task reward for every aviary whatever the configuration says -- the
+// physics and the actions stay right, no parameter of the truncation test changes it, spilling SGPRs to memory instead of VGPR
+// lanes does not either, and the same source is correct under max-ilp (tests/test_gpu_policy.py, bitwise against gpd_step).
+// A scheduler-dependent miscompile or an undefined behaviour we could not find; until it is understood the variants that
+// inline the controller stay where their tests pass.
+struct GpdPolicyLaunch {
+    const GpdParams* params; const GpdState* state; const GpdStepCfg* cfg; const void* span; const GpdPolicy* policy;
+    const float* obs12_in; const float* target_pos; const float* init_pose; float* actions_out; float* obs12; float* reward;
+    uint8_t* terminated; uint8_t* truncated; void* stream; unsigned grid; int hist;
+};
+void gpd_detail_launch_policy_pid(const GpdPolicyLaunch& a);
 #ifndef GPD_POLICY_TU
 std::string& gpd_detail_last_error() {
     thread_local std::string e;
@@ -2296,6 +2308,29 @@ int step_impl(const char* who, const GpdParams* params, const GpdState* state, c
 // ==================================================================================================
 // C ABI
 // ==================================================================================================
+#ifndef GPD_POLICY_TU
+void gpd_detail_launch_policy_pid(const GpdPolicyLaunch& a) {
+    const Span& T = *static_cast<const Span*>(a.span);
+    const dim3 grid(a.grid);
+    hipStream_t st = static_cast<hipStream_t>(a.stream);
+#define GPD_POL(AW_, ACT_, NK1_)                                                                                                   \
+    do {                                                                                                                            \
+        if (a.policy->activation == 1)                                                                                              \
+            hipLaunchKernelGGL((gpd_rollout_policy_kernel<true, AW_, ACT_, NK1_, true>), grid, dim3(kBlock), 0, st, *a.params, *a.state, *a.cfg, T, \
+                               *a.policy, a.obs12_in, a.target_pos, a.init_pose, a.actions_out, a.obs12, a.reward, a.terminated, a.truncated); \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((gpd_rollout_policy_kernel<true, AW_, ACT_, NK1_, false>), grid, dim3(kBlock), 0, st, *a.params, *a.state, *a.cfg, T, \
+                               *a.policy, a.obs12_in, a.target_pos, a.init_pose, a.actions_out, a.obs12, a.reward, a.terminated, a.truncated); \
+    } while (0)
+    switch (a.cfg->act_type) {
+        case GPD_ACT_VEL: if (a.hist) GPD_POL(4, GPD_ACT_VEL, 5); else GPD_POL(4, GPD_ACT_VEL, 1); break;
+        case GPD_ACT_PID: if (a.hist) GPD_POL(3, GPD_ACT_PID, 4); else GPD_POL(3, GPD_ACT_PID, 1); break;
+        default: if (a.hist) GPD_POL(1, GPD_ACT_ONE_D_PID, 2); else GPD_POL(1, GPD_ACT_ONE_D_PID, 1); break;
+    }
+#undef GPD_POL
+}
+#endif
+
 extern "C" {
 
 #ifndef GPD_POLICY_TU
@@ -2386,12 +2421,14 @@ int gpd_rollout_policy(const GpdParams* params, const GpdState* state, const Gpd
             hipLaunchKernelGGL((gpd_rollout_policy_kernel<PID_, AW_, ACT_, NK1_, false>), grid, dim3(kBlock), 0, st, *params, *state, c, T, \
                                *policy, obs12_in, target_pos, init_pose, actions_out, obs12, reward, terminated, truncated);        \
     } while (0)
-    switch (cfg->act_type) {     // NK1 = K-steps of layer 1: 16*NK1 >= 12 + history features
-        case GPD_ACT_RPM: if (hist) GPD_POL(false, 4, GPD_ACT_RPM, 5); else GPD_POL(false, 4, GPD_ACT_RPM, 1); break;
-        case GPD_ACT_VEL: if (hist) GPD_POL(true, 4, GPD_ACT_VEL, 5); else GPD_POL(true, 4, GPD_ACT_VEL, 1); break;
-        case GPD_ACT_PID: if (hist) GPD_POL(true, 3, GPD_ACT_PID, 4); else GPD_POL(true, 3, GPD_ACT_PID, 1); break;
-        case GPD_ACT_ONE_D_PID: if (hist) GPD_POL(true, 1, GPD_ACT_ONE_D_PID, 2); else GPD_POL(true, 1, GPD_ACT_ONE_D_PID, 1); break;
-        default: if (hist) GPD_POL(false, 1, GPD_ACT_ONE_D_RPM, 2); else GPD_POL(false, 1, GPD_ACT_ONE_D_RPM, 1); break;
+    if (pid) {                   // (instantiated in the main unit, see GpdPolicyLaunch)
+        const GpdPolicyLaunch a{params, state, &c, &T, policy, obs12_in, target_pos, init_pose, actions_out, obs12, reward, terminated,
+                                truncated, stream, grid.x, hist ? 1 : 0};
+        gpd_detail_launch_policy_pid(a);
+    } else if (cfg->act_type == GPD_ACT_RPM) {      // NK1 = K-steps of layer 1: 16*NK1 >= 12 + history features
+        if (hist) GPD_POL(false, 4, GPD_ACT_RPM, 5); else GPD_POL(false, 4, GPD_ACT_RPM, 1);
+    } else {
+        if (hist) GPD_POL(false, 1, GPD_ACT_ONE_D_RPM, 2); else GPD_POL(false, 1, GPD_ACT_ONE_D_RPM, 1);
     }
 #undef GPD_POL
     hipError_t e = hipGetLastError();

@@ -18,7 +18,7 @@ from conftest import REPO
 HEADLINE = "gpd_rollout1_kernelILb0ELb0ELi4ELi0ELb1ELb0ELb0E"  # <PID=0, EXT=0, AW=4, ACT=RPM, S1=1, MULTI=0, NT_OBS=0>
 
 
-POLICY = "gpd_rollout_policy_kernelILb1ELi4ELi0ELi5ELb0E"  # <EXT=1, AW=4, ACT=RPM, NK1=5 (72-float rows), tanh>
+POLICY = "gpd_rollout_policy_kernelILb0ELi4ELi0ELi5ELb0E"  # <PID=0, AW=4, ACT=RPM, NK1=5 (72-float rows), tanh>
 
 
 def _asm(unit, extra):
