@@ -130,3 +130,31 @@ def test_policy_argument_errors(gpu_device):
         _env("rpm", 240, "lazy", 64, gpu_device).rollout_policy(MlpPolicy.random(12 + 120 * 4, 4, device=gpu_device), 4)
     with pytest.raises(ValueError):
         MlpPolicy(np.zeros((32, 12)), np.zeros(32), np.zeros((32, 32)), np.zeros(32), np.zeros((4, 32)), np.zeros(4), device=gpu_device)
+
+
+@pytest.mark.parametrize("act,ctrl,hist", [("rpm", 30, True), ("rpm", 240, False), ("one_d_rpm", 30, True), ("one_d_rpm", 48, False),
+                                           ("vel", 240, False), ("pid", 30, True)])
+@pytest.mark.parametrize("tweak", [dict(task=0), dict(auto_reset=0), dict(xy_bound=0.2, tilt_bound=0.05), dict(trunc_counter=3),
+                                   dict(z_bound=1e9, xy_bound=1e9, tilt_bound=1e9, trunc_counter=2 ** 30)])
+def test_policy_rollout_reads_the_step_configuration_like_gpd_step(gpu_device, act, ctrl, hist, tweak):
+    """Every field of GpdStepCfg the task evaluation reads (task switch, auto-reset, the truncation box and tilt bound, the time
+    limit), changed one at a time: the policy kernel must keep following gpd_step bit for bit -- rewards and flags included.
+    (A build of the VEL variant under another instruction scheduler once returned truncated = 1 and a task reward for every
+    aviary regardless of these fields, DESIGN.md section 3.7: this is the test that would have caught it in any variant.)"""
+    from gym_pybullet_drones_amd.policy import MlpPolicy
+    E, K = 300, 12
+    mode = "lazy" if hist else False
+    a, b = (_env(act, ctrl, mode, E, gpu_device, episode_len_sec=1.0) for _ in range(2))
+    for env in (a, b):
+        for k, v in tweak.items():
+            setattr(env.core._cfg, k, v)
+    A, H = a.ACT_DIM, ctrl // 2
+    pol = MlpPolicy.random(12 + (H * A if hist else 0), A, seed=5, gain=1.2, device=gpu_device)
+    obs, rew, term, trunc, acts = a.rollout_policy(pol, K)
+    for t in range(K):
+        o, r, te, tr, _ = b.step(acts[t])
+        assert torch.equal(r, rew[t]) and torch.equal(te, term[t]) and torch.equal(tr, trunc[t]) and torch.equal(o, obs[t]), (t, tweak)
+    if tweak.get("task", 1) == 0:
+        assert bool((rew == -1).all()) and not bool(trunc.any())
+    if "trunc_counter" in tweak and tweak["trunc_counter"] == 3:
+        assert bool(trunc.any())
