@@ -103,3 +103,63 @@ def test_policy_kernel_runs_its_layers_on_the_matrix_cores(policy_asm):
     assert ops["v_mfma_f32_32x32x16_bf16"] == 132, ops["v_mfma_f32_32x32x16_bf16"]
     assert ops["v_permlane32_swap_b32_e32"] >= 40 and ops["v_exp_f32_e32"] == 128 and ops["v_cvt_pk_bf16_f32"] >= 140
     assert not [op for op in ops if op.startswith("scratch_")]
+
+
+TORN = """_Z4tornv:
+; %bb.0:
+	s_load_dwordx8 s[48:55], s[0:1], 0x19c
+	s_load_dwordx4 s[8:11], s[0:1], 0x228
+	s_waitcnt lgkmcnt(0)
+	v_cmp_gt_u32_e32 vcc, s8, v0
+	s_and_saveexec_b64 s[22:23], vcc
+	s_cbranch_execz .LBB0_2
+; %bb.1:
+	v_mov_b32_e32 v1, s9
+.LBB0_2:
+	s_or_b64 exec, exec, s[22:23]
+	s_load_dwordx16 s[{lo}:{hi}], s[0:1], 0x18
+	s_waitcnt lgkmcnt(0)
+	v_writelane_b32 v164, s48, 29
+	s_nop 1
+	v_writelane_b32 v164, s49, 30
+	v_writelane_b32 v164, s50, 31
+	v_writelane_b32 v164, s51, 32
+	v_writelane_b32 v164, s52, 33
+	v_writelane_b32 v164, s53, 34
+	v_writelane_b32 v164, s54, 35
+	v_writelane_b32 v164, s55, 36
+	v_mul_f32_e32 v2, s{hi}, v1
+	v_readlane_b32 s12, v164, 29
+	s_cmp_lg_u32 s12, 0
+	s_cbranch_scc1 .LBB0_2
+; %bb.3:
+	s_endpgm
+.Lfunc_end0:
+"""
+
+
+def test_spill_checker_recognises_the_miscompile_it_was_written_for():
+    """The shape hipcc (ROCm 7.2) produced for gpd_rollout_policy_kernel<PID, 4, VEL, 1, tanh> under the default scheduler
+    (DESIGN.md section 3.7): GpdStepCfg loaded into s[48:55], GpdParams loaded over s[48:51] one block later, s[48:55] spilled
+    after that as if intact.  The same code with the second load elsewhere is clean."""
+    import isa_spill_check as chk
+    (name, body), = chk.kernels(TORN.format(lo=36, hi=51))
+    found = chk.torn_spills(body)
+    assert len(found) == 1 and found[0][2] == [48, 49, 50, 51] and found[0][3]["lanes"] == list(range(29, 37))
+    (name, body), = chk.kernels(TORN.format(lo=56, hi=71))
+    assert chk.torn_spills(body) == []
+
+
+def test_no_kernel_saves_a_half_overwritten_argument_tuple(gpd_asm, policy_asm):
+    """Every kernel of both units, every instantiation: no scalar-load destination tuple is spilled after part of it was
+    overwritten (backward SGPR liveness over the kernel's control-flow graph, tests/isa_spill_check.py).  All of these kernels
+    run with their 106 SGPRs full and spill kernel arguments to VGPR lanes, so the register allocator's handling of exactly
+    this is load-bearing for every GpdParams / GpdStepCfg field they read."""
+    import isa_spill_check as chk
+    n = 0
+    for asm in (gpd_asm, policy_asm):
+        for name, body in chk.kernels("\n".join(asm)):
+            n += 1
+            found = chk.torn_spills(body)
+            assert not found, (name, [(l, dead, run["lanes"]) for _, l, dead, run in found])
+    assert n >= 130, n
