@@ -73,15 +73,21 @@ def test_policy_actions_match_the_float64_actor_every_step(gpu_device, act, ctrl
 @pytest.mark.parametrize("act,ctrl,hist,phys", [("rpm", 30, True, "dyn"), ("one_d_rpm", 240, False, "dyn"), ("rpm", 48, False, "dyn"),
                                                 ("rpm", 30, True, "pyb_gnd_drag_dw"), ("one_d_rpm", 30, True, "pyb_drag"),
                                                 ("pid", 30, True, "dyn"), ("vel", 48, False, "pyb_gnd_drag_dw"), ("one_d_pid", 30, True, "dyn")])
-def test_policy_rollout_is_bitwise_stepping_its_actions(gpu_device, act, ctrl, hist, phys):
+@pytest.mark.parametrize("scramble", [False, True])
+def test_policy_rollout_is_bitwise_stepping_its_actions(gpu_device, act, ctrl, hist, phys, scramble):
     """The physics inside the policy kernel is the shared `env_step`: feeding the actions it chose to `gpd_step` one at a time
-    reproduces its observations, rewards, flags, state and action ring bit for bit."""
+    reproduces its observations, rewards, flags, state and action ring bit for bit.  `scramble`: with every float word of the
+    by-value kernel arguments scaled by a factor of its own (test_gpu_rollout._scramble_arguments), so that both kernels must
+    have read the same word for every field."""
     from gym_pybullet_drones_amd.policy import MlpPolicy
     E, K = 777, 25
     mode = "lazy" if hist else False
     from gym_pybullet_drones_amd.utils.enums import Physics
     a, b = (_env(act, ctrl, mode, E, gpu_device, episode_len_sec=10.0 / ctrl, physics=Physics(phys)) for _ in range(2))
     A, H = a.ACT_DIM, ctrl // 2
+    if scramble:
+        from test_gpu_rollout import _scramble_arguments
+        _scramble_arguments(np.random.default_rng(78), a.core, b.core)
     pol = MlpPolicy.random(12 + (H * A if hist else 0), A, seed=3, gain=1.2, device=gpu_device)
     obs, rew, term, trunc, acts = a.rollout_policy(pol, K)
     for t in range(K):

@@ -45,7 +45,7 @@ RAGGED = [  # act, flags, D, S, model, E, K: ragged last workgroups, whole-aviar
 
 @pytest.mark.parametrize("keep_term", [True, False])
 @pytest.mark.parametrize("act,flags,D,S,model,E,K", [c + (1536 // c[2], 24) for c in CASES] + RAGGED)
-def test_rollout_is_bitwise_k_steps(gpu_device, act, flags, D, S, model, E, K, keep_term):
+def test_rollout_is_bitwise_k_steps(gpu_device, act, flags, D, S, model, E, K, keep_term, scramble=False):
     """Same state, same actions: one rollout of K steps == K single-step launches, bit for bit, including the
     same-step auto-reset (short episodes so that resets happen inside the rollout), the terminal observations,
     the DSLPID members, last RPMs and step counters.  `keep_term` selects the kernel: single-drone aviaries without
@@ -55,6 +55,8 @@ def test_rollout_is_bitwise_k_steps(gpu_device, act, flags, D, S, model, E, K, k
     a, b = _pair(act, flags, D, S, model, gpu_device, E, rng, keep_term=keep_term)
     for c in (a, b):   # episodes of 10 physics steps -> several resets within K steps
         c._cfg.trunc_counter = 10
+    if scramble:
+        _scramble_arguments(np.random.default_rng(77), a, b)
     # give the state some velocity so the PID memories / drag see non-trivial values
     kin = a.kin.clone()
     kin[7:13] = torch.as_tensor(rng.uniform(-0.5, 0.5, size=(6, a.ld)), dtype=torch.float32, device=gpu_device)
@@ -83,6 +85,29 @@ def test_rollout_is_bitwise_k_steps(gpu_device, act, flags, D, S, model, E, K, k
     for k in range(K):
         m = done[k].repeat_interleave(D)
         assert torch.equal(tob[k][m], tobs_s[k][m])
+
+
+def _scramble_arguments(rng, *cores):
+    """Every float word of GpdParams and the float bounds of GpdStepCfg get a factor of their own (the same on every core)."""
+    import ctypes
+    words = ctypes.sizeof(cores[0]._params) // 4
+    fac = rng.uniform(0.9, 1.1, size=words).astype(np.float32)
+    cf = rng.uniform(0.7, 1.3, size=4)
+    for c in cores:
+        w = np.frombuffer((ctypes.c_char * (4 * words)).from_address(ctypes.addressof(c._params)), dtype=np.float32)
+        w[1:] *= fac[1:]                      # (word 0 is the integer airframe code)
+        for k, name in enumerate(("xy_bound", "z_bound", "tilt_bound", "term_dist")):
+            setattr(c._cfg, name, getattr(c._cfg, name) * cf[k])
+
+
+@pytest.mark.parametrize("keep_term", [True, False])
+@pytest.mark.parametrize("act,flags,D,S,model", CASES)
+def test_rollout_is_bitwise_with_every_argument_word_distinct(gpu_device, act, flags, D, S, model, keep_term):
+    """The same comparison with every float of the by-value kernel arguments scaled by a factor of its own: the kernels are
+    compiled separately (three kernel families, ~130 instantiations, 106 SGPRs full and kernel arguments spilled to VGPR lanes
+    in all of them) and must have read the SAME word for every field -- which the shipped constants, full of equal values,
+    cannot show.  (Not a physical airframe any more; nothing here is compared with the oracle.)"""
+    test_rollout_is_bitwise_k_steps(gpu_device, act, flags, D, S, model, 1536 // D, 24, keep_term, scramble=True)
 
 
 def test_rollout_strides_zero(gpu_device):
