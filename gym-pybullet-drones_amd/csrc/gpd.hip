@@ -1958,99 +1958,187 @@ __global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const float* __rest
     }
 }
 
-// One workgroup per grid cell; every drone of the cell sweeps the candidates of the cell's 3x3 neighbourhood, staged
-// through LDS (broadcast reads instead of a dependent global load per candidate).
-constexpr int kDwTile = 1024;     // candidates staged in LDS at a time (16 KiB)
+// Every drone sweeps the candidates of the 3x3 cells around its own, staged through LDS.  A lane = a drone, and of the ~650 candidates of a drone ~100 are above it and within 10 m, ~35 close enough for
+// a contribution the fixed-point sum resolves: evaluating the model (two reciprocals, an exponential, a conversion: ~36 issue
+// slots) for every candidate, as the first version of this kernel did, spends 95 % of the vector unit on masked-off lanes --
+// and with 64 lanes SOME lane nearly always passes, so no wave-level branch ever skips it.  Hence test and evaluation are
+// separated, per chunk of 32 candidates:
+//   A  the tests only, two candidates per packed instruction, no compare and no branch: with d = (candidate - drone),
+//      q = dxy^2 - min(100.01, 80.02 beta(dz)^2) (the 10 m cut-off and the arg < 40 cut, without a division) and the sign
+//      bits of q and of -dz ANDed and shifted into a per-lane 32-bit mask (v_and + v_alignbit): 7 slots per candidate, LDS reads
+//      at wave-uniform addresses;
+//   Q  the set bits become (drone lane, candidate) pairs in a per-wave LDS queue: a DPP prefix sum of the lanes' popcounts
+//      gives each lane its slice;
+//   E  whenever the queue holds 64 pairs, every lane takes one: drone through ds_bpermute, candidate gathered from the tile, the
+//      EXACT tests and the model, and a 64-bit LDS atomic onto the drone's fixed-point sum.  All 64 lanes busy.
+// Phase A is a conservative filter (100.01 / 80.02 instead of 100 / 80): it may queue a pair that the exact tests of E then
+// reject, never the reverse.  The per-pair arithmetic and the integer sum are those of the first version, so the result is the
+// same bit for bit -- except that the first version also kept pairs beyond arg = 40 when alpha > 1e8 N (two drones within
+// 28 micrometres of the same height); each such pair now drops less than 4.3e-18 alpha.
+constexpr int kDwTile = 1024;     // candidates staged in LDS at a time (3 x 4 KiB, x / y / z planes)
+constexpr int kDwChunk = 32;      // candidates per mask word
+constexpr int kDwQueue = 64 + kDwChunk * 64;   // pending (< 64) + everything one chunk can add
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_add(int v) {   // v + (v of the lane the DPP control selects; 0 where there is none / the row is masked)
+    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    v = dpp_add<0x111, 0xf>(v);      // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);      // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);      // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);      // row_shr:8      -> inclusive within each row of 16
+    v = dpp_add<0x142, 0xa>(v);      // row_bcast:15   -> rows 1 and 3 add the total of the row before
+    v = dpp_add<0x143, 0xc>(v);      // row_bcast:31   -> rows 2 and 3 add the total of the first half
+    return v;
+}
+
+// One workgroup per 64 CONSECUTIVE drones of the sorted array (lane = drone; all four waves hold the same 64 and split the
+// candidates four ways -- the partial sums are integers, the split changes no bit).  Sorted by cell, row-major, 64 consecutive
+// drones cover one or a few cells of one grid row (a dense swarm: one or two; a sparse one: many), and their candidates are
+// the three rows around it, each a CONTIGUOUS stretch of the sorted array from the cell left of the first to the cell right of
+// the last: three runs, six when the periodic grid wraps.  Every lane is busy whatever the cells hold -- a workgroup per CELL,
+// as in the first version, swept all candidates a second time for the few drones beyond the 64th of a cell.  A group that
+// straddles the end of a grid row is swept once per row segment, with the lanes of the other segment switched off.
 __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, const DwGrid G,
                                                            const int* __restrict__ start, const int* __restrict__ order,
                                                            const float4* __restrict__ sorted, float* __restrict__ dw_out,
                                                            int* __restrict__ cursor) {
-    // The drones of the cell are taken 64 at a time, and ALL FOUR waves hold the same 64 (lane i of every wave = drone
-    // base + i): the waves split the CANDIDATES of a tile four ways instead of the drones -- a cell holds ~64 drones, so
-    // splitting the drones would leave three of the four waves sweeping for nobody.  The partial sums are 64-bit fixed
-    // point, hence the four-way split changes no bit of the result.
-    __shared__ float4 tile[kDwTile];
-    __shared__ long long part[kBlock];
+    __shared__ __attribute__((aligned(16))) float tx[kDwTile], ty[kDwTile], tz[kDwTile];
+    __shared__ unsigned short queue[kBlock / 64][kDwQueue];
+    __shared__ unsigned long long sums[kBlock / 64][64];
     const int nx = G.nx, ny = G.ny, nz = G.nz;
-    const int c = blockIdx.x;
-    const int cy = c / nx, cx = c - cy * nx;
-    const int m0 = start[c * nz], m1 = start[(c + 1) * nz];   // the drones of this cell, ordered by height bin
+    const int keys = nx * ny * nz;
     // the sort's per-key counters / cursors are done with: leave them zeroed for the next call (no memset node per call)
-    if (threadIdx.x < nz) cursor[c * nz + threadIdx.x] = 0;
-    if (c == 0 && threadIdx.x == 0) cursor[nx * ny * nz] = 0;
-    if (m0 == m1) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = blockIdx.x * kBlock + threadIdx.x; k <= keys; k += gridDim.x * kBlock) cursor[k] = 0;
+    const int sorted_n = start[keys];                      // drones with a finite position (the others: force 0, set by the sort)
+    const int base = 64 * blockIdx.x;
+    if (base >= sorted_n) return;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    unsigned short* const my_queue = queue[wave];
+    unsigned long long* const my_sums = sums[wave];
     const float kr = 0.25f * P.prop_radius;
-    // The candidates of the 3x3 neighbourhood (periodic; nx, ny >= 3: nine distinct cells) are nine runs of the sorted
-    // array.  They are staged as ONE concatenated list, kDwTile at a time: one pair of barriers and one round of global
-    // loads per ~1000 candidates instead of per cell (the loads' latency sits between the two barriers).
-    int nb_cell[9];
-#pragma unroll
-    for (int nb = 0; nb < 9; ++nb) nb_cell[nb] = ((cy + nb / 3 - 1 + ny) % ny) * nx + (cx + nb % 3 - 1 + nx) % nx;
-    // Groups of 64 drones (lane = drone).  One group: the four waves hold the SAME 64 drones and split the candidates four ways;
-    // two groups left: two waves per group, candidates split two ways; three or more: one group per wave.  A cell holds ~64 drones
-    // with a Poisson spread, so nearly half the cells have a second, mostly empty group -- it now rides along in the same pass
-    // over the candidates instead of costing a pass of its own.  (Fixed-point partial sums: the split changes no bit.)
-    const int ngroups = (m1 - m0 + 63) >> 6;
-    for (int g0 = 0; g0 < ngroups;) {
-        const int rem = ngroups - g0;
-        const int gp = rem >= 3 ? 4 : rem;                 // groups in this pass: 1, 2 or 4 (a fourth may be empty)
-        const int ways = 4 / gp;                           // waves per group
-        const int grp = wave % gp, split = wave / gp;
-        const int base = m0 + 64 * (g0 + grp);
-        const int s = base + lane;
-        const bool have = s < m1;
-        const float4 me = have ? sorted[s] : make_float4(0.0f, 0.0f, 3.0e38f, 0.0f);   // (no drone: nothing is above it)
-        // the pass's lowest height bin is its first drone's (the cell is ordered by bin): every neighbour cell's run starts
-        // at that bin -- candidates in lower bins are below all drones of the pass and would only fail the dz > 0 test one by one
-        const int bmin = __float_as_int(sorted[m0 + 64 * g0].w) % nz;
-        int run0[9], pre[10];                              // first element of each run; prefix sums of the run lengths
+    const float cut = 8.9454f;                             // sqrt(80.02): arg < 40  <=>  dxy^2 < 80 beta^2
+    const fp2 b1 = splat(-P.dw_coeff[1] * cut), b0 = splat(P.dw_coeff[2] * cut);
+    const int s = base + lane;
+    const bool have = s < sorted_n;
+    const float4 me = have ? sorted[s] : make_float4(0.0f, 0.0f, 3.0e38f, 0.0f);
+    const int my_cell = have ? __float_as_int(me.w) / nz : -1;
+    const int c_first = __float_as_int(sorted[base].w) / nz, c_last = __float_as_int(sorted[min(base + 63, sorted_n - 1)].w) / nz;
+    my_sums[lane] = 0ull;                                  // sum of contributions in units of 2^-30 N: order-independent
+    for (int cs = c_first; cs <= c_last;) {                // row segments of the group's cells (nearly always one)
+        const int cy = cs / nx;
+        const int ce = min(c_last, cy * nx + nx - 1);
+        const int cxa = cs - cy * nx, w = ce - cs + 3;     // columns cxa - 1 .. cxb + 1, periodic
+        const bool active = have && my_cell >= cs && my_cell <= ce;
+        const float mez = active ? me.z : 3.0e38f;         // (switched off: nothing is above it)
+        int run0[6], pre[7];                               // first element of each run; prefix sums of the run lengths
         pre[0] = 0;
 #pragma unroll
-        for (int nb = 0; nb < 9; ++nb) {
-            run0[nb] = start[nb_cell[nb] * nz + bmin];
-            pre[nb + 1] = pre[nb] + (start[(nb_cell[nb] + 1) * nz] - run0[nb]);
-        }
-        const int total = pre[9];
-        long long acc = 0;                                 // sum of contributions in units of 2^-30 N: order-independent
-        for (int v0 = 0; v0 < total; v0 += kDwTile) {
-            const int cnt = min(kDwTile, total - v0);
-            __syncthreads();
-            for (int j = threadIdx.x; j < cnt; j += kBlock) {
-                const int v = v0 + j;                      // position in the concatenated list -> run r, element src
-                int src = run0[0] + v;
-#pragma unroll
-                for (int q = 1; q < 9; ++q) src = (v >= pre[q]) ? run0[q] + (v - pre[q]) : src;
-                tile[j] = sorted[src];
+        for (int r = 0; r < 3; ++r) {
+            const int row = ((cy + r - 1 + ny) % ny) * nx;
+            int a0, a1, b0c, b1c;                          // run A: cells a0 .. a1; run B (the wrapped part): b0c .. b1c, or empty
+            if (w >= nx) { a0 = 0; a1 = nx - 1; b0c = 0; b1c = -1; }
+            else {
+                const int a = (cxa - 1 + nx) % nx;
+                a0 = a; a1 = min(a + w - 1, nx - 1);
+                b0c = 0; b1c = a + w - 1 - nx;             // (< 0: no wrap)
             }
-            __syncthreads();
-#pragma unroll 4
-            for (int j = split; j < cnt; j += ways) {      // this wave's share of the candidates
-                const float4 o = tile[j];
-                const float dz = o.z - me.z;
-                const float ddx = o.x - me.x, ddy = o.y - me.y;
-                const float dxy2 = fmaf(ddy, ddy, ddx * ddx);
-                if (dz > 0.0f && dxy2 < 100.0f) {          // dz > 0 and dxy < 10 m  (:800-801)
-                    const float ratio = kr * fast_rcp(dz);
-                    const float alpha = P.dw_coeff[0] * (ratio * ratio);
-                    const float beta = fmaf(P.dw_coeff[1], dz, P.dw_coeff[2]);
-                    const float ib = fast_rcp(beta);
-                    const float arg = 0.5f * (dxy2 * (ib * ib));
-                    // exp(-40) = 4e-18: below the 2^-31 N the fixed-point sum resolves for any alpha < 1e8 N -- most
-                    // candidates of the 3x3 cells end here without evaluating the exponential
-                    if (arg < 40.0f || alpha > 1.0e8f) acc += __float2ll_rn((alpha * fast_exp(-arg)) * 1073741824.0f);
+            run0[2 * r] = start[(row + a0) * nz];
+            pre[2 * r + 1] = pre[2 * r] + (start[(row + a1 + 1) * nz] - run0[2 * r]);
+            run0[2 * r + 1] = start[(row + b0c) * nz];
+            pre[2 * r + 2] = pre[2 * r + 1] + (b1c >= 0 ? start[(row + b1c + 1) * nz] - run0[2 * r + 1] : 0);
+        }
+        const int total = pre[6];
+        const fp2 mx = splat(me.x), my = splat(me.y), mz = splat(mez);
+        int pending = 0;                                   // pairs in this wave's queue (wave-uniform)
+        // one queued pair: the exact tests and the model (:798-808), added to the drone's sum
+        // (called by ALL lanes -- ds_bpermute reads nothing from a lane that is masked off -- with `valid` false where there is no pair)
+        auto evaluate = [&](unsigned e, bool valid) {
+            const int dl = static_cast<int>(e >> 10), ci = static_cast<int>(e & 1023u);
+            const float px = __shfl(me.x, dl), py = __shfl(me.y, dl), pz = __shfl(me.z, dl);
+            const float dz = tz[ci] - pz;
+            const float ddx = tx[ci] - px, ddy = ty[ci] - py;
+            const float dxy2 = fmaf(ddy, ddy, ddx * ddx);
+            if (valid && dz > 0.0f && dxy2 < 100.0f) {     // dz > 0 and dxy < 10 m  (:800-801)
+                const float ratio = kr * fast_rcp(dz);
+                const float alpha = P.dw_coeff[0] * (ratio * ratio);
+                const float beta = fmaf(P.dw_coeff[1], dz, P.dw_coeff[2]);
+                const float ib = fast_rcp(beta);
+                const float arg = 0.5f * (dxy2 * (ib * ib));
+                if (arg < 40.0f) {                         // exp(-40) = 4e-18: below the 2^-31 N the sum resolves
+                    const float sc = (alpha * fast_exp(-arg)) * 1073741824.0f;
+                    // (< 4 N, i.e. unless two drones are centimetres apart: one conversion instead of the 14-instruction
+                    // float -> int64 sequence; the same integer either way)
+                    unsigned long long v;
+                    if (__builtin_amdgcn_ballot_w64(!(sc >= 0.0f && sc < 4.0e9f)) != 0) {
+                        asm volatile("; a contribution of 4 N or more" ::: "memory");      // (keeps this a branch, not a select)
+                        v = static_cast<unsigned long long>(__float2ll_rn(sc));
+                    } else {
+                        v = static_cast<unsigned long long>(__float2uint_rn(sc));
+                    }
+                    atomicAdd(&my_sums[dl], v);
                 }
             }
+        };
+        for (int v0 = 0; v0 < total; v0 += kDwTile) {
+            const int cnt = min(kDwTile, total - v0);
+            const int chunks = (cnt + kDwChunk - 1) / kDwChunk;
+            __syncthreads();
+            for (int j = threadIdx.x; j < chunks * kDwChunk; j += kBlock) {
+                float4 o = make_float4(0.0f, 0.0f, -3.0e38f, 0.0f);        // (padding of the last chunk: below everything)
+                if (j < cnt) {
+                    const int v = v0 + j;                  // position in the concatenated list -> run r, element src
+                    int src = run0[0] + v;
+#pragma unroll
+                    for (int q = 1; q < 6; ++q) src = (v >= pre[q]) ? run0[q] + (v - pre[q]) : src;
+                    o = sorted[src];
+                }
+                tx[j] = o.x; ty[j] = o.y; tz[j] = o.z;
+            }
+            __syncthreads();
+            for (int ch = wave; ch < chunks; ch += kBlock / 64) {       // this wave's share of the candidates
+                const int j0 = ch * kDwChunk;
+                uint32_t mask = 0;                                     // candidate j0 + j of the chunk -> bit 31 - j
+#pragma unroll 8
+                for (int j = 0; j < kDwChunk; j += 2) {
+                    const fp2 ox = *reinterpret_cast<const fp2*>(&tx[j0 + j]), oy = *reinterpret_cast<const fp2*>(&ty[j0 + j]),
+                              oz = *reinterpret_cast<const fp2*>(&tz[j0 + j]);
+                    const fp2 ddx = ox - mx, ddy = oy - my, below = mz - oz;       // below < 0: the candidate is above
+                    const fp2 d2 = fma2(ddy, ddy, ddx * ddx);
+                    const fp2 bs = fma2(b1, below, b0);                            // sqrt(80.02) beta(dz)
+                    const fp2 lim = bs * bs;
+                    const fp2 q = d2 - fp2{fminf(lim.x, 100.01f), fminf(lim.y, 100.01f)};
+                    mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(q.x) & __float_as_uint(below.x), 31);
+                    mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(q.y) & __float_as_uint(below.y), 31);
+                }
+                const int mine = __builtin_popcount(mask);
+                const int upto = wave_inclusive_scan(mine);
+                int pos = pending + upto - mine;
+                while (mask != 0u) {                                   // this lane's pairs -> its slice of the queue
+                    const int j = __builtin_clz(mask);
+                    mask &= ~(0x80000000u >> j);
+                    my_queue[pos++] = static_cast<unsigned short>((lane << 10) | (j0 + j));
+                }
+                pending += __builtin_amdgcn_readlane(upto, 63);
+                __builtin_amdgcn_wave_barrier();
+                while (pending >= 64) {                                // full batches, taken from the end
+                    pending -= 64;
+                    evaluate(my_queue[pending + lane], true);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (pending > 0) evaluate(lane < pending ? my_queue[lane] : 0u, lane < pending);   // (the tile is about to be replaced)
+            pending = 0;
         }
-        __syncthreads();                                   // (all waves are done with `part` of the previous pass)
-        part[threadIdx.x] = acc;
-        __syncthreads();
-        if (split == 0 && have) {                          // the group's first wave adds up the shares of its `ways` waves
-            long long sum = 0;
-            for (int k = 0; k < ways; ++k) sum += part[(k * gp + grp) * 64 + lane];
-            dw_out[order[s]] = -static_cast<float>(static_cast<double>(sum) * (1.0 / 1073741824.0));
-        }
-        g0 += gp;
+        cs = ce + 1;
+    }
+    __syncthreads();
+    if (wave == 0 && have) {                               // add up the four waves' shares
+        unsigned long long sum = 0;
+#pragma unroll
+        for (int k = 0; k < kBlock / 64; ++k) sum += sums[k][lane];
+        dw_out[order[s]] = -static_cast<float>(static_cast<double>(static_cast<long long>(sum)) * (1.0 / 1073741824.0));
     }
 }
 
@@ -2517,7 +2605,7 @@ int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, i
     hipLaunchKernelGGL(dwg_scan_kernel, dim3(1), dim3(1024), 0, st, cell_count, cell_start, keys);
     hipLaunchKernelGGL(dwg_scatter_kernel, grid, dim3(kBlock), 0, st, kin, ld, n, G, visit_order, cell_count, cell_start, order,
                        reinterpret_cast<float4*>(sorted_xyzc), dw_out);
-    hipLaunchKernelGGL(dwg_force_kernel, dim3(static_cast<unsigned>(cells)), dim3(kBlock), 0, st, *params, G, cell_start,
+    hipLaunchKernelGGL(dwg_force_kernel, dim3(static_cast<unsigned>((n + 63) / 64)), dim3(kBlock), 0, st, *params, G, cell_start,
                        order, reinterpret_cast<const float4*>(sorted_xyzc), dw_out, cell_count);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gpd_downwash_global launch");
