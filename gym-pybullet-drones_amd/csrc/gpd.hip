@@ -1977,7 +1977,8 @@ __global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const float* __rest
 // 28 micrometres of the same height); each such pair now drops less than 4.3e-18 alpha.
 constexpr int kDwTile = 1024;     // candidates staged in LDS at a time (3 x 4 KiB, x / y / z planes)
 constexpr int kDwChunk = 32;      // candidates per mask word
-constexpr int kDwQueue = 64 + kDwChunk * 64;   // pending (< 64) + everything one chunk can add
+constexpr int kDwBatches = 4;     // queued batches of 64 pairs that trigger an evaluation
+constexpr int kDwQueue = 64 * kDwBatches + kDwChunk * 64;   // pending (< 64 kDwBatches) + everything one chunk can add
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_add(int v) {   // v + (v of the lane the DPP control selects; 0 where there is none / the row is masked)
@@ -2122,13 +2123,20 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
                 }
                 pending += __builtin_amdgcn_readlane(upto, 63);
                 __builtin_amdgcn_wave_barrier();
-                while (pending >= 64) {                                // full batches, taken from the end
-                    pending -= 64;
-                    evaluate(my_queue[pending + lane], true);
+                // Full batches once kDwBatches of them wait: a lane's pairs sit next to each other in the queue, so a batch of 64
+                // CONSECUTIVE pairs would hit each drone's sum ~5 times in one ds_add_u64 (the LDS serialises those); batch b takes
+                // every nb-th pair instead, taken from the end (the < 64 oldest stay where they are).
+                if (pending >= 64 * kDwBatches) {
+                    const int nb = pending >> 6;
+                    pending &= 63;
+                    for (int b = 0; b < nb; ++b) evaluate(my_queue[pending + b + lane * nb], true);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-            if (pending > 0) evaluate(lane < pending ? my_queue[lane] : 0u, lane < pending);   // (the tile is about to be replaced)
+            {                                                          // (the tile is about to be replaced: everything goes)
+                const int nb = (pending + 63) >> 6;
+                for (int b = 0; b < nb; ++b) { const int k = b + lane * nb; evaluate(k < pending ? my_queue[k] : 0u, k < pending); }
+            }
             pending = 0;
         }
         cs = ce + 1;
