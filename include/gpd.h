@@ -321,15 +321,16 @@ int gpd_full_obs(const GpdState* state, int32_t num_steps, int32_t n_drones, int
  * the 3x3 neighbourhood of each drone's cell.  The grid is periodic: a drone outside the box the grid was laid over
  * lands in the cell its coordinates wrap to (still exact: every candidate pair is distance-tested, aliased far-apart
  * drones are rejected; the swarm may spread without piling up in border cells).  The per-drone sum is accumulated
- * in 64-bit fixed point (2^-30 N), so the result does not depend on the order the sort leaves the neighbours in.
+ * in 64-bit fixed point (2^-30 N), so the result does not depend on the order the sort leaves the neighbours in; a pair
+ * whose exponent 0.5 (dxy / (DW2*dz + DW3))^2 reaches 40 is dropped (it is below e^-40 = 4.3e-18 of its own amplitude).
  *
  *   kin, ld       the state block of gpd_step (rows 0..2 = positions are read)
  *   cell, x0, y0, nx, ny   grid: cell size [m] (>= 10), lower-left corner, cells per side (nx, ny >= 3)
  *   z0, zbin, nz  every cell is split into nz height bins of zbin metres starting at z0 (bin 0 also holds everything below z0,
  *                 bin nz-1 everything above; nz = 1: no bins, z0/zbin ignored); nx*ny*nz <= 65536.  The sort key is
- *                 cell*nz + bin, so inside a cell the drones are ordered by height bin and a group of 64 drones skips every
- *                 candidate in a bin below its own lowest one (such a candidate is below all of them: the model ignores it).
- *                 Pruning only: any (z0, zbin, nz) gives the same forces bit for bit.
+ *                 cell*nz + bin, so inside a cell the drones are ordered by height bin.  Ordering only: any (z0, zbin, nz)
+ *                 gives the same forces bit for bit (the force kernel of ABI 4's first builds pruned by bin; the present
+ *                 one does not, nz = 1 is the sensible choice).
  *   visit_order   [n] int32 permutation of 0..n-1 or NULL (= 0, 1, 2 ...): the order the sort visits the drones in.
  *                 Any permutation gives the same forces bit for bit; handing in the `order` buffer the PREVIOUS call
  *                 filled (two buffers, ping-pong: it must not alias `order`) makes neighbouring lanes share a cell, and
