@@ -329,6 +329,36 @@ def test_swarm_downwash_is_order_independent_and_matches_the_workgroup_path(gpu_
     assert torch.allclose(sa, sv, rtol=0, atol=2e-6)
 
 
+def test_swarm_downwash_dense_cells_many_tiles_and_large_terms(gpu_device):
+    """What the sparse scenes do not reach in the force kernel: a cell with thousands of drones (a group's candidates fill
+    several 1024-candidate tiles; nearly every candidate of a chunk passes the test for nearly every lane, so the pair queue
+    takes its worst case, 64 x 32 pairs per chunk), and contributions of 4 N and more (two drones 5 cm above each other:
+    the 64-bit conversion path).  Against the float64 all-pairs loop of the oracle."""
+    from conftest import urdf
+    from gym_pybullet_drones_amd.envs import SwarmAviary
+    from gym_pybullet_drones_amd.utils.enums import Physics
+    from oracle.batched_oracle import BatchedAviary
+    rng = np.random.default_rng(21)
+    N = 3000
+    # thirty layers 0.3 m apart over a 9 m x 9 m patch (one or two grid cells): inside a layer a 0.9 m lattice, the lattices
+    # of the layers shifted against each other so that vertical neighbours are >= 0.25 m apart laterally (dz = 0.3 m: |beta| =
+    # 0.062 m, the term is ~1e-4 N there and steep), every pair within the 10 m cut-off
+    sites = np.array([(x, y) for x in np.arange(0, 9, 0.9) for y in np.arange(0, 9, 0.9)])            # 100
+    layer, site = np.divmod(np.arange(N), len(sites))
+    xyz = np.concatenate([sites[site] + 0.3 * np.stack([layer % 3, (layer // 3) % 3], 1) + rng.uniform(-0.02, 0.02, size=(N, 2)),
+                          (1.0 + 0.3 * layer)[:, None]], axis=1)
+    xyz[1] = xyz[0] + np.array([0.001, 0.0, 0.05])          # 0.0762 / 0.05^2 = 30 N on drone 0
+    xyz = xyz[rng.permutation(N)]
+    env = SwarmAviary(N, initial_xyzs=xyz, physics=Physics.PYB_DW, device=gpu_device)
+    orc = BatchedAviary(urdf("cf2x"), "cf2x", num_envs=1, num_drones=N, initial_xyzs=xyz[None], physics_flags=4,
+                        pyb_freq=240, ctrl_freq=240, act="raw_rpm", task="none", pid_urdf_path=urdf("cf2x"))
+    f = env.downwash().cpu().numpy().astype(np.float64)
+    ref = orc.downwash_force_all()[0]
+    assert np.abs(ref).max() > 4.0 and (np.abs(ref) > 1e-4).mean() > 0.5
+    np.testing.assert_allclose(f, ref, rtol=3e-3, atol=1e-7)
+    assert torch.equal(env.downwash(), env.downwash())       # (and again with the previous call's visit order)
+
+
 def test_swarm_downwash_outside_the_grid_box(gpu_device):
     """The grid is periodic: drones far outside the box it was laid over (and far-apart drones aliasing into
     neighbouring cells) still get exactly the forces of the all-pairs loop."""
