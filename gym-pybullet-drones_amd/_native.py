@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(CSRC, "libgpd.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # Two translation units (csrc/gpd.hip, csrc/gpd_policy.hip = the same source with GPD_POLICY_TU defined), one library:
 #   -mllvm -amdgpu-sched-strategy=max-ilp for the step / rollout kernels: it interleaves independent dependency chains, which

@@ -1844,7 +1844,7 @@ __global__ __launch_bounds__(kBlock) void gpd_hist_advance_kernel(int K, int E, 
 
 // ------------------------------------------------------------------------------------------------
 // Downwash inside ONE aviary of any size (envs/BaseAviary.py:785-811): uniform 2-D grid, counting sort by cell,
-// 3x3 neighbourhood search.  Four small kernels per physics sub-step.
+// 3x3 neighbourhood search.  Three kernels per physics sub-step (count, scan + scatter, force).
 // ------------------------------------------------------------------------------------------------
 // cell of a position: the grid is periodic (cells wrap around), so drones that leave the box the grid was laid over
 // keep spreading over all cells instead of piling up at its border; far-apart drones that alias into neighbouring
@@ -1904,8 +1904,8 @@ __global__ __launch_bounds__(kBlock) void dwg_count_kernel(const float* __restri
     if (lane == head_lane && c >= 0) atomicAdd(&count[c], len);
 }
 
-// exclusive scan of count[0..cells) into start[0..cells], one workgroup; count is zeroed for the scatter's cursors
-__global__ __launch_bounds__(1024) void dwg_scan_kernel(int* __restrict__ count, int* __restrict__ start, int cells) {
+// exclusive scan of count[0..cells) into start[0..cells], one workgroup (only for more keys than the scatter kernel scans itself)
+__global__ __launch_bounds__(1024) void dwg_scan_kernel(const int* __restrict__ count, int* __restrict__ start, int cells) {
     __shared__ int part[1024];
     const int t = threadIdx.x;
     const int per = (cells + 1023) / 1024;
@@ -1921,17 +1921,47 @@ __global__ __launch_bounds__(1024) void dwg_scan_kernel(int* __restrict__ count,
         __syncthreads();
     }
     int run = t == 0 ? 0 : part[t - 1];
-    for (int c = lo; c < hi; ++c) { const int k = count[c]; start[c] = run; run += k; count[c] = 0; }
+    for (int c = lo; c < hi; ++c) { const int k = count[c]; start[c] = run; run += k; }
     if (t == 1023) start[cells] = part[1023];
 }
 
+// FUSED (up to kDwScanMax keys): every workgroup turns the counts into start offsets ITSELF, in LDS -- a few thousand integers
+// from L2 and eight rounds of a 256-wide scan cost less than the launch of a scan kernel between count and scatter (the
+// dependent launches, not the work in them, are what a swarm sub-step is made of); workgroup 0 also
+// writes them out for the force kernel.
+constexpr int kDwScanMax = 4096;
+template <bool FUSED>
 __global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const float* __restrict__ kin, int64_t ld, int n, const DwGrid G,
-                                                             const int* __restrict__ visit, int* __restrict__ cursor,
-                                                             const int* __restrict__ start, int* __restrict__ order,
-                                                             float4* __restrict__ sorted, float* __restrict__ dw_out) {
+                                                             const int* __restrict__ visit, const int* __restrict__ count,
+                                                             int* __restrict__ cursor, int* __restrict__ start_g,
+                                                             int* __restrict__ order, float4* __restrict__ sorted,
+                                                             float* __restrict__ dw_out) {
+    __shared__ int lstart[FUSED ? kDwScanMax + 1 : 1];
+    __shared__ int part[FUSED ? kBlock : 1];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int keys = G.nx * G.ny * G.nz;
+    if constexpr (FUSED) {
+        const int t = threadIdx.x;
+        const int per = (keys + kBlock - 1) / kBlock;
+        const int lo = t * per, hi = min(lo + per, keys);
+        int sum = 0;
+        for (int k = lo; k < hi; ++k) sum += count[k];
+        part[t] = sum;
+        __syncthreads();
+        for (int off = 1; off < kBlock; off <<= 1) {      // Hillis-Steele inclusive scan of the 256 partial sums
+            const int v = t >= off ? part[t - off] : 0;
+            __syncthreads();
+            part[t] += v;
+            __syncthreads();
+        }
+        int run = t == 0 ? 0 : part[t - 1];
+        for (int k = lo; k < hi; ++k) { lstart[k] = run; run += count[k]; }
+        if (t == kBlock - 1) lstart[keys] = part[kBlock - 1];
+        __syncthreads();
+        if (blockIdx.x == 0) for (int k = t; k <= keys; k += kBlock) start_g[k] = lstart[k];
+    }
+    auto start = [&](int k) { if constexpr (FUSED) return lstart[k]; else return start_g[k]; };
     int c = -1 - lane, d = 0;
     float x = 0.0f, y = 0.0f, z = 0.0f;
     if (i < n) {
@@ -1943,13 +1973,13 @@ __global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const float* __rest
             // (see dwg_count_kernel) no force on it, none from it; it keeps a slot behind the sorted drones so that `order`
             // stays a permutation (the next call visits the drones in this order)
             dw_out[d] = 0.0f;
-            order[start[keys] + atomicAdd(&cursor[keys], 1)] = d;
+            order[start(keys) + atomicAdd(&cursor[keys], 1)] = d;
         }
     }
     int head_lane, len;
     run_of(c, lane, head_lane, len);
     int base = 0;
-    if (lane == head_lane && c >= 0) base = start[c] + atomicAdd(&cursor[c], len);   // one atomic per run of equal keys
+    if (lane == head_lane && c >= 0) base = start(c) + atomicAdd(&cursor[c], len);   // one atomic per run of equal keys
     base = __shfl(base, head_lane);
     if (c >= 0) {
         const int slot = base + (lane - head_lane);
@@ -2011,7 +2041,7 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
     const int nx = G.nx, ny = G.ny, nz = G.nz;
     const int keys = nx * ny * nz;
     // the sort's per-key counters / cursors are done with: leave them zeroed for the next call (no memset node per call)
-    for (int k = blockIdx.x * kBlock + threadIdx.x; k <= keys; k += gridDim.x * kBlock) cursor[k] = 0;
+    for (int k = blockIdx.x * kBlock + threadIdx.x; k < 2 * (keys + 1); k += gridDim.x * kBlock) cursor[k] = 0;   // (counts | cursors)
     const int sorted_n = start[keys];                      // drones with a finite position (the others: force 0, set by the sort)
     const int base = 64 * blockIdx.x;
     if (base >= sorted_n) return;
@@ -2610,9 +2640,15 @@ int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, i
     hipError_t e;
     const dim3 grid(static_cast<unsigned>((n + kBlock - 1) / kBlock));
     hipLaunchKernelGGL(dwg_count_kernel, grid, dim3(kBlock), 0, st, kin, ld, n, G, visit_order, cell_count);
-    hipLaunchKernelGGL(dwg_scan_kernel, dim3(1), dim3(1024), 0, st, cell_count, cell_start, keys);
-    hipLaunchKernelGGL(dwg_scatter_kernel, grid, dim3(kBlock), 0, st, kin, ld, n, G, visit_order, cell_count, cell_start, order,
-                       reinterpret_cast<float4*>(sorted_xyzc), dw_out);
+    int32_t* const cursors = cell_count + keys + 1;       // second half of cell_count: the scatter's per-key cursors
+    if (keys <= kDwScanMax) {
+        hipLaunchKernelGGL(dwg_scatter_kernel<true>, grid, dim3(kBlock), 0, st, kin, ld, n, G, visit_order, cell_count, cursors,
+                           cell_start, order, reinterpret_cast<float4*>(sorted_xyzc), dw_out);
+    } else {
+        hipLaunchKernelGGL(dwg_scan_kernel, dim3(1), dim3(1024), 0, st, cell_count, cell_start, keys);
+        hipLaunchKernelGGL(dwg_scatter_kernel<false>, grid, dim3(kBlock), 0, st, kin, ld, n, G, visit_order, cell_count, cursors,
+                           cell_start, order, reinterpret_cast<float4*>(sorted_xyzc), dw_out);
+    }
     hipLaunchKernelGGL(dwg_force_kernel, dim3(static_cast<unsigned>((n + 63) / 64)), dim3(kBlock), 0, st, *params, G, cell_start,
                        order, reinterpret_cast<const float4*>(sorted_xyzc), dw_out, cell_count);
     e = hipGetLastError();

@@ -80,7 +80,7 @@ class SwarmAviary:
         self.z0 = float(xyz[:, 0, 2].min() - self.zbin)
         self.nz = int(max(1, min(nz, 65536 // cells)))
         i32 = dict(dtype=torch.int32, device=dev)
-        self._count, self._start = torch.zeros(cells * self.nz + 1, **i32), torch.zeros(cells * self.nz + 1, **i32)
+        self._count, self._start = torch.zeros(2 * (cells * self.nz + 1), **i32), torch.zeros(cells * self.nz + 1, **i32)
         self._order = torch.zeros(N, **i32)          # sorted slot -> drone, filled by every call ...
         self._visit = torch.zeros(N, **i32)          # ... and the previous call's, which the next sort visits the drones in
         self._have_visit = False

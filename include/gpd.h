@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GPD_ABI_VERSION 4
+#define GPD_ABI_VERSION 5
 
 /* DroneModel (utils/enums.py:3-8) */
 enum { GPD_MODEL_CF2X = 0, GPD_MODEL_CF2P = 1, GPD_MODEL_RACE = 2 };
@@ -335,8 +335,9 @@ int gpd_full_obs(const GpdState* state, int32_t num_steps, int32_t n_drones, int
  *                 Any permutation gives the same forces bit for bit; handing in the `order` buffer the PREVIOUS call
  *                 filled (two buffers, ping-pong: it must not alias `order`) makes neighbouring lanes share a cell, and
  *                 the sort then issues one atomic per run of equal cells instead of one per drone.
- *   cell_count    [nx*ny*nz + 1] int32: ZERO before the first call; every call leaves it zeroed again (the last kernel
- *                 clears what the sort counted: no memset per call)          cell_start  [nx*ny*nz + 1] int32 scratch
+ *   cell_count    [2 (nx*ny*nz + 1)] int32 (per-key counts | per-key cursors of the sort): ZERO before the first call; every
+ *                 call leaves it zeroed again (the last kernel clears it: no memset per call)
+ *   cell_start    [nx*ny*nz + 1] int32 scratch
  *   order         [n] int32 out (drone index of sorted slot: a permutation of 0..n-1)
  *   sorted_xyzc   [n][4] float scratch (x, y, z, sort key as int bits), sorted by key
  *   dw_out        [n] out: the force of drone i at dw_out[i]  (pass it to gpd_step as state.dw_force)

@@ -315,6 +315,9 @@ def test_swarm_downwash_is_order_independent_and_matches_the_workgroup_path(gpu_
         assert c.nz == kw["nz"] and torch.equal(c.downwash(), fa), kw
         assert torch.equal(c.downwash(), fa)                 # ... also on the second call (visit order = the previous call's order)
     assert torch.equal(fa[torch.as_tensor(perm, device=gpu_device)], fb)
+    # (4) more sort keys than the scatter kernel scans in LDS itself (4096): the path with a scan kernel of its own
+    big = SwarmAviary(N, initial_xyzs=xyz, physics=Physics.PYB_DW, world_min=(-350, -350), world_max=(350, 350), device=gpu_device)
+    assert big.nx * big.ny * big.nz > 4096 and torch.equal(big.downwash(), fa) and torch.equal(big.downwash(), fa)
     # the first call visits the drones as 0, 1, 2 ..., every later one in the previous call's cell order (one atomic per run
     # of equal cells): same forces, and `order` stays a permutation
     for _ in range(3):
