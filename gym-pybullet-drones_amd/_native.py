@@ -99,7 +99,7 @@ _SIGNATURES = {
                                     ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_int64, _P]),
     "gpd_downwash_global": (ctypes.c_int, [ctypes.POINTER(GpdParams), _P, ctypes.c_int64, ctypes.c_int32, ctypes.c_float,
                                            ctypes.c_float, ctypes.c_float, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
-                                           ctypes.c_float, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P]),
+                                           ctypes.c_float, ctypes.c_int32, _P, _P, _P, _P, _P, _P, ctypes.POINTER(GpdState), _P, _P, _P]),
     "gpd_reset": (ctypes.c_int, [ctypes.POINTER(GpdState), _P, ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_int32,
                                  ctypes.c_int32, _P, _P]),
     "gpd_pid": (ctypes.c_int, [ctypes.POINTER(GpdParams), _P, ctypes.c_int64, ctypes.c_float, _P, _P, _P, _P, _P, _P,

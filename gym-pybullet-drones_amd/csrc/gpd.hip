@@ -1842,6 +1842,21 @@ __global__ __launch_bounds__(kBlock) void gpd_hist_advance_kernel(int K, int E, 
     if (e < E) ring_pos[e] = (ring_pos[e] + K) % H;
 }
 
+// one row of BaseAviary._getDroneStateVector (envs/BaseAviary.py:541-561) from the SoA state and the obs12 row of the latest step
+__device__ __forceinline__ void state20_row(const GpdState& S, const float* __restrict__ obs12, float* __restrict__ out, int64_t n) {
+    const int64_t ld = S.ld;
+    const float* kin = S.kin + n;
+    const float* o = obs12 + n * 12;
+    float4* w = reinterpret_cast<float4*>(out + n * 20);
+    const float l0 = S.last_rpm ? S.last_rpm[0 * ld + n] : 0.0f, l1 = S.last_rpm ? S.last_rpm[1 * ld + n] : 0.0f;
+    const float l2 = S.last_rpm ? S.last_rpm[2 * ld + n] : 0.0f, l3 = S.last_rpm ? S.last_rpm[3 * ld + n] : 0.0f;
+    w[0] = make_float4(kin[0 * ld], kin[1 * ld], kin[2 * ld], kin[3 * ld]);
+    w[1] = make_float4(kin[4 * ld], kin[5 * ld], kin[6 * ld], o[3]);
+    w[2] = make_float4(o[4], o[5], kin[7 * ld], kin[8 * ld]);
+    w[3] = make_float4(kin[9 * ld], o[9], o[10], o[11]);
+    w[4] = make_float4(l0, l1, l2, l3);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Downwash inside ONE aviary of any size (envs/BaseAviary.py:785-811): uniform 2-D grid, counting sort by cell,
 // 3x3 neighbourhood search.  Three kernels per physics sub-step (count, scan + scatter, force).
@@ -1887,13 +1902,19 @@ __device__ __forceinline__ void run_of(int c, int lane, int& head_lane, int& len
     len = (above ? __builtin_ctzll(above) : 64) - head_lane;
 }
 
+// VEC: the pass over all drones also writes their [n][20] state vectors (what gpd_state_vectors does) -- a caller that steps
+// a swarm needs both after every step, and at this size a launch costs more than the rows.
+template <bool VEC>
 __global__ __launch_bounds__(kBlock) void dwg_count_kernel(const float* __restrict__ kin, int64_t ld, int n, const DwGrid G,
-                                                           const int* __restrict__ visit, int* __restrict__ count) {
+                                                           const int* __restrict__ visit, int* __restrict__ count,
+                                                           const GpdState VS, const float* __restrict__ vec_obs12,
+                                                           float* __restrict__ vec_out) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int c = -1 - lane;                                      // (no drone: a run of its own, no atomic)
     if (i < n) {
         const int d = visit ? visit[i] : i;
+        if constexpr (VEC) state20_row(VS, vec_obs12, vec_out, i);      // (row i, not row d: coalesced, the two jobs only share the launch)
         const float x = kin[d], y = kin[ld + d], z = kin[2 * ld + d];
         // a drone whose position is no longer finite (the downwash model diverges when two drones pass each other
         // vertically, dz -> 0+) takes no part: it would otherwise alias into cell 0 together with every other such drone
@@ -2227,17 +2248,7 @@ __global__ __launch_bounds__(kBlock) void gpd_state20_kernel(const GpdState S, c
                                                              float* __restrict__ out, int n_total) {
     const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (n >= n_total) return;
-    const int64_t ld = S.ld;
-    const float* kin = S.kin + n;
-    const float* o = obs12 + n * 12;
-    float4* w = reinterpret_cast<float4*>(out + n * 20);
-    const float l0 = S.last_rpm ? S.last_rpm[0 * ld + n] : 0.0f, l1 = S.last_rpm ? S.last_rpm[1 * ld + n] : 0.0f;
-    const float l2 = S.last_rpm ? S.last_rpm[2 * ld + n] : 0.0f, l3 = S.last_rpm ? S.last_rpm[3 * ld + n] : 0.0f;
-    w[0] = make_float4(kin[0 * ld], kin[1 * ld], kin[2 * ld], kin[3 * ld]);
-    w[1] = make_float4(kin[4 * ld], kin[5 * ld], kin[6 * ld], o[3]);
-    w[2] = make_float4(o[4], o[5], kin[7 * ld], kin[8 * ld]);
-    w[3] = make_float4(kin[9 * ld], o[9], o[10], o[11]);
-    w[4] = make_float4(l0, l1, l2, l3);
+    state20_row(S, obs12, out, n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2625,7 +2636,7 @@ int gpd_full_obs(const GpdState* state, int32_t num_steps, int32_t n_drones, int
 int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, int32_t n, float cell, float x0,
                         float y0, int32_t nx, int32_t ny, float z0, float zbin, int32_t nz, const int32_t* visit_order,
                         int32_t* cell_count, int32_t* cell_start, int32_t* order, float* sorted_xyzc, float* dw_out,
-                        void* stream) {
+                        const GpdState* vec_state, const float* vec_obs12, float* vec_out, void* stream) {
     if (!params || !kin || !cell_count || !cell_start || !order || !sorted_xyzc || !dw_out)
         return fail(GPD_EINVAL, "gpd_downwash_global: NULL argument");
     if (n <= 0 || ld < n) return fail(GPD_EINVAL, "gpd_downwash_global: need 0 < n <= ld");
@@ -2639,7 +2650,15 @@ int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, i
     const DwGrid G{1.0f / cell, x0, y0, nx, ny, z0, nz > 1 ? 1.0f / zbin : 0.0f, nz};
     hipError_t e;
     const dim3 grid(static_cast<unsigned>((n + kBlock - 1) / kBlock));
-    hipLaunchKernelGGL(dwg_count_kernel, grid, dim3(kBlock), 0, st, kin, ld, n, G, visit_order, cell_count);
+    if (vec_out) {
+        if (!vec_state || !vec_state->kin || !vec_obs12) return fail(GPD_EINVAL, "gpd_downwash_global: vec_out needs vec_state and vec_obs12");
+        if (vec_state->ld < n) return fail(GPD_EINVAL, "gpd_downwash_global: vec_state.ld < n");
+        hipLaunchKernelGGL(dwg_count_kernel<true>, grid, dim3(kBlock), 0, st, kin, ld, n, G, visit_order, cell_count, *vec_state,
+                           vec_obs12, vec_out);
+    } else {
+        hipLaunchKernelGGL(dwg_count_kernel<false>, grid, dim3(kBlock), 0, st, kin, ld, n, G, visit_order, cell_count, GpdState{},
+                           nullptr, nullptr);
+    }
     int32_t* const cursors = cell_count + keys + 1;       // second half of cell_count: the scatter's per-key cursors
     if (keys <= kDwScanMax) {
         hipLaunchKernelGGL(dwg_scatter_kernel<true>, grid, dim3(kBlock), 0, st, kin, ld, n, G, visit_order, cell_count, cursors,

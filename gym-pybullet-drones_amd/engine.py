@@ -152,8 +152,13 @@ class SimCore:
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    #: bumped by every method that changes the kinematic state (callers that cache something derived from the positions --
+    #: SwarmAviary's downwash forces -- compare it)
+    state_version = 0
+
     def reset(self, mask=None, reset_pid: bool = False):
         """Masked reset (mask: uint8/bool tensor [E] on the device, None = all envs)."""
+        self.state_version += 1
         if mask is not None:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
         with torch.cuda.device(self.device):
@@ -172,6 +177,7 @@ class SimCore:
             action = action.to(device=self.device, dtype=torch.float32).contiguous()
         if action.numel() != self.N * self.A:
             raise ValueError(f"action has {action.numel()} elements, expected {self.N}x{self.A}")
+        self.state_version += 1
         with torch.cuda.device(self.device):
             rc = self.lib.gpd_step(ctypes.byref(self._params), ctypes.byref(self._state), ctypes.byref(self._cfg),
                                    _ptr(action), _ptr(self.target), _ptr(self.init_pose), _ptr(self.obs12),
@@ -379,6 +385,7 @@ class SimCore:
 
     def set_state(self, kin=None, last_rpm=None, pid=None, step_counter=None):
         n = self.N
+        self.state_version += 1
         if kin is not None:
             self.kin[:, :n].copy_(torch.as_tensor(kin, dtype=torch.float32))
         if last_rpm is not None and self.last_rpm is not None:

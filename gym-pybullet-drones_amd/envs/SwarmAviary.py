@@ -89,10 +89,13 @@ class SwarmAviary:
         if self.flags & PHYS_DW:
             self.core._state.dw_force = self.dw_force.data_ptr()
         self.step_counter = 0
+        self._dw_version = -1                        # core.state_version the forces in dw_force were computed for
 
     # ------------------------------------------------------------------------------------------
-    def downwash(self) -> torch.Tensor:
-        """Body-z downwash force of every drone for the current positions (`gpd_downwash_global`) -> [N] view."""
+    def downwash(self, vectors: torch.Tensor = None) -> torch.Tensor:
+        """Body-z downwash force of every drone for the current positions (`gpd_downwash_global`) -> [N] view.
+        `vectors`: an (N, 20) tensor that the sort's first pass fills with the state vectors on the way (one launch less
+        than `state_vectors()` after it)."""
         c = self.core
         with torch.cuda.device(self.device):
             self._order, self._visit = self._visit, self._order      # ping-pong: last call's order is this call's visit order
@@ -100,9 +103,11 @@ class SwarmAviary:
                                            self.y0, self.nx, self.ny, self.z0, self.zbin, self.nz,
                                            _ptr(self._visit) if self._have_visit else None,
                                            _ptr(self._count), _ptr(self._start), _ptr(self._order), _ptr(self._sorted),
-                                           _ptr(self.dw_force), c._stream())
+                                           _ptr(self.dw_force), ctypes.byref(c._state) if vectors is not None else None,
+                                           _ptr(c.obs12) if vectors is not None else None, _ptr(vectors), c._stream())
         _native.check(rc, "gpd_downwash_global")
         self._have_visit = True
+        self._dw_version = c.state_version                           # (the forces belong to this state)
         return self.dw_force[:self.NUM_DRONES]
 
     def reset(self, seed=None, options=None):
@@ -110,7 +115,11 @@ class SwarmAviary:
         if self.ctrl is not None:
             self.ctrl.reset()
         self.step_counter = 0
-        return self.state_vectors(), {"answer": 42}
+        if not (self.flags & PHYS_DW):
+            return self.state_vectors(), {"answer": 42}
+        vectors = torch.empty((self.NUM_DRONES, 20), dtype=torch.float32, device=self.device)
+        self.downwash(vectors)                        # the forces of the first sub-step (see step())
+        return vectors, {"answer": 42}
 
     def _kernel_action(self, action) -> torch.Tensor:
         """What the step kernel is fed: the raw action itself (the kernel maps it to RPMs), or -- waypoint actions -- the
@@ -124,14 +133,31 @@ class SwarmAviary:
         return rpm
 
     def step(self, action):
-        """One control step = PYB_STEPS_PER_CTRL × { downwash of the snapshot, one physics sub-step }."""
+        """One control step = PYB_STEPS_PER_CTRL × { downwash of the snapshot, one physics sub-step }.
+
+        The forces a sub-step uses are computed right AFTER the sub-step before it, on the snapshot it left (the same
+        positions: `envs/BaseAviary.py:346-347, 785-811`), so that the pass that bins the drones also writes the state vectors
+        this method returns -- five dependent launches per step instead of six.  After a reset, a `set_state` or any other
+        change of the state behind this class's back (call `invalidate()` then), the first sub-step computes its own."""
         rpm = self._kernel_action(action).contiguous()
-        for _ in range(self.PYB_STEPS_PER_CTRL):
-            if self.flags & PHYS_DW:
+        if not (self.flags & PHYS_DW):
+            for _ in range(self.PYB_STEPS_PER_CTRL):
+                self.core.step(rpm)
+            self.step_counter += self.PYB_STEPS_PER_CTRL
+            return self.state_vectors(), -1, False, False, {"answer": 42}
+        vectors = torch.empty((self.NUM_DRONES, 20), dtype=torch.float32, device=self.device)
+        for s in range(self.PYB_STEPS_PER_CTRL):
+            if self._dw_version != self.core.state_version:
                 self.downwash()
             self.core.step(rpm)
+            self.downwash(vectors if s == self.PYB_STEPS_PER_CTRL - 1 else None)
         self.step_counter += self.PYB_STEPS_PER_CTRL
-        return self.state_vectors(), -1, False, False, {"answer": 42}
+        return vectors, -1, False, False, {"answer": 42}
+
+    def invalidate(self):
+        """Tell the aviary that the state was changed without going through `reset()` / `core.set_state()` (e.g. by writing
+        into `core.kin`): the next step recomputes the downwash forces first."""
+        self._dw_version = -1
 
     def state_vectors(self) -> torch.Tensor:
         """(N, 20) `_getDroneStateVector` rows (envs/BaseAviary.py:559-561)."""

@@ -341,13 +341,16 @@ int gpd_full_obs(const GpdState* state, int32_t num_steps, int32_t n_drones, int
  *   order         [n] int32 out (drone index of sorted slot: a permutation of 0..n-1)
  *   sorted_xyzc   [n][4] float scratch (x, y, z, sort key as int bits), sorted by key
  *   dw_out        [n] out: the force of drone i at dw_out[i]  (pass it to gpd_step as state.dw_force)
+ *   vec_state, vec_obs12, vec_out   optional (vec_out NULL: none): the sort's first pass also writes the [n][20] state vectors
+ *                 of gpd_state_vectors(vec_state, vec_obs12, vec_out, n) -- a caller that computes the forces for the NEXT
+ *                 sub-step right after a gpd_step needs both, and saves a launch
  * Call it once per physics sub-step, before the gpd_step launch of that sub-step (positions are the snapshot every
  * drone sees, envs/BaseAviary.py:346-347).
  */
 int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, int32_t n, float cell, float x0,
                         float y0, int32_t nx, int32_t ny, float z0, float zbin, int32_t nz, const int32_t* visit_order,
                         int32_t* cell_count, int32_t* cell_start, int32_t* order, float* sorted_xyzc, float* dw_out,
-                        void* stream);
+                        const GpdState* vec_state, const float* vec_obs12, float* vec_out, void* stream);
 
 /*
  * Masked reset.  Replaces BaseAviary.reset/_housekeeping (envs/BaseAviary.py:220-255, 451-477)
