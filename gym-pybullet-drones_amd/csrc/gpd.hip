@@ -2028,7 +2028,7 @@ __global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const float* __rest
 // 28 micrometres of the same height); each such pair now drops less than 4.3e-18 alpha.
 constexpr int kDwTile = 1024;     // candidates staged in LDS at a time (3 x 4 KiB, x / y / z planes)
 constexpr int kDwChunk = 32;      // candidates per mask word
-constexpr int kDwBatches = 4;     // queued batches of 64 pairs that trigger an evaluation
+constexpr int kDwBatches = 4;     // queued batches of 64 pairs that trigger an evaluation (1 .. 8: no measurable difference)
 constexpr int kDwQueue = 64 * kDwBatches + kDwChunk * 64;   // pending (< 64 kDwBatches) + everything one chunk can add
 
 template <int CTRL, int ROW_MASK>
