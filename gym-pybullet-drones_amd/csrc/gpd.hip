@@ -1280,6 +1280,10 @@ struct RollOut {
 // env_step, no workgroup barrier).  Every lane of an aviary ends a step with the aviary's reward and flags and stores
 // them to the aviary's slot -- D identical writes instead of a branch; a lane without a drone is a clone of the drone with
 // the same index d in its workgroup's first aviary, so whole clone aviaries replay that aviary bit for bit.
+#ifdef GPD_EXP_TS
+__device__ unsigned long long gpd_ts[8 * 4096 * 4];
+__device__ unsigned int gpd_ts_cnt[4096];
+#endif
 template <bool PID, bool EXT, int AW, int ACT, bool S1, bool MULTI, bool NT_OBS = true>
 __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     const GpdParams P, const GpdState S, const GpdStepCfg C, const Span T, const float* __restrict__ action,
@@ -1287,6 +1291,9 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     float* __restrict__ reward, uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
     float* __restrict__ term_obs12) {
     const int tid = threadIdx.x;
+#ifdef GPD_EXP_TS
+    const unsigned long long ts0 = wall_clock64();
+#endif
     // (workgroup -> drones is the identity: giving every XCD one contiguous block of drones instead of every eighth workgroup
     // changed nothing, 0.816 vs 0.813-0.821 us per step, round-2 A/B)
     const uint32_t bid = blockIdx.x;
@@ -1339,6 +1346,9 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     // The ONLY workgroup barrier of the launch: every wave has its state in registers before any wave can reach its
     // store_carry, so a clone lane (above) has read its original's state of step 0, not of step K.
     __builtin_amdgcn_s_barrier();
+#ifdef GPD_EXP_TS
+    const unsigned long long ts1 = wall_clock64();
+#endif
     c.roll = c.pitch = c.yaw = 0.0f;
     if (PID) quat_to_rpy(c.k.qx, c.k.qy, c.k.qz, c.k.qw, c.roll, c.pitch, c.yaw);
 
@@ -1385,8 +1395,27 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
             a = b;
         }
     }
+#ifdef GPD_EXP_TS
+    const unsigned long long ts2 = wall_clock64();
+#endif
     ro.flush();                                                      // the last step's bursts
     if (L.active) store_carry<PID>(S, L, c);
+#ifdef GPD_EXP_TS
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    const unsigned long long ts3 = wall_clock64();
+    if (tid == 0 && bid < 4096) {
+        const unsigned int slot = gpd_ts_cnt[bid]++ & 7u;
+        unsigned long long* o = gpd_ts + (static_cast<size_t>(slot) * 4096 + bid) * 4;
+        o[0] = ts0; o[2] = ts2; o[3] = ts3;
+#ifdef GPD_EXP_HWID
+        (void)ts1;
+        o[1] = (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11))) << 32) |
+               static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)));
+#else
+        o[1] = ts1;
+#endif
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2761,6 +2790,14 @@ int gpd_allgather_obs(void* comm, const float* shard, float* full, size_t count,
     return 0;
 }
 
+#ifdef GPD_EXP_TS
+extern "C" int gpd_debug_ts(unsigned long long* ts, unsigned int* cnt) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(ts, HIP_SYMBOL(gpd_ts), sizeof(unsigned long long) * 8 * 4096 * 4);
+    hipMemcpyFromSymbol(cnt, HIP_SYMBOL(gpd_ts_cnt), sizeof(unsigned int) * 4096);
+    return 0;
+}
+#endif
 int gpd_clock_probe(double* shader_ghz, double* ns_per_fma, void* stream) {
     if (!shader_ghz) return fail(GPD_EINVAL, "gpd_clock_probe: NULL shader_ghz");
     hipStream_t st = static_cast<hipStream_t>(stream);
