@@ -588,7 +588,7 @@ __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C
                                          const float tgz, const bool ip_regs, const float* __restrict__ ipose,
                                          const float ip0, const float ip1, const float ip2, const float ip3,
                                          const float ip4, const float ip5, const float ip6, float* sh_pos,
-                                         float* sh_red, Carry& c, StepOut& out) {
+                                         float* sh_red, Carry& c, StepOut& out, const float* irpy = nullptr) {
     Kin& k = c.k;
     float rpm[4], g[4];                                      // RPMs; rotor thrusts minus the hover thrust
     map_action<PID, AW, ACT>(P, C, act, c, rpm, g);
@@ -720,7 +720,10 @@ __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C
         out.to[6] = k.vx; out.to[7] = k.vy; out.to[8] = k.vz; out.to[9] = avx; out.to[10] = avy; out.to[11] = avz;
         if (ip_regs) k = Kin{ip0, ip1, ip2, ip3, ip4, ip5, ip6, 0, 0, 0, 0, 0, 0};
         else k = Kin{ipose[0], ipose[1], ipose[2], ipose[3], ipose[4], ipose[5], ipose[6], 0, 0, 0, 0, 0, 0};
-        quat_to_rpy(k.qx, k.qy, k.qz, k.qw, c.roll, c.pitch, c.yaw);
+        // (the Euler angles of the reset pose: the K-step kernels compute them once per launch -- in the headline workload an
+        // aviary of some wave's 64 ends its episode in one step out of six, and this block is what that wave then runs)
+        if (irpy) { c.roll = irpy[0]; c.pitch = irpy[1]; c.yaw = irpy[2]; }
+        else quat_to_rpy(k.qx, k.qy, k.qz, k.qw, c.roll, c.pitch, c.yaw);
         avx = avy = avz = 0.0f;
         c.l0 = c.l1 = c.l2 = c.l3 = 0.0f;                      // last_clipped_action zeroed (BaseAviary.py:468)
     } }
@@ -1355,10 +1358,12 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     (void)term_obs12;   // (terminal observations: the host routes such calls to gpd_rollout_kernel -- a conditional
                         // store in this loop body would make the wait counts conservative again)
     RollOut<NT_OBS> ro(obs12, reward, terminated, truncated, T, goff, eoff4, L.env, sh_rows + tid * 12, lsrc);
+    float irpy[3] = {0.0f, 0.0f, 0.0f};
+    if (C.auto_reset) quat_to_rpy(ip[3], ip[4], ip[5], ip[6], irpy[0], irpy[1], irpy[2]);
     auto do_step = [&](const int t, const float4 act) {
         StepOut out;
         env_step<PID, EXT, MULTI, AW, ACT, S1>(P, C, flags, D, L, act, tgx, tgy, tgz, true, ipose, ip[0], ip[1], ip[2], ip[3],
-                                               ip[4], ip[5], ip[6], sh_pos, sh_red, c, out);
+                                               ip[4], ip[5], ip[6], sh_pos, sh_red, c, out, irpy);
         ro.emit(out, t > 0);                                          // (see RollOut: pipelined bursts, unconditional stores)
     };
     // Action rows, three steps per loop iteration: the rows of the NEXT iteration (b0..b2) are requested at the top of
