@@ -12,7 +12,7 @@
 //   gpd_rollout1_kernel  K env steps per launch, aviaries of 1, 2, 4 .. 64 drones (gpd_rollout)
 //   gpd_rollout_kernel   K env steps per launch, compute waves + a store wave     (gpd_rollout: other aviary
 //                        sizes, terminal observations)
-//   gpd_full_obs_kernel / gpd_hist_push_kernel   action ring + full KIN rows      (gpd_full_obs)
+//   gpd_hist_rows_kernel / gpd_hist_push_kernel  action ring + full KIN rows      (gpd_hist_rows, gpd_full_obs)
 //   dwg_*_kernel         downwash inside one aviary of any size, grid binning     (gpd_downwash_global)
 //   gpd_reset_kernel, gpd_pid_kernel, gpd_state20_kernel
 //
@@ -1783,76 +1783,69 @@ __global__ __launch_bounds__(kBlock) void gpd_reset_kernel(const GpdState S, con
 // slot-major; the H most recent actions of an aviary are the H consecutive slots starting at its ring_pos).  Pure data
 // movement: one lane per output float, so that a wave writes 256 contiguous bytes.
 // ------------------------------------------------------------------------------------------------
-// rows of the CURRENT state (after gpd_step, which pushed its action itself).  A workgroup owns 64 consecutive drones and
-// (blockIdx.y) one chunk of 16 history slots; it is a transpose through LDS, coalesced on both sides:
-//   in : slot i of the ring is a contiguous [N][A] block -> wave w reads the 64 drones' A floats of slot i (lane = drone:
-//        one 16-byte load for A = 4), four slots in flight per workgroup;
-//   out: a drone's 16*A history floats of the chunk are contiguous in its row -> one wave writes them as one 256-byte
-//        segment (A = 4), sixteen drones per wave.
-// Chunk 0 also copies the twelve kinematic floats.  (The lane-per-output-float form this replaces fetched sixteen 16-byte
-// pieces from sixteen different 1 MB-apart slots per wave: 2.2 TB/s at N = 65 536.)
-constexpr int kHistSlots = 16;                               // history slots per chunk
-__global__ __launch_bounds__(kBlock) void gpd_hist_rows_kernel(uint32_t N, int D, int A, int H, const float* __restrict__ ring,
+// A workgroup owns R consecutive drones (R = 64, 32, 16 ...: as many as fit WHOLE rows into 48 KiB of LDS) and (blockIdx.y) one
+// step; it is a transpose through LDS, and what it writes is ONE contiguous block of global memory -- the R rows follow each
+// other -- streamed out as 16-byte pieces:
+//   in : a history slot -- of the ring, or an action block of the call -- is a contiguous [N][A] block -> R lanes read the R
+//        drones' A floats of slot i (one 16-byte load per lane for A = 4: R x 16 contiguous bytes), 256 / R slots in flight;
+//        the twelve kinematic floats of the R rows are contiguous in obs12;
+//   out: R x (12 + H*A) floats, contiguous.
+// (History of this kernel at N = 65 536, 240 Hz rows of 492 floats: one lane per output float, sixteen 16-byte pieces from
+// sixteen 1 MB-apart slots per wave: 116 us per step; 64 drones x 16 slots per workgroup, a 256-byte segment per drone written
+// by whichever workgroup held that chunk: 57-60 us -- segments that start and end inside 128-byte lines, rewritten piecemeal;
+// whole rows per workgroup: see DESIGN.md section 3.3.)  Two callers:
+//   gpd_hist_rows  rows of the CURRENT state (after gpd_step, which pushed its action itself): slot i of the window is ring slot
+//                  ring_pos + i;
+//   gpd_full_obs   rows of the K steps of a rollout: slot i of step t's window is the action of step s = t - (H-1) + i of this
+//                  call (s >= 0), or -- for steps before the call -- ring slot ring_pos + H + s, the ring as the rollout found it.
+__global__ __launch_bounds__(kBlock) void gpd_hist_rows_kernel(uint32_t N, int D, int A, int H, int R, const float* __restrict__ ring,
                                                                const int32_t* __restrict__ ring_pos,
-                                                               const float* __restrict__ obs12, float* __restrict__ out) {
-    __shared__ float tile[64 * (kHistSlots * 4 + 1)];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint32_t n0 = blockIdx.x * 64u;
-    const int i0 = blockIdx.y * kHistSlots;                  // first history slot of this chunk
-    const int cnt = min(kHistSlots, H - i0);                 // slots in this chunk
-    const size_t W = 12u + static_cast<size_t>(H) * A;
-    const int pitch = kHistSlots * A + 1;                    // odd: lane-strided LDS writes are conflict-free
-    const uint32_t n = n0 + lane;
-    const bool have = n < N;
+                                                               const float* __restrict__ obs12, int64_t obs_stride,
+                                                               const float* __restrict__ actions, int64_t act_stride,
+                                                               float* __restrict__ out, int64_t out_stride) {
+    extern __shared__ __attribute__((aligned(16))) float hist_tile[];     // [R][Wp], Wp = W | 1 (odd: drone-strided accesses spread over the banks)
+    const int tid = threadIdx.x;
+    const uint32_t n0 = blockIdx.x * static_cast<uint32_t>(R);
+    const int t = blockIdx.y;                                // step of the call (0 for the current-state rows)
+    const uint32_t W = 12u + static_cast<uint32_t>(H * A), Wp = W | 1u;
+    const uint32_t rows = N - n0 < static_cast<uint32_t>(R) ? N - n0 : static_cast<uint32_t>(R);
+    obs12 += t * obs_stride;
+    out += t * out_stride;
+    // ---- in: history slots ----
+    const int d = tid % R, sl0 = tid / R, spp = kBlock / R;  // this thread's drone; slots per pass
+    const uint32_t n = n0 + d;
+    const bool have = static_cast<uint32_t>(d) < rows;
     const int p = have ? ring_pos[n / static_cast<uint32_t>(D)] : 0;
-    for (int s = wave; s < cnt; s += 4) {                    // this wave's slots: lane = drone
-        const float* src = ring + (static_cast<size_t>(p + i0 + s) * N + n) * A;
-        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = sl0; i < H; i += spp) {
+        const int s = t - (H - 1) + i;                       // (rollout rows) the step of this call the action belongs to
+        const float* src = (actions && s >= 0) ? actions + s * act_stride + static_cast<size_t>(n) * A
+                                               : ring + (static_cast<size_t>(p + (actions ? H + s : i)) * N + n) * A;
         if (have) {
-            if (A == 4) { const float4 q = *reinterpret_cast<const float4*>(src); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
-            else for (int a = 0; a < A; ++a) v[a] = src[a];
+            float* dst = hist_tile + d * Wp + 12 + i * A;
+            if (A == 4) { const float4 q = *reinterpret_cast<const float4*>(src); dst[0] = q.x; dst[1] = q.y; dst[2] = q.z; dst[3] = q.w; }
+            else for (int a = 0; a < A; ++a) dst[a] = src[a];
         }
-        for (int a = 0; a < A; ++a) tile[lane * pitch + s * A + a] = v[a];
+    }
+    // ---- in: the kinematic part, rows x 12 floats, contiguous in obs12 ----
+    for (uint32_t j = tid; j < rows * 12u; j += kBlock) {
+        const uint32_t r = j / 12u, c = j - r * 12u;
+        hist_tile[r * Wp + c] = obs12[static_cast<size_t>(n0) * 12 + j];
     }
     __syncthreads();
-    const int width = cnt * A;                               // floats of this chunk per drone (<= 64)
-    const uint32_t rows = N - n0 < 64u ? N - n0 : 64u;
-    for (uint32_t r = wave; r < rows; r += 4)                // one drone per wave and iteration: lane = float of its chunk
-        if (lane < width) out[(n0 + r) * W + 12 + static_cast<size_t>(i0) * A + lane] = tile[r * pitch + lane];
-    if (blockIdx.y == 0) {                                   // the kinematic part: 64 rows x 12 floats, contiguous in obs12
-        for (uint32_t j = tid; j < rows * 12u; j += kBlock) {
-            const uint32_t r = j / 12u, c = j - r * 12u;
-            out[(n0 + r) * W + c] = obs12[static_cast<size_t>(n0) * 12 + j];
+    // ---- out: rows x W floats, contiguous ----
+    float* const dst = out + static_cast<size_t>(n0) * W;
+    if ((W % 4u) == 0u && (reinterpret_cast<uintptr_t>(dst) % 16u) == 0u) {
+        for (uint32_t j = tid; j < rows * (W / 4u); j += kBlock) {
+            const uint32_t f = 4u * j, r = f / W, c = f - r * W;
+            const float* tp = hist_tile + r * Wp + c;
+            __builtin_nontemporal_store(f4v{tp[0], tp[1], tp[2], tp[3]}, reinterpret_cast<f4v*>(dst + f));
         }
-    }
-}
-
-// rows of the K steps of a rollout: the source of a float is the obs12 row of its step, an action block of this call, or --
-// for steps before the call -- the ring as the rollout found it
-__global__ __launch_bounds__(kBlock) void gpd_full_obs_kernel(
-    int K, uint32_t N, int D, int A, int H, const float* __restrict__ ring, const int32_t* __restrict__ ring_pos,
-    const float* __restrict__ obs12, int64_t obs_stride, const float* __restrict__ actions, int64_t act_stride,
-    float* __restrict__ out, int64_t out_stride) {
-    const uint32_t W = 12u + static_cast<uint32_t>(H * A);
-    const uint32_t per_step = N * W;                        // floats per step (< 2^32 by the host-side check)
-    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
-    const int t = blockIdx.y;
-    if (j >= per_step) return;
-    const uint32_t n = j / W, col = j - n * W;
-    float v;
-    if (col < 12u) {
-        v = obs12[t * obs_stride + static_cast<int64_t>(n) * 12 + col];
     } else {
-        const uint32_t i = (col - 12u) / static_cast<uint32_t>(A), a = (col - 12u) - i * static_cast<uint32_t>(A);
-        const int s = t - (H - 1) + static_cast<int>(i);    // step of this call the action belongs to (< 0: earlier)
-        if (s >= 0) {
-            v = actions[s * act_stride + static_cast<int64_t>(n) * A + a];
-        } else {                                            // s = -1 is the newest action before the call: slot p + H - 1
-            const int p = ring_pos[n / static_cast<uint32_t>(D)];
-            v = ring[(static_cast<size_t>(p + H + s) * N + n) * A + a];
+        for (uint32_t f = tid; f < rows * W; f += kBlock) {
+            const uint32_t r = f / W, c = f - r * W;
+            __builtin_nontemporal_store(hist_tile[r * Wp + c], dst + f);
         }
     }
-    out[t * out_stride + j] = v;
 }
 
 // pushes the actions of the K steps of a call into the ring (the last H of them survive): blockIdx.y = 0 is the newest step
@@ -2616,17 +2609,28 @@ static int hist_args(const char* who, const GpdState* st, int32_t n_drones, int3
         return bad(GPD_EINVAL, "n_drones must be a positive multiple of drones_per_env and act_dim in 1..4");
     const int64_t W = 12 + static_cast<int64_t>(st->hist_len) * A;
     if (static_cast<int64_t>(n_drones) * W >= (1LL << 32)) return bad(GPD_ERANGE, "n_drones*(12+hist_len*act_dim) must be < 2^32");
+    if ((W | 1) * 4 > 48 * 1024) return bad(GPD_ERANGE, "a row of 12+hist_len*act_dim floats must fit 48 KiB");
     return 0;
+}
+
+// drones per workgroup of gpd_hist_rows_kernel: the largest power of two <= 64 whose whole rows fit 48 KiB of LDS
+static int hist_rows_per_wg(int64_t W) {
+    int R = 64;
+    while (R > 1 && static_cast<int64_t>(R) * (W | 1) * 4 > 48 * 1024) R >>= 1;
+    return R;
 }
 
 int gpd_hist_rows(const GpdState* state, int32_t n_drones, int32_t drones_per_env, int32_t act_dim, const float* obs12,
                   float* obs_full, void* stream) {
     if (int rc = hist_args("gpd_hist_rows", state, n_drones, drones_per_env, act_dim)) return rc;
     if (!obs12 || !obs_full) return fail(GPD_EINVAL, "gpd_hist_rows: NULL obs12/obs_full");
-    const dim3 grid(static_cast<unsigned>((n_drones + 63) / 64), static_cast<unsigned>((state->hist_len + kHistSlots - 1) / kHistSlots));
-    hipLaunchKernelGGL(gpd_hist_rows_kernel, grid, dim3(kBlock), 0,
-                       static_cast<hipStream_t>(stream), static_cast<uint32_t>(n_drones), drones_per_env, act_dim, state->hist_len,
-                       state->act_ring, state->ring_pos, obs12, obs_full);
+    const int64_t W = 12 + static_cast<int64_t>(state->hist_len) * act_dim;
+    const int R = hist_rows_per_wg(W);
+    const dim3 grid(static_cast<unsigned>((n_drones + R - 1) / R));
+    hipLaunchKernelGGL(gpd_hist_rows_kernel, grid, dim3(kBlock), static_cast<size_t>(R) * (W | 1) * 4,
+                       static_cast<hipStream_t>(stream), static_cast<uint32_t>(n_drones), drones_per_env, act_dim, state->hist_len, R,
+                       state->act_ring, state->ring_pos, obs12, static_cast<int64_t>(0), static_cast<const float*>(nullptr),
+                       static_cast<int64_t>(0), obs_full, static_cast<int64_t>(0));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gpd_hist_rows launch");
     return 0;
@@ -2645,11 +2649,11 @@ int gpd_full_obs(const GpdState* state, int32_t num_steps, int32_t n_drones, int
     const int64_t W = 12 + static_cast<int64_t>(H) * act_dim;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (obs_full) {
-        const int64_t per_step = static_cast<int64_t>(n_drones) * W;
-        const dim3 grid(static_cast<unsigned>((per_step + kBlock - 1) / kBlock), static_cast<unsigned>(num_steps));
-        hipLaunchKernelGGL(gpd_full_obs_kernel, grid, dim3(kBlock), 0, st, num_steps, static_cast<uint32_t>(n_drones),
-                           drones_per_env, act_dim, H, state->act_ring, state->ring_pos, obs12, obs_step_stride, actions,
-                           action_step_stride, obs_full, full_step_stride);
+        const int R = hist_rows_per_wg(W);
+        const dim3 grid(static_cast<unsigned>((n_drones + R - 1) / R), static_cast<unsigned>(num_steps));
+        hipLaunchKernelGGL(gpd_hist_rows_kernel, grid, dim3(kBlock), static_cast<size_t>(R) * (W | 1) * 4, st,
+                           static_cast<uint32_t>(n_drones), drones_per_env, act_dim, H, R, state->act_ring, state->ring_pos, obs12,
+                           obs_step_stride, actions, action_step_stride, obs_full, full_step_stride);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "gpd_full_obs launch");
     }
