@@ -93,7 +93,8 @@ _SIGNATURES = {
                                    ctypes.c_int32, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_int64, _P, _P, _P,
                                    ctypes.c_int64, _P, _P]),
     "gpd_rollout_policy": (ctypes.c_int, [ctypes.POINTER(GpdParams), ctypes.POINTER(GpdState), ctypes.POINTER(GpdStepCfg), _P,
-                                          ctypes.c_int32, _P, _P, _P, _P, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_int64, _P]),
+                                          ctypes.c_int32, _P, _P, _P, _P, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_int64, _P,
+                                          ctypes.POINTER(ctypes.c_float), _P, _P]),
     "gpd_hist_rows": (ctypes.c_int, [ctypes.POINTER(GpdState), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P]),
     "gpd_full_obs": (ctypes.c_int, [ctypes.POINTER(GpdState), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P,
                                     ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_int64, _P]),

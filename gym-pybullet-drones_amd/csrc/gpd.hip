@@ -1480,12 +1480,17 @@ template <int NK1> struct PolLds {     // weights as A operands: [block][hi|lo][
 
 // PID: a DSLPID action type (the policy's output is the controller's set-point); the add-on physics terms are always compiled in
 // (wave-uniform run-time tests: a handful of slots next to the policy's ~2 500)
-template <bool PID, int AW, int ACT, int NK1, bool RELU>
-__global__ __launch_bounds__(kBlock) void gpd_rollout_policy_kernel(
-    const GpdParams P, const GpdState S, const GpdStepCfg C, const Span T, const GpdPolicy Pol,
+// NOISE (training rollouts, SB3's DiagGaussianDistribution with a state-independent log_std): the action is
+// mean + std[k] * eps with eps ~ N(0, 1) handed in per step and drone ([K][N][A], e.g. torch.randn), clipped to the action space
+// for the environment (what SB3's collect_rollouts does before env.step) -- the log-probability follows from eps alone on the
+// host; the unclipped MEAN is written out on request.  The body is shared; the deterministic kernels keep their signature.
+template <bool PID, int AW, int ACT, int NK1, bool RELU, bool NOISE>
+__device__ __forceinline__ void rollout_policy_body(
+    const GpdParams& P, const GpdState& S, const GpdStepCfg& C, const Span& T, const GpdPolicy& Pol,
     const float* __restrict__ obs12_in, const float* __restrict__ target_pos, const float* __restrict__ init_pose,
     float* __restrict__ actions_out, float* __restrict__ obs12, float* __restrict__ reward, uint8_t* __restrict__ terminated,
-    uint8_t* __restrict__ truncated) {
+    uint8_t* __restrict__ truncated, const float* __restrict__ noise, float* __restrict__ mean_out, const float sd0, const float sd1,
+    const float sd2, const float sd3) {
     constexpr int CAP = 16 * NK1 - 12;                       // history capacity in features
     constexpr int NP = 8 * NK1;                              // packed feature registers (two bf16 features each)
     constexpr bool HIST = NK1 > 1;
@@ -1619,6 +1624,12 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout_policy_kernel(
 
     const size_t obs_step = static_cast<size_t>(T.obs_stride), env_stride = static_cast<size_t>(T.env_stride);
     for (int t = 0; t < K; ++t) {
+        float eps[4] = {0.0f, 0.0f, 0.0f, 0.0f};             // (requested here, used after the three layers)
+        if constexpr (NOISE) {
+            const float* er = noise + (static_cast<size_t>(t) * N + L.n) * AW;
+            if (AW == 4) { const float4 q = *reinterpret_cast<const float4*>(er); eps[0] = q.x; eps[1] = q.y; eps[2] = q.z; eps[3] = q.w; }
+            else { eps[0] = er[0]; if (AW == 3) { eps[1] = er[1]; eps[2] = er[2]; } }
+        }
         // ---- features of this step: the observation row (the history registers are current) ------------------------------
 #pragma unroll
         for (int i = 0; i < 6; ++i) split_pair(o[2 * i], o[2 * i + 1], Fhi[i], Flo[i]);
@@ -1675,7 +1686,13 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout_policy_kernel(
 #pragma unroll
         for (int k = 0; k < AW; ++k) {                       // unit k sits in register k of lanes 0..31: drones 0..31 keep y0, drones 32..63 fetch y1
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(y0[k]), __float_as_uint(y1[k]), false, false);
-            a[k] = clampf(__uint_as_float(sw[0]), -1.0f, 1.0f);
+            if constexpr (NOISE) {
+                const float mu = __uint_as_float(sw[0]), sd = k == 0 ? sd0 : (k == 1 ? sd1 : (k == 2 ? sd2 : sd3));
+                if (mean_out && L.active) mean_out[(static_cast<size_t>(t) * N + L.n) * AW + k] = mu;
+                a[k] = clampf(fmaf(sd, eps[k], mu), -1.0f, 1.0f);
+            } else {
+                a[k] = clampf(__uint_as_float(sw[0]), -1.0f, 1.0f);
+            }
         }
         // ---- the env step ---------------------------------------------------------------------------------------------------------
         StepOut out;
@@ -1738,6 +1755,26 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout_policy_kernel(
     if (!L.active) return;
     store_carry<PID>(S, L, c);
     if (ring) S.ring_pos[L.env] = ring_q;
+}
+
+template <bool PID, int AW, int ACT, int NK1, bool RELU>
+__global__ __launch_bounds__(kBlock) void gpd_rollout_policy_kernel(
+    const GpdParams P, const GpdState S, const GpdStepCfg C, const Span T, const GpdPolicy Pol,
+    const float* __restrict__ obs12_in, const float* __restrict__ target_pos, const float* __restrict__ init_pose,
+    float* __restrict__ actions_out, float* __restrict__ obs12, float* __restrict__ reward, uint8_t* __restrict__ terminated,
+    uint8_t* __restrict__ truncated) {
+    rollout_policy_body<PID, AW, ACT, NK1, RELU, false>(P, S, C, T, Pol, obs12_in, target_pos, init_pose, actions_out, obs12, reward,
+                                                        terminated, truncated, nullptr, nullptr, 0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+template <int AW, int ACT, int NK1, bool RELU>
+__global__ __launch_bounds__(kBlock) void gpd_rollout_policy_noise_kernel(
+    const GpdParams P, const GpdState S, const GpdStepCfg C, const Span T, const GpdPolicy Pol,
+    const float* __restrict__ obs12_in, const float* __restrict__ target_pos, const float* __restrict__ init_pose,
+    float* __restrict__ actions_out, float* __restrict__ obs12, float* __restrict__ reward, uint8_t* __restrict__ terminated,
+    uint8_t* __restrict__ truncated, const float* __restrict__ noise, float* __restrict__ mean_out, const float4 sd) {
+    rollout_policy_body<false, AW, ACT, NK1, RELU, true>(P, S, C, T, Pol, obs12_in, target_pos, init_pose, actions_out, obs12, reward,
+                                                         terminated, truncated, noise, mean_out, sd.x, sd.y, sd.z, sd.w);
 }
 
 #ifndef GPD_POLICY_TU
@@ -2492,6 +2529,7 @@ void gpd_detail_launch_policy_pid(const GpdPolicyLaunch& a) {
         default: if (a.hist) GPD_POL(1, GPD_ACT_ONE_D_PID, 2); else GPD_POL(1, GPD_ACT_ONE_D_PID, 1); break;
     }
 #undef GPD_POL
+#undef GPD_POLN
 }
 #endif
 
@@ -2538,8 +2576,11 @@ int gpd_rollout(const GpdParams* params, const GpdState* state, const GpdStepCfg
 int gpd_rollout_policy(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, const GpdPolicy* policy,
                        int32_t num_steps, const float* obs12_in, const float* target_pos, const float* init_pose,
                        float* actions_out, float* obs12, int64_t obs_step_stride, float* reward, uint8_t* terminated,
-                       uint8_t* truncated, int64_t env_step_stride, void* stream) {
+                       uint8_t* truncated, int64_t env_step_stride, const float* noise, const float* action_std, float* mean_out,
+                       void* stream) {
     auto bad = [&](int code, const char* msg) { return fail(code, (std::string("gpd_rollout_policy: ") + msg).c_str()); };
+    if ((noise != nullptr) != (action_std != nullptr)) return bad(GPD_EINVAL, "noise and action_std come together");
+    if (mean_out && !noise) return bad(GPD_EINVAL, "mean_out is written by the sampling kernels only (pass noise)");
     if (!params || !state || !cfg || !policy) return bad(GPD_EINVAL, "NULL params/state/cfg/policy");
     if (!state->kin || !state->step_counter) return bad(GPD_EINVAL, "NULL state.kin/step_counter");
     if (!obs12_in || !obs12 || !reward || !terminated || !truncated) return bad(GPD_EINVAL, "NULL obs12_in/obs12/reward/terminated/truncated");
@@ -2585,6 +2626,24 @@ int gpd_rollout_policy(const GpdParams* params, const GpdState* state, const Gpd
             hipLaunchKernelGGL((gpd_rollout_policy_kernel<PID_, AW_, ACT_, NK1_, false>), grid, dim3(kBlock), 0, st, *params, *state, c, T, \
                                *policy, obs12_in, target_pos, init_pose, actions_out, obs12, reward, terminated, truncated);        \
     } while (0)
+#define GPD_POLN(AW_, ACT_, NK1_)                                                                                                    \
+    do {                                                                                                                            \
+        const float4 sd = make_float4(action_std[0], AW_ > 1 ? action_std[1] : 0.0f, AW_ > 2 ? action_std[2] : 0.0f,                 \
+                                      AW_ > 3 ? action_std[3] : 0.0f);                                                               \
+        if (policy->activation == 1)                                                                                                \
+            hipLaunchKernelGGL((gpd_rollout_policy_noise_kernel<AW_, ACT_, NK1_, true>), grid, dim3(kBlock), 0, st, *params, *state, c, \
+                               T, *policy, obs12_in, target_pos, init_pose, actions_out, obs12, reward, terminated, truncated, noise, \
+                               mean_out, sd);                                                                                       \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((gpd_rollout_policy_noise_kernel<AW_, ACT_, NK1_, false>), grid, dim3(kBlock), 0, st, *params, *state, c, \
+                               T, *policy, obs12_in, target_pos, init_pose, actions_out, obs12, reward, terminated, truncated, noise, \
+                               mean_out, sd);                                                                                       \
+    } while (0)
+    if (noise) {                 // sampling: the RPM action types (the ones examples/learn.py and the reference's learn.py train)
+        if (pid) return bad(GPD_ENOTSUP, "sampling (noise) is implemented for ActionType.RPM and ONE_D_RPM");
+        if (cfg->act_type == GPD_ACT_RPM) { if (hist) GPD_POLN(4, GPD_ACT_RPM, 5); else GPD_POLN(4, GPD_ACT_RPM, 1); }
+        else { if (hist) GPD_POLN(1, GPD_ACT_ONE_D_RPM, 2); else GPD_POLN(1, GPD_ACT_ONE_D_RPM, 1); }
+    } else
     if (pid) {                   // (instantiated in the main unit, see GpdPolicyLaunch)
         const GpdPolicyLaunch a{params, state, &c, &T, policy, obs12_in, target_pos, init_pose, actions_out, obs12, reward, terminated,
                                 truncated, stream, grid.x, hist ? 1 : 0};
@@ -2595,6 +2654,7 @@ int gpd_rollout_policy(const GpdParams* params, const GpdState* state, const Gpd
         if (hist) GPD_POL(false, 1, GPD_ACT_ONE_D_RPM, 2); else GPD_POL(false, 1, GPD_ACT_ONE_D_RPM, 1);
     }
 #undef GPD_POL
+#undef GPD_POLN
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gpd_rollout_policy launch");
     return 0;

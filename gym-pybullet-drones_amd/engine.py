@@ -235,14 +235,30 @@ class SimCore:
             self.truncated.copy_(trunc[K - 1])
         return obs, rew, term, trunc
 
-    def rollout_policy(self, policy, num_steps: int, want_actions: bool = True):
+    def rollout_policy(self, policy, num_steps: int, want_actions: bool = True, noise: torch.Tensor = None, action_std=None,
+                       mean_out: torch.Tensor = None):
         """K env steps in ONE launch with `policy` (a `policy.MlpPolicy`) evaluated inside the kernel
         (`gpd_rollout_policy`): a_t = policy(o_t), o_{t+1}, r_t, ... = step(a_t), starting from the latest observation.
         Returns `(obs12 [K,N,12], reward [K,E], terminated [K,E], truncated [K,E], actions [K,N,A] or None)` -- the same
-        persistent buffers `rollout()` uses; the latest-step tensors (`obs12`, `reward`, ...) are updated as well."""
+        persistent buffers `rollout()` uses; the latest-step tensors (`obs12`, `reward`, ...) are updated as well.
+
+        Training rollouts: `noise` `[K,N,A]` (standard-normal draws, e.g. `torch.randn`) and `action_std` (A floats =
+        exp(log_std)) make it `a_t = clip(mean_t + action_std * noise_t, -1, 1)`, SB3's collection loop; `mean_out`
+        `[K,N,A]` receives the unclipped means."""
         K = int(num_steps)
         if K < 1:
             raise ValueError("num_steps must be >= 1")
+        std = None
+        if noise is not None:
+            if noise.device != self.device or noise.dtype != torch.float32 or not noise.is_contiguous() or noise.numel() != K * self.N * self.A:
+                raise ValueError(f"noise must be a contiguous float32 tensor of {K}x{self.N}x{self.A} elements on {self.device}")
+            vals = [float(v) for v in (action_std.detach().cpu().reshape(-1).tolist() if torch.is_tensor(action_std) else list(action_std))]
+            if len(vals) != self.A:
+                raise ValueError(f"action_std must hold {self.A} values")
+            std = (ctypes.c_float * self.A)(*vals)
+            if mean_out is not None and (mean_out.device != self.device or mean_out.dtype != torch.float32 or not mean_out.is_contiguous()
+                                         or mean_out.numel() != K * self.N * self.A):
+                raise ValueError("mean_out must be a contiguous float32 tensor like noise")
         obs, rew, term, trunc, _ = self._rollout_buffers(K)
         cache = self.__dict__.setdefault("_policy_actions", {})
         acts = None
@@ -256,7 +272,7 @@ class SimCore:
             rc = self.lib.gpd_rollout_policy(ctypes.byref(self._params), ctypes.byref(self._state), ctypes.byref(self._cfg),
                                              ctypes.byref(ps), K, _ptr(self.obs12), _ptr(self.target), _ptr(self.init_pose),
                                              _ptr(acts), _ptr(obs), self.N * 12, _ptr(rew), _ptr(term), _ptr(trunc), self.E,
-                                             self._stream())
+                                             _ptr(noise), std, _ptr(mean_out), self._stream())
         _native.check(rc, "gpd_rollout_policy")
         self.obs12.copy_(obs[K - 1])
         self.reward.copy_(rew[K - 1])

@@ -145,12 +145,15 @@ class VectorAviary:
             self.core.full_obs(actions, num_steps=K, want_rows=False)      # ring update only
         return obs.view(K, self.NUM_ENVS, self.NUM_DRONES, -1), reward, terminated, truncated
 
-    def rollout_policy(self, policy, num_steps: int):
+    def rollout_policy(self, policy, num_steps: int, noise: torch.Tensor = None, action_std=None, mean_out: torch.Tensor = None):
         """K env steps in ONE launch with the policy in the loop (`policy.MlpPolicy`; the loop of
         `examples/learn.py:157-192`).  The policy's input is the (12,) kinematic row, or -- `full_obs` True / "lazy" and
         `policy.in_dim == 12 + H*A` -- the reference's full row with the action history.  Returns
-        `(obs (K,E,1,12), reward (K,E), terminated (K,E), truncated (K,E), actions (K,E,1,A))`."""
-        obs, reward, terminated, truncated, acts = self.core.rollout_policy(policy, num_steps)
+        `(obs (K,E,1,12), reward (K,E), terminated (K,E), truncated (K,E), actions (K,E,1,A))`.
+        `noise` (K,E,1,A) + `action_std` (A): sampled actions for training, `clip(mean + std * noise, -1, 1)`; `mean_out`
+        (K,E,1,A) receives the unclipped means (see `SimCore.rollout_policy`)."""
+        obs, reward, terminated, truncated, acts = self.core.rollout_policy(policy, num_steps, noise=noise, action_std=action_std,
+                                                                            mean_out=mean_out)
         if self.full_obs:
             self.core.history_rows()
         E, D = self.NUM_ENVS, self.NUM_DRONES

@@ -277,6 +277,14 @@ typedef struct GpdPolicy {
  *   obs12_in     [E][12] the latest observation rows (the obs12 output of the previous step / reset / rollout)
  *   actions_out  [K][E][A] out or NULL: the actions the policy chose, step t at actions_out + t*E*A
  *   obs12 / reward / terminated / truncated and the strides: as in gpd_rollout
+ *   noise, action_std, mean_out   training rollouts (all NULL: the deterministic policy above).  The collection loop of
+ *                Stable-Baselines3's PPO (`model.learn()`, examples/learn.py:61-95: DiagGaussianDistribution with a
+ *                state-independent log_std, actions clipped to the Box before env.step):
+ *                    a_t = clip(mean_t + action_std[k] * noise[t][e][k], -1, 1)
+ *                noise [K][E][A]: standard-normal draws of the caller (device memory); action_std [A]: exp(log_std), HOST
+ *                memory; mean_out [K][E][A] out or NULL: the unclipped means.  actions_out and the action ring receive the
+ *                clipped actions (what the environment saw); the log-probability of the unclipped sample is a function of
+ *                noise and action_std alone.  ActionType.RPM and ONE_D_RPM.
  * With in_dim > 12 the action ring of `state` is read at the start and rewritten (with ring_pos = 0) at the end.
  * GPD_ENOTSUP: drones_per_env > 1, hidden != 64, in_dim not one of the two forms, or a history longer than 17 actions of 4 or
  * 3 floats / 20 actions of 1 float (the reference's 30 Hz control: 15).
@@ -284,7 +292,8 @@ typedef struct GpdPolicy {
 int gpd_rollout_policy(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, const GpdPolicy* policy,
                        int32_t num_steps, const float* obs12_in, const float* target_pos, const float* init_pose,
                        float* actions_out, float* obs12, int64_t obs_step_stride, float* reward, uint8_t* terminated,
-                       uint8_t* truncated, int64_t env_step_stride, void* stream);
+                       uint8_t* truncated, int64_t env_step_stride, const float* noise, const float* action_std, float* mean_out,
+                       void* stream);
 
 /*
  * Full KIN observation rows with the action-history tail.  Replaces the row assembly of BaseRLAviary._computeObs

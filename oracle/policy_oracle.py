@@ -16,13 +16,15 @@ PARITY UNPINNED against SB3 itself (no SB3 here); the arithmetic is three affine
 import numpy as np
 
 
-def mlp_actor(obs, w1, b1, w2, b2, w3, b3, activation="tanh"):
-    """obs [..., in_dim] -> clipped deterministic action [..., act_dim], all float64."""
+def mlp_actor(obs, w1, b1, w2, b2, w3, b3, activation="tanh", clip=True):
+    """obs [..., in_dim] -> clipped deterministic action [..., act_dim], all float64 (`clip=False`: the mean of the action
+    distribution before `predict()` clips it to the Box)."""
     f = np.tanh if activation == "tanh" else (lambda x: np.maximum(x, 0.0))
     x = np.asarray(obs, dtype=np.float64)
     h = f(x @ np.asarray(w1, dtype=np.float64).T + np.asarray(b1, dtype=np.float64))
     h = f(h @ np.asarray(w2, dtype=np.float64).T + np.asarray(b2, dtype=np.float64))
-    return np.clip(h @ np.asarray(w3, dtype=np.float64).T + np.asarray(b3, dtype=np.float64), -1.0, 1.0)
+    y = h @ np.asarray(w3, dtype=np.float64).T + np.asarray(b3, dtype=np.float64)
+    return np.clip(y, -1.0, 1.0) if clip else y
 
 
 def policy_loop(aviary, weights, num_steps, obs0, history=None, activation="tanh"):

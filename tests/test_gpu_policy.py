@@ -164,3 +164,75 @@ def test_policy_rollout_reads_the_step_configuration_like_gpd_step(gpu_device, a
         assert bool((rew == -1).all()) and not bool(trunc.any())
     if "trunc_counter" in tweak and tweak["trunc_counter"] == 3:
         assert bool(trunc.any())
+
+
+@pytest.mark.parametrize("act,ctrl,hist,activation", [("rpm", 30, True, "tanh"), ("rpm", 240, False, "relu"), ("one_d_rpm", 30, True, "tanh"),
+                                                      ("one_d_rpm", 48, False, "tanh")])
+def test_sampled_actions_for_training_rollouts(gpu_device, act, ctrl, hist, activation):
+    """`noise` + `action_std` (SB3's PPO collection: DiagGaussianDistribution, state-independent log_std, actions clipped before
+    env.step): (1) zero noise reproduces the deterministic kernel bit for bit and `mean_out` holds the unclipped means;
+    (2) with standard-normal noise every action is clip(mean + std * noise) of the kernel's own mean, the means are the float64
+    actor's on the kernel's own previous row, and stepping the sampled actions through gpd_step reproduces the rollout bit for
+    bit (ring included)."""
+    from gym_pybullet_drones_amd.policy import MlpPolicy
+    E, K = 900, 30
+    mode = "lazy" if hist else False
+    a, b, c = (_env(act, ctrl, mode, E, gpu_device, episode_len_sec=10.0 / ctrl) for _ in range(3))
+    A, H = a.ACT_DIM, ctrl // 2
+    pol = MlpPolicy.random(12 + (H * A if hist else 0), A, seed=9, gain=1.3, activation=activation, device=gpu_device)
+    std = [0.6, 0.45, 0.7, 0.5][:A]
+    g = torch.Generator(device=gpu_device).manual_seed(3)
+    noise = torch.randn((K, E, 1, A), generator=g, device=gpu_device)
+    # (1) zero noise
+    det = [x.clone() for x in a.rollout_policy(pol, K)]
+    mean0 = torch.empty((K, E, 1, A), device=gpu_device)
+    zer = [x.clone() for x in b.rollout_policy(pol, K, noise=torch.zeros_like(noise), action_std=std, mean_out=mean0)]
+    for x, y in zip(det, zer):
+        assert torch.equal(x, y)
+    assert torch.equal(mean0.clamp(-1, 1), det[4]) and float(mean0.abs().max()) > 0.2
+    # (2) sampled
+    obs0 = c.core.obs12.clone()
+    hist0 = c.history().clone() if hist else None
+    mean = torch.empty((K, E, 1, A), device=gpu_device)
+    obs, rew, term, trunc, acts = c.rollout_policy(pol, K, noise=noise, action_std=std, mean_out=mean)
+    want = (mean.double() + torch.tensor(std, dtype=torch.float64, device=gpu_device) * noise.double()).clamp(-1, 1)
+    assert float((acts.double() - want).abs().max()) < 2e-7
+    assert float((acts.abs() == 1).float().mean()) > 0.01, "the test must exercise the clipping"
+    w = _weights(pol)
+    o_prev = obs0.cpu().numpy().astype(np.float64).reshape(E, 12)
+    h = hist0.cpu().numpy().astype(np.float64).reshape(E, H, A) if hist else None
+    worst = 0.0
+    for t in range(K):
+        row = o_prev if h is None else np.concatenate([o_prev, h.reshape(E, -1)], axis=1)
+        mu = mlp_actor(row, *w, activation=activation, clip=False)
+        worst = max(worst, float(np.abs(mean[t].cpu().numpy().astype(np.float64).reshape(E, A) - mu).max()))
+        got = acts[t].cpu().numpy().astype(np.float64).reshape(E, A)
+        if h is not None:
+            h = np.concatenate([h[:, 1:], got[:, None, :]], axis=1)
+        o_prev = obs[t].cpu().numpy().astype(np.float64).reshape(E, 12)
+    print(f"{act} ctrl={ctrl} hist={hist}: max |kernel mean - float64 actor| over {K} steps = {worst:.2e}")
+    assert worst < 1e-4
+    d = _env(act, ctrl, mode, E, gpu_device, episode_len_sec=10.0 / ctrl)
+    for t in range(K):
+        o, r, te, tr, _ = d.step(acts[t])
+        assert torch.equal(o, obs[t]) and torch.equal(r, rew[t]) and torch.equal(te, term[t]) and torch.equal(tr, trunc[t]), t
+    if hist:
+        assert torch.equal(c.history(), d.history())
+    assert (term | trunc).any()
+
+
+def test_sampling_argument_errors(gpu_device):
+    from gym_pybullet_drones_amd import _native
+    from gym_pybullet_drones_amd.policy import MlpPolicy
+    env = _env("rpm", 30, False, 64, gpu_device)
+    pol = MlpPolicy.random(12, 4, device=gpu_device)
+    noise = torch.zeros((4, 64, 1, 4), device=gpu_device)
+    with pytest.raises(ValueError):
+        env.rollout_policy(pol, 4, noise=noise[:2], action_std=[1, 1, 1, 1])
+    with pytest.raises(ValueError):
+        env.rollout_policy(pol, 4, noise=noise, action_std=[1, 1])
+    with pytest.raises(_native.GpdError, match="noise"):
+        env.rollout_policy(pol, 4, mean_out=torch.zeros_like(noise))
+    penv = _env("pid", 30, False, 64, gpu_device)
+    with pytest.raises(_native.GpdError, match="RPM"):
+        penv.rollout_policy(MlpPolicy.random(12, 3, device=gpu_device), 4, noise=torch.zeros((4, 64, 1, 3), device=gpu_device), action_std=[1, 1, 1])
