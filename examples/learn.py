@@ -35,7 +35,11 @@ class ActorCritic(torch.nn.Module):
 
 
 def run(num_envs=4096, iters=60, horizon=128, target=474.0, epochs=4, minibatches=8, lr=1e-3, gamma=0.99, lam=0.95, clip=0.2,
-        seed=0, device="cuda:0", verbose=True):
+        seed=0, device="cuda:0", verbose=True, collect="kernel"):
+    """collect = "kernel": the `horizon` steps of every PPO iteration are ONE launch (`gpd_rollout_policy` with noise rows:
+    a_t = clip(mean_t + std * eps_t), SB3's collection loop inside the kernel); "torch": the policy as torch operations between
+    two `env.step()` launches (what the loop looked like before)."""
+    from gym_pybullet_drones_amd.policy import MlpPolicy
     torch.manual_seed(seed)
     env = VectorHoverAviary(num_envs, act=ActionType.ONE_D_RPM, ctrl_freq=30, full_obs=True, auto_reset=True, device=device)
     dev, E = env.device, num_envs
@@ -50,8 +54,34 @@ def run(num_envs=4096, iters=60, horizon=128, target=474.0, epochs=4, minibatche
         A = torch.empty((horizon, E, act_dim), device=dev)
         LP, R, Dn, V = (torch.empty((horizon, E), device=dev) for _ in range(4))
         finished = []
+        if collect == "kernel":
+            with torch.no_grad():
+                pol = MlpPolicy(net.pi[0].weight.detach(), net.pi[0].bias.detach(), net.pi[2].weight.detach(), net.pi[2].bias.detach(),
+                                net.pi[4].weight.detach(), net.pi[4].bias.detach(), device=dev)
+                H = env.ACTION_BUFFER_SIZE
+                eps = torch.randn((horizon, E, 1, act_dim), device=dev)
+                mean = torch.empty_like(eps)
+                before = env.history().reshape(E, H, act_dim).permute(1, 0, 2).clone()          # the H actions before the call, oldest first
+                o12, r, term, trunc, acts = env.rollout_policy(pol, horizon, noise=eps, action_std=net.log_std.exp(), mean_out=mean)
+                # the row the policy saw at step t: kinematics after step t-1 | the H (clipped) actions up to step t-1
+                windows = torch.cat([before, acts.reshape(horizon, E, act_dim)]).unfold(0, H, 1).permute(0, 1, 3, 2)   # [horizon+1, E, H, A]
+                kin = torch.cat([obs[None, :, :12], o12.reshape(horizon, E, 12)])
+                rows = torch.cat([kin, windows.reshape(horizon + 1, E, H * act_dim)], dim=2)
+                O.copy_(rows[:horizon])
+                A.copy_((mean + net.log_std.exp() * eps).reshape(horizon, E, act_dim))
+                LP.copy_((-0.5 * eps.pow(2) - net.log_std - 0.9189385332046727).sum(-1).reshape(horizon, E))
+                V.copy_(net.v(O.view(-1, obs_dim)).view(horizon, E))
+                done = term | trunc
+                R.copy_(r)
+                Dn.copy_(done.float())
+                for t in range(horizon):                                 # (episode statistics only)
+                    ep_ret += r[t]
+                    if done[t].any():
+                        finished.append(ep_ret[done[t]].clone())
+                        ep_ret[done[t]] = 0
+                obs = rows[horizon].clone()
         with torch.no_grad():
-            for t in range(horizon):
+            for t in range(horizon if collect != "kernel" else 0):
                 d = net.dist(obs)
                 a = d.sample()
                 O[t], A[t], LP[t], V[t] = obs, a, d.log_prob(a).sum(-1), net.v(obs).squeeze(-1)
@@ -121,7 +151,6 @@ def run(num_envs=4096, iters=60, horizon=128, target=474.0, epochs=4, minibatche
                 obs = obs_n.view(E, obs_dim)
 
     def in_kernel():
-        from gym_pybullet_drones_amd.policy import MlpPolicy
         pol = MlpPolicy(net.pi[0].weight.detach(), net.pi[0].bias.detach(), net.pi[2].weight.detach(), net.pi[2].bias.detach(),
                         net.pi[4].weight.detach(), net.pi[4].bias.detach(), device=dev)
         fresh_episode()
@@ -146,5 +175,6 @@ if __name__ == "__main__":
     ap.add_argument("--iters", default=60, type=int)
     ap.add_argument("--target", default=474.0, type=float)
     ap.add_argument("--seed", default=0, type=int)
+    ap.add_argument("--collect", default="kernel", choices=["kernel", "torch"], help="where the policy runs while PPO collects its rollouts")
     a = ap.parse_args()
-    run(num_envs=a.num_envs, iters=a.iters, target=a.target, seed=a.seed)
+    run(num_envs=a.num_envs, iters=a.iters, target=a.target, seed=a.seed, collect=a.collect)

@@ -53,9 +53,12 @@ def test_learn(gpu_device):
     aviary and stops at a mean episode reward of 474 -- essentially the bang-bang optimum of this task: 484 minus the
     ~10 lost while climbing 0.89 m at +-10 % thrust).  A few seconds of training must get most of the way there."""
     m = _load("learn")
-    history, eval_ret = m.run(num_envs=2048, iters=25, verbose=False, device=gpu_device)
+    history, eval_ret = m.run(num_envs=2048, iters=25, verbose=False, device=gpu_device)      # rollouts collected INSIDE the kernel
     assert history[0] < 250                      # an untrained policy drifts away / times out low
     assert eval_ret > 440 and max(history) > 430
+    # ... and with the policy as torch operations between the steps (how the loop looked before the kernel could sample)
+    history_t, eval_t = m.run(num_envs=2048, iters=25, verbose=False, device=gpu_device, collect="torch")
+    assert history_t[0] < 250 and eval_t > 440 and max(history_t) > 430
     # the evaluation episode ran twice: 242 launches with the actor as torch operations in between, and ONE launch with the
     # trained actor inside the kernel -- the same policy from the same start, the same return (fp32 torch vs bf16 hi/lo MFMA)
-    assert abs(m.run.last_eval_torch - eval_ret) < 0.1
+    assert abs(m.run.last_eval_torch - eval_t) < 0.1
