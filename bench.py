@@ -69,6 +69,8 @@ WORKLOADS = {
     # two gpd_step launches (rows gathered for it every step), one hipGraph
     "hover65536_30hz_policy": dict(E=65536, D=1, phys=0, ctrl=30, act="rpm", task="hover", full_obs="lazy", policy=True),
     "hover65536_240hz_policy12": dict(E=65536, D=1, phys=0, ctrl=240, act="rpm", task="hover", policy=True),
+    # ... and PPO's collection loop: the same kernel with noise rows, a = clip(mean + std * eps) (examples/learn.py --collect kernel)
+    "hover65536_30hz_policy_sample": dict(E=65536, D=1, phys=0, ctrl=30, act="rpm", task="hover", full_obs="lazy", policy=True, sample=True),
     "hover4m_240hz": dict(E=4194304, D=1, phys=0, ctrl=240, act="rpm", task="hover"),
     "hover16m_240hz": dict(E=16777216, D=1, phys=0, ctrl=240, act="rpm", task="hover"),
     # BASELINE.json configs 4 and 5, per GPU, verbatim (launch with --gpus 8 under torch.distributed.run)
@@ -121,6 +123,9 @@ def make_env(w, device, seed, E=None):
         from gym_pybullet_drones_amd.policy import MlpPolicy
         hist = env.ACTION_BUFFER_SIZE * env.ACT_DIM if w.get("full_obs") else 0
         env.bench_policy = MlpPolicy.random(12 + hist, env.ACT_DIM, seed=seed, gain=1.0, device=device)
+        if w.get("sample"):
+            env.bench_noise = torch.randn((64, env.core.N, env.ACT_DIM), device=device)     # (64 = the steps of the longest launch, POOL)
+            env.bench_mean = torch.empty_like(env.bench_noise)
     return env
 
 
@@ -306,7 +311,11 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
         for e, a in zip(envs, actions):
             hist = getattr(e, "full_obs", False) or getattr(e, "lazy_history", False)
             if getattr(e, "bench_policy", None) is not None:
-                out = e.core.rollout_policy(e.bench_policy, n, want_actions=True)
+                if getattr(e, "bench_noise", None) is not None:
+                    out = e.core.rollout_policy(e.bench_policy, n, want_actions=True, noise=e.bench_noise[:n], action_std=[0.6] * e.ACT_DIM,
+                                                mean_out=e.bench_mean[:n])
+                else:
+                    out = e.core.rollout_policy(e.bench_policy, n, want_actions=True)
             else:
                 out = e.rollout(a[:n]) if hist else e.core.rollout(a[:n], update_latest=False)
             if n in gathers:

@@ -42,7 +42,7 @@ import json; d=json.load(open('gpurun_out/r02_bench_kernarg$k.json')); print('HI
 workloads|workloads2|workloads3)
   if [ $what = workloads ]; then list="hover65536_30hz hover65536_pid_240hz stack8x8192_ext_240hz multihover2x16384_240hz hover65536_240hz_fullobs hover65536_30hz_fullobs hover65536_240hz_history hover65536_30hz_history swarm65536_ext_240hz hover4m_240hz"
   elif [ $what = workloads2 ]; then list="hover65536_240hz_fullobs hover65536_30hz_fullobs hover65536_240hz_history hover65536_30hz_history swarm65536_ext_240hz"
-  else list="swarm65536_ext_240hz hover65536_30hz_policy hover65536_240hz_policy12"; fi
+  else list="swarm65536_ext_240hz hover65536_30hz_policy hover65536_240hz_policy12 hover65536_30hz_policy_sample"; fi
   for w in $list; do
     timeout 300 python -X faulthandler bench.py --workload $w --no-cpu-baseline > gpurun_out/r02_bench_$w.out 2>gpurun_out/r02_bench_$w.err; echo "$w rc $?"
     tail -1 gpurun_out/r02_bench_$w.out > gpurun_out/r02_bench_$w.json
