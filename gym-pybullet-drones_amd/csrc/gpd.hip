@@ -2073,9 +2073,9 @@ __global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const float* __rest
     }
 }
 
-// Every drone sweeps the candidates of the 3x3 cells around its own, staged through LDS.  A lane = a drone, and of the ~650 candidates of a drone ~100 are above it and within 10 m, ~35 close enough for
-// a contribution the fixed-point sum resolves: evaluating the model (two reciprocals, an exponential, a conversion: ~36 issue
-// slots) for every candidate, as the first version of this kernel did, spends 95 % of the vector unit on masked-off lanes --
+// Every drone sweeps the candidates of the 3x3 cells around its own, staged through LDS.  A lane = a drone, and of the ~650
+// candidates of a drone ~100 are above it and within 10 m, ~35 close enough for a contribution the fixed-point sum resolves:
+// evaluating the model (two reciprocals, an exponential, a conversion: ~36 issue slots) for every candidate, as the first version of this kernel did, spends 95 % of the vector unit on masked-off lanes --
 // and with 64 lanes SOME lane nearly always passes, so no wave-level branch ever skips it.  Hence test and evaluation are
 // separated, per chunk of 32 candidates:
 //   A  the tests only, two candidates per packed instruction, no compare and no branch: with d = (candidate - drone),

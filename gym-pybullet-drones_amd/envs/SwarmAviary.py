@@ -97,6 +97,9 @@ class SwarmAviary:
         `vectors`: an (N, 20) tensor that the sort's first pass fills with the state vectors on the way (one launch less
         than `state_vectors()` after it)."""
         c = self.core
+        if vectors is not None and (vectors.device != self.device or vectors.dtype != torch.float32 or not vectors.is_contiguous()
+                                    or tuple(vectors.shape) != (self.NUM_DRONES, 20)):
+            raise ValueError(f"vectors must be a contiguous float32 ({self.NUM_DRONES}, 20) tensor on {self.device}")
         with torch.cuda.device(self.device):
             self._order, self._visit = self._visit, self._order      # ping-pong: last call's order is this call's visit order
             rc = c.lib.gpd_downwash_global(ctypes.byref(c._params), _ptr(c.kin), c.ld, self.NUM_DRONES, self.cell, self.x0,
