@@ -581,6 +581,11 @@ __device__ __forceinline__ void task_single(const GpdStepCfg& C, float px, float
     trunc = my_out | (counter > C.trunc_counter);
 }
 
+// the value the neighbouring lane (lane ^ 1) holds: quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ float pair_mate(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));
+}
+
 // ACT >= 0: the action type is a compile-time constant; S1: so is substeps == 1
 template <bool PID, bool EXT, bool MULTI, int AW, int ACT = -1, bool S1 = false>
 __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C, const uint32_t flags, const int D,
@@ -638,16 +643,22 @@ __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C
             if (L.shfl) {
                 // the aviary is D aligned lanes of THIS wave: one 16-byte LDS write per lane, one broadcast read per
                 // mate, and neither a barrier nor a wait in between (the LDS executes a wave's instructions in order)
+                if (D == 2) {
+                    // a pair: the mate is the neighbouring lane -- three DPP moves (quad_perm [1,0,3,2]) instead of a trip through
+                    // LDS, and the drone's own position (dz = 0: no contribution, whatever its turn in the reference's loop) is
+                    // not evaluated at all
+                    wake_of(pair_mate(k.px), pair_mate(k.py), pair_mate(k.pz));
+                } else {
                 float4* sp = reinterpret_cast<float4*>(sh_pos);
                 __builtin_amdgcn_wave_barrier();
                 sp[L.tid] = make_float4(k.px, k.py, k.pz, 0.0f);
                 __builtin_amdgcn_wave_barrier();
                 const int base = L.le * D;
-                // D is a power of two here: pairs (D = 2) or groups of four, so that the LDS reads of a group are issued
-                // together and the loop branch (a taken branch costs ~60 cycles at one wave per SIMD) is paid once per group
+                // D is a power of two here: groups of four, so that the LDS reads of a group are issued together and the loop
+                // branch (a taken branch costs ~60 cycles at one wave per SIMD) is paid once per group
                 auto mate = [&](int j) { const float4 o = sp[base + j]; wake_of(o.x, o.y, o.z); };
-                if (D == 2) { mate(0); mate(1); }
-                else for (int j = 0; j < D; j += 4) { mate(j); mate(j + 1); mate(j + 2); mate(j + 3); }
+                for (int j = 0; j < D; j += 4) { mate(j); mate(j + 1); mate(j + 2); mate(j + 3); }
+                }
             } else {
                 wg_barrier();
                 sh_pos[L.tid] = k.px; sh_pos[kBlock + L.tid] = k.py; sh_pos[2 * kBlock + L.tid] = k.pz;
@@ -686,15 +697,16 @@ __device__ __forceinline__ void env_step(const GpdParams& P, const GpdStepCfg& C
                                 fabsf(c.roll) > C.tilt_bound || fabsf(c.pitch) > C.tilt_bound;
             float r = 0.0f, dsum = 0.0f, o = 0.0f;
             const float my_o = my_out ? 1.0f : 0.0f;
-            if (L.shfl) {                                      // wave-local LDS exchange, as for the downwash
+            if (L.shfl && D == 2) {                            // a pair: the mate's three values by DPP (a + b either way round)
+                r = my_rew + pair_mate(my_rew); dsum = my_dist + pair_mate(my_dist); o = my_o + pair_mate(my_o);
+            } else if (L.shfl) {                               // wave-local LDS exchange, as for the downwash
                 float4* sr = reinterpret_cast<float4*>(sh_red);
                 __builtin_amdgcn_wave_barrier();
                 sr[L.tid] = make_float4(my_rew, my_dist, my_o, 0.0f);
                 __builtin_amdgcn_wave_barrier();
                 const int base = L.le * D;
                 auto mate = [&](int j) { const float4 v = sr[base + j]; r += v.x; dsum += v.y; o += v.z; };   // sequential, like the
-                if (D == 2) { mate(0); mate(1); }                                                               // reference's loops
-                else for (int j = 0; j < D; j += 4) { mate(j); mate(j + 1); mate(j + 2); mate(j + 3); }
+                for (int j = 0; j < D; j += 4) { mate(j); mate(j + 1); mate(j + 2); mate(j + 3); }             // reference's loops
             } else {
                 wg_barrier();
                 sh_red[L.tid] = my_rew; sh_red[kBlock + L.tid] = my_dist; sh_red[2 * kBlock + L.tid] = my_o;
