@@ -163,3 +163,29 @@ def test_no_kernel_saves_a_half_overwritten_argument_tuple(gpd_asm, policy_asm):
             found = chk.torn_spills(body)
             assert not found, (name, [(l, dead, run["lanes"]) for _, l, dead, run in found])
     assert n >= 130, n
+
+
+def test_swarm_force_kernel_tests_pairs_packed_and_evaluates_them_compacted(gpd_asm):
+    """dwg_force_kernel: phase A is packed and branch-free (v_pk_* + v_and + v_alignbit, no compare in
+    the sweep), the compaction is a DPP prefix sum into an LDS queue of 16-bit pairs, the evaluation gathers its drone by
+    ds_bpermute and adds 64-bit integers with LDS atomics; no scratch, at most 128 VGPRs (four workgroups per CU)."""
+    body, meta = _kernel(gpd_asm, "dwg_force_kernel")
+    assert re.search(r"ScratchSize: 0\b", meta)
+    assert int(re.search(r"; NumVgprs: (\d+)", meta).group(1)) <= 128
+    ops = Counter(op for op, _ in _ops(body))
+    assert ops["v_alignbit_b32"] >= 16 and ops["v_pk_fma_f32"] >= 8 and ops["v_pk_add_f32"] >= 24
+    assert ops["v_mov_b32_dpp"] == 6 and ops["ds_write_b16"] >= 1 and ops["ds_bpermute_b32"] == 6 and ops["ds_add_u64"] == 2
+    assert ops["v_exp_f32_e32"] == 2 and not [op for op in ops if op.startswith("scratch_")]      # (the model: two evaluate() sites)
+    # the sweep: from the first alignbit to the last, only packed arithmetic, bit operations, LDS reads and their waits
+    first = next(i for i, l in enumerate(body) if "v_alignbit_b32" in l)
+    last = max(i for i, l in enumerate(body) if "v_alignbit_b32" in l)
+    sweep = Counter(op for op, _ in _ops(body[first:last + 1]))
+    assert not [op for op in sweep if op.startswith(("v_cmp", "s_cbranch", "v_rcp", "v_exp"))], sweep
+
+
+def test_history_rows_are_streamed_out_in_16_byte_pieces(gpd_asm):
+    """gpd_hist_rows_kernel: whole rows per workgroup, written as ONE contiguous block with non-temporal 16-byte stores."""
+    body, meta = _kernel(gpd_asm, "gpd_hist_rows_kernel")
+    assert re.search(r"ScratchSize: 0\b", meta)
+    stores = [s for op, s in _ops(body) if op.startswith("global_store")]
+    assert any(s.startswith("global_store_dwordx4") and s.endswith(" nt") for s in stores) and all(s.endswith(" nt") for s in stores), stores
