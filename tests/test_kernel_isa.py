@@ -189,3 +189,10 @@ def test_history_rows_are_streamed_out_in_16_byte_pieces(gpd_asm):
     assert re.search(r"ScratchSize: 0\b", meta)
     stores = [s for op, s in _ops(body) if op.startswith("global_store")]
     assert any(s.startswith("global_store_dwordx4") and s.endswith(" nt") for s in stores) and all(s.endswith(" nt") for s in stores), stores
+
+
+def test_two_drone_aviaries_exchange_through_dpp(gpd_asm):
+    """MULTI rollout kernel, RPM, all force terms (BASELINE config 5's kernel): the mate's position (3 values) and its reward /
+    distance / out-of-bounds terms (3) arrive by `quad_perm:[1,0,3,2]` moves -- in each of the three copies of the step."""
+    body, _ = _kernel(gpd_asm, "gpd_rollout1_kernelILb0ELb1ELi4ELi0ELb0ELb1ELb1E")
+    assert sum("quad_perm:[1,0,3,2]" in l for l in body) == 18
