@@ -1901,15 +1901,24 @@ __global__ __launch_bounds__(kBlock) void gpd_hist_rows_kernel(uint32_t N, int D
 __global__ __launch_bounds__(kBlock) void gpd_hist_push_kernel(int K, uint32_t N, int D, int A, int H,
                                                                const float* __restrict__ actions, int64_t act_stride,
                                                                float* __restrict__ ring, const int32_t* __restrict__ ring_pos) {
-    const uint32_t NA = N * static_cast<uint32_t>(A);
-    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    // one drone per thread (A = 4: one 16-byte load, two 16-byte stores -- the float-per-thread form took 68 us for the 64 steps
+    // of a rollout of 65 536 drones, most of it integer division)
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
     const int s = K - 1 - static_cast<int>(blockIdx.y);
-    if (j >= NA || s < 0) return;
-    const uint32_t n = j / static_cast<uint32_t>(A);
-    const int q = (ring_pos[n / static_cast<uint32_t>(D)] + s) % H;
-    const float v = actions[s * act_stride + j];
-    ring[static_cast<size_t>(q) * NA + j] = v;
-    ring[static_cast<size_t>(q + H) * NA + j] = v;
+    if (n >= N || s < 0) return;
+    const size_t NA = static_cast<size_t>(N) * A;
+    int q = ring_pos[n / static_cast<uint32_t>(D)] + s;
+    q -= (q / H) * H;
+    const float* src = actions + s * act_stride + static_cast<size_t>(n) * A;
+    float* r0 = ring + static_cast<size_t>(q) * NA + static_cast<size_t>(n) * A;
+    float* r1 = r0 + static_cast<size_t>(H) * NA;
+    if (A == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(src);
+        *reinterpret_cast<float4*>(r0) = v;
+        *reinterpret_cast<float4*>(r1) = v;
+    } else {
+        for (int a = 0; a < A; ++a) { const float v = src[a]; r0[a] = v; r1[a] = v; }
+    }
 }
 
 // ... and then, in a launch of its own (every lane of the push has read the old value), the aviaries' ring positions advance
@@ -2731,8 +2740,7 @@ int gpd_full_obs(const GpdState* state, int32_t num_steps, int32_t n_drones, int
     }
     // the ring is read by the kernel above and updated by the next two: same stream, in order
     const int keep = num_steps < H ? num_steps : H;
-    const int64_t NA = static_cast<int64_t>(n_drones) * act_dim;
-    const dim3 grid2(static_cast<unsigned>((NA + kBlock - 1) / kBlock), static_cast<unsigned>(keep));
+    const dim3 grid2(static_cast<unsigned>((n_drones + kBlock - 1) / kBlock), static_cast<unsigned>(keep));
     hipLaunchKernelGGL(gpd_hist_push_kernel, grid2, dim3(kBlock), 0, st, num_steps, static_cast<uint32_t>(n_drones),
                        drones_per_env, act_dim, H, actions, action_step_stride, state->act_ring, state->ring_pos);
     const int E = n_drones / drones_per_env;
