@@ -1299,7 +1299,10 @@ struct RollOut {
 __device__ unsigned long long gpd_ts[8 * 4096 * 4];
 __device__ unsigned int gpd_ts_cnt[4096];
 #endif
-template <bool PID, bool EXT, int AW, int ACT, bool S1, bool MULTI, bool NT_OBS = true>
+// RING (gpd_rollout_history): every step's raw action is also pushed into the action ring, like gpd_step does (slots q and
+// q + H of the double ring; two more stores per lane and step, which the explicit wait counts of the loop include because
+// they are unconditional -- a compile-time variant, not a run-time test).
+template <bool PID, bool EXT, int AW, int ACT, bool S1, bool MULTI, bool NT_OBS = true, bool RING = false>
 __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     const GpdParams P, const GpdState S, const GpdStepCfg C, const Span T, const float* __restrict__ action,
     const float* __restrict__ target_pos, const float* __restrict__ init_pose, float* __restrict__ obs12,
@@ -1353,10 +1356,13 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     const float* ipose = reinterpret_cast<const float*>(reinterpret_cast<const char*>(init_pose) +
                                                         (C.init_per_env ? L.n * 28u : static_cast<uint32_t>(L.d) * 28u));
     load_carry<PID, EXT>(S, C, flags, L, target_pos, C.auto_reset ? ipose : S.kin, c, tgx, tgy, tgz, ip);
+    int ring_q = 0;                                                  // RING: the slot this aviary's next action goes to
+    if constexpr (RING) ring_q = S.ring_pos[L.env];
     asm volatile("" :: "v"(c.k.px), "v"(c.k.py), "v"(c.k.pz), "v"(c.k.qx), "v"(c.k.qy), "v"(c.k.qz), "v"(c.k.qw), "v"(c.k.vx),
                        "v"(c.k.vy), "v"(c.k.vz), "v"(c.k.wx), "v"(c.k.wy), "v"(c.k.wz), "v"(tgx), "v"(tgy), "v"(tgz),
                        "v"(c.counter), "v"(ip[0]), "v"(ip[1]), "v"(ip[2]), "v"(ip[3]), "v"(ip[4]), "v"(ip[5]), "v"(ip[6])
                  : "memory");
+    if constexpr (RING) asm volatile("" :: "v"(ring_q) : "memory");
     __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0): the loop starts with nothing pending
     // The ONLY workgroup barrier of the launch: every wave has its state in registers before any wave can reach its
     // store_carry, so a clone lane (above) has read its original's state of step 0, not of step K.
@@ -1377,6 +1383,14 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
         env_step<PID, EXT, MULTI, AW, ACT, S1>(P, C, flags, D, L, act, tgx, tgy, tgz, true, ipose, ip[0], ip[1], ip[2], ip[3],
                                                ip[4], ip[5], ip[6], sh_pos, sh_red, c, out, irpy);
         ro.emit(out, t > 0);                                          // (see RollOut: pipelined bursts, unconditional stores)
+        if constexpr (RING) {
+            const size_t slot = static_cast<size_t>(N) * AW;
+            float* r0 = S.act_ring + static_cast<size_t>(ring_q) * slot + static_cast<size_t>(L.n) * AW;
+            float* r1 = r0 + static_cast<size_t>(S.hist_len) * slot;
+            if (AW == 4) { *reinterpret_cast<float4*>(r0) = act; *reinterpret_cast<float4*>(r1) = act; }
+            else { r0[0] = act.x; r1[0] = act.x; if (AW == 3) { r0[1] = act.y; r0[2] = act.z; r1[1] = act.y; r1[2] = act.z; } }
+            ring_q = ring_q + 1 == S.hist_len ? 0 : ring_q + 1;
+        }
     };
     // Action rows, three steps per loop iteration: the rows of the NEXT iteration (b0..b2) are requested at the top of
     // this one and claimed at its end with an explicit vmcnt(18) -- "everything but the youngest 18 operations", i.e.
@@ -1417,6 +1431,7 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
 #endif
     ro.flush();                                                      // the last step's bursts
     if (L.active) store_carry<PID>(S, L, c);
+    if constexpr (RING) { if (L.active && L.d == 0) S.ring_pos[L.env] = ring_q; }
 #ifdef GPD_EXP_TS
     __builtin_amdgcn_s_waitcnt(0x0F70);
     const unsigned long long ts3 = wall_clock64();
@@ -2436,6 +2451,17 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
         Tr.ring = ((!multi || shfl) && grid.x <= 2u * 256u) ? 4 : 2;   // <= 2 workgroups per CU: LDS is not what limits occupancy
         const size_t lds = static_cast<size_t>(Tr.ring) * kSlotBytes;
         static const bool store_wave_variant = getenv("GPD_ROLLOUT_STOREWAVE") != nullptr;   // A/B switch, diagnostics only
+        if (S.act_ring && !store_wave_variant && term_obs12 == nullptr && (shfl || !multi)) {   // gpd_rollout_history (it checked the shape)
+            if (shfl)
+                hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false, true, true, true>), grid, dim3(kBlock), 0, st, P, S, C, Tr,
+                                   action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+            else if (C.substeps == 1)
+                hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, true, false, true, true>), grid, dim3(kBlock), 0, st, P, S, C, Tr,
+                                   action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+            else
+                hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false, false, true, true>), grid, dim3(kBlock), 0, st, P, S, C, Tr,
+                                   action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+        } else
         if (shfl && !store_wave_variant && term_obs12 == nullptr) {   // aviaries of 2..64 (power of two) drones: no helper wave either
             hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false, true>), grid, dim3(kBlock), 0, st, P, S, C, Tr, action,
                                target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
@@ -2590,6 +2616,23 @@ int gpd_rollout(const GpdParams* params, const GpdState* state, const GpdStepCfg
     if (state) { no_ring = *state; no_ring.act_ring = nullptr; }
     return step_impl("gpd_rollout", params, state ? &no_ring : nullptr, cfg, T, actions, target_pos, init_pose, obs12, reward,
                      terminated, truncated, term_obs12, stream);
+}
+
+int gpd_rollout_history(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, int32_t num_steps,
+                        const float* actions, int64_t action_step_stride, const float* target_pos, const float* init_pose,
+                        float* obs12, int64_t obs_step_stride, float* reward, uint8_t* terminated, uint8_t* truncated,
+                        int64_t env_step_stride, void* stream) {
+    if (num_steps <= 0) return fail(GPD_EINVAL, "gpd_rollout_history: num_steps must be positive");
+    if (action_step_stride < 0 || obs_step_stride < 0 || env_step_stride < 0)
+        return fail(GPD_EINVAL, "gpd_rollout_history: strides must be non-negative");
+    if (!state || !state->act_ring || !state->ring_pos || state->hist_len <= 0)
+        return fail(GPD_EINVAL, "gpd_rollout_history: state has no action ring (act_ring / ring_pos / hist_len)");
+    if (cfg && cfg->drones_per_env > 1 && (cfg->drones_per_env > 64 || (cfg->drones_per_env & (cfg->drones_per_env - 1)) != 0))
+        return fail(GPD_ENOTSUP, "gpd_rollout_history: aviaries of 1, 2, 4 .. 64 drones (use gpd_rollout + gpd_full_obs otherwise)");
+    if (getenv("GPD_ROLLOUT_STOREWAVE")) return fail(GPD_ENOTSUP, "gpd_rollout_history: not with the GPD_ROLLOUT_STOREWAVE diagnostic");
+    const Span T{num_steps, action_step_stride, obs_step_stride, env_step_stride, 2};
+    return step_impl("gpd_rollout_history", params, state, cfg, T, actions, target_pos, init_pose, obs12, reward, terminated,
+                     truncated, nullptr, stream);
 }
 
 #endif  // !GPD_POLICY_TU

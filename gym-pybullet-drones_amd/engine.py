@@ -187,7 +187,7 @@ class SimCore:
         return self.obs12, self.reward, self.terminated, self.truncated
 
     def rollout(self, actions: torch.Tensor, num_steps: int = None, last_only: bool = False,
-                update_latest: bool = True):
+                update_latest: bool = True, push_history: bool = False):
         """K consecutive env steps of every aviary in ONE kernel launch (`gpd_rollout`).
 
         `actions`: float32 device tensor `[K, E*D*A]` (any shape with K leading and E*D*A trailing
@@ -222,11 +222,19 @@ class SimCore:
             buf = self._rollout_buffers(K)
             obs, rew, term, trunc, tobs = buf
             o_stride, e_stride = self.N * 12, self.E
+        self.pushed_history = False
         with torch.cuda.device(self.device):
-            rc = self.lib.gpd_rollout(ctypes.byref(self._params), ctypes.byref(self._state), ctypes.byref(self._cfg),
-                                      K, _ptr(actions), a_stride, _ptr(self.target), _ptr(self.init_pose),
-                                      _ptr(obs), o_stride, _ptr(rew), _ptr(term), _ptr(trunc), e_stride,
-                                      _ptr(tobs), self._stream())
+            if push_history and getattr(self, "act_ring", None) is not None and tobs is None:
+                # the kernel pushes every step's action into the ring itself (`gpd_rollout_history`)
+                rc = self.lib.gpd_rollout_history(ctypes.byref(self._params), ctypes.byref(self._state), ctypes.byref(self._cfg),
+                                                  K, _ptr(actions), a_stride, _ptr(self.target), _ptr(self.init_pose),
+                                                  _ptr(obs), o_stride, _ptr(rew), _ptr(term), _ptr(trunc), e_stride, self._stream())
+                self.pushed_history = rc == 0
+            if not self.pushed_history:           # (no fused variant for this shape: the caller updates the ring with full_obs())
+                rc = self.lib.gpd_rollout(ctypes.byref(self._params), ctypes.byref(self._state), ctypes.byref(self._cfg),
+                                          K, _ptr(actions), a_stride, _ptr(self.target), _ptr(self.init_pose),
+                                          _ptr(obs), o_stride, _ptr(rew), _ptr(term), _ptr(trunc), e_stride,
+                                          _ptr(tobs), self._stream())
         _native.check(rc, "gpd_rollout")
         if not last_only and update_latest:
             self.obs12.copy_(obs[K - 1])

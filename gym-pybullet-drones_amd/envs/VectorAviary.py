@@ -135,13 +135,14 @@ class VectorAviary:
         """K env steps in ONE launch (`gpd_rollout`): actions (K, E, D, A) known up front (open-loop sequences,
         DSLPID waypoint lists).  Returns (obs (K,E,D,OBS_DIM), reward (K,E), terminated (K,E), truncated (K,E))."""
         K = actions.shape[0]
-        obs, reward, terminated, truncated = self.core.rollout(actions)
+        # (lazy history: the rollout kernel pushes the actions into the ring itself when it has a variant for the shape)
+        obs, reward, terminated, truncated = self.core.rollout(actions, push_history=bool(self.lazy_history) and not self.full_obs)
         if self.full_obs:
             obs = self.core.full_obs(actions, obs12=obs, num_steps=K)
             if self.core.obs_full is None:
                 self.core.history_rows()
             self.core.obs_full.copy_(obs[K - 1])
-        elif self.lazy_history:
+        elif self.lazy_history and not self.core.pushed_history:
             self.core.full_obs(actions, num_steps=K, want_rows=False)      # ring update only
         return obs.view(K, self.NUM_ENVS, self.NUM_DRONES, -1), reward, terminated, truncated
 

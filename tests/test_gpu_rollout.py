@@ -193,3 +193,42 @@ def test_full_observation_rows_step_vs_rollout(gpu_device, act, D, ctrl):
         want = sent[idx] if idx >= 0 else np.zeros((E, D, A), dtype=np.float32)
         np.testing.assert_array_equal(tail[:, :, h, :], want)
     assert torch.equal(a.action_history(), b.action_history())
+
+
+@pytest.mark.parametrize("act,D,ctrl,E,K,fused", [("rpm", 1, 240, 1000, 7, True), ("rpm", 1, 30, 333, 40, True), ("pid", 1, 48, 300, 30, True),
+                                                  ("one_d_rpm", 2, 30, 257, 20, True), ("vel", 4, 240, 130, 9, True), ("rpm", 3, 48, 100, 12, False)])
+def test_rollout_with_lazy_history_pushes_the_ring_inside_the_kernel(gpu_device, act, D, ctrl, E, K, fused):
+    """`gpd_rollout_history` (VectorAviary(full_obs="lazy").rollout): every step's action goes into the action ring inside the
+    rollout kernel.  Same observations, same ring (the zero-copy history view, the ring positions), same continuation as K
+    single steps -- for rollouts shorter and longer than the history, ragged batches, aviaries of 2 and 4 drones; an aviary of
+    3 drones has no fused variant and takes the post-pass (`pushed_history` False), with the same result."""
+    from gym_pybullet_drones_amd.envs import VectorAviary
+    from gym_pybullet_drones_amd.utils.enums import ActionType
+    rng = np.random.default_rng(K)
+    mk = lambda: VectorAviary(E, D, act=ActionType(act), ctrl_freq=ctrl, task="hover" if D == 1 else "multihover",  # noqa: E731
+                              full_obs="lazy", auto_reset=True, episode_len_sec=0.1, device=gpu_device)
+    a, b = mk(), mk()
+    A = a.ACT_DIM
+    acts = torch.as_tensor(rng.uniform(-1, 1, size=(2 * K + 3, E, D, A)).astype(np.float32), device=gpu_device)
+    for k in range(3):                       # some history first
+        a.step(acts[k]); b.step(acts[k])
+    rows = []
+    for k in range(3, 3 + 2 * K):
+        o, *_ = a.step(acts[k])
+        rows.append(o.clone())
+    o1 = b.rollout(acts[3:3 + K])[0].clone()
+    assert b.core.pushed_history == fused
+    h_mid = b.history().clone()
+    o2 = b.rollout(acts[3 + K:])[0]
+    assert torch.equal(torch.cat([o1, o2]), torch.stack(rows))
+    assert torch.equal(a.history(), b.history()) and torch.equal(a.core.ring_pos, b.core.ring_pos)
+    assert torch.equal(a.core.act_ring, b.core.act_ring)
+    # the view after the first rollout ends with that rollout's last actions, oldest first
+    H = a.ACTION_BUFFER_SIZE
+    sent = acts[:3 + K].cpu().numpy()
+    tail = h_mid.cpu().numpy().reshape(E, D, H, A)
+    for h in range(H):
+        idx = 3 + K - 1 - (H - 1) + h
+        np.testing.assert_array_equal(tail[:, :, h, :], sent[idx] if idx >= 0 else np.zeros((E, D, A), dtype=np.float32))
+    o, *_ = a.step(acts[0]); p, *_ = b.step(acts[0])          # and stepping goes on from the same ring
+    assert torch.equal(o, p) and torch.equal(a.history(), b.history())
