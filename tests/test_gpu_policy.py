@@ -142,7 +142,8 @@ def test_policy_argument_errors(gpu_device):
                                            ("vel", 240, False), ("pid", 30, True)])
 @pytest.mark.parametrize("tweak", [dict(task=0), dict(auto_reset=0), dict(xy_bound=0.2, tilt_bound=0.05), dict(trunc_counter=3),
                                    dict(z_bound=1e9, xy_bound=1e9, tilt_bound=1e9, trunc_counter=2 ** 30)])
-def test_policy_rollout_reads_the_step_configuration_like_gpd_step(gpu_device, act, ctrl, hist, tweak):
+@pytest.mark.parametrize("sampled", [False, True])
+def test_policy_rollout_reads_the_step_configuration_like_gpd_step(gpu_device, act, ctrl, hist, tweak, sampled):
     """Every field of GpdStepCfg the task evaluation reads (task switch, auto-reset, the truncation box and tilt bound, the time
     limit), changed one at a time: the policy kernel must keep following gpd_step bit for bit -- rewards and flags included.
     (A build of the VEL variant under another instruction scheduler once returned truncated = 1 and a task reward for every
@@ -156,7 +157,13 @@ def test_policy_rollout_reads_the_step_configuration_like_gpd_step(gpu_device, a
             setattr(env.core._cfg, k, v)
     A, H = a.ACT_DIM, ctrl // 2
     pol = MlpPolicy.random(12 + (H * A if hist else 0), A, seed=5, gain=1.2, device=gpu_device)
-    obs, rew, term, trunc, acts = a.rollout_policy(pol, K)
+    if sampled:        # the sampling kernels are separate instantiations (own register allocation): the same matrix for them
+        if act not in ("rpm", "one_d_rpm"):
+            pytest.skip("sampling: RPM action types")
+        noise = torch.randn((K, E, 1, A), generator=torch.Generator(device=gpu_device).manual_seed(1), device=gpu_device)
+        obs, rew, term, trunc, acts = a.rollout_policy(pol, K, noise=noise, action_std=[0.5] * A)
+    else:
+        obs, rew, term, trunc, acts = a.rollout_policy(pol, K)
     for t in range(K):
         o, r, te, tr, _ = b.step(acts[t])
         assert torch.equal(r, rew[t]) and torch.equal(te, term[t]) and torch.equal(tr, trunc[t]) and torch.equal(o, obs[t]), (t, tweak)
