@@ -209,18 +209,25 @@ def test_rollout_with_lazy_history_pushes_the_ring_inside_the_kernel(gpu_device,
                               full_obs="lazy", auto_reset=True, episode_len_sec=0.1, device=gpu_device)
     a, b = mk(), mk()
     A = a.ACT_DIM
+    # (every float of the kernel arguments scaled by a factor of its own: the fused variants are instantiations of their own,
+    # with their own register allocation -- see test_rollout_is_bitwise_with_every_argument_word_distinct)
+    _scramble_arguments(np.random.default_rng(79), a.core, b.core)
     acts = torch.as_tensor(rng.uniform(-1, 1, size=(2 * K + 3, E, D, A)).astype(np.float32), device=gpu_device)
     for k in range(3):                       # some history first
         a.step(acts[k]); b.step(acts[k])
-    rows = []
+    rows, flags = [], []
     for k in range(3, 3 + 2 * K):
-        o, *_ = a.step(acts[k])
-        rows.append(o.clone())
-    o1 = b.rollout(acts[3:3 + K])[0].clone()
+        o, r, te, tr, _ = a.step(acts[k])
+        rows.append(o.clone()); flags.append((r.clone(), te.clone(), tr.clone()))
+    o1, r1, te1, tr1 = (x.clone() for x in b.rollout(acts[3:3 + K]))
     assert b.core.pushed_history == fused
     h_mid = b.history().clone()
-    o2 = b.rollout(acts[3 + K:])[0]
+    o2, r2, te2, tr2 = b.rollout(acts[3 + K:])
     assert torch.equal(torch.cat([o1, o2]), torch.stack(rows))
+    for k, (r, te, tr) in enumerate(flags):
+        assert torch.equal(r, (r1 if k < K else r2)[k % K]) and torch.equal(te, (te1 if k < K else te2)[k % K]) and \
+            torch.equal(tr, (tr1 if k < K else tr2)[k % K]), k
+    assert torch.stack([f[2] for f in flags]).any() or 2 * K + 3 < 0.1 * ctrl or act in ("pid", "vel"), "the test should see episodes end"
     assert torch.equal(a.history(), b.history()) and torch.equal(a.core.ring_pos, b.core.ring_pos)
     assert torch.equal(a.core.act_ring, b.core.act_ring)
     # the view after the first rollout ends with that rollout's last actions, oldest first
