@@ -153,14 +153,15 @@ def host_threads():
     return n
 
 
-def cpu_baseline(w, budget_s=12.0):
+def cpu_baseline(w, budget_s=12.0, phys=None):
     """Time the loop-structured float64 oracle (the CPU 'port' of the reference's per-drone Python/numpy
     path; PyBullet itself is not installable here) on ONE host core, on a bounded sample of the workload."""
     from oracle.aviary_oracle import OracleAviary
     urdf = os.path.join(REPO, "gym-pybullet-drones_amd", "assets", "cf2x.urdf")
     D = w["D"]
+    phys = w["phys"] if phys is None else phys      # (the flags the device path really runs with: Physics.PYB* adds the ground plane)
     task = w["task"] if w["task"] != "hover" or D == 1 else "multihover"
-    env = OracleAviary(urdf, "cf2x", num_drones=D, physics_flags=w["phys"], pyb_freq=240, ctrl_freq=w["ctrl"],
+    env = OracleAviary(urdf, "cf2x", num_drones=D, physics_flags=phys, pyb_freq=240, ctrl_freq=w["ctrl"],
                        act=w["act"], task=task)
     rng = np.random.default_rng(0)
     A = env.action_buffer[0].shape[1]
@@ -185,7 +186,7 @@ def cpu_baseline(w, budget_s=12.0):
 
         def timed(E, threads, secs):
             c_oracle.lib().orc_set_threads(threads)
-            c = CAviary(urdf, "cf2x", E, D, physics_flags=w["phys"], pyb_freq=240, ctrl_freq=w["ctrl"], act=w["act"], task=task)
+            c = CAviary(urdf, "cf2x", E, D, physics_flags=phys, pyb_freq=240, ctrl_freq=w["ctrl"], act=w["act"], task=task)
             ac = rng.uniform(-1, 1, size=(4, E, D, A))
             c.step_in_place(ac[0])          # (first touch of every array by the threads that will own its pages)
             c.step_in_place(ac[1])
@@ -222,6 +223,24 @@ def cpu_baseline(w, budget_s=12.0):
     return out
 
 
+def swarm_cpu_baseline(w, env, budget_s=10.0):
+    """ONE aviary of N drones on the CPU: the reference's `_downwash` is an O(N^2) Python loop per sub-step
+    (envs/BaseAviary.py:785-811).  Timed: the float64 C restatement of one sub-step of the whole swarm -- all-pairs downwash
+    + the explicit integrator -- on a bounded SAMPLE of the swarm (the first n drones of the bench scene, n chosen so that a
+    sub-step takes about a second), all usable threads; the figure for the full swarm is extrapolated with the pair count."""
+    from oracle import c_oracle
+    if not hasattr(c_oracle, "swarm_substep_seconds"):
+        return {"error": "oracle/c_oracle.py has no swarm restatement"}
+    n = min(env.NUM_DRONES, 16384)
+    th = min(host_threads(), c_oracle.lib().orc_max_threads())
+    secs, reps = c_oracle.swarm_substep_seconds(env.INIT_XYZS[:n], threads=th, budget_s=budget_s)
+    N = env.NUM_DRONES
+    full = secs * (N / n) ** 2
+    return {"value": N / full, "unit": "drone-steps/s", "cores": th, "kind": "port",
+            "sample": f"{reps} sub-steps of the first {n} drones of the scene (all-pairs downwash + integrator, oracle/gpd_oracle.c, float64, "
+                      f"{th} threads): {secs * 1e3:.1f} ms each; extrapolated to {N} drones by the pair count (x{(N / n) ** 2:.0f})"}
+
+
 def pybullet_baseline(budget_s=8.0):
     """The reference's REAL CPU path (BASELINE config 1: `HoverAviary()` defaults, Physics.PYB through Bullet's own
     integrator, envs/BaseAviary.py:679-711), timed when a box has `pybullet` + the reference package installed.  This
@@ -246,8 +265,113 @@ def pybullet_baseline(budget_s=8.0):
             "sample": f"{n} env.step() of the reference's HoverAviary() (Physics.PYB, 30 Hz control / 240 Hz physics) in {dt:.1f}s"}
 
 
+def parity_check(w, env, actions, K, POOL, max_steps=256):
+    """Ties the bench line to a parity figure from the SAME process (checker code: the product path stays oracle-free).
+
+    After the timed region the device state is snapshotted and ONE K-step schedule of the exact timed workload -- the same
+    launches (`launch_rollout`, the groups of `groups_of(K, POOL)`), the same pre-generated action blocks, same-step
+    auto-reset on -- is replayed on the device and, from the identical fp32-rounded state and actions, through the float64 C
+    restatement (`oracle/gpd_oracle.c`, all usable host threads).  Errors are SURVEY.md section 8(d)'s metric per field group:
+    max |x32 - x64| / max(max |x64| over the batch and the replayed steps, floor), floors 1 m / 1 / 1 m/s / 1 rad/s.
+    An aviary whose terminated / truncated flags differ in some step (a value within rounding of a threshold: one side resets,
+    the other does not) is counted in `flag_mismatch_frac` and leaves the comparison from that step on.  The schedule is cut
+    after `max_steps` env steps (bounded CPU time)."""
+    from oracle import bullet_math as bm
+    from oracle import c_oracle
+    from oracle.c_oracle import CAviary
+    core = env.core
+    E, D, N, A, S = core.E, core.D, core.N, core.A, core.S
+    urdf = os.path.join(REPO, "gym-pybullet-drones_amd", "assets", "cf2x.urdf")
+    task = {0: "none", 1: "hover", 2: "multihover"}[core.task]
+    torch.cuda.synchronize()
+    st = core.get_state()
+    orc = CAviary(urdf, "cf2x", E, D, physics_flags=core.physics_flags, pyb_freq=240, ctrl_freq=w["ctrl"], act=w["act"], task=task,
+                  auto_reset=bool(core.auto_reset), target_pos=np.broadcast_to(core.TARGET_POS, (E, D, 3)))
+    pose = core.init_pose.cpu().numpy().astype(np.float64).reshape(-1, D, 7)      # the fp32 reset poses the kernel uses
+    orc.INIT_XYZS = np.ascontiguousarray(np.broadcast_to(pose[..., :3], (E, D, 3)))
+    orc.INIT_QUAT = np.ascontiguousarray(np.broadcast_to(pose[..., 3:], (E, D, 4)))
+    kin = st["kin"].cpu().numpy().astype(np.float64).T                              # [N][13]
+    orc.pos, orc.quat = kin[:, 0:3].reshape(E, D, 3).copy(), kin[:, 3:7].reshape(E, D, 4).copy()
+    orc.vel, orc.rpy_rates = kin[:, 7:10].reshape(E, D, 3).copy(), kin[:, 10:13].reshape(E, D, 3).copy()
+    orc.rpy = np.ascontiguousarray(bm.euler_from_quaternion_b(orc.quat))
+    orc.step_counter = st["step_counter"].cpu().numpy().astype(np.int64)
+    if "last_rpm" in st:
+        orc.last_rpm = np.ascontiguousarray(st["last_rpm"].cpu().numpy().astype(np.float64).T.reshape(E, D, 4))
+    if "pid" in st:
+        orc.pid_state = np.ascontiguousarray(st["pid"].cpu().numpy().astype(np.float64).T.reshape(E, D, 9))
+    groups, left = [], max_steps
+    for n in groups_of(K, POOL):
+        if left <= 0:
+            break
+        groups.append(min(n, left))
+        left -= groups[-1]
+    names = ("pos", "quat", "vel", "rates")
+    sl = {"pos": slice(0, 3), "quat": slice(3, 7), "vel": slice(7, 10), "rates": slice(10, 13)}
+    osl = {"pos": slice(0, 3), "rpy": slice(3, 6), "vel": slice(6, 9), "ang_v": slice(9, 12)}
+    scale = {g: 1.0 for g in list(sl) + list(osl)}
+    obs_err = {g: 0.0 for g in osl}
+    alive = np.ones(E, dtype=bool)                  # aviaries whose flags agreed in every step so far
+    rew_err, checked, n_done = 0.0, 0, 0
+    c_oracle.lib().orc_set_threads(min(host_threads(), c_oracle.lib().orc_max_threads()))
+    try:
+        for n in groups:
+            out = launch_rollout(env, actions, n)
+            torch.cuda.synchronize()
+            obs = out[0].reshape(-1, N, 12)[:n].cpu().numpy().astype(np.float64)
+            rew, term, trunc = (x[:n].cpu().numpy() for x in out[1:4])
+            a64 = actions[:n].cpu().numpy().astype(np.float64)
+            for k in range(n):
+                orc.step_in_place(a64[k])
+                same = (term[k] == orc.terminated.astype(bool)) & (trunc[k] == orc.truncated.astype(bool))
+                alive &= same
+                n_done += int((term[k] | trunc[k]).sum())
+                m = np.repeat(alive, D)
+                o64 = orc.obs.reshape(N, 12)
+                for g, s_ in osl.items():
+                    scale[g] = max(scale[g], float(np.abs(o64[:, s_]).max()))
+                    obs_err[g] = max(obs_err[g], float(np.abs(obs[k][m][:, s_] - o64[m][:, s_]).max()) if m.any() else 0.0)
+                if alive.any():
+                    rew_err = max(rew_err, float(np.abs(rew[k][alive].astype(np.float64) - orc.reward[alive]).max()))
+                k64 = np.concatenate([orc.pos.reshape(N, 3), orc.quat.reshape(N, 4), orc.vel.reshape(N, 3), orc.rpy_rates.reshape(N, 3)], axis=1)
+                for g in names:
+                    scale[g] = max(scale[g], float(np.abs(k64[:, sl[g]]).max()))
+                checked += 1
+    finally:
+        c_oracle.lib().orc_set_threads(1)
+    torch.cuda.synchronize()
+    kin32 = core.kin[:, :N].cpu().numpy().astype(np.float64).T
+    m = np.repeat(alive, D)
+    res = {"checked_steps": checked, "launches": [f"rollout{n}" for n in groups], "aviaries": E, "drones": N,
+           "episodes_ended_in_window": n_done}
+    worst = 0.0
+    for g in names:
+        res[g] = float(np.abs(kin32[m][:, sl[g]] - k64[m][:, sl[g]]).max() / scale[g])
+        worst = max(worst, res[g])
+    res["obs_every_step"] = {g: obs_err[g] / scale[g] for g in osl}
+    res["flag_mismatch_frac"] = float(1.0 - alive.mean())
+    res["reward_max_abs"] = rew_err
+    res["max"] = worst
+    res["tolerance"] = 1e-4
+    res["ok"] = bool(worst < 1e-4)
+    res["oracle"] = "oracle/gpd_oracle.c (float64), from the device state after the timed region, same action blocks, auto-reset on"
+    res["metric"] = "max|x32-x64| / max(max|x64| over batch and window, 1): final state per field group; obs_every_step: the same over every replayed step"
+    return res
+
+
 def groups_of(k, pool):
     return [pool] * (k // pool) + ([k % pool] if k % pool else [])
+
+
+def launch_rollout(e, a, n):
+    """One rollout launch of n env steps of the aviaries of `e` with the action blocks a[:n] -- THE timed call of rollout mode
+    (also what `parity_check` replays).  Returns (obs12 [n,N,12], reward, terminated, truncated[, actions])."""
+    hist = getattr(e, "full_obs", False) or getattr(e, "lazy_history", False)
+    if getattr(e, "bench_policy", None) is not None:
+        if getattr(e, "bench_noise", None) is not None:
+            return e.core.rollout_policy(e.bench_policy, n, want_actions=True, noise=e.bench_noise[:n], action_std=[0.6] * e.ACT_DIM,
+                                         mean_out=e.bench_mean[:n])
+        return e.core.rollout_policy(e.bench_policy, n, want_actions=True)
+    return e.rollout(a[:n]) if hist else e.core.rollout(a[:n], update_latest=False)
 
 
 def measure(mode, args, envs, actions, gather, device, world, POOL):
@@ -304,20 +428,19 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
     sizes = set(groups_of(K, POOL)) | set(groups_of(W, POOL))
     gathers = {}
     if mode == "rollout" and gather is not None:
-        for n in sorted(sizes):                                            # (same order on every rank: collective inits)
-            gathers[n] = type(gather)(n * core.N, 12, device=device)       # one larger collective per rollout
+        for n in sorted(sizes):             # one larger collective per rollout; every length shares the ONE communicator of `gather`
+            gathers[n] = gather.sized(n * core.N)
+
+    # rollout mode with --split C: sub-batch c is an independent chain of launches on stream c -- no join inside the timed
+    # region (the aviaries share nothing), so one chain's kernel boundary and straggler tail hide under the others' steady state
+    indep = mode == "rollout" and len(envs) > 1
+    if indep:
+        for e, s in zip(envs[1:], side):
+            e.core.use_stream(s)
 
     def one_rollout(n):
         for e, a in zip(envs, actions):
-            hist = getattr(e, "full_obs", False) or getattr(e, "lazy_history", False)
-            if getattr(e, "bench_policy", None) is not None:
-                if getattr(e, "bench_noise", None) is not None:
-                    out = e.core.rollout_policy(e.bench_policy, n, want_actions=True, noise=e.bench_noise[:n], action_std=[0.6] * e.ACT_DIM,
-                                                mean_out=e.bench_mean[:n])
-                else:
-                    out = e.core.rollout_policy(e.bench_policy, n, want_actions=True)
-            else:
-                out = e.rollout(a[:n]) if hist else e.core.rollout(a[:n], update_latest=False)
+            out = launch_rollout(e, a, n)
             if n in gathers:
                 gathers[n](out[0].reshape(-1, 12))
 
@@ -365,8 +488,14 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ev0.record()          # on the current stream = the stream every gpd_* launch above goes to
+        if indep:             # fork: the other chains start behind ev0 ...
+            for s_ in side:
+                s_.wait_event(ev0)
         for _ in range(reps):
             run(K)
+        if indep:             # ... and ev1 sits behind the last launch of EVERY chain (one join, after the last step)
+            for s_ in side:
+                main.wait_stream(s_)
         ev1.record()
         torch.cuda.synchronize()
         if world > 1:
@@ -391,7 +520,9 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
         if getattr(e, "full_obs", False):
             return c.bytes_full_rows(n, push=rollout)
         if getattr(e, "lazy_history", False) and rollout:
-            return c.bytes_full_rows(n, push=True) - c.bytes_full_rows(n)
+            if getattr(c, "pushed_history", False):     # gpd_rollout_history: the action (already counted) goes to both ring halves
+                return n * c.N * 2 * c.A * 4 + 2 * 4 * c.E          # + the ring position of every aviary, read and written once
+            return c.bytes_full_rows(n, push=True) - c.bytes_full_rows(n)     # post-pass (gpd_full_obs, ring update only)
         return 0
 
     if mode == "rollout":
@@ -400,7 +531,7 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
     else:
         per_pass = K * sum(e.core.bytes_per_step() + extra(e, 1, False) for e in envs)
         launches_pass = K
-    launches = launches_pass * repeats
+    launches = launches_pass * repeats * (len(envs) if indep else 1)       # (independent chains: C concurrent launches per group)
     bytes_total = per_pass * repeats
     n_rank = sum(c.N for c in cores)
     n_total = n_rank * world
@@ -418,8 +549,10 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
                      "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS, "traffic": None, "kernel": kernel,
                      "env_steps_per_launch": steps_per_launch, "bytes_per_launch": bytes_total / launches,
                      "bytes_per_drone_per_env_step": per_pass / (n_rank * K),
-                     "launch_us_hip_events": ev_s * 1e6 / launches, "launches_timed": launches,
-                     "clock": "HIP events on the launch stream, max over ranks"},
+                     "launch_us_hip_events": ev_s * 1e6 / (launches_pass * repeats), "launches_timed": launches,
+                     "concurrent_chains": len(envs) if indep else 1,
+                     "clock": "HIP events on the launch stream, max over ranks" +
+                              (f"; {len(envs)} independent chains forked behind the first event, the second event behind the last launch of each" if indep else "")},
     }
 
 
@@ -474,7 +607,10 @@ def main():
                     help="rollout: gpd_rollout, up to 64 env steps per launch (state in registers, actions pre-staged); "
                          "graph: one launch per env step, hipGraph of up to 64 steps; eager: one host launch per step")
     ap.add_argument("--min-time", type=float, default=0.25, help="repeat the K-step schedule until the timed region lasts this long [s]")
-    ap.add_argument("--split", type=int, default=1, help="graph/eager: step C sub-batches of E/C aviaries as C independent chains on C streams")
+    ap.add_argument("--split", type=int, default=1,
+                    help="C sub-batches of E/C aviaries as C independent chains on C streams: rollout mode -- C concurrent rollout launches, "
+                         "no join inside the timed region; graph/eager -- C chains of single-step launches")
+    ap.add_argument("--no-parity", action="store_true", help="skip the replay of one schedule through the float64 C oracle")
     ap.add_argument("--allgather", action="store_true", help="all-gather the obs shards over RCCL")
     ap.add_argument("--allgather-impl", default="auto", choices=["auto", "native", "torch"],
                     help="native: the C-ABI's gpd_allgather_obs (ncclAllGather); torch: torch.distributed")
@@ -512,22 +648,45 @@ def main():
 
     envs, actions = build(1)
     core = envs[0].core
-    gather, impl = None, None
+    gather, impl, gather_note, ranks_seen = None, None, None, None
     if want_gather:
         impl = args.allgather_impl
         if impl == "auto":
             impl = "native" if (world == 1 or backend == "nccl") else "torch"
-        gather = (gdist.NativeObsAllGather if impl == "native" else gdist.ObsAllGather)(core.N, 12, device=device)
+        if impl == "native":
+            # ONE communicator for every count (NativeComm.shared), exercised once before anything is timed; a failure on
+            # ANY rank sends ALL ranks to torch.distributed's all-gather together instead of aborting the job
+            err = None
+            try:
+                gather = gdist.NativeObsAllGather(core.N, 12, device=device)
+                gather(core.obs12)
+                torch.cuda.synchronize()
+                ranks_seen = gather.nc.ranks_seen
+            except Exception as e:      # noqa: BLE001 -- reported in the JSON line
+                err = f"{type(e).__name__}: {e}"[:300]
+            if not gdist.all_ranks_ok(err is None, device=device):
+                gather_note = f"native RCCL all-gather unavailable ({err or 'failed on another rank'}): fell back to torch.distributed"
+                impl, gather = "torch", None
+        if impl == "torch":
+            gather = gdist.ObsAllGather(core.N, 12, device=device)
 
     second = None
     if args.mode == "rollout" and not args.no_second_leg:
-        senvs, sacts = (envs, actions) if args.split == 1 else build(args.split)
-        second = measure("graph", args, senvs, sacts, gather if args.split == 1 else None, device, world, POOL)
+        second = measure("graph", args, envs, actions, gather, device, world, POOL)
         for e in envs:
             e.reset()
-    if args.mode != "rollout" and args.split > 1:
+    if args.split > 1:
+        if w.get("policy") or w.get("full_obs"):
+            raise SystemExit("--split: plain obs12 workloads only (no policy / history rows)")
         envs, actions = build(args.split)
     m = measure(args.mode, args, envs, actions, gather if len(envs) == 1 else None, device, world, POOL)
+
+    parity = None
+    if rank == 0 and not args.no_parity and args.mode == "rollout" and not w.get("policy") and not w.get("swarm"):
+        try:
+            parity = parity_check(w, envs[0], actions[0], args.steps, POOL)
+        except Exception as e:          # noqa: BLE001 -- the checker must never take the measurement down with it
+            parity = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     clock_ghz = None
     try:        # the shader clock a one-wave-per-SIMD FMA chain runs at right after the timed region (diagnostics)
@@ -553,11 +712,13 @@ def main():
             "repeats": m["repeats"], "timed_steps": m["timed_steps"], "timed_region_ms": m["ev_s"] * 1e3,
             "wall_ms_per_step": m["wall_s"] * 1e3 / m["timed_steps"], "value_wall": m["value_wall"],
             "config": {"workload": args.workload, "envs_per_gpu": w["E"], "drones_per_env": D,
-                       "total_drones": n_total, "physics": "DYN" + "".join(n for b, n in ((1, "+GND"), (2, "+DRAG"), (4, "+DW")) if w["phys"] & b),
+                       "total_drones": n_total, "physics": "DYN" + "".join(n for b, n in ((1, "+GND"), (2, "+DRAG"), (4, "+DW"), (8, "+GROUND_PLANE")) if core.physics_flags & b),
+                       "physics_flags": core.physics_flags,
                        "pyb_freq": 240, "ctrl_freq": w["ctrl"], "substeps_per_step": S, "action": w["act"],
                        "task": w["task"], "auto_reset": True, "mode": args.mode, "launch": launch, "split": len(envs),
                        "full_obs": w.get("full_obs", False), "policy": "MlpPolicy 64x64 tanh, in the kernel (rollout) / torch between steps (graph)" if w.get("policy") else None,
-                       "obs_allgather": want_gather, "allgather_impl": impl,
+                       "obs_allgather": want_gather, "allgather_impl": impl, "allgather_note": gather_note,
+                       "n_ranks_seen_by_rccl": ranks_seen,
                        "env_steps_per_s": m["env_steps_per_s"]},
             "roofline": m["roofline"],
         }
@@ -569,16 +730,17 @@ def main():
             out["shader_clock_ghz_probe"] = clock_ghz
         if second is not None:
             sec = {"value": second["value"], "unit": "drone-steps/s", "steps": second["K"], "repeats": second["repeats"],
-                   "timed_steps": second["timed_steps"], "us_per_step": second["us_per_step"], "split": args.split,
-                   "launch": f"graph (hipGraph of {min(second['K'], POOL)} single-step launches" +
-                             (f", {args.split} sub-batches on {args.split} streams)" if args.split > 1 else ")"),
+                   "timed_steps": second["timed_steps"], "us_per_step": second["us_per_step"], "split": 1,
+                   "launch": f"graph (hipGraph of {min(second['K'], POOL)} single-step launches)",
                    "roofline": second["roofline"]}
             si = attach_counters(sec["roofline"], f"{args.workload}:graph", second, core, clock_ghz)
             if si is not None:
                 sec["roofline_valu_issue"] = si
             out["one_launch_per_step"] = sec
+        if parity is not None:
+            out["parity"] = parity
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(w)
+            out["cpu_baseline"] = swarm_cpu_baseline(w, envs[0]) if w.get("swarm") else cpu_baseline(w, phys=core.physics_flags)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

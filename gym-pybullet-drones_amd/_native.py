@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(CSRC, "libgpd.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # Two translation units (csrc/gpd.hip, csrc/gpd_policy.hip = the same source with GPD_POLICY_TU defined), one library:
 #   -mllvm -amdgpu-sched-strategy=max-ilp for the step / rollout kernels: it interleaves independent dependency chains, which
@@ -112,11 +112,13 @@ _SIGNATURES = {
     "gpd_comm_unique_id": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint8)]),
     "gpd_comm_init": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32,
                                      ctypes.c_int32]),
+    "gpd_comm_count": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int32)]),
     "gpd_comm_destroy": (ctypes.c_int, [_P]),
     "gpd_allgather_obs": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, _P]),
     "gpd_clock_probe": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _P]),
 }
 COMM_ID_BYTES = 128
+GPD_EINVAL, GPD_ERANGE, GPD_ENOTSUP = -1, -2, -3
 
 
 def lib() -> ctypes.CDLL:

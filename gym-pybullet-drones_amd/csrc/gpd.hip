@@ -373,6 +373,12 @@ __device__ __forceinline__ void substep(const GpdParams& P, float h, uint32_t fl
         Fy = fmaf(-(P.drag_coeff[1] * k.vy), wsum, Fy);
         Fz = fmaf(-(P.drag_coeff[2] * k.vz), wsum, Fz);
     }
+    if (EXT && (flags & GPD_PHYS_DAMP)) {
+        // Bullet's default multibody damping (NOT in the reference's Physics.DYN, see gpd.h): force -M d (1 + |v|) v
+        const float vn = fast_sqrt(fmaf(k.vz, k.vz, fmaf(k.vy, k.vy, k.vx * k.vx)));
+        const float ml = -(P.M * GPD_BULLET_DAMPING) * (1.0f + vn);
+        Fx = fmaf(ml, k.vx, Fx); Fy = fmaf(ml, k.vy, Fy); Fz = fmaf(ml, k.vz, Fz);
+    }
     // z torque from KM*rpm_i^2 = (KM/KF)*(F_h + g_i): alternating signs, F_h cancels (ground effect not included, :842).
     // The airframe variants are folded into signed constants and one bit-select: no branch and no per-step select chain
     // (negating a factor negates the product exactly, so the bits are those of "compute, then flip the sign").
@@ -388,8 +394,14 @@ __device__ __forceinline__ void substep(const GpdParams& P, float h, uint32_t fl
     // Euler's rotation equation with diagonal J
     const fp2 jwxy = fp2{P.J[0], P.J[1]} * fp2{k.wx, k.wy};
     const float jwx = jwxy.x, jwy = jwxy.y, jwz = P.J[2] * k.wz;
-    const fp2 txy = fp2{tx, ty} - fp2{fmaf(k.wy, jwz, -(k.wz * jwy)), fmaf(k.wz, jwx, -(k.wx * jwz))};
-    const float tzz = tz - fmaf(k.wx, jwy, -(k.wy * jwx));
+    fp2 txy = fp2{tx, ty} - fp2{fmaf(k.wy, jwz, -(k.wz * jwy)), fmaf(k.wz, jwx, -(k.wx * jwz))};
+    float tzz = tz - fmaf(k.wx, jwy, -(k.wy * jwx));
+    if (EXT && (flags & GPD_PHYS_DAMP)) {                  // ... and torque -J w d (1 + |w|)
+        const float wn = fast_sqrt(fmaf(k.wz, k.wz, fmaf(k.wy, k.wy, k.wx * k.wx)));
+        const float da = -GPD_BULLET_DAMPING * (1.0f + wn);
+        txy = fma2(jwxy, splat(da), txy);
+        tzz = fmaf(jwz, da, tzz);
+    }
     // semi-implicit Euler (:860-862): position uses the NEW velocity; x and y as packed pairs
     const fp2 hh = splat(h);
     const fp2 vxy = fma2(hh, fp2{Fx, Fy} * splat(P.inv_M), fp2{k.vx, k.vy});
@@ -884,6 +896,10 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     const float* ipose = reinterpret_cast<const float*>(reinterpret_cast<const char*>(init_pose) +
                                                         (C.init_per_env ? L.n * 28u : static_cast<uint32_t>(L.d) * 28u));
     load_carry<PID, EXT>(S, C, flags, L, target_pos, S.kin, c, tgx, tgy, tgz, ip);
+    // An aviary that spans several waves of the workgroup (D not a power of two <= 64): its lane 0 publishes ring_pos + 1 at
+    // the end of this kernel, and with no task and no downwash nothing else synchronises the waves -- every wave must have
+    // READ ring_pos before any of them gets there (the barrier also waits for the loads above: vmcnt(0))
+    if (MULTI && !L.shfl && S.act_ring) __syncthreads();
     c.roll = c.pitch = c.yaw = 0.0f;
     if (PID) quat_to_rpy(c.k.qx, c.k.qy, c.k.qz, c.k.qw, c.roll, c.pitch, c.yaw);
 
@@ -2505,7 +2521,7 @@ int step_impl(const char* who, const GpdParams* params, const GpdState* state, c
     if (cfg->drones_per_env > kBlock) return bad(GPD_ERANGE, "drones_per_env > 256 is not supported");
     if (cfg->act_type < GPD_ACT_RPM || cfg->act_type > GPD_ACT_DIRECT_RPM) return bad(GPD_EINVAL, "unknown act_type");
     if (cfg->task < GPD_TASK_NONE || cfg->task > GPD_TASK_MULTIHOVER) return bad(GPD_EINVAL, "unknown task");
-    if (cfg->physics_flags & ~15u) return bad(GPD_EINVAL, "unknown physics flag");
+    if (cfg->physics_flags & ~31u) return bad(GPD_EINVAL, "unknown physics flag");
     const int64_t N = static_cast<int64_t>(cfg->num_envs) * cfg->drones_per_env;
     if (state->ld < N) return bad(GPD_EINVAL, "state.ld < num_envs*drones_per_env");
     if (N > (1LL << 26)) return bad(GPD_ERANGE, "more than 2^26 drones per launch (32-bit byte offsets)");
@@ -2657,7 +2673,7 @@ int gpd_rollout_policy(const GpdParams* params, const GpdState* state, const Gpd
     if (pid && !state->pid) return bad(GPD_EINVAL, "PID action type needs state.pid");
     if (pid && params->pid_kf <= 0.0f) return bad(GPD_ENOTSUP, "no DSLPID controller for this airframe (CF2X/CF2P only)");
     if (cfg->task < GPD_TASK_NONE || cfg->task > GPD_TASK_MULTIHOVER) return bad(GPD_EINVAL, "unknown task");
-    if (cfg->physics_flags & ~15u) return bad(GPD_EINVAL, "unknown physics flag");
+    if (cfg->physics_flags & ~31u) return bad(GPD_EINVAL, "unknown physics flag");
     if (policy->hidden != kPolHidden) return bad(GPD_ENOTSUP, "hidden must be 64");
     if (policy->activation != 0 && policy->activation != 1) return bad(GPD_EINVAL, "activation must be 0 (tanh) or 1 (relu)");
     const int64_t N = cfg->num_envs;
@@ -2901,6 +2917,16 @@ int gpd_comm_init(void** comm, const uint8_t id[GPD_COMM_ID_BYTES], int32_t rank
     ncclResult_t e = rccl().CommInitRank(&c, world_size, u, rank);
     if (e != ncclSuccess) return rccl_fail(e, "ncclCommInitRank");
     *comm = c;
+    return 0;
+}
+
+int gpd_comm_count(void* comm, int32_t* n_ranks) {
+    if (!comm || !n_ranks) return fail(GPD_EINVAL, "gpd_comm_count: NULL comm/n_ranks");
+    if (int rc = need_rccl("gpd_comm_count")) return rc;
+    int n = 0;
+    ncclResult_t e = rccl().CommCount(static_cast<ncclComm_t>(comm), &n);
+    if (e != ncclSuccess) return rccl_fail(e, "ncclCommCount");
+    *n_ranks = n;
     return 0;
 }
 

@@ -8,7 +8,8 @@ learner would consume.  Two implementations of that one collective:
 
 * `NativeObsAllGather` -- the C-ABI entry `gpd_allgather_obs` (`ncclAllGather` of RCCL over xGMI on the
   caller's stream, capturable in one hipGraph with the `gpd_step` launch that produced the shard, no torch
-  in the data path); `torch.distributed` is only used once, to hand rank 0's communicator id to the others;
+  in the data path) on ONE communicator per process (`NativeComm`); `torch.distributed` is only used once,
+  to hand rank 0's communicator id to the others;
 * `ObsAllGather` -- `torch.distributed.all_gather_into_tensor` (RCCL with the "nccl" backend on ROCm; with
   the gloo backend -- CPU tests, or the single-device test hook of bench.py -- device shards are staged
   through host memory).
@@ -76,6 +77,14 @@ class ObsAllGather:
         # gloo moves host memory only: device shards are staged (tests / bench.py's single-device hook)
         self._stage = self.world > 1 and _backend(group) == "gloo" and self.full.is_cuda
 
+    def sized(self, shard_elems: int):
+        """A gather of `shard_elems` elements per rank (equal shards), same group -- torch's collectives take any count."""
+        if shard_elems % self.cols:
+            raise ValueError(f"shard_elems must be a multiple of {self.cols}")
+        if self.uniform and shard_elems == self.rows[self.rank] * self.cols:
+            return self
+        return ObsAllGather(shard_elems // self.cols, self.cols, device=self.full.device, dtype=self.full.dtype, group=self.group)
+
     def __call__(self, shard: torch.Tensor, async_op: bool = False):
         """Gather `shard` (rows, cols) from every rank into `self.full` (sum of rows, cols)."""
         shard = shard.reshape(-1, self.cols)
@@ -101,22 +110,23 @@ class ObsAllGather:
         return (self.full, work) if async_op else self.full
 
 
-class NativeObsAllGather:
-    """The same collective through the C-ABI (`gpd_comm_*`, `gpd_allgather_obs`): `ncclAllGather` of RCCL on the
-    current stream.  Equal shards only (what `ncclAllGather` offers).  `torch.distributed` (any backend) carries the
-    128-byte communicator id from rank 0 to the other ranks, once."""
+class NativeComm:
+    """ONE RCCL communicator of this process for the C-ABI collectives (`gpd_comm_*`): `ncclCommInitRank` runs once, every
+    `NativeObsAllGather` -- whatever its element count -- shares it (`ncclAllGather` takes the count per call).
+    `torch.distributed` (any backend) carries the 128-byte communicator id from rank 0 to the other ranks, once."""
 
-    def __init__(self, shard_rows: int, cols: int = 12, device=None, group=None):
+    _shared = None
+
+    def __init__(self, device=None, group=None):
         from . import _native
         self._native = _native
         self.lib = _native.lib()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-        self.count = int(shard_rows) * cols
-        self.full = torch.empty((self.world * int(shard_rows), cols), dtype=torch.float32, device=self.device)
         ident = (ctypes.c_uint8 * _native.COMM_ID_BYTES)()
         blob = [None]
+        self.comm = None
         with torch.cuda.device(self.device):
             if self.rank == 0:
                 _native.check(self.lib.gpd_comm_unique_id(ident), "gpd_comm_unique_id")
@@ -124,28 +134,78 @@ class NativeObsAllGather:
             if self.world > 1:
                 dist.broadcast_object_list(blob, src=0, group=group)
                 ident = (ctypes.c_uint8 * _native.COMM_ID_BYTES).from_buffer_copy(blob[0])
-            self.comm = ctypes.c_void_p()
-            _native.check(self.lib.gpd_comm_init(ctypes.byref(self.comm), ident, self.rank, self.world), "gpd_comm_init")
+            comm = ctypes.c_void_p()
+            _native.check(self.lib.gpd_comm_init(ctypes.byref(comm), ident, self.rank, self.world), "gpd_comm_init")
+            self.comm = comm
+        n = ctypes.c_int32(0)
+        _native.check(self.lib.gpd_comm_count(self.comm, ctypes.byref(n)), "gpd_comm_count")
+        self.ranks_seen = int(n.value)              # what RCCL itself says the communicator spans (ncclCommCount)
 
-    def __call__(self, shard: torch.Tensor):
-        if shard.numel() != self.count or shard.dtype != torch.float32 or not shard.is_contiguous():
-            raise ValueError(f"shard must be a contiguous float32 tensor of {self.count} elements")
-        with torch.cuda.device(self.device):
-            rc = self.lib.gpd_allgather_obs(self.comm, ctypes.c_void_p(shard.data_ptr()), ctypes.c_void_p(self.full.data_ptr()),
-                                            self.count, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
-        self._native.check(rc, "gpd_allgather_obs")
-        return self.full
+    @classmethod
+    def shared(cls, device=None, group=None):
+        """The process-wide communicator (created on first use; collective: every rank must call it)."""
+        if cls._shared is None or cls._shared.comm is None:
+            cls._shared = cls(device=device, group=group)
+        return cls._shared
 
     def close(self):
         if getattr(self, "comm", None):
             self.lib.gpd_comm_destroy(self.comm)
             self.comm = None
+        if NativeComm._shared is self:
+            NativeComm._shared = None
 
     def __del__(self):
         try:
             self.close()
         except Exception:
             pass
+
+
+class NativeObsAllGather:
+    """The same collective through the C-ABI (`gpd_allgather_obs`): `ncclAllGather` of RCCL on the current stream, on the
+    process's ONE communicator (`NativeComm.shared()` unless `comm` is given).  Equal shards only (what `ncclAllGather`
+    offers).  `sized(n)` returns a gather of another element count on the same communicator."""
+
+    def __init__(self, shard_rows: int, cols: int = 12, device=None, group=None, comm: "NativeComm" = None):
+        self.nc = comm if comm is not None else NativeComm.shared(device=device, group=group)
+        self._native, self.lib = self.nc._native, self.nc.lib
+        self.world, self.rank, self.device = self.nc.world, self.nc.rank, self.nc.device
+        self.cols = cols
+        self.count = int(shard_rows) * cols
+        self.full = torch.empty((self.world * int(shard_rows), cols), dtype=torch.float32, device=self.device)
+
+    @property
+    def comm(self):
+        return self.nc.comm
+
+    def sized(self, shard_elems: int):
+        """A gather of `shard_elems` floats per rank (a multiple of `cols`) on the SAME communicator."""
+        if shard_elems % self.cols:
+            raise ValueError(f"shard_elems must be a multiple of {self.cols}")
+        return self if shard_elems == self.count else NativeObsAllGather(shard_elems // self.cols, self.cols, comm=self.nc)
+
+    def __call__(self, shard: torch.Tensor):
+        if shard.numel() != self.count or shard.dtype != torch.float32 or not shard.is_contiguous():
+            raise ValueError(f"shard must be a contiguous float32 tensor of {self.count} elements")
+        with torch.cuda.device(self.device):
+            rc = self.lib.gpd_allgather_obs(self.nc.comm, ctypes.c_void_p(shard.data_ptr()), ctypes.c_void_p(self.full.data_ptr()),
+                                            self.count, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        self._native.check(rc, "gpd_allgather_obs")
+        return self.full
+
+    def close(self):
+        """(the communicator is the process's: `NativeComm.shared().close()` ends it)"""
+
+
+def all_ranks_ok(ok: bool, device=None) -> bool:
+    """True iff `ok` holds on EVERY rank (a MIN all-reduce through torch.distributed): lets all ranks take the same branch
+    after a step that may fail on some of them only, e.g. fall back together from the native collective to torch's."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(ok)
+    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=device if _backend() != "gloo" else None)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item() > 0.5)
 
 
 def max_over_ranks(value: float, device=None) -> float:

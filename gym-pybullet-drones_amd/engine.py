@@ -20,7 +20,7 @@ import torch
 
 from . import _native
 from .params import DroneParams, PIDGains, euler_to_quat, trunc_counter
-from .utils.enums import ACT_RAW_RPM, ActionType, DroneModel, PHYS_DRAG, PHYS_GROUND, Physics
+from .utils.enums import ACT_RAW_RPM, ActionType, DroneModel, PHYS_DRAG, Physics
 
 TASK_NONE, TASK_HOVER, TASK_MULTIHOVER = 0, 1, 2
 _ACT_DIM = {0: 4, 1: 3, 2: 4, 3: 1, 4: 1, 5: 4, 6: 4}
@@ -61,7 +61,8 @@ class SimCore:
                  task: int = TASK_NONE, initial_xyzs=None, initial_rpys=None, target_pos=None,
                  episode_len_sec: float = 8.0, xy_bound: float = 1.5, z_bound: float = 2.0, tilt_bound: float = 0.4,
                  term_dist: float = 1e-4, auto_reset: bool = False, track_rpm: bool = True,
-                 keep_terminal_obs: bool = False, device=None, gains: PIDGains = None, force_pid: bool = False):
+                 keep_terminal_obs: bool = False, device=None, gains: PIDGains = None, force_pid: bool = False,
+                 pyb_like: bool = None):
         if pyb_freq % ctrl_freq != 0:
             raise ValueError("[ERROR] pyb_freq is not divisible by ctrl_freq.")
         self.lib = _native.lib()                      # raises if the HIP extension is missing
@@ -77,8 +78,9 @@ class SimCore:
             raise ValueError("drones_per_env must be in 1..256")
         self.ld = (self.N + 63) // 64 * 64
         self.P = DroneParams(drone_model)
-        # a `Physics` member selects the add-on force models and, for PYB*, the ground plane; an int is the raw GPD_PHYS_* mask
-        self.physics_flags = (physics.flags | (PHYS_GROUND if physics.ground else 0)) if isinstance(physics, Physics) else int(physics)
+        # a `Physics` member selects the add-on force models and, for PYB* (unless pyb_like is off), the ground plane and Bullet's
+        # default damping; an int is the raw GPD_PHYS_* mask
+        self.physics_flags = physics.mask(pyb_like) if isinstance(physics, Physics) else int(physics)
         self.act_code = int(act_code)
         self.A = _ACT_DIM[self.act_code]
         self.uses_pid = self.act_code in _PID_ACTS
@@ -150,7 +152,19 @@ class SimCore:
             self._cfg.target_per_env = self.target_per_env
 
     def _stream(self):
+        if self._own_stream is not None:
+            return self._own_stream
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    _own_stream = None
+
+    def use_stream(self, stream: "torch.cuda.Stream" = None):
+        """Pin every launch of this core to `stream` (None: back to torch's current stream).  For independent batches that
+        advance as independent chains of launches on their own streams (bench.py --split): the caller orders them against the
+        rest of the program with events / `wait_stream`; the torch-side copies of `rollout(update_latest=True)` still go to
+        torch's current stream."""
+        self._pinned = stream           # (keeps the torch stream object alive)
+        self._own_stream = None if stream is None else ctypes.c_void_p(stream.cuda_stream)
 
     #: bumped by every method that changes the kinematic state (callers that cache something derived from the positions --
     #: SwarmAviary's downwash forces -- compare it)
@@ -223,19 +237,22 @@ class SimCore:
             obs, rew, term, trunc, tobs = buf
             o_stride, e_stride = self.N * 12, self.E
         self.pushed_history = False
+        self.state_version += 1
         with torch.cuda.device(self.device):
             if push_history and getattr(self, "act_ring", None) is not None and tobs is None:
                 # the kernel pushes every step's action into the ring itself (`gpd_rollout_history`)
                 rc = self.lib.gpd_rollout_history(ctypes.byref(self._params), ctypes.byref(self._state), ctypes.byref(self._cfg),
                                                   K, _ptr(actions), a_stride, _ptr(self.target), _ptr(self.init_pose),
                                                   _ptr(obs), o_stride, _ptr(rew), _ptr(term), _ptr(trunc), e_stride, self._stream())
-                self.pushed_history = rc == 0
+                if rc != _native.GPD_ENOTSUP:     # only "no fused variant for this shape" falls through (nothing was launched);
+                    _native.check(rc, "gpd_rollout_history")     # a real failure must not be retried on an already advanced state
+                    self.pushed_history = True
             if not self.pushed_history:           # (no fused variant for this shape: the caller updates the ring with full_obs())
                 rc = self.lib.gpd_rollout(ctypes.byref(self._params), ctypes.byref(self._state), ctypes.byref(self._cfg),
                                           K, _ptr(actions), a_stride, _ptr(self.target), _ptr(self.init_pose),
                                           _ptr(obs), o_stride, _ptr(rew), _ptr(term), _ptr(trunc), e_stride,
                                           _ptr(tobs), self._stream())
-        _native.check(rc, "gpd_rollout")
+                _native.check(rc, "gpd_rollout")
         if not last_only and update_latest:
             self.obs12.copy_(obs[K - 1])
             self.reward.copy_(rew[K - 1])
@@ -252,11 +269,14 @@ class SimCore:
 
         Training rollouts: `noise` `[K,N,A]` (standard-normal draws, e.g. `torch.randn`) and `action_std` (A floats =
         exp(log_std)) make it `a_t = clip(mean_t + action_std * noise_t, -1, 1)`, SB3's collection loop; `mean_out`
-        `[K,N,A]` receives the unclipped means."""
+        `[K,N,A]` receives the unclipped means.  No terminal observations (`term_obs12` is not written: the adapters that
+        promise them step through `step()` / `rollout()`)."""
         K = int(num_steps)
         if K < 1:
             raise ValueError("num_steps must be >= 1")
         std = None
+        if noise is not None and action_std is None:
+            raise ValueError("noise comes with action_std (A floats = exp(log_std))")
         if noise is not None:
             if noise.device != self.device or noise.dtype != torch.float32 or not noise.is_contiguous() or noise.numel() != K * self.N * self.A:
                 raise ValueError(f"noise must be a contiguous float32 tensor of {K}x{self.N}x{self.A} elements on {self.device}")
@@ -276,6 +296,7 @@ class SimCore:
                 cache.clear()
                 acts = cache[K] = torch.zeros((K, self.N, self.A), dtype=torch.float32, device=self.device)
         ps = policy.struct()
+        self.state_version += 1
         with torch.cuda.device(self.device):
             rc = self.lib.gpd_rollout_policy(ctypes.byref(self._params), ctypes.byref(self._state), ctypes.byref(self._cfg),
                                              ctypes.byref(ps), K, _ptr(self.obs12), _ptr(self.target), _ptr(self.init_pose),

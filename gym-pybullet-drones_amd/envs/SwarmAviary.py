@@ -34,7 +34,8 @@ class SwarmAviary:
 
     def __init__(self, num_drones: int, drone_model: DroneModel = DroneModel.CF2X, initial_xyzs=None, initial_rpys=None,
                  physics: Physics = Physics.PYB_DW, pyb_freq: int = 240, ctrl_freq: int = 240, act="raw_rpm",
-                 world_min=None, world_max=None, cell: float = 10.0, zbin: float = 1.0, nz: int = 1, device=None):
+                 world_min=None, world_max=None, cell: float = 10.0, zbin: float = 1.0, nz: int = 1, device=None,
+                 pyb_like: bool = None):
         if pyb_freq % ctrl_freq != 0:
             raise ValueError("[ERROR] in SwarmAviary.__init__(), pyb_freq is not divisible by ctrl_freq.")
         if act not in ("raw_rpm", ActionType.RPM, ActionType.PID):
@@ -58,7 +59,7 @@ class SwarmAviary:
         act_code = {"raw_rpm": ACT_RAW_RPM, ActionType.RPM: ActionType.RPM.code, ActionType.PID: ACT_DIRECT_RPM}[act]
         self.core = engine.SimCore(drone_model=drone_model, num_envs=N, drones_per_env=1, physics=physics, pyb_freq=pyb_freq,
                                    ctrl_freq=pyb_freq, act_code=act_code, task=engine.TASK_NONE, initial_xyzs=xyz,
-                                   initial_rpys=rpy, auto_reset=False, track_rpm=True, device=device)
+                                   initial_rpys=rpy, auto_reset=False, track_rpm=True, device=device, pyb_like=pyb_like)
         self.device = dev = self.core.device
         self.flags = self.core.physics_flags
         self.ctrl = DSLPIDControlBatch(N, drone_model, device=dev) if act == ActionType.PID else None

@@ -43,6 +43,7 @@ class VectorAviary:
                  full_obs: bool = False,
                  keep_terminal_obs: bool = False,
                  track_rpm: bool = False,
+                 pyb_like: bool = None,
                  device=None):
         if obs != ObservationType.KIN:
             raise NotImplementedError("only ObservationType.KIN is on the MI355X hot path")
@@ -70,7 +71,7 @@ class VectorAviary:
                                    task=_TASKS[task], initial_xyzs=init, initial_rpys=initial_rpys,
                                    target_pos=target_pos, episode_len_sec=episode_len_sec, xy_bound=xy,
                                    auto_reset=auto_reset, track_rpm=track_rpm, keep_terminal_obs=keep_terminal_obs,
-                                   device=device)
+                                   device=device, pyb_like=pyb_like)
         self.device = self.core.device
         self.ACT_DIM = self.core.A
         self.INIT_XYZS, self.INIT_RPYS, self.TARGET_POS = self.core.INIT_XYZS, self.core.INIT_RPYS, self.core.TARGET_POS

@@ -48,6 +48,25 @@ class Physics(Enum):
         include/gpd.h), `DYN` -> off, exactly the reference's `DYN`."""
         return self != Physics.DYN
 
+    @property
+    def damping(self) -> bool:
+        """Whether Bullet's default damping acts (`GPD_PHYS_DAMP`): every `PYB*` run of the reference integrates the drone as a
+        Bullet multibody with linear and angular damping 0.04 (`p.loadURDF`, `BaseAviary.py:488-494`; the reference never calls
+        `changeDynamics`), `DYN` has none (`:831-877`)."""
+        return self != Physics.DYN
+
+    def mask(self, pyb_like: bool = None) -> int:
+        """The `GPD_PHYS_*` mask a kernel launch gets for this member: the add-on force models, plus -- for `PYB*`, unless
+        `pyb_like` is False -- the two stand-ins for what Bullet itself adds to such a run (ground plane, default damping).
+        `pyb_like=None` reads the process default (`set_pyb_like`, env `GPD_PYB_LIKE=0`): with False a `PYB_*` member means
+        exactly "the reference's explicit `Physics.DYN` integrator + the selected add-on models"."""
+        if pyb_like is None:
+            pyb_like = _pyb_like
+        m = self.flags
+        if pyb_like:
+            m |= (PHYS_GROUND if self.ground else 0) | (PHYS_DAMP if self.damping else 0)
+        return m
+
 
 class ImageType(Enum):
     RGB = 0
@@ -89,8 +108,9 @@ _warned_pyb = False
 def warn_if_pyb(physics) -> None:
     """One `UserWarning` per process when a `Physics.PYB*` member is requested: this package has no Bullet -- the
     explicit `Physics.DYN` integrator runs instead (with the selected add-on force models inside it), so there is
-    no Featherstone integrator, no collision shapes and no Bullet damping; the ground is the contact model of
-    `GPD_PHYS_GROUND` (a plane at z = 0 the airframe's collision cylinder rests on), not Bullet's solver."""
+    no Featherstone integrator and no collision shapes; the ground is the contact model of `GPD_PHYS_GROUND` (a plane at
+    z = 0 the airframe's collision cylinder rests on), not Bullet's solver, and the damping is `GPD_PHYS_DAMP` (Bullet's
+    default multibody damping restated inside the explicit integrator)."""
     global _warned_pyb
     if _warned_pyb or not isinstance(physics, Physics) or physics == Physics.DYN:
         return
@@ -104,7 +124,19 @@ def warn_if_pyb(physics) -> None:
 
 
 #: physics add-on bits, mirrored in include/gpd.h
-PHYS_GND, PHYS_DRAG, PHYS_DW, PHYS_GROUND = 1, 2, 4, 8
+PHYS_GND, PHYS_DRAG, PHYS_DW, PHYS_GROUND, PHYS_DAMP = 1, 2, 4, 8, 16
+
+import os as _os
+_pyb_like = _os.environ.get("GPD_PYB_LIKE", "1") not in ("0", "false", "False", "")
+
+
+def set_pyb_like(on: bool) -> None:
+    """Process-wide default of `Physics.mask()`: whether `Physics.PYB*` adds the ground plane and Bullet's default damping
+    (both extensions with no counterpart in the reference's explicit integrator, include/gpd.h) to the explicit integrator.
+    The drop-in classes keep the reference's constructor signatures, so this switch (or `GPD_PYB_LIKE=0`) is their opt-out;
+    the batched classes also take `pyb_like=` per instance."""
+    global _pyb_like
+    _pyb_like = bool(on)
 #: raw-RPM action clipped to [0, MAX_RPM] (CtrlAviary, `CtrlAviary.py:140`); kernel-only code
 ACT_RAW_RPM = 5
 #: RPMs taken as they are (output of a user subclass's own `_preprocessAction`); kernel-only code

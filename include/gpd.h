@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GPD_ABI_VERSION 5
+#define GPD_ABI_VERSION 6
 
 /* DroneModel (utils/enums.py:3-8) */
 enum { GPD_MODEL_CF2X = 0, GPD_MODEL_CF2P = 1, GPD_MODEL_RACE = 2 };
@@ -63,8 +63,18 @@ enum {
  * for what Bullet's solver does for Physics.PYB* with that plane: after every physics sub-step a drone whose collision
  * cylinder (URDF: COLLISION_H, COLLISION_Z_OFFSET) would sink below z = 0 is put back ON the plane
  * (z = params.ground_z), its downward velocity is removed (restitution 0) and it sticks laterally (vx = vy = 0); body
- * rates and attitude are left to the rigid-body equations.  The Python classes enable it for Physics.PYB* only. */
-enum { GPD_PHYS_GND = 1, GPD_PHYS_DRAG = 2, GPD_PHYS_DW = 4, GPD_PHYS_GROUND = 8 };
+ * rates and attitude are left to the rigid-body equations.  The Python classes enable it for Physics.PYB* only.
+ *
+ * GPD_PHYS_DAMP is not part of the reference's Physics.DYN either.  It is the damping every Physics.PYB* run of the reference
+ * carries without a line of the reference saying so: `p.loadURDF` (envs/BaseAviary.py:488-494) creates the drone as a Bullet
+ * btMultiBody, whose default linear and angular damping is 0.04 (PyBullet's `changeDynamics` defaults; the reference never
+ * changes them) and acts on the base as the forces  -M v d (1 + |v|)  and  -J w d (1 + |w|)  (Bullet 3.2.x,
+ * src/BulletDynamics/Featherstone/btMultiBody.cpp, computeAccelerationsArticulatedBodyAlgorithmMultiDof, "adding damping
+ * terms (only)", DAMPING_K1 = DAMPING_K2 = the coefficient; third-party source, not under the reference checkout: parity
+ * unpinned).  Evaluated on the velocities at the start of the sub-step, like drag.  The Python classes enable it together with
+ * GPD_PHYS_GROUND for Physics.PYB* (`pyb_like=False` opts out of both: the reference's explicit integrator + the add-on models). */
+enum { GPD_PHYS_GND = 1, GPD_PHYS_DRAG = 2, GPD_PHYS_DW = 4, GPD_PHYS_GROUND = 8, GPD_PHYS_DAMP = 16 };
+#define GPD_BULLET_DAMPING 0.04f
 
 /* Which task's reward / termination / truncation is evaluated in the step kernel */
 enum {
@@ -297,7 +307,10 @@ typedef struct GpdPolicy {
  *                memory; mean_out [K][E][A] out or NULL: the unclipped means.  actions_out and the action ring receive the
  *                clipped actions (what the environment saw); the log-probability of the unclipped sample is a function of
  *                noise and action_std alone.  ActionType.RPM and ONE_D_RPM.
- * With in_dim > 12 the action ring of `state` is read at the start and rewritten (with ring_pos = 0) at the end.
+ * With in_dim > 12 the action ring of `state` is read at the start, and EVERY step pushes its (clipped) action into both halves
+ * of the ring and advances ring_pos by one (mod hist_len), exactly as gpd_step does: after the call the ring and ring_pos are what
+ * num_steps gpd_step calls with the same actions would have left (history() / gpd_hist_rows / a following gpd_step continue
+ * seamlessly).  No terminal observations are produced.
  * GPD_ENOTSUP: drones_per_env > 1, hidden != 64, in_dim not one of the two forms, or a history longer than 17 actions of 4 or
  * 3 floats / 20 actions of 1 float (the reference's 30 Hz control: 15).
  */
@@ -419,12 +432,16 @@ int gpd_state_vectors(const GpdState* state, const float* obs12, float* state20,
  *   gpd_allgather_obs    ncclAllGather of `count` floats per rank: shard [count] -> full [world_size*count], rank r's
  *                        shard at full + r*count.  Asynchronous on `stream`, capturable in a hipGraph together with the
  *                        gpd_step / gpd_rollout launch that produced the shard.
+ *   gpd_comm_count       ncclCommCount: the number of ranks RCCL itself says the communicator spans (a harness prints it
+ *                        next to its throughput line: a run that silently fell apart into one-rank worlds shows here)
  *   gpd_comm_destroy     ncclCommDestroy (NULL is a no-op)
+ * ONE communicator per process serves every count: create it once, pass any `count` to gpd_allgather_obs.
  * RCCL errors are returned as 1000 + ncclResult_t.
  */
 #define GPD_COMM_ID_BYTES 128
 int gpd_comm_unique_id(uint8_t id[GPD_COMM_ID_BYTES]);
 int gpd_comm_init(void** comm, const uint8_t id[GPD_COMM_ID_BYTES], int32_t rank, int32_t world_size);
+int gpd_comm_count(void* comm, int32_t* n_ranks);
 int gpd_comm_destroy(void* comm);
 int gpd_allgather_obs(void* comm, const float* shard, float* full, size_t count, void* stream);
 

@@ -33,6 +33,20 @@ PHYS_GND, PHYS_DRAG, PHYS_DW = 1, 2, 4
 #: its downward velocity and sticks laterally.  UNPINNED by construction: the reference resolves ground contact only
 #: through Bullet's solver (Physics.PYB*), which is not available; this restates the kernel's definition in float64.
 PHYS_GROUND = 8
+#: EXTENSION, not in the reference's Physics.DYN either (include/gpd.h, GPD_PHYS_DAMP): Bullet's default damping of a body that
+#: `p.loadURDF` created (envs/BaseAviary.py:488-494 loads the drone without `useMaximalCoordinates`, i.e. as a btMultiBody), which
+#: every `Physics.PYB*` run of the reference carries and no line of the reference mentions.  THIRD-PARTY ORIGIN: Bullet 3.2.x
+#: (`pybullet ^3.2.7`, pyproject.toml:19; sources not under /root/reference), src/BulletDynamics/Featherstone/btMultiBody.cpp:
+#: the constructor sets m_linearDamping = m_angularDamping = 0.04 (PyBullet's documented `changeDynamics` defaults, which the
+#: reference never changes), and computeAccelerationsArticulatedBodyAlgorithmMultiDof adds to the base's bias force
+#:     m_baseMass * v * (K1 + K2 |v|)   and   m_baseInertia (.) w * (K1 + K2 |w|),   K1 = K2 = the damping coefficient
+#: ("adding damping terms (only)"; DAMPING_K1_LINEAR = DAMPING_K2_LINEAR = m_linearDamping, same for ANGULAR), i.e.
+#:     dv/dt -= d (1 + |v|) v,      dw/dt -= d (1 + |w|) w,      d = 0.04,
+#: evaluated on the velocities at the start of the sub-step, like every other force of the explicit integrator.  (A body in
+#: maximal coordinates would instead get btRigidBody::applyDamping, v *= (1 - d)^dt: the same to first order at |v| << 1.)
+#: PARITY UNPINNED: restated from knowledge of the Bullet sources; there is no Bullet here to run it against.
+PHYS_DAMP = 16
+BULLET_DAMPING = 0.04
 ACT_DIM = {"rpm": 4, "pid": 3, "vel": 4, "one_d_rpm": 1, "one_d_pid": 1, "raw_rpm": 4}
 
 
@@ -291,6 +305,9 @@ class OracleAviary:
         tau = np.array([tx, ty, tz]) - np.cross(w, C.J @ w)
         w_dot = C.J_INV @ tau
         a = F_world / C.M
+        if self.PHYS & PHYS_DAMP:                         # extension (see PHYS_DAMP): Bullet's default multibody damping
+            a = a - BULLET_DAMPING * (1.0 + np.linalg.norm(v)) * v
+            w_dot = w_dot - BULLET_DAMPING * (1.0 + np.linalg.norm(w)) * w
         v = v + h * a                                     # semi-implicit Euler: x uses the NEW v
         w = w + h * w_dot
         x = x + h * v

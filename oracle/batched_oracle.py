@@ -10,7 +10,7 @@ auto-reset of SB3's DummyVecEnv (examples/learn.py:54-58 is the calling pattern;
 import numpy as np
 
 from . import bullet_math as bm
-from .aviary_oracle import ACT_DIM, PHYS_DRAG, PHYS_DW, PHYS_GND, PHYS_GROUND, UrdfConstants
+from .aviary_oracle import ACT_DIM, BULLET_DAMPING, PHYS_DAMP, PHYS_DRAG, PHYS_DW, PHYS_GND, PHYS_GROUND, UrdfConstants
 
 
 def _cross(a, b):
@@ -210,8 +210,12 @@ class BatchedAviary:
         w = self.rpy_rates
         Jd = np.diag(C.J)
         tau = np.stack([tx, ty, tz], axis=-1) - _cross(w, Jd * w)
-        w = w + h * (tau * np.diag(C.J_INV))
-        v = self.vel + h * (F / C.M)
+        w_dot, a = tau * np.diag(C.J_INV), F / C.M
+        if self.PHYS & PHYS_DAMP:                         # extension (aviary_oracle.PHYS_DAMP): Bullet's default multibody damping
+            a = a - BULLET_DAMPING * (1.0 + _norm(self.vel))[..., None] * self.vel
+            w_dot = w_dot - BULLET_DAMPING * (1.0 + _norm(w))[..., None] * w
+        w = w + h * w_dot
+        v = self.vel + h * a
         x = self.pos + h * v
         if self.PHYS & PHYS_GROUND:                       # extension (aviary_oracle.PHYS_GROUND): the plane at z = 0
             z_rest = C.COLLISION_H / 2 - C.COLLISION_Z_OFFSET

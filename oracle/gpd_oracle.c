@@ -47,7 +47,10 @@ typedef struct OrcCfg {
 
 enum { ACT_RPM = 0, ACT_PID = 1, ACT_VEL = 2, ACT_ONE_D_RPM = 3, ACT_ONE_D_PID = 4, ACT_RAW_RPM = 5, ACT_DIRECT_RPM = 6 };
 /* PHYS_GROUND: EXTENSION, not in the reference's Physics.DYN (see oracle/aviary_oracle.py, include/gpd.h) */
-enum { PHYS_GND = 1, PHYS_DRAG = 2, PHYS_DW = 4, PHYS_GROUND = 8 };
+/* PHYS_DAMP: EXTENSION as well -- Bullet's default multibody damping, d = 0.04 (btMultiBody.cpp, "adding damping terms (only)":
+ * dv/dt -= d (1 + |v|) v, dw/dt -= d (1 + |w|) w; third-party origin and derivation in oracle/aviary_oracle.py) */
+enum { PHYS_GND = 1, PHYS_DRAG = 2, PHYS_DW = 4, PHYS_GROUND = 8, PHYS_DAMP = 16 };
+#define BULLET_DAMPING 0.04
 
 static double clip(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -171,9 +174,14 @@ static void substep(const OrcParams* P, const OrcCfg* C, const double* rpm, cons
     }
     const double jw[3] = {P->J[0] * w[0], P->J[1] * w[1], P->J[2] * w[2]};
     const double tau[3] = {tx - (w[1] * jw[2] - w[2] * jw[1]), ty - (w[2] * jw[0] - w[0] * jw[2]), tz - (w[0] * jw[1] - w[1] * jw[0])};
+    double dl = 0, da = 0;                        /* damping rates d (1 + |v|), d (1 + |w|) of the velocities BEFORE the update */
+    if (C->physics_flags & PHYS_DAMP) {
+        dl = BULLET_DAMPING * (1.0 + sqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]));
+        da = BULLET_DAMPING * (1.0 + sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]));
+    }
     for (int k = 0; k < 3; ++k) {
-        vel[k] += h * (F[k] / P->M);
-        w[k] += h * (P->J_INV[k] * tau[k]);
+        vel[k] += h * (F[k] / P->M - dl * vel[k]);
+        w[k] += h * (P->J_INV[k] * tau[k] - da * w[k]);
         pos[k] += h * vel[k];
     }
     if ((C->physics_flags & PHYS_GROUND) && pos[2] < P->ground_z) {   /* the plane at z = 0 */

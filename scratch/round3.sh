@@ -1,0 +1,45 @@
+#!/bin/bash
+# One GPU-box call of round 3.  usage: bash scratch/round3.sh [diag] [tests] [bench] [split] [configs] [swarm] ...
+mkdir -p gpurun_out
+show() { python - "$1" "$2" <<'PY'
+import json, sys
+name, path = sys.argv[1], sys.argv[2]
+try:
+    d = json.load(open(path))
+except Exception as e:
+    print(name, "NO LINE", e); sys.exit(0)
+o = d.get("one_launch_per_step") or {}
+p = d.get("parity") or {}
+print(name, "us/step %.4f" % (d["ms_per_step"] * 1e3), "value %.4g" % d["value"], "frac %.3f" % d["roofline"]["frac"], "B/drone/step %.1f" % d["roofline"]["bytes_per_drone_per_env_step"],
+      "repeats", d["repeats"], "wall us %.4f" % (d["wall_ms_per_step"] * 1e3), "chains", d["roofline"].get("concurrent_chains"),
+      ("| step: us %.3f frac %.3f" % (o["us_per_step"], o["roofline"]["frac"])) if o else "",
+      "| parity", {k: (("%.2e" % v) if isinstance(v, float) else v) for k, v in p.items() if k in ("checked_steps", "pos", "quat", "vel", "rates", "flag_mismatch_frac", "reward_max_abs", "max", "ok", "error", "episodes_ended_in_window")})
+PY
+}
+for what in "$@"; do
+case $what in
+diag)
+  timeout 300 python scratch/smoke_diag.py > gpurun_out/r03_smoke_diag.txt 2>&1; echo "diag rc $?"; cat gpurun_out/r03_smoke_diag.txt | cut -c1-700
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r03_smoke.log 2>&1; echo "smoke rc $?"; tail -12 gpurun_out/r03_smoke.log | cut -c1-400 ;;
+tests)
+  timeout 1800 python -m pytest tests -m gpu -q -s -x > gpurun_out/pytest_r03.log 2>&1; echo "pytest rc $?"; grep -E "^(FAILED|ERROR)" gpurun_out/pytest_r03.log | head -20; tail -5 gpurun_out/pytest_r03.log | cut -c1-600 ;;
+tests-all)
+  timeout 1800 python -m pytest tests -m gpu -q > gpurun_out/pytest_r03.log 2>&1; echo "pytest rc $?"; grep -E "^(FAILED|ERROR)" gpurun_out/pytest_r03.log | head -30; tail -5 gpurun_out/pytest_r03.log | cut -c1-600 ;;
+newtests)
+  timeout 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -q -s -k "timed_workload" > gpurun_out/pytest_r03_new.log 2>&1; echo "pytest rc $?"; grep -E "^(FAILED|ERROR)|checked_steps" gpurun_out/pytest_r03_new.log | cut -c1-900 | head; tail -3 gpurun_out/pytest_r03_new.log | cut -c1-300
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_rollout.py -m gpu -q -k "16 or 24 or 31" > gpurun_out/pytest_r03_damp.log 2>&1; echo "pytest damp rc $?"; grep -E "^(FAILED|ERROR)" gpurun_out/pytest_r03_damp.log | head; tail -3 gpurun_out/pytest_r03_damp.log | cut -c1-300 ;;
+bench)
+  timeout 400 python bench.py --steps 20 --warmup 5 2>gpurun_out/r03_bench_driver_cmd.err | tail -1 > gpurun_out/r03_bench_driver_cmd.json; show driver_cmd gpurun_out/r03_bench_driver_cmd.json
+  timeout 400 python bench.py --no-cpu-baseline 2>gpurun_out/r03_bench_default.err | tail -1 > gpurun_out/r03_bench_default.json; show default gpurun_out/r03_bench_default.json ;;
+split)
+  for k in 20 64; do for c in 1 2 4 8; do
+    timeout 200 python bench.py --steps $k --warmup 5 --split $c --no-cpu-baseline --no-second-leg 2>gpurun_out/r03_bench_rollout${k}_split$c.err | tail -1 > gpurun_out/r03_bench_rollout${k}_split$c.json
+    show "rollout$k split $c" gpurun_out/r03_bench_rollout${k}_split$c.json
+  done; done ;;
+configs)
+  for w in hover4096_240hz hover65536_ext_240hz hover65536_240hz_history hover65536_30hz_history; do
+    timeout 400 python bench.py --workload $w 2>gpurun_out/r03_bench_$w.err | tail -1 > gpurun_out/r03_bench_$w.json; show $w gpurun_out/r03_bench_$w.json
+  done ;;
+*) echo "unknown stage $what" ;;
+esac
+done

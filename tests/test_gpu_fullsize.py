@@ -263,3 +263,28 @@ def test_multihover_131072x2_reward_is_sum_of_hover_rewards(gpu_device):
         r = s.reward.view(E, D)
         assert torch.allclose(m.reward, (r[:, 0] + r[:, 1]), rtol=0, atol=2e-6)
     assert int(m.step_counter[0]) == steps * 8
+
+
+@pytest.mark.parametrize("workload,K,steps", [("hover65536_240hz", 20, 240), ("hover65536_240hz", 64, 128),
+                                              ("hover65536_ext_240hz", 20, 120), ("multihover2x16384_240hz", 20, 120)])
+def test_the_timed_workload_of_bench_py_against_the_c_oracle(gpu_device, workload, K, steps):
+    """What bench.py TIMES, not a gentler stand-in: 65 536 HoverAviaries at 240 Hz, U(-1, 1) RPM actions that change every step,
+    same-step auto-reset on, through `gpd_rollout` with K steps per launch (K = 20: the driver's `--steps 20`) -- replayed
+    through the float64 C oracle from the device's own state by bench.py's `parity_check` (the block the bench line carries).
+    SURVEY.md section 8(d)'s metric, every field group below 1e-4; episodes do end inside the window (tilt / box truncation:
+    the reset path is exercised), and the aviaries whose flags flip within rounding of a threshold stay a handful."""
+    import bench
+    w = bench.WORKLOADS[workload]
+    env = bench.make_env(w, gpu_device, seed=1000)
+    acts = bench.make_actions(w, env, gpu_device, seed=2000, pool=64)
+    for _ in range(3):                                   # not from the reset poses: a few launches in, like after a timed region
+        bench.launch_rollout(env, acts, K)
+    res = bench.parity_check(w, env, acts, steps, K, max_steps=steps)
+    print(res)
+    assert res["checked_steps"] == steps and res["launches"] == [f"rollout{K}"] * (steps // K)
+    assert res["max"] < 1e-4 and res["ok"], res
+    assert max(res["obs_every_step"].values()) < 1e-4, res
+    assert res["flag_mismatch_frac"] < 2e-3, res
+    assert res["reward_max_abs"] < 1e-3, res
+    if w["D"] == 1 and not w["phys"]:
+        assert res["episodes_ended_in_window"] > w["E"] // 4, res

@@ -96,7 +96,10 @@ def _actions(rng, act, shape, hover_rpm):
                                        (4, 2, 1), (7, 2, 8), (7, 1, 1),
                                        # GPD_PHYS_GROUND (8), the plane at z = 0 (an extension, see include/gpd.h): alone, with
                                        # the ground effect it belongs with, and with every term in a multi-drone aviary
-                                       (8, 1, 1), (9, 1, 8), (15, 2, 2)])
+                                       (8, 1, 1), (9, 1, 8), (15, 2, 2),
+                                       # GPD_PHYS_DAMP (16), Bullet's default multibody damping (an extension as well): alone, as
+                                       # Physics.PYB resolves (ground + damping), and with everything in a multi-drone aviary
+                                       (16, 1, 1), (24, 1, 8), (31, 2, 2)])
 def test_one_step_parity(gpu_device, model, act, flags, D, S):
     if model == "racer" and act in ("pid", "vel", "one_d_pid"):
         pytest.skip("no DSLPID controller for the racer")

@@ -17,6 +17,7 @@ CASES = [  # act, flags, D, S, model
     ("pid", 7, 3, 2, "cf2x"), ("vel", 2, 2, 4, "cf2p"), ("one_d_pid", 5, 8, 1, "cf2x"), ("raw_rpm", 7, 5, 2, "racer"),
     ("rpm", 4, 2, 8, "cf2x"),
     ("rpm", 15, 1, 2, "cf2x"), ("one_d_rpm", 9, 4, 8, "cf2p"),      # the ground plane (GPD_PHYS_GROUND = 8) in both rollout kernels
+    ("rpm", 24, 1, 1, "cf2x"), ("pid", 31, 3, 2, "cf2x"),           # Bullet's default damping (GPD_PHYS_DAMP = 16), what Physics.PYB resolves to
 ]
 
 

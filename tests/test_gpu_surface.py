@@ -269,7 +269,7 @@ def test_swarm_aviary_global_downwash(gpu_device, N, act):
     env = SwarmAviary(N, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.PYB_GND_DRAG_DW, pyb_freq=240, ctrl_freq=120,
                       act="raw_rpm" if act == "raw_rpm" else ActionType.PID, device=gpu_device)
     orc = BatchedAviary(urdf("cf2x"), "cf2x", num_envs=1, num_drones=N, initial_xyzs=xyz[None], initial_rpys=rpy[None],
-                        physics_flags=7, pyb_freq=240, ctrl_freq=120, act="raw_rpm" if act == "raw_rpm" else "pid", task="none",
+                        physics_flags=Physics.PYB_GND_DRAG_DW.mask(True), pyb_freq=240, ctrl_freq=120, act="raw_rpm" if act == "raw_rpm" else "pid", task="none",
                         pid_urdf_path=urdf("cf2x"))
     assert env.nx * env.ny >= 12
     # the force itself, on the initial snapshot

@@ -68,6 +68,10 @@ def test_enums_are_value_compatible():
     assert [m.value for m in ObservationType] == ["kin", "rgb"]
     assert [a.dim for a in ActionType] == [4, 3, 4, 1, 1]
     assert Physics.PYB_GND_DRAG_DW.flags == 7 and Physics.DYN.flags == 0
+    # PYB* = the add-on models + the two stand-ins for what Bullet adds to such a run (ground plane 8, default damping 16);
+    # pyb_like=False: exactly the reference's explicit integrator + the add-on models
+    assert Physics.PYB.mask(True) == 24 and Physics.PYB_GND_DRAG_DW.mask(True) == 31 and Physics.DYN.mask(True) == 0
+    assert Physics.PYB.mask(False) == 0 and Physics.PYB_DW.mask(False) == 4
 
 
 def test_trunc_counter_is_the_float64_threshold():

@@ -22,7 +22,7 @@ def _actions(rng, act, steps, E, D, hover_rpm, max_rpm):
 
 @pytest.mark.parametrize("model", ["cf2x", "cf2p", "racer"])
 @pytest.mark.parametrize("act", ["rpm", "one_d_rpm", "pid", "vel", "one_d_pid", "raw_rpm"])
-@pytest.mark.parametrize("flags,D,S", [(0, 1, 1), (7, 3, 2), (2, 2, 8), (5, 4, 1)])
+@pytest.mark.parametrize("flags,D,S", [(0, 1, 1), (7, 3, 2), (2, 2, 8), (5, 4, 1), (16, 1, 2), (31, 2, 4)])
 def test_batched_equals_loop(model, act, flags, D, S):
     if model == "racer" and act in ("pid", "vel", "one_d_pid"):
         pytest.skip("DSLPID has no racer controller (BaseRLAviary.py:75-78)")

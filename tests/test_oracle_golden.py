@@ -148,3 +148,30 @@ def test_velocity_aviary_matches_reference():
         tol = dict(rtol=1e-9, atol=1e-10) if k < 20 else dict(rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(sv[:, :16], g["obs"][k][:, :16], err_msg=f"step {k}", **tol)
         np.testing.assert_allclose(sv[:, 16:], g["obs"][k][:, 16:], rtol=tol["rtol"], atol=1e-3, err_msg=f"rpm, step {k}")
+
+
+def test_bullet_damping_known_answer():
+    """GPD_PHYS_DAMP (an extension: Bullet's default multibody damping, d = 0.04 -- third-party origin, parity unpinned, see
+    oracle/aviary_oracle.py): at exactly the hover RPM thrust cancels weight and nothing else acts, so ONE sub-step from a known
+    (v, w) is  v' = v - h d (1 + |v|) v,  w' = w - h [J^-1 (w x J w) + d (1 + |w|) w],  x' = x + h v'.  Without the flag the
+    same state keeps its velocity (the reference's Physics.DYN has no damping, envs/BaseAviary.py:831-877)."""
+    from oracle.aviary_oracle import BULLET_DAMPING, PHYS_DAMP
+    h, d = 1 / 240, BULLET_DAMPING
+    assert d == 0.04
+    v0, w0, x0 = np.array([3.0, -4.0, 12.0]), np.array([0.3, -0.4, 1.2]), np.array([0.5, 0.5, 2.0])
+    out = {}
+    for flags in (0, PHYS_DAMP):
+        env = OracleAviary(urdf("cf2x"), "cf2x", num_drones=1, initial_xyzs=x0[None], physics_flags=flags, pyb_freq=240,
+                           ctrl_freq=240, act="raw_rpm", task="none")
+        env.vel[0], env.rpy_rates[0] = v0, w0
+        env.step(np.full((1, 4), env.C.HOVER_RPM))
+        out[flags] = (env.pos[0].copy(), env.vel[0].copy(), env.rpy_rates[0].copy())
+        C = env.C
+    gyro = np.diag(C.J_INV) * np.cross(w0, np.diag(C.J) * w0)
+    np.testing.assert_allclose(out[0][1], v0, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(out[0][2], w0 - h * gyro, rtol=1e-12)
+    v1 = v0 - h * d * (1 + 13.0) * v0                     # |v0| = 13, |w0| = 1.3
+    w1 = w0 - h * (gyro + d * (1 + 1.3) * w0)
+    np.testing.assert_allclose(out[PHYS_DAMP][1], v1, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(out[PHYS_DAMP][2], w1, rtol=1e-12)
+    np.testing.assert_allclose(out[PHYS_DAMP][0], x0 + h * v1, rtol=1e-12)
