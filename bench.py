@@ -435,8 +435,28 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
     # region (the aviaries share nothing), so one chain's kernel boundary and straggler tail hide under the others' steady state
     indep = mode == "rollout" and len(envs) > 1
     if indep:
-        for e, s in zip(envs[1:], side):
-            e.core.use_stream(s)
+        if getattr(args, "cu_mask", False):
+            # every chain on a stream restricted to its own XCDs (hipExtStreamCreateWithCUMask; mask bit i = CU i/8 of XCD i%8,
+            # the KFD's layout for multi-XCC parts): without it the dispatchers of two queues place their workgroups on the
+            # same CUs from CU 0 on, and the chains share SIMDs instead of splitting the chip
+            hip = ctypes.CDLL("libamdhip64.so")
+            C = len(envs)
+            side = []
+            for c in range(C):
+                words = (ctypes.c_uint32 * 8)()
+                for i in range(256):
+                    if (i % 8) * C // 8 == c:
+                        words[i // 32] |= 1 << (i % 32)
+                h = ctypes.c_void_p()
+                rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words)
+                if rc != 0:
+                    raise SystemExit(f"hipExtStreamCreateWithCUMask failed ({rc})")
+                side.append(torch.cuda.ExternalStream(h.value, device=device))
+            for e, s in zip(envs, side):
+                e.core.use_stream(s)
+        else:
+            for e, s in zip(envs[1:], side):
+                e.core.use_stream(s)
 
     def one_rollout(n):
         for e, a in zip(envs, actions):
@@ -610,6 +630,7 @@ def main():
     ap.add_argument("--split", type=int, default=1,
                     help="C sub-batches of E/C aviaries as C independent chains on C streams: rollout mode -- C concurrent rollout launches, "
                          "no join inside the timed region; graph/eager -- C chains of single-step launches")
+    ap.add_argument("--cu-mask", action="store_true", help="rollout --split C: chain c runs on a stream restricted to its own 8/C XCDs")
     ap.add_argument("--no-parity", action="store_true", help="skip the replay of one schedule through the float64 C oracle")
     ap.add_argument("--allgather", action="store_true", help="all-gather the obs shards over RCCL")
     ap.add_argument("--allgather-impl", default="auto", choices=["auto", "native", "torch"],

@@ -413,7 +413,10 @@ __device__ __forceinline__ void substep(const GpdParams& P, float h, uint32_t fl
     if (EXT && (flags & GPD_PHYS_GROUND)) {
         // the ground plane (NOT in the reference's Physics.DYN, see gpd.h): a drone whose collision cylinder would sink
         // below z = 0 is put back on the plane, loses its downward velocity (restitution 0) and sticks laterally
-        const bool hit = k.pz < P.ground_z;
+        // (second clause: a drone RESTING on the plane whose downward velocity is too small to move its fp32 height, h |vz| below
+        // half an ulp of ground_z, would otherwise be neither caught nor free -- it slid laterally, unstuck, until vz had grown;
+        // in exact arithmetic the clause only decides the tie pz == ground_z)
+        const bool hit = (k.pz < P.ground_z) | ((k.pz <= P.ground_z) & (k.vz < 0.0f));
         k.pz = hit ? P.ground_z : k.pz;
         k.vz = hit ? fmaxf(k.vz, 0.0f) : k.vz;
         k.vx = hit ? 0.0f : k.vx;

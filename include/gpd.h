@@ -63,7 +63,9 @@ enum {
  * for what Bullet's solver does for Physics.PYB* with that plane: after every physics sub-step a drone whose collision
  * cylinder (URDF: COLLISION_H, COLLISION_Z_OFFSET) would sink below z = 0 is put back ON the plane
  * (z = params.ground_z), its downward velocity is removed (restitution 0) and it sticks laterally (vx = vy = 0); body
- * rates and attitude are left to the rigid-body equations.  The Python classes enable it for Physics.PYB* only.
+ * rates and attitude are left to the rigid-body equations.  "Would sink": z < ground_z, or z == ground_z with vz < 0 (a
+ * resting drone whose downward velocity is too small to change its fp32 height is still in contact).  The Python classes
+ * enable it for Physics.PYB* only.
  *
  * GPD_PHYS_DAMP is not part of the reference's Physics.DYN either.  It is the damping every Physics.PYB* run of the reference
  * carries without a line of the reference saying so: `p.loadURDF` (envs/BaseAviary.py:488-494) creates the drone as a Bullet

@@ -313,7 +313,7 @@ class OracleAviary:
         x = x + h * v
         if self.PHYS & PHYS_GROUND:                       # extension (see PHYS_GROUND): the plane at z = 0
             z_rest = C.COLLISION_H / 2 - C.COLLISION_Z_OFFSET
-            if x[2] < z_rest:
+            if x[2] < z_rest or (x[2] <= z_rest and v[2] < 0):      # (second clause: the tie x_z == z_rest, see include/gpd.h)
                 x = np.array([x[0], x[1], z_rest])
                 v = np.array([0.0, 0.0, max(v[2], 0.0)])
         q = self._integrateQ(q, w, h)

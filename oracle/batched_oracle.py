@@ -219,7 +219,7 @@ class BatchedAviary:
         x = self.pos + h * v
         if self.PHYS & PHYS_GROUND:                       # extension (aviary_oracle.PHYS_GROUND): the plane at z = 0
             z_rest = C.COLLISION_H / 2 - C.COLLISION_Z_OFFSET
-            hit = x[..., 2] < z_rest
+            hit = (x[..., 2] < z_rest) | ((x[..., 2] <= z_rest) & (v[..., 2] < 0))      # (second clause: the tie x_z == z_rest)
             x = np.where(hit[..., None], np.stack([x[..., 0], x[..., 1], np.full_like(x[..., 2], z_rest)], axis=-1), x)
             v = np.where(hit[..., None], np.stack([np.zeros_like(v[..., 0]), np.zeros_like(v[..., 1]), np.maximum(v[..., 2], 0.0)], axis=-1), v)
         n = _norm(w)

@@ -184,7 +184,7 @@ static void substep(const OrcParams* P, const OrcCfg* C, const double* rpm, cons
         w[k] += h * (P->J_INV[k] * tau[k] - da * w[k]);
         pos[k] += h * vel[k];
     }
-    if ((C->physics_flags & PHYS_GROUND) && pos[2] < P->ground_z) {   /* the plane at z = 0 */
+    if ((C->physics_flags & PHYS_GROUND) && (pos[2] < P->ground_z || (pos[2] <= P->ground_z && vel[2] < 0))) {   /* the plane at z = 0 (second clause: the tie) */
         pos[2] = P->ground_z;
         vel[0] = 0; vel[1] = 0;
         if (vel[2] < 0) vel[2] = 0;

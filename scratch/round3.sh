@@ -19,7 +19,7 @@ PY
 for what in "$@"; do
 case $what in
 diag)
-  timeout 300 python scratch/smoke_diag.py > gpurun_out/r03_smoke_diag.txt 2>&1; echo "diag rc $?"; cat gpurun_out/r03_smoke_diag.txt | cut -c1-700
+  for f in 15 31; do timeout 300 python scratch/smoke_diag.py $f; done > gpurun_out/r03_smoke_diag.txt 2>&1; echo "diag rc $?"; cat gpurun_out/r03_smoke_diag.txt | cut -c1-330
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r03_smoke.log 2>&1; echo "smoke rc $?"; tail -12 gpurun_out/r03_smoke.log | cut -c1-400 ;;
 tests)
   timeout 1800 python -m pytest tests -m gpu -q -s -x > gpurun_out/pytest_r03.log 2>&1; echo "pytest rc $?"; grep -E "^(FAILED|ERROR)" gpurun_out/pytest_r03.log | head -20; tail -5 gpurun_out/pytest_r03.log | cut -c1-600 ;;
@@ -35,6 +35,11 @@ split)
   for k in 20 64; do for c in 1 2 4 8; do
     timeout 200 python bench.py --steps $k --warmup 5 --split $c --no-cpu-baseline --no-second-leg 2>gpurun_out/r03_bench_rollout${k}_split$c.err | tail -1 > gpurun_out/r03_bench_rollout${k}_split$c.json
     show "rollout$k split $c" gpurun_out/r03_bench_rollout${k}_split$c.json
+  done; done ;;
+mask)
+  for k in 20 64; do for c in 2 4 8; do
+    timeout 200 python bench.py --steps $k --warmup 5 --split $c --cu-mask --no-cpu-baseline --no-second-leg 2>gpurun_out/r03_bench_rollout${k}_split${c}_cumask.err | tail -1 > gpurun_out/r03_bench_rollout${k}_split${c}_cumask.json
+    show "rollout$k split $c cu-mask" gpurun_out/r03_bench_rollout${k}_split${c}_cumask.json
   done; done ;;
 configs)
   for w in hover4096_240hz hover65536_ext_240hz hover65536_240hz_history hover65536_30hz_history; do

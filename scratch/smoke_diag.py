@@ -22,9 +22,11 @@ for _ in range(10):
     rng.uniform(-1, 1, size=(256, 1, 3))
 rng.uniform(-1, 1, size=(6, 256, 1, 3))
 stack = np.array([[0.0, 0.0, 0.2], [0.05, 0.0, 0.5]])
-env = VectorMultiHoverAviary(64, 2, initial_xyzs=stack, physics=Physics.PYB_GND_DRAG_DW, act=ActionType.RPM, ctrl_freq=30,
+FLAGS = int(sys.argv[1]) if len(sys.argv) > 1 else 31       # 15: round 2's smoke scene (no damping); 31: Physics.PYB_GND_DRAG_DW now
+env = VectorMultiHoverAviary(64, 2, initial_xyzs=stack, physics=FLAGS, act=ActionType.RPM, ctrl_freq=30,
                              auto_reset=False, device=dev)
-orc = BatchedAviary(urdf, "cf2x", 64, 2, initial_xyzs=stack, physics_flags=31, pyb_freq=240, ctrl_freq=30, act="rpm", task="multihover")
+orc = BatchedAviary(urdf, "cf2x", 64, 2, initial_xyzs=stack, physics_flags=FLAGS, pyb_freq=240, ctrl_freq=30, act="rpm", task="multihover")
+print("physics flags", FLAGS)
 env.reset()
 gz = float(env.core.P.COLLISION_H / 2 - env.core.P.COLLISION_Z_OFFSET) if hasattr(env.core.P, "COLLISION_H") else None
 print("ground_z", gz)
