@@ -81,10 +81,13 @@ WORKLOADS = {
     "multihover2x16384x8": dict(E=16384, D=2, phys=4, ctrl=240, act="rpm", task="multihover"),
     # ONE aviary of 65 536 drones, pairwise downwash over the whole swarm (gpd_downwash_global + gpd_step per sub-step)
     "swarm65536_ext_240hz": dict(E=1, D=65536, phys=7, ctrl=240, act="raw_rpm", task="none", swarm=True),
+    # ... and of 1 048 576: with --gpus N the ONE world is shared by the N ranks (strong scaling: every rank steps its block of
+    # drones, the ranks all-gather 16 bytes per drone per sub-step, every rank evaluates the downwash of its own drones)
+    "swarm1m_ext_240hz": dict(E=1, D=1048576, phys=7, ctrl=240, act="raw_rpm", task="none", swarm=True),
 }
 
 
-def make_env(w, device, seed, E=None):
+def make_env(w, device, seed, E=None, world=1, rank=0, exchange=None):
     from gym_pybullet_drones_amd.envs import SwarmAviary, VectorAviary
     from gym_pybullet_drones_amd.utils.enums import ActionType, Physics
     E, D = E or w["E"], w["D"]
@@ -102,8 +105,10 @@ def make_env(w, device, seed, E=None):
         xy = np.stack([(site % side) * 4.0 + layer % 4, (site // side) * 4.0 + layer // 4], axis=1) - 2.0 * side + \
             rng.uniform(-0.1, 0.1, size=(D, 2))
         xyz = np.concatenate([xy, (1.0 + layer)[:, None]], axis=1)
+        kw = {k: v for k, v in (("cell", os.environ.get("GPD_SWARM_CELL")), ("rebin_every", os.environ.get("GPD_SWARM_REBIN"))) if v}
         env = SwarmAviary(D, initial_xyzs=xyz, initial_rpys=rng.uniform(-0.05, 0.05, size=(D, 3)), physics=Physics.PYB_GND_DRAG_DW,
-                          pyb_freq=240, ctrl_freq=w["ctrl"], act="raw_rpm", device=device)
+                          pyb_freq=240, ctrl_freq=w["ctrl"], act="raw_rpm", device=device, world_size=world, rank=rank, exchange=exchange,
+                          cell=float(kw.get("cell", 10.5)), rebin_every=int(kw["rebin_every"]) if "rebin_every" in kw else None)
         env.NUM_ENVS, env.ACT_DIM = 1, 4
         # a single world has no task and no auto-reset: every pass of the schedule starts from the initial lattice (one reset
         # launch per pass), otherwise thousands of open-loop steps let drones pass each other vertically, where the
@@ -558,6 +563,7 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
     achieved = bytes_total / ev_s / 1e9
     steps_per_launch = K / launches_pass
     kernel = "gpd_rollout_policy_kernel" if (mode == "rollout" and getattr(envs[0], "bench_policy", None) is not None) else \
+        "dwg_force_kernel (+ gpd_swarm_step_kernel; a binning every few sub-steps)" if hasattr(envs[0], "pos4") else \
         "gpd_step_kernel" if mode != "rollout" else \
         ("gpd_rollout1_kernel" if core.D & (core.D - 1) == 0 and core.D <= 64 else "gpd_rollout_kernel")
     return {
@@ -663,9 +669,28 @@ def main():
     def build(split):
         if split > 1 and (w.get("swarm") or w["E"] % split):
             raise SystemExit(f"--split {split} does not divide {w['E']} aviaries")
+        if w.get("swarm"):      # ONE world: the same scene on every rank, rank r takes its block of drones
+            exch = None
+            if world > 1:
+                from gym_pybullet_drones_amd.envs import NativeSlabExchange, TorchSlabExchange
+                err = None
+                try:
+                    exch = NativeSlabExchange(device=device) if backend == "nccl" else None
+                except Exception as e:      # noqa: BLE001
+                    err = f"{type(e).__name__}: {e}"[:200]
+                if not gdist.all_ranks_ok(exch is not None, device=device):
+                    exch = TorchSlabExchange()
+                    swarm_note.append(f"position exchange through torch.distributed ({err or 'no native RCCL communicator'})")
+                else:
+                    swarm_note.append(f"position exchange: gpd_allgather_obs in place, {exch.nc.ranks_seen} ranks seen by RCCL")
+            envs = [make_env(w, device, seed=1000, world=world, rank=rank, exchange=exch)]
+            acts = [make_actions(w, envs[0], device, seed=2000 + rank * 16, pool=POOL)]
+            return envs, acts
         envs = [make_env(w, device, seed=1000 + rank * 16 + c, E=w["E"] // split) for c in range(split)]
         acts = [make_actions(w, e, device, seed=2000 + rank * 16 + c, pool=POOL) for c, e in enumerate(envs)]
         return envs, acts
+
+    swarm_note = []
 
     envs, actions = build(1)
     core = envs[0].core
@@ -728,7 +753,8 @@ def main():
         out = {
             "metric": metric,
             "value": m["value"], "unit": "drone-steps/s", "n_gpus": world, "steps": m["K"], "warmup": m["W"],
-            "ms_per_step": m["ev_s"] * 1e3 / m["timed_steps"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": m["ev_s"] * 1e3 / m["timed_steps"], "higher_is_better": True,
+            "scaling": "strong" if w.get("swarm") else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "repeats": m["repeats"], "timed_steps": m["timed_steps"], "timed_region_ms": m["ev_s"] * 1e3,
             "wall_ms_per_step": m["wall_s"] * 1e3 / m["timed_steps"], "value_wall": m["value_wall"],
@@ -740,7 +766,10 @@ def main():
                        "full_obs": w.get("full_obs", False), "policy": "MlpPolicy 64x64 tanh, in the kernel (rollout) / torch between steps (graph)" if w.get("policy") else None,
                        "obs_allgather": want_gather, "allgather_impl": impl, "allgather_note": gather_note,
                        "n_ranks_seen_by_rccl": ranks_seen,
-                       "env_steps_per_s": m["env_steps_per_s"]},
+                       "env_steps_per_s": m["env_steps_per_s"],
+                       **({"swarm": {"total_drones": envs[0].TOTAL_DRONES, "ranks": envs[0].WORLD_SIZE, "cell_m": envs[0].cell,
+                                     "grid": [envs[0].nx, envs[0].ny], "rebin_every": envs[0].rebin_every, "note": "; ".join(swarm_note) or None}}
+                          if w.get("swarm") else {})},
             "roofline": m["roofline"],
         }
         key_launch = "rollout64" if args.mode == "rollout" else args.mode

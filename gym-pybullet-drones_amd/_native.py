@@ -48,6 +48,18 @@ class GpdStepCfg(ctypes.Structure):
                 ("init_per_env", ctypes.c_int32), ("auto_reset", ctypes.c_int32)]
 
 
+class GpdSwarm(ctypes.Structure):
+    """mirror of `struct GpdSwarm`"""
+    _fields_ = [("n_rows", ctypes.c_int32), ("slab", ctypes.c_int32), ("world_size", ctypes.c_int32), ("rank", ctypes.c_int32),
+                ("own_count", ctypes.c_int32), ("nx", ctypes.c_int32), ("ny", ctypes.c_int32), ("nz", ctypes.c_int32),
+                ("cell", ctypes.c_float), ("x0", ctypes.c_float), ("y0", ctypes.c_float), ("z0", ctypes.c_float),
+                ("zbin", ctypes.c_float), ("meta_rows", ctypes.c_int32),
+                ("pos4", ctypes.c_void_p), ("bin_pos", ctypes.c_void_p), ("cell_count", ctypes.c_void_p),
+                ("cell_start", ctypes.c_void_p), ("order", ctypes.c_void_p), ("visit", ctypes.c_void_p), ("visit_out", ctypes.c_void_p),
+                ("slot_key", ctypes.c_void_p), ("dw_force", ctypes.c_void_p), ("slot_of", ctypes.c_void_p),
+                ("pos_sorted", ctypes.c_void_p)]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/gpd.hip + csrc/gpd_policy.hip -> csrc/libgpd.so for gfx950.  Returns the library path."""
     srcs = [os.path.join(CSRC, u) for u, _ in UNITS]
@@ -104,6 +116,12 @@ _SIGNATURES = {
     "gpd_downwash_global": (ctypes.c_int, [ctypes.POINTER(GpdParams), _P, ctypes.c_int64, ctypes.c_int32, ctypes.c_float,
                                            ctypes.c_float, ctypes.c_float, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                            ctypes.c_float, ctypes.c_int32, _P, _P, _P, _P, _P, _P, ctypes.POINTER(GpdState), _P, _P, _P]),
+    "gpd_sizeof_swarm": (ctypes.c_int, []),
+    "gpd_swarm_step": (ctypes.c_int, [ctypes.POINTER(GpdParams), ctypes.POINTER(GpdState), ctypes.POINTER(GpdStepCfg),
+                                      ctypes.POINTER(GpdSwarm), _P, _P, _P, _P]),
+    "gpd_swarm_pack": (ctypes.c_int, [ctypes.POINTER(GpdState), ctypes.POINTER(GpdSwarm), _P, _P, _P]),
+    "gpd_swarm_bin": (ctypes.c_int, [ctypes.POINTER(GpdSwarm), _P]),
+    "gpd_swarm_forces": (ctypes.c_int, [ctypes.POINTER(GpdParams), ctypes.POINTER(GpdSwarm), _P]),
     "gpd_reset": (ctypes.c_int, [ctypes.POINTER(GpdState), _P, ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_int32,
                                  ctypes.c_int32, _P, _P]),
     "gpd_pid": (ctypes.c_int, [ctypes.POINTER(GpdParams), _P, ctypes.c_int64, ctypes.c_float, _P, _P, _P, _P, _P, _P,
@@ -149,6 +167,8 @@ def lib() -> ctypes.CDLL:
     want = (ctypes.sizeof(GpdParams), ctypes.sizeof(GpdState), ctypes.sizeof(GpdStepCfg))
     if tuple(sizes) != want:
         raise GpdError(f"struct layout mismatch: library {tuple(sizes)} vs binding {want}")
+    if L.gpd_sizeof_swarm() != ctypes.sizeof(GpdSwarm):
+        raise GpdError(f"struct layout mismatch: GpdSwarm is {L.gpd_sizeof_swarm()} bytes in the library, {ctypes.sizeof(GpdSwarm)} in the binding")
     _lib = L
     return L
 

@@ -2023,8 +2023,15 @@ __device__ __forceinline__ void run_of(int c, int lane, int& head_lane, int& len
 
 // VEC: the pass over all drones also writes their [n][20] state vectors (what gpd_state_vectors does) -- a caller that steps
 // a swarm needs both after every step, and at this size a launch costs more than the rows.
+// where the positions come from: the SoA state block (gpd_downwash_global), or the packed [rows][4] array of a GpdSwarm
+struct DwPos { const float* kin; int64_t ld; const float4* pos4; };
+__device__ __forceinline__ void dw_pos(const DwPos& S, int d, float& x, float& y, float& z) {
+    if (S.pos4) { const float4 p = S.pos4[d]; x = p.x; y = p.y; z = p.z; }
+    else { x = S.kin[d]; y = S.kin[S.ld + d]; z = S.kin[2 * S.ld + d]; }
+}
+
 template <bool VEC>
-__global__ __launch_bounds__(kBlock) void dwg_count_kernel(const float* __restrict__ kin, int64_t ld, int n, const DwGrid G,
+__global__ __launch_bounds__(kBlock) void dwg_count_kernel(const DwPos src, int n, const DwGrid G,
                                                            const int* __restrict__ visit, int* __restrict__ count,
                                                            const GpdState VS, const float* __restrict__ vec_obs12,
                                                            float* __restrict__ vec_out) {
@@ -2034,7 +2041,8 @@ __global__ __launch_bounds__(kBlock) void dwg_count_kernel(const float* __restri
     if (i < n) {
         const int d = visit ? visit[i] : i;
         if constexpr (VEC) state20_row(VS, vec_obs12, vec_out, i);      // (row i, not row d: coalesced, the two jobs only share the launch)
-        const float x = kin[d], y = kin[ld + d], z = kin[2 * ld + d];
+        float x, y, z;
+        dw_pos(src, d, x, y, z);
         // a drone whose position is no longer finite (the downwash model diverges when two drones pass each other
         // vertically, dz -> 0+) takes no part: it would otherwise alias into cell 0 together with every other such drone
         if (isfinite(x) && isfinite(y) && isfinite(z)) c = key_of(x, y, z, G);
@@ -2070,12 +2078,22 @@ __global__ __launch_bounds__(1024) void dwg_scan_kernel(const int* __restrict__ 
 // dependent launches, not the work in them, are what a swarm sub-step is made of); workgroup 0 also
 // writes them out for the force kernel.
 constexpr int kDwScanMax = 4096;
+// what a GpdSwarm binning writes on top of the sort (all NULL / 0 for gpd_downwash_global)
+struct DwBinOut {
+    int* slot_key;         // [n] sort key of every sorted slot
+    int* slot_of;          // [n] or NULL: row -> sorted slot (rows without a finite position: -1)
+    int* visit_out;        // [n] or NULL: a second copy of `order`, for the NEXT binning to visit the rows in
+    float4* bin_pos;       // [n] x, y, z of every row at this binning
+    float* pos4_w;         // pos4 as floats: the w of every rank's meta rows (the last meta_rows of its slab) goes back to 0
+    int slab, world, meta_rows;
+    int own_lo, own_cnt;   // rows whose force lands in dw_out[row - own_lo]
+};
 template <bool FUSED>
-__global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const float* __restrict__ kin, int64_t ld, int n, const DwGrid G,
+__global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const DwPos src, int n, const DwGrid G,
                                                              const int* __restrict__ visit, const int* __restrict__ count,
                                                              int* __restrict__ cursor, int* __restrict__ start_g,
                                                              int* __restrict__ order, float4* __restrict__ sorted,
-                                                             float* __restrict__ dw_out) {
+                                                             float* __restrict__ dw_out, const DwBinOut B) {
     __shared__ int lstart[FUSED ? kDwScanMax + 1 : 1];
     __shared__ int part[FUSED ? kBlock : 1];
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -2102,18 +2120,25 @@ __global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const float* __rest
         if (blockIdx.x == 0) for (int k = t; k <= keys; k += kBlock) start_g[k] = lstart[k];
     }
     auto start = [&](int k) { if constexpr (FUSED) return lstart[k]; else return start_g[k]; };
+    if (B.pos4_w && blockIdx.x == 0)                       // every rank bins on the same sub-steps: all displacements restart
+        for (int k = threadIdx.x; k < B.world * B.meta_rows; k += kBlock)
+            B.pos4_w[(static_cast<size_t>(k / B.meta_rows + 1) * B.slab - B.meta_rows + k % B.meta_rows) * 4 + 3] = 0.0f;
     int c = -1 - lane, d = 0;
     float x = 0.0f, y = 0.0f, z = 0.0f;
     if (i < n) {
         d = visit ? visit[i] : i;
-        x = kin[d]; y = kin[ld + d]; z = kin[2 * ld + d];
+        dw_pos(src, d, x, y, z);
+        if (B.bin_pos) B.bin_pos[d] = make_float4(x, y, z, 0.0f);
         if (isfinite(x) && isfinite(y) && isfinite(z)) {
             c = key_of(x, y, z, G);
         } else {
+            if (B.slot_of) B.slot_of[d] = -1;
             // (see dwg_count_kernel) no force on it, none from it; it keeps a slot behind the sorted drones so that `order`
             // stays a permutation (the next call visits the drones in this order)
-            dw_out[d] = 0.0f;
-            order[start(keys) + atomicAdd(&cursor[keys], 1)] = d;
+            if (d >= B.own_lo && d < B.own_lo + B.own_cnt) dw_out[d - B.own_lo] = 0.0f;
+            const int slot = start(keys) + atomicAdd(&cursor[keys], 1);
+            order[slot] = d;
+            if (B.visit_out) B.visit_out[slot] = d;
         }
     }
     int head_lane, len;
@@ -2124,7 +2149,10 @@ __global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const float* __rest
     if (c >= 0) {
         const int slot = base + (lane - head_lane);
         order[slot] = d;
-        sorted[slot] = make_float4(x, y, z, __int_as_float(c));
+        if (sorted) sorted[slot] = make_float4(x, y, z, __int_as_float(c));
+        if (B.slot_key) B.slot_key[slot] = c;
+        if (B.slot_of) B.slot_of[d] = slot;
+        if (B.visit_out) B.visit_out[slot] = d;
     }
 }
 
@@ -2167,60 +2195,119 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
 // One workgroup per 64 CONSECUTIVE drones of the sorted array (lane = drone; all four waves hold the same 64 and split the
 // candidates four ways -- the partial sums are integers, the split changes no bit).  Sorted by cell, row-major, 64 consecutive
 // drones cover one or a few cells of one grid row (a dense swarm: one or two; a sparse one: many), and their candidates are
-// the three rows around it, each a CONTIGUOUS stretch of the sorted array from the cell left of the first to the cell right of
-// the last: three runs, six when the periodic grid wraps.  Every lane is busy whatever the cells hold -- a workgroup per CELL,
-// as in the first version, swept all candidates a second time for the few drones beyond the 64th of a cell.  A group that
-// straddles the end of a grid row is swept once per row segment, with the lanes of the other segment switched off.
-__global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, const DwGrid G,
+// the 2R+1 rows around it, each a CONTIGUOUS stretch of the sorted array from R cells left of the first to R cells right of
+// the last: three runs for R = 1, six when the periodic grid wraps.  Every lane is busy whatever the cells hold -- a workgroup
+// per CELL, as in the first version, swept all candidates a second time for the few drones beyond the 64th of a cell.  A group
+// that straddles the end of a grid row is swept once per row segment, with the lanes of the other segment switched off.
+//
+// GpdSwarm (DwWorld.pos4 != NULL): the sort is STALE -- `order`, `start` and the keys are those of the last binning, the
+// positions (of the group's drones and of the candidates) are the current ones, read through slot -> row -> pos4.  Two drones
+// within 10 m of each other now were within 10 m + 2 dmax at the binning (dmax: the largest lateral displacement of any drone
+// since, the maximum of the ranks' meta rows), i.e. at most R = ceil((10 + 2 dmax) / cell) cells apart: the search widens to
+// (2R+1) x (2R+1) cells and stays exact.  R beyond kDwMaxR (or the grid): the group sweeps every sorted drone.  Only the rows
+// own_lo .. own_lo + own_cnt - 1 get a force (the rank's drones); a group without one exits.
+constexpr int kDwMaxR = 3, kDwMaxRuns = 2 * (2 * kDwMaxR + 1);
+struct DwWorld {
+    const float4* pos4;    // current positions by ROW (read through `order`), or NULL: `sorted` holds the current positions by SLOT
+                           // (binned in this very call, or kept current by the step kernel: a single rank's world)
+    const int* slot_key;   // sort key per slot, or NULL: the key sits in sorted[].w
+    const float4* meta;    // the position array whose meta rows hold the ranks' dmax^2, or NULL: no displacement since the binning
+    int own_lo, own_cnt;   // rows this launch produces forces for (dw_out[row - own_lo])
+    int slab, world, meta_rows;
+    float cell;
+};
+__global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, const DwGrid G, const DwWorld Wd,
                                                            const int* __restrict__ start, const int* __restrict__ order,
                                                            const float4* __restrict__ sorted, float* __restrict__ dw_out,
                                                            int* __restrict__ cursor) {
     __shared__ __attribute__((aligned(16))) float tx[kDwTile], ty[kDwTile], tz[kDwTile];
     __shared__ unsigned short queue[kBlock / 64][kDwQueue];
     __shared__ unsigned long long sums[kBlock / 64][64];
+    __shared__ int run0[kDwMaxRuns], pre[kDwMaxRuns + 1];  // first element of each candidate run; prefix sums of the run lengths
     const int nx = G.nx, ny = G.ny, nz = G.nz;
     const int keys = nx * ny * nz;
-    // the sort's per-key counters / cursors are done with: leave them zeroed for the next call (no memset node per call)
+    // the sort's per-key counters / cursors are done with: leave them zeroed for the next binning (no memset node per call)
     for (int k = blockIdx.x * kBlock + threadIdx.x; k < 2 * (keys + 1); k += gridDim.x * kBlock) cursor[k] = 0;   // (counts | cursors)
     const int sorted_n = start[keys];                      // drones with a finite position (the others: force 0, set by the sort)
     const int base = 64 * blockIdx.x;
     if (base >= sorted_n) return;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int s = base + lane;
+    const bool have = s < sorted_n;
+    const int my_row = have ? order[s] : -1;
+    const bool own = have && my_row >= Wd.own_lo && my_row < Wd.own_lo + Wd.own_cnt;
+    if (__builtin_amdgcn_ballot_w64(own) == 0) return;     // (the four waves hold the same 64 slots: the whole workgroup leaves)
     unsigned short* const my_queue = queue[wave];
     unsigned long long* const my_sums = sums[wave];
     const float kr = 0.25f * P.prop_radius;
     const float cut = 8.9454f;                             // sqrt(80.02): arg < 40  <=>  dxy^2 < 80 beta^2
     const fp2 b1 = splat(-P.dw_coeff[1] * cut), b0 = splat(P.dw_coeff[2] * cut);
-    const int s = base + lane;
-    const bool have = s < sorted_n;
-    const float4 me = have ? sorted[s] : make_float4(0.0f, 0.0f, 3.0e38f, 0.0f);
-    const int my_cell = have ? __float_as_int(me.w) / nz : -1;
-    const int c_first = __float_as_int(sorted[base].w) / nz, c_last = __float_as_int(sorted[min(base + 63, sorted_n - 1)].w) / nz;
+    auto key_at = [&](int slot) { return Wd.slot_key ? Wd.slot_key[slot] : __float_as_int(sorted[slot].w); };
+    auto pos_at = [&](int slot) { return Wd.pos4 ? Wd.pos4[order[slot]] : sorted[slot]; };
+    float4 me = make_float4(0.0f, 0.0f, 3.0e38f, 0.0f);
+    if (own) me = Wd.pos4 ? Wd.pos4[my_row] : sorted[s];
+    const int my_cell = own ? key_at(s) / nz : -1;
+    const int c_first = key_at(base) / nz, c_last = key_at(min(base + 63, sorted_n - 1)) / nz;
+    // search radius in cells
+    int R = 1;
+    if (Wd.meta) {
+        // dmax^2: the largest of the step kernel's per-workgroup maxima (one meta row each, every rank's)
+        float d2 = 0.0f;
+        const int tot = Wd.world * Wd.meta_rows;
+        for (int k = threadIdx.x; k < tot; k += kBlock)
+            d2 = fmaxf(d2, Wd.meta[static_cast<size_t>(k / Wd.meta_rows + 1) * Wd.slab - Wd.meta_rows + k % Wd.meta_rows].w);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, off));
+        float* const red = reinterpret_cast<float*>(pre);      // (free until the first segment)
+        if (lane == 0) red[wave] = d2;
+        __syncthreads();
+        d2 = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+        if (d2 > 0.0f) {                                   // (rounded up: a wider search is still exact, a narrower one is not)
+            const float reach = 10.0f + 2.0002f * sqrtf(d2) + 2.0e-6f;
+            const float cells = ceilf(reach / Wd.cell * 1.000001f);
+            R = cells < 1.0e6f ? static_cast<int>(cells) : (1 << 20);          // (also catches inf)
+        }
+        R = __builtin_amdgcn_readfirstlane(R);
+    }
+    const bool sweep_all = R > kDwMaxR;                    // the group's candidates: every sorted drone, one run
+    const int nrows = sweep_all ? 0 : min(2 * R + 1, ny);
     my_sums[lane] = 0ull;                                  // sum of contributions in units of 2^-30 N: order-independent
     for (int cs = c_first; cs <= c_last;) {                // row segments of the group's cells (nearly always one)
         const int cy = cs / nx;
-        const int ce = min(c_last, cy * nx + nx - 1);
-        const int cxa = cs - cy * nx, w = ce - cs + 3;     // columns cxa - 1 .. cxb + 1, periodic
-        const bool active = have && my_cell >= cs && my_cell <= ce;
+        const int ce = sweep_all ? c_last : min(c_last, cy * nx + nx - 1);
+        const int cxa = cs - cy * nx, w = ce - cs + 1 + 2 * R;     // columns cxa - R .. cxb + R, periodic
+        const bool active = own && my_cell >= cs && my_cell <= ce;
         const float mez = active ? me.z : 3.0e38f;         // (switched off: nothing is above it)
-        int run0[6], pre[7];                               // first element of each run; prefix sums of the run lengths
-        pre[0] = 0;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int row = ((cy + r - 1 + ny) % ny) * nx;
-            int a0, a1, b0c, b1c;                          // run A: cells a0 .. a1; run B (the wrapped part): b0c .. b1c, or empty
-            if (w >= nx) { a0 = 0; a1 = nx - 1; b0c = 0; b1c = -1; }
-            else {
-                const int a = (cxa - 1 + nx) % nx;
-                a0 = a; a1 = min(a + w - 1, nx - 1);
-                b0c = 0; b1c = a + w - 1 - nx;             // (< 0: no wrap)
+        __syncthreads();                                   // (the previous segment's tiles are done with run0 / pre)
+        const int nruns = sweep_all ? 1 : 2 * nrows;
+        if (static_cast<int>(threadIdx.x) < nruns) {       // run q: row q >> 1, part A (up to the end of the row) or B (the wrapped rest)
+            const int q = threadIdx.x;
+            int first = 0, len = sorted_n;
+            if (!sweep_all) {
+                const int r = q >> 1;
+                const int gy = (2 * R + 1 < ny) ? ((cy - R + r) % ny + ny) % ny : r;        // (every row once when the rows wrap)
+                const int row = gy * nx;
+                int a0, a1, b1c;                           // run A: cells a0 .. a1; run B: cells 0 .. b1c (< 0: none)
+                if (w >= nx) { a0 = 0; a1 = nx - 1; b1c = -1; }
+                else {
+                    const int a = ((cxa - R) % nx + nx) % nx;
+                    a0 = a; a1 = min(a + w - 1, nx - 1);
+                    b1c = a + w - 1 - nx;
+                }
+                if ((q & 1) == 0) { first = start[(row + a0) * nz]; len = start[(row + a1 + 1) * nz] - first; }
+                else { first = start[row * nz]; len = b1c >= 0 ? start[(row + b1c + 1) * nz] - first : 0; }
             }
-            run0[2 * r] = start[(row + a0) * nz];
-            pre[2 * r + 1] = pre[2 * r] + (start[(row + a1 + 1) * nz] - run0[2 * r]);
-            run0[2 * r + 1] = start[(row + b0c) * nz];
-            pre[2 * r + 2] = pre[2 * r + 1] + (b1c >= 0 ? start[(row + b1c + 1) * nz] - run0[2 * r + 1] : 0);
+            run0[q] = first;
+            pre[q + 1] = len;                              // (lengths for now, prefix sums below)
         }
-        const int total = pre[6];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            pre[0] = 0;
+            for (int q = 0; q < nruns; ++q) pre[q + 1] += pre[q];
+        }
+        __syncthreads();
+        const int total = pre[nruns];
         const fp2 mx = splat(me.x), my = splat(me.y), mz = splat(mez);
         int pending = 0;                                   // pairs in this wave's queue (wave-uniform)
         // one queued pair: the exact tests and the model (:798-808), added to the drone's sum
@@ -2259,11 +2346,10 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
             for (int j = threadIdx.x; j < chunks * kDwChunk; j += kBlock) {
                 float4 o = make_float4(0.0f, 0.0f, -3.0e38f, 0.0f);        // (padding of the last chunk: below everything)
                 if (j < cnt) {
-                    const int v = v0 + j;                  // position in the concatenated list -> run r, element src
+                    const int v = v0 + j;                  // position in the concatenated list -> run q, element src
                     int src = run0[0] + v;
-#pragma unroll
-                    for (int q = 1; q < 6; ++q) src = (v >= pre[q]) ? run0[q] + (v - pre[q]) : src;
-                    o = sorted[src];
+                    for (int q = 1; q < nruns; ++q) src = (v >= pre[q]) ? run0[q] + (v - pre[q]) : src;
+                    o = pos_at(src);
                 }
                 tx[j] = o.x; ty[j] = o.y; tz[j] = o.z;
             }
@@ -2312,11 +2398,11 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
         cs = ce + 1;
     }
     __syncthreads();
-    if (wave == 0 && have) {                               // add up the four waves' shares
+    if (wave == 0 && own) {                                // add up the four waves' shares
         unsigned long long sum = 0;
 #pragma unroll
         for (int k = 0; k < kBlock / 64; ++k) sum += sums[k][lane];
-        dw_out[order[s]] = -static_cast<float>(static_cast<double>(static_cast<long long>(sum)) * (1.0 / 1073741824.0));
+        dw_out[my_row - Wd.own_lo] = -static_cast<float>(static_cast<double>(static_cast<long long>(sum)) * (1.0 / 1073741824.0));
     }
 }
 
@@ -2368,6 +2454,96 @@ __global__ __launch_bounds__(kBlock) void gpd_state20_kernel(const GpdState S, c
     const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (n >= n_total) return;
     state20_row(S, obs12, out, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// GpdSwarm: the physics sub-step of ONE world's drones (single-drone lanes of env_step, all add-on terms possible, the downwash
+// force from state.dw_force), which also hands the next launch what it needs: the drone's new position in the packed array the
+// force kernel (and, across ranks, the all-gather) reads, how far it has moved since the last binning, its state vector.
+// ------------------------------------------------------------------------------------------------
+struct SwarmOut {
+    float4* pos4_own;          // pos4 + rank * slab: row i = own drone i
+    const float4* bin_pos_own; // bin_pos + rank * slab
+    float* dmax2;              // the w of the rank's first meta row (workgroup b's: 4 b floats on)
+    const int* slot_of_own;    // slot_of + rank * slab, or NULL
+    float4* pos_sorted;        // [n_rows] current positions by sorted slot (with slot_of)
+    float* vec_out;            // [n][20] or NULL
+};
+// the drone's new position for the next launch (by row; by sorted slot when this rank holds the whole world), and how far it
+// is from where it was binned: the workgroup's maximum goes to the workgroup's own meta row -- a plain store (1024 wavefronts
+// updating ONE word with atomics cost 13 us: atomics on one address are served one after the other; the force kernel, which
+// needs the maximum over all of them, reads a few hundred words instead)
+__device__ __forceinline__ void swarm_tail(const SwarmOut& O, bool active, uint32_t n, float px, float py, float pz) {
+    __shared__ float wg_max[kBlock / 64];
+    float d2 = 0.0f;
+    if (active) {
+        O.pos4_own[n] = make_float4(px, py, pz, 0.0f);
+        if (O.slot_of_own) { const int slot = O.slot_of_own[n]; if (slot >= 0) O.pos_sorted[slot] = make_float4(px, py, pz, 0.0f); }
+        const float4 b = O.bin_pos_own[n];
+        const float dx = px - b.x, dy = py - b.y, dz = pz - b.z;
+        d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        d2 = d2 == d2 ? d2 : 0.0f;                            // (a drone without a finite position takes no part in the sort)
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, off));
+    if ((threadIdx.x & 63) == 0) wg_max[threadIdx.x >> 6] = d2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = wg_max[0];
+#pragma unroll
+        for (int k = 1; k < kBlock / 64; ++k) m = fmaxf(m, wg_max[k]);
+        O.dmax2[4 * blockIdx.x] = m;
+    }
+}
+template <int ACT>
+__global__ __launch_bounds__(kBlock) void gpd_swarm_step_kernel(const GpdParams P, const GpdState S, const GpdStepCfg C,
+                                                                const float* __restrict__ action, float* __restrict__ obs12,
+                                                                const SwarmOut O) {
+    const uint32_t N = static_cast<uint32_t>(C.num_envs);
+    const uint32_t n_raw = blockIdx.x * kBlock + threadIdx.x;
+    Lane L;
+    L.tid = threadIdx.x;
+    L.active = n_raw < N;
+    L.n = L.active ? n_raw : 0u;
+    L.le = L.tid; L.d = 0; L.env = L.n; L.shfl = false;
+    const uint32_t flags = C.physics_flags;
+    Carry c;
+    float tgx, tgy, tgz, ip[7];
+    const float4 act = load_action<4>(action, L.n);
+    load_carry<false, true>(S, C, flags, L, S.kin, S.kin, c, tgx, tgy, tgz, ip);     // (no task, no reset: readable dummies)
+    c.roll = c.pitch = c.yaw = 0.0f;
+    StepOut out;
+    env_step<false, true, false, 4, ACT, true>(P, C, flags, 1, L, act, tgx, tgy, tgz, false, S.kin, ip[0], ip[1], ip[2], ip[3], ip[4],
+                                               ip[5], ip[6], nullptr, nullptr, c, out);
+    swarm_tail(O, L.active, L.n, c.k.px, c.k.py, c.k.pz);
+    if (!L.active) return;
+    store_obs12(obs12, L.n, out.o[0], out.o[1], out.o[2], out.o[3], out.o[4], out.o[5], out.o[6], out.o[7], out.o[8],
+                out.o[9], out.o[10], out.o[11]);
+    if (O.vec_out) {                                       // BaseAviary._getDroneStateVector (envs/BaseAviary.py:541-561)
+        float4* w = reinterpret_cast<float4*>(O.vec_out + static_cast<size_t>(L.n) * 20);
+        const Kin& k = c.k;
+        w[0] = make_float4(k.px, k.py, k.pz, k.qx);
+        w[1] = make_float4(k.qy, k.qz, k.qw, out.o[3]);
+        w[2] = make_float4(out.o[4], out.o[5], k.vx, k.vy);
+        w[3] = make_float4(k.vz, out.o[9], out.o[10], out.o[11]);
+        w[4] = make_float4(c.l0, c.l1, c.l2, c.l3);
+    }
+    store_carry<false>(S, L, c);
+}
+
+// after a reset / an outside change of the state: the rank's slab of pos4 from state.kin -- its drones, the rows without one
+// (non-finite), the meta row (dmax^2 = 0) -- and, on request, the state vectors
+__global__ __launch_bounds__(kBlock) void gpd_swarm_pack_kernel(const GpdState S, int n, int slab, float4* __restrict__ pos4_own,
+                                                                const float* __restrict__ obs12, float* __restrict__ vec_out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= slab) return;
+    const float nan = __int_as_float(0x7fc00000);
+    if (i < n) {
+        pos4_own[i] = make_float4(S.kin[i], S.kin[S.ld + i], S.kin[2 * S.ld + i], 0.0f);
+        if (vec_out) state20_row(S, obs12, vec_out, i);
+    } else {
+        pos4_own[i] = make_float4(nan, nan, nan, 0.0f);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2613,6 +2789,8 @@ void gpd_struct_sizes(int32_t out[3]) {
     out[2] = static_cast<int32_t>(sizeof(GpdStepCfg));
 }
 
+int gpd_sizeof_swarm(void) { return static_cast<int>(sizeof(GpdSwarm)); }
+
 int gpd_step(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, const float* action,
              const float* target_pos, const float* init_pose, float* obs12, float* reward, uint8_t* terminated,
              uint8_t* truncated, float* term_obs12, void* stream) {
@@ -2830,28 +3008,136 @@ int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, i
     const DwGrid G{1.0f / cell, x0, y0, nx, ny, z0, nz > 1 ? 1.0f / zbin : 0.0f, nz};
     hipError_t e;
     const dim3 grid(static_cast<unsigned>((n + kBlock - 1) / kBlock));
+    const DwPos src{kin, ld, nullptr};
     if (vec_out) {
         if (!vec_state || !vec_state->kin || !vec_obs12) return fail(GPD_EINVAL, "gpd_downwash_global: vec_out needs vec_state and vec_obs12");
         if (vec_state->ld < n) return fail(GPD_EINVAL, "gpd_downwash_global: vec_state.ld < n");
-        hipLaunchKernelGGL(dwg_count_kernel<true>, grid, dim3(kBlock), 0, st, kin, ld, n, G, visit_order, cell_count, *vec_state,
+        hipLaunchKernelGGL(dwg_count_kernel<true>, grid, dim3(kBlock), 0, st, src, n, G, visit_order, cell_count, *vec_state,
                            vec_obs12, vec_out);
     } else {
-        hipLaunchKernelGGL(dwg_count_kernel<false>, grid, dim3(kBlock), 0, st, kin, ld, n, G, visit_order, cell_count, GpdState{},
+        hipLaunchKernelGGL(dwg_count_kernel<false>, grid, dim3(kBlock), 0, st, src, n, G, visit_order, cell_count, GpdState{},
                            nullptr, nullptr);
     }
     int32_t* const cursors = cell_count + keys + 1;       // second half of cell_count: the scatter's per-key cursors
+    const DwBinOut B{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, n};
     if (keys <= kDwScanMax) {
-        hipLaunchKernelGGL(dwg_scatter_kernel<true>, grid, dim3(kBlock), 0, st, kin, ld, n, G, visit_order, cell_count, cursors,
-                           cell_start, order, reinterpret_cast<float4*>(sorted_xyzc), dw_out);
+        hipLaunchKernelGGL(dwg_scatter_kernel<true>, grid, dim3(kBlock), 0, st, src, n, G, visit_order, cell_count, cursors,
+                           cell_start, order, reinterpret_cast<float4*>(sorted_xyzc), dw_out, B);
     } else {
         hipLaunchKernelGGL(dwg_scan_kernel, dim3(1), dim3(1024), 0, st, cell_count, cell_start, keys);
-        hipLaunchKernelGGL(dwg_scatter_kernel<false>, grid, dim3(kBlock), 0, st, kin, ld, n, G, visit_order, cell_count, cursors,
-                           cell_start, order, reinterpret_cast<float4*>(sorted_xyzc), dw_out);
+        hipLaunchKernelGGL(dwg_scatter_kernel<false>, grid, dim3(kBlock), 0, st, src, n, G, visit_order, cell_count, cursors,
+                           cell_start, order, reinterpret_cast<float4*>(sorted_xyzc), dw_out, B);
     }
-    hipLaunchKernelGGL(dwg_force_kernel, dim3(static_cast<unsigned>((n + 63) / 64)), dim3(kBlock), 0, st, *params, G, cell_start,
+    const DwWorld Wd{nullptr, nullptr, nullptr, 0, n, 0, 0, 0, cell};
+    hipLaunchKernelGGL(dwg_force_kernel, dim3(static_cast<unsigned>((n + 63) / 64)), dim3(kBlock), 0, st, *params, G, Wd, cell_start,
                        order, reinterpret_cast<const float4*>(sorted_xyzc), dw_out, cell_count);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gpd_downwash_global launch");
+    return 0;
+}
+
+static int swarm_args(const char* who, const GpdSwarm* w, bool sorted_buffers) {
+    auto bad = [&](int code, const char* msg) { return fail(code, (std::string(who) + ": " + msg).c_str()); };
+    if (!w) return bad(GPD_EINVAL, "NULL swarm");
+    if (w->world_size < 1 || w->world_size > kBlock || w->rank < 0 || w->rank >= w->world_size) return bad(GPD_EINVAL, "need 0 <= rank < world_size <= 256");
+    if (w->meta_rows < 1 || w->own_count < 0 || w->own_count > w->slab - w->meta_rows)
+        return bad(GPD_EINVAL, "need 0 <= own_count <= slab - meta_rows (the last meta_rows rows of a slab are its meta rows)");
+    if (static_cast<int64_t>(w->meta_rows) * kBlock < w->own_count) return bad(GPD_EINVAL, "need meta_rows >= ceil(own_count / 256): one per workgroup of gpd_swarm_step");
+    if ((w->slot_of == nullptr) != (w->pos_sorted == nullptr)) return bad(GPD_EINVAL, "slot_of and pos_sorted come together");
+    if (w->slot_of && w->world_size != 1) return bad(GPD_EINVAL, "positions by sorted slot (slot_of / pos_sorted) need the whole world on this rank");
+    if (static_cast<int64_t>(w->slab) * w->world_size != w->n_rows) return bad(GPD_EINVAL, "n_rows must be world_size * slab");
+    if (w->n_rows > (1 << 26)) return bad(GPD_ERANGE, "more than 2^26 rows");
+    if (!w->pos4 || !w->bin_pos) return bad(GPD_EINVAL, "NULL pos4 / bin_pos");
+    if (sorted_buffers) {
+        if (!w->cell_count || !w->cell_start || !w->order || !w->slot_key) return bad(GPD_EINVAL, "NULL cell_count / cell_start / order / slot_key");
+        if (w->visit && (w->visit == w->order || w->visit == w->visit_out)) return bad(GPD_EINVAL, "visit must alias neither order nor visit_out (ping-pong visit / visit_out)");
+        if (!(w->cell >= 10.0f)) return bad(GPD_EINVAL, "cell must be >= 10 m (the model's lateral cut-off)");
+        if (w->nz < 1 || w->nz > kBlock || (w->nz > 1 && !(w->zbin > 0.0f))) return bad(GPD_EINVAL, "need 1 <= nz <= 256 and zbin > 0");
+        if (w->nx < 3 || w->ny < 3 || static_cast<int64_t>(w->nx) * w->ny * w->nz > 65536)
+            return bad(GPD_ERANGE, "need nx, ny >= 3 (periodic search) and nx*ny*nz <= 65536");
+    }
+    return 0;
+}
+
+int gpd_swarm_step(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, const GpdSwarm* swarm,
+                   const float* action, float* obs12, float* vec_out, void* stream) {
+    auto bad = [&](int code, const char* msg) { return fail(code, (std::string("gpd_swarm_step: ") + msg).c_str()); };
+    if (!params || !state || !cfg || !action || !obs12) return bad(GPD_EINVAL, "NULL params/state/cfg/action/obs12");
+    if (int rc = swarm_args("gpd_swarm_step", swarm, false)) return rc;
+    if (!state->kin || !state->step_counter) return bad(GPD_EINVAL, "NULL state.kin/step_counter");
+    if (cfg->drones_per_env != 1 || cfg->num_envs != swarm->own_count || cfg->num_envs <= 0) return bad(GPD_EINVAL, "need drones_per_env == 1 and num_envs == swarm.own_count > 0");
+    if (cfg->substeps != 1 || cfg->task != GPD_TASK_NONE || cfg->auto_reset) return bad(GPD_ENOTSUP, "one physics sub-step per call, no task, no auto-reset");
+    if (cfg->act_type != GPD_ACT_RPM && cfg->act_type != GPD_ACT_RAW_RPM && cfg->act_type != GPD_ACT_DIRECT_RPM)
+        return bad(GPD_ENOTSUP, "act_type RPM, RAW_RPM or DIRECT_RPM (waypoints: gpd_pid first)");
+    if (cfg->physics_flags & ~31u) return bad(GPD_EINVAL, "unknown physics flag");
+    if (state->ld < cfg->num_envs) return bad(GPD_EINVAL, "state.ld < num_envs");
+    if ((cfg->physics_flags & GPD_PHYS_DRAG) && !state->last_rpm) return bad(GPD_EINVAL, "GPD_PHYS_DRAG needs state.last_rpm");
+    const size_t lo = static_cast<size_t>(swarm->rank) * swarm->slab;
+    const SwarmOut O{reinterpret_cast<float4*>(swarm->pos4) + lo, reinterpret_cast<const float4*>(swarm->bin_pos) + lo,
+                     swarm->pos4 + (lo + swarm->slab - swarm->meta_rows) * 4 + 3, swarm->slot_of ? swarm->slot_of + lo : nullptr,
+                     reinterpret_cast<float4*>(swarm->pos_sorted), vec_out};
+    const dim3 grid(static_cast<unsigned>((cfg->num_envs + kBlock - 1) / kBlock));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (cfg->act_type) {
+        case GPD_ACT_RAW_RPM: hipLaunchKernelGGL(gpd_swarm_step_kernel<GPD_ACT_RAW_RPM>, grid, dim3(kBlock), 0, st, *params, *state, *cfg, action, obs12, O); break;
+        case GPD_ACT_DIRECT_RPM: hipLaunchKernelGGL(gpd_swarm_step_kernel<GPD_ACT_DIRECT_RPM>, grid, dim3(kBlock), 0, st, *params, *state, *cfg, action, obs12, O); break;
+        default: hipLaunchKernelGGL(gpd_swarm_step_kernel<GPD_ACT_RPM>, grid, dim3(kBlock), 0, st, *params, *state, *cfg, action, obs12, O); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gpd_swarm_step launch");
+    return 0;
+}
+
+int gpd_swarm_pack(const GpdState* state, const GpdSwarm* swarm, const float* obs12, float* vec_out, void* stream) {
+    if (!state || !state->kin) return fail(GPD_EINVAL, "gpd_swarm_pack: NULL state / state.kin");
+    if (int rc = swarm_args("gpd_swarm_pack", swarm, false)) return rc;
+    if (state->ld < swarm->own_count) return fail(GPD_EINVAL, "gpd_swarm_pack: state.ld < own_count");
+    if (vec_out && !obs12) return fail(GPD_EINVAL, "gpd_swarm_pack: vec_out needs obs12");
+    const size_t lo = static_cast<size_t>(swarm->rank) * swarm->slab;
+    hipLaunchKernelGGL(gpd_swarm_pack_kernel, dim3(static_cast<unsigned>((swarm->slab + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), *state, swarm->own_count, swarm->slab, reinterpret_cast<float4*>(swarm->pos4) + lo,
+                       obs12, vec_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gpd_swarm_pack launch");
+    return 0;
+}
+
+int gpd_swarm_bin(const GpdSwarm* w, void* stream) {
+    if (int rc = swarm_args("gpd_swarm_bin", w, true)) return rc;
+    if (!w->dw_force) return fail(GPD_EINVAL, "gpd_swarm_bin: NULL dw_force (a drone without a finite position gets force 0 here)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int n = w->n_rows, keys = w->nx * w->ny * w->nz;
+    const DwGrid G{1.0f / w->cell, w->x0, w->y0, w->nx, w->ny, w->z0, w->nz > 1 ? 1.0f / w->zbin : 0.0f, w->nz};
+    const dim3 grid(static_cast<unsigned>((n + kBlock - 1) / kBlock));
+    const DwPos src{nullptr, 0, reinterpret_cast<const float4*>(w->pos4)};
+    hipLaunchKernelGGL(dwg_count_kernel<false>, grid, dim3(kBlock), 0, st, src, n, G, w->visit, w->cell_count, GpdState{}, nullptr, nullptr);
+    int32_t* const cursors = w->cell_count + keys + 1;
+    const DwBinOut B{w->slot_key, w->slot_of, w->visit_out, reinterpret_cast<float4*>(w->bin_pos), w->pos4, w->slab, w->world_size, w->meta_rows, w->rank * w->slab, w->own_count};
+    float4* const srt = reinterpret_cast<float4*>(w->pos_sorted);
+    if (keys <= kDwScanMax) {
+        hipLaunchKernelGGL(dwg_scatter_kernel<true>, grid, dim3(kBlock), 0, st, src, n, G, w->visit, w->cell_count, cursors,
+                           w->cell_start, w->order, srt, w->dw_force, B);
+    } else {
+        hipLaunchKernelGGL(dwg_scan_kernel, dim3(1), dim3(1024), 0, st, w->cell_count, w->cell_start, keys);
+        hipLaunchKernelGGL(dwg_scatter_kernel<false>, grid, dim3(kBlock), 0, st, src, n, G, w->visit, w->cell_count, cursors,
+                           w->cell_start, w->order, srt, w->dw_force, B);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gpd_swarm_bin launch");
+    return 0;
+}
+
+int gpd_swarm_forces(const GpdParams* params, const GpdSwarm* w, void* stream) {
+    if (!params) return fail(GPD_EINVAL, "gpd_swarm_forces: NULL params");
+    if (int rc = swarm_args("gpd_swarm_forces", w, true)) return rc;
+    if (!w->dw_force) return fail(GPD_EINVAL, "gpd_swarm_forces: NULL dw_force");
+    const DwGrid G{1.0f / w->cell, w->x0, w->y0, w->nx, w->ny, w->z0, w->nz > 1 ? 1.0f / w->zbin : 0.0f, w->nz};
+    const float4* const p4 = reinterpret_cast<const float4*>(w->pos4);
+    const DwWorld Wd{w->pos_sorted ? nullptr : p4, w->slot_key, p4, w->rank * w->slab, w->own_count, w->slab, w->world_size, w->meta_rows, w->cell};
+    hipLaunchKernelGGL(dwg_force_kernel, dim3(static_cast<unsigned>((w->n_rows + 63) / 64)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       *params, G, Wd, w->cell_start, w->order, reinterpret_cast<const float4*>(w->pos_sorted), w->dw_force, w->cell_count);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gpd_swarm_forces launch");
     return 0;
 }
 

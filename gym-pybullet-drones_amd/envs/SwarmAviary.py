@@ -1,18 +1,28 @@
-"""`SwarmAviary`: ONE aviary of N drones, any N — with the pairwise downwash of the whole swarm.
+"""`SwarmAviary`: ONE aviary of N drones, any N — with the pairwise downwash of the whole swarm — on one GPU or sharded
+across several.
 
 The reference simulates one world per aviary and couples its drones only through `_downwash`
 (`envs/BaseAviary.py:785-811`): an O(N²) Python loop over every pair with `dz > 0` and `dxy < 10 m`, once per
 physics sub-step, on the positions all drones had at the start of the sub-step (`:346-347`).  The fused step
 kernel covers aviaries of up to 256 drones (one workgroup, positions exchanged through LDS).  This class is the
-large-world counterpart: the swarm is stepped as N single-drone lanes of the same kernel, and
-the downwash force of each drone is computed per sub-step by `gpd_downwash_global` — uniform, periodic 10 m grid, counting
-sort by cell, 3×3-cell neighbourhood search, order-independent fixed-point accumulation — and handed to the step
-kernel as `state.dw_force`.
+large-world counterpart, built on the `GpdSwarm` entries of the C-ABI (`include/gpd.h`):
 
-Interface: `CtrlAviary`-like.  `step(action)` takes raw RPMs `(N, 4)` clipped to `[0, MAX_RPM]`
-(`envs/CtrlAviary.py:140`) — or, with `act=ActionType.PID`, waypoints `(N, 3)` tracked by N `DSLPIDControl`s
-(`examples/downwash.py:93-113`) — and returns the `(N, 20)` state vectors.  Everything stays on the GPU.
-One process / one GPU: a single world does not shard by aviary.
+* a physics sub-step is TWO launches: `gpd_swarm_step` (the step kernel's arithmetic for this rank's drones; it also writes
+  each drone's new position into the packed `pos4` array, tracks the largest lateral displacement since the drones were last
+  binned, and — on the last sub-step — the `(n, 20)` state vectors) and `gpd_swarm_forces` (downwash of the NEXT sub-step on
+  the snapshot this one left);
+* the counting sort by grid cell (`gpd_swarm_bin`) runs every `rebin_every` sub-steps only; in between the force kernel
+  searches the stale cell order with current positions and a radius that grows with the tracked displacement — every pair the
+  reference would sum is evaluated whatever the drones do, in order-independent 64-bit fixed point;
+* `world_size` ranks share one world: rank r owns a contiguous block of drones, and after every sub-step the ranks all-gather
+  their 16 bytes per drone (`exchange`: RCCL through the C-ABI's `gpd_allgather_obs`, or `torch.distributed`) — the one
+  collective of a sub-step.  Every rank bins all positions and evaluates the forces of its own drones; the sums are integers,
+  so a world stepped by 1, 2 or 8 ranks follows the same trajectory bit for bit.
+
+Interface: `CtrlAviary`-like.  `step(action)` takes raw RPMs `(n_own, 4)` clipped to `[0, MAX_RPM]`
+(`envs/CtrlAviary.py:140`) — or, with `act=ActionType.PID`, waypoints `(n_own, 3)` tracked by `DSLPIDControl`s
+(`examples/downwash.py:93-113`) — and returns the `(n_own, 20)` state vectors of this rank's drones.  Everything stays on the
+GPU.
 """
 import ctypes
 
@@ -29,18 +39,76 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+def swarm_partition(num_drones: int, world_size: int):
+    """How one world of `num_drones` is dealt to `world_size` ranks: `(per, slab, counts)` — rank r owns the drones
+    `r*per .. r*per + counts[r] - 1` (contiguous blocks of `per = ceil(N / W)`), which sit in the rows `r*slab ..` of the packed
+    position array; `slab = per + meta` rows per rank, the last `meta = ceil(per / 256)` being the rank's meta rows (one per
+    workgroup of the step kernel; `include/gpd.h`, `GpdSwarm`)."""
+    if num_drones < world_size:
+        raise ValueError("every rank needs at least one drone")
+    per = -(-num_drones // world_size)
+    counts = [max(0, min(per, num_drones - r * per)) for r in range(world_size)]
+    if min(counts) == 0:
+        raise ValueError(f"{num_drones} drones do not fill {world_size} ranks (blocks of {per}): every rank needs at least one drone")
+    return per, per + -(-per // 256), counts
+
+
+class TorchSlabExchange:
+    """The all-gather of the ranks' position slabs through `torch.distributed` (RCCL with the "nccl" backend; with gloo the
+    slabs are staged through host memory: CPU tests and the single-device test hook)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.stage = dist.get_backend(group) == "gloo"
+
+    def __call__(self, pos4: torch.Tensor, rank: int, slab: int):
+        mine = pos4[rank * slab:(rank + 1) * slab].clone()       # (the send buffer must not alias the output for torch)
+        if self.stage:
+            host = torch.empty(pos4.shape, dtype=pos4.dtype)
+            self.dist.all_gather_into_tensor(host.view(-1), mine.cpu().view(-1).contiguous(), group=self.group)
+            pos4.copy_(host)
+        else:
+            self.dist.all_gather_into_tensor(pos4.view(-1), mine.view(-1), group=self.group)
+
+
+class NativeSlabExchange:
+    """The same all-gather through the C-ABI (`gpd_allgather_obs`: `ncclAllGather`, IN PLACE -- the send buffer is the rank's
+    own slab inside the receive buffer) on the process's one communicator (`dist.NativeComm`)."""
+
+    def __init__(self, comm=None, device=None):
+        from ..dist import NativeComm
+        self.nc = comm if comm is not None else NativeComm.shared(device=device)
+
+    def __call__(self, pos4: torch.Tensor, rank: int, slab: int):
+        with torch.cuda.device(pos4.device):
+            rc = self.nc.lib.gpd_allgather_obs(self.nc.comm, ctypes.c_void_p(pos4.data_ptr() + rank * slab * 16), _ptr(pos4), slab * 4,
+                                               ctypes.c_void_p(torch.cuda.current_stream(pos4.device).cuda_stream))
+        _native.check(rc, "gpd_allgather_obs")
+
+
 class SwarmAviary:
-    """One world, `num_drones` drones, explicit integrator + the selected force models over the whole swarm."""
+    """One world, `num_drones` drones, explicit integrator + the selected force models over the whole swarm; this object holds
+    the drones of rank `rank` of `world_size`."""
 
     def __init__(self, num_drones: int, drone_model: DroneModel = DroneModel.CF2X, initial_xyzs=None, initial_rpys=None,
                  physics: Physics = Physics.PYB_DW, pyb_freq: int = 240, ctrl_freq: int = 240, act="raw_rpm",
-                 world_min=None, world_max=None, cell: float = 10.0, zbin: float = 1.0, nz: int = 1, device=None,
-                 pyb_like: bool = None):
+                 world_min=None, world_max=None, cell: float = 10.5, zbin: float = 1.0, nz: int = 1, device=None,
+                 pyb_like: bool = None, world_size: int = 1, rank: int = 0, exchange=None, rebin_every: int = None):
         if pyb_freq % ctrl_freq != 0:
             raise ValueError("[ERROR] in SwarmAviary.__init__(), pyb_freq is not divisible by ctrl_freq.")
         if act not in ("raw_rpm", ActionType.RPM, ActionType.PID):
             raise ValueError("SwarmAviary supports act = 'raw_rpm', ActionType.RPM or ActionType.PID")
-        self.NUM_DRONES = N = int(num_drones)
+        if not 0 <= rank < world_size:
+            raise ValueError("need 0 <= rank < world_size")
+        if world_size > 1 and exchange is None:
+            raise ValueError("a world shared by several ranks needs an `exchange` (TorchSlabExchange / NativeSlabExchange)")
+        self.TOTAL_DRONES = N = int(num_drones)
+        self.WORLD_SIZE, self.RANK, self.exchange = int(world_size), int(rank), exchange
+        self.per, self.slab, counts = swarm_partition(N, self.WORLD_SIZE)
+        self.FIRST_DRONE = self.RANK * self.per                  # global index of this rank's first drone
+        self.NUM_DRONES = n = counts[self.RANK]                  # drones of THIS rank
+        self.n_rows = self.slab * self.WORLD_SIZE
         self.DRONE_MODEL, self.PHYSICS, self.ACT_TYPE = drone_model, physics, act
         warn_if_pyb(physics)
         self.PYB_FREQ, self.CTRL_FREQ = pyb_freq, ctrl_freq
@@ -50,23 +118,27 @@ class SwarmAviary:
         self.HOVER_RPM, self.MAX_RPM = P.HOVER_RPM, P.MAX_RPM
         if initial_xyzs is None:
             initial_xyzs = P.default_init_xyzs(N)
-        xyz = np.asarray(initial_xyzs, dtype=np.float64).reshape(N, 1, 3)
-        rpy = np.zeros((N, 1, 3)) if initial_rpys is None else np.asarray(initial_rpys, dtype=np.float64).reshape(N, 1, 3)
+        xyz_all = np.asarray(initial_xyzs, dtype=np.float64).reshape(N, 3)            # the WHOLE world (every rank passes the same)
+        rpy_all = np.zeros((N, 3)) if initial_rpys is None else np.asarray(initial_rpys, dtype=np.float64).reshape(N, 3)
+        own = slice(self.FIRST_DRONE, self.FIRST_DRONE + n)
+        xyz, rpy = xyz_all[own].reshape(n, 1, 3), rpy_all[own].reshape(n, 1, 3)
         self.INIT_XYZS, self.INIT_RPYS = xyz[:, 0], rpy[:, 0]
-        # the kernel runs N single-drone lanes, one physics sub-step per launch.  The action -> RPM mapping is the kernel's own
+        # the kernel runs n single-drone lanes, one physics sub-step per launch.  The action -> RPM mapping is the kernel's own
         # (GPD_ACT_RAW_RPM: clip to [0, MAX_RPM], envs/CtrlAviary.py:140; GPD_ACT_RPM: HOVER_RPM (1 + 0.05 a),
         # envs/BaseRLAviary.py:191-192); waypoint actions go through the batched DSLPID kernel and arrive as RPMs.
         act_code = {"raw_rpm": ACT_RAW_RPM, ActionType.RPM: ActionType.RPM.code, ActionType.PID: ACT_DIRECT_RPM}[act]
-        self.core = engine.SimCore(drone_model=drone_model, num_envs=N, drones_per_env=1, physics=physics, pyb_freq=pyb_freq,
+        self.core = engine.SimCore(drone_model=drone_model, num_envs=n, drones_per_env=1, physics=physics, pyb_freq=pyb_freq,
                                    ctrl_freq=pyb_freq, act_code=act_code, task=engine.TASK_NONE, initial_xyzs=xyz,
                                    initial_rpys=rpy, auto_reset=False, track_rpm=True, device=device, pyb_like=pyb_like)
         self.device = dev = self.core.device
         self.flags = self.core.physics_flags
-        self.ctrl = DSLPIDControlBatch(N, drone_model, device=dev) if act == ActionType.PID else None
-        # ---- downwash grid ------------------------------------------------------------------------
+        self.ctrl = DSLPIDControlBatch(n, drone_model, device=dev) if act == ActionType.PID else None
+        # ---- downwash grid (the same on every rank: laid over the whole world) --------------------
         self.cell = float(cell)
-        lo = xyz[:, 0, :2].min(axis=0) - 2 * self.cell if world_min is None else np.asarray(world_min, dtype=np.float64)
-        hi = xyz[:, 0, :2].max(axis=0) + 2 * self.cell if world_max is None else np.asarray(world_max, dtype=np.float64)
+        if not self.cell >= 10.0:
+            raise ValueError("cell must be >= 10 m (the downwash model's lateral cut-off)")
+        lo = xyz_all[:, :2].min(axis=0) - 2 * self.cell if world_min is None else np.asarray(world_min, dtype=np.float64)
+        hi = xyz_all[:, :2].max(axis=0) + 2 * self.cell if world_max is None else np.asarray(world_max, dtype=np.float64)
         self.x0, self.y0 = float(lo[0]), float(lo[1])
         self.nx = max(3, int(np.ceil((hi[0] - lo[0]) / self.cell)))
         self.ny = max(3, int(np.ceil((hi[1] - lo[1]) / self.cell)))
@@ -74,44 +146,97 @@ class SwarmAviary:
             self.cell *= 2
             self.nx, self.ny = max(3, int(np.ceil((hi[0] - lo[0]) / self.cell))), max(3, int(np.ceil((hi[1] - lo[1]) / self.cell)))
         cells = self.nx * self.ny
-        # optional height bins inside every cell (sort key = cell * nz + bin): a group of 64 drones sweeps the candidates from
-        # its lowest bin upwards.  Off by default (nz = 1): it pays only when the 64 drones of a group share a height band --
-        # with twelve layers mixed in every cell it prunes nothing and the 16x larger key space costs 20 us per step (measured)
+        # optional height bins inside every cell (sort key = cell * nz + bin): ordering only, any value gives the same forces
         self.zbin = float(zbin)
-        self.z0 = float(xyz[:, 0, 2].min() - self.zbin)
+        self.z0 = float(xyz_all[:, 2].min() - self.zbin)
         self.nz = int(max(1, min(nz, 65536 // cells)))
+        # How often the drones are re-binned.  Between two binnings the search radius is R = ceil((10 m + 2 dmax) / cell) cells
+        # (dmax: the largest lateral displacement since the binning), so the skin cell - 10 m buys sub-steps with R = 1:
+        # with no skin every sub-step re-bins (R = 1 always, the round-2 behaviour); otherwise every 8th by default -- 0.25 m of
+        # lateral travel in 1/30 s is 7.5 m/s, the airframe's top speed (MAX_SPEED_KMH = 30); faster drones widen the search
+        # for a few sub-steps, they never break it.
+        self.rebin_every = int(rebin_every) if rebin_every is not None else (1 if self.cell <= 10.0 else 8)
+        if self.rebin_every < 1:
+            raise ValueError("rebin_every must be >= 1")
         i32 = dict(dtype=torch.int32, device=dev)
-        self._count, self._start = torch.zeros(2 * (cells * self.nz + 1), **i32), torch.zeros(cells * self.nz + 1, **i32)
-        self._order = torch.zeros(N, **i32)          # sorted slot -> drone, filled by every call ...
-        self._visit = torch.zeros(N, **i32)          # ... and the previous call's, which the next sort visits the drones in
-        self._have_visit = False
-        self._sorted = torch.zeros((N, 4), dtype=torch.float32, device=dev)
+        keys = cells * self.nz
+        self._count, self._start = torch.zeros(2 * (keys + 1), **i32), torch.zeros(keys + 1, **i32)
+        self._order = torch.zeros(self.n_rows, **i32)          # sorted slot -> row of the latest binning (what the force kernel reads)
+        # ... and two copies of it in turn: the one the latest binning wrote is what the next one visits the rows in
+        # (both start as the identity: whatever runs or is merely CAPTURED in between -- a captured binning has not written its
+        # copy yet when an eager one reads it -- a visit buffer always holds a permutation of the rows)
+        self._visit_in, self._visit_out = torch.arange(self.n_rows, **i32), torch.arange(self.n_rows, **i32)
+        self._slot_key = torch.zeros(self.n_rows, **i32)
+        self.pos4 = torch.full((self.n_rows, 4), float("nan"), dtype=torch.float32, device=dev)
+        self._bin_pos = torch.full((self.n_rows, 4), float("nan"), dtype=torch.float32, device=dev)
+        # a rank that holds the whole world keeps the positions by sorted slot as well (no exchange in row order to serve)
+        self._slot_of = torch.full((self.n_rows,), -1, **i32) if self.WORLD_SIZE == 1 else None
+        self._pos_sorted = torch.full((self.n_rows, 4), float("nan"), dtype=torch.float32, device=dev) if self.WORLD_SIZE == 1 else None
         self.dw_force = torch.zeros(self.core.ld, dtype=torch.float32, device=dev)
         if self.flags & PHYS_DW:
             self.core._state.dw_force = self.dw_force.data_ptr()
+        self._sw = _native.GpdSwarm(n_rows=self.n_rows, slab=self.slab, world_size=self.WORLD_SIZE, rank=self.RANK, own_count=n,
+                                    nx=self.nx, ny=self.ny, nz=self.nz, cell=self.cell, x0=self.x0, y0=self.y0, z0=self.z0,
+                                    zbin=self.zbin, meta_rows=self.slab - self.per, pos4=self.pos4.data_ptr(), bin_pos=self._bin_pos.data_ptr(),
+                                    cell_count=self._count.data_ptr(), cell_start=self._start.data_ptr(),
+                                    order=self._order.data_ptr(), visit=None, visit_out=self._visit_out.data_ptr(),
+                                    slot_key=self._slot_key.data_ptr(),
+                                    dw_force=self.dw_force.data_ptr(),
+                                    slot_of=self._slot_of.data_ptr() if self._slot_of is not None else None,
+                                    pos_sorted=self._pos_sorted.data_ptr() if self._pos_sorted is not None else None)
         self.step_counter = 0
+        self._since_bin = 0                          # sub-steps since the last binning
         self._dw_version = -1                        # core.state_version the forces in dw_force were computed for
 
-    # ------------------------------------------------------------------------------------------
-    def downwash(self, vectors: torch.Tensor = None) -> torch.Tensor:
-        """Body-z downwash force of every drone for the current positions (`gpd_downwash_global`) -> [N] view.
-        `vectors`: an (N, 20) tensor that the sort's first pass fills with the state vectors on the way (one launch less
-        than `state_vectors()` after it)."""
+    # ---- the pieces of a sub-step (LocalSwarmGroup drives several ranks of one process through them) --------------------
+    def _pack(self, vectors=None):
+        """pos4 rows of this rank from the state block (after a reset / an outside change); the sort is stale afterwards"""
         c = self.core
+        with torch.cuda.device(self.device):
+            rc = c.lib.gpd_swarm_pack(ctypes.byref(c._state), ctypes.byref(self._sw), _ptr(c.obs12), _ptr(vectors), c._stream())
+        _native.check(rc, "gpd_swarm_pack")
+        self._since_bin = self.rebin_every           # (forces a binning)
+
+    def _substep(self, rpm, vectors=None):
+        c = self.core
+        c.state_version += 1
+        with torch.cuda.device(self.device):
+            rc = c.lib.gpd_swarm_step(ctypes.byref(c._params), ctypes.byref(c._state), ctypes.byref(c._cfg), ctypes.byref(self._sw),
+                                      _ptr(rpm), _ptr(c.obs12), _ptr(vectors), c._stream())
+        _native.check(rc, "gpd_swarm_step")
+        self._since_bin += 1
+
+    def _exchange(self):
+        if self.WORLD_SIZE > 1:
+            self.exchange(self.pos4, self.RANK, self.slab)
+
+    def _forces(self):
+        """(binning when one is due,) the downwash forces of this rank's drones for the positions in pos4"""
+        c = self.core
+        with torch.cuda.device(self.device):
+            if self._since_bin >= self.rebin_every:
+                self._visit_in, self._visit_out = self._visit_out, self._visit_in      # the last binning's copy is this one's visit order
+                self._sw.visit = self._visit_in.data_ptr()
+                self._sw.visit_out = self._visit_out.data_ptr()
+                _native.check(c.lib.gpd_swarm_bin(ctypes.byref(self._sw), c._stream()), "gpd_swarm_bin")
+                self._since_bin = 0
+            _native.check(c.lib.gpd_swarm_forces(ctypes.byref(c._params), ctypes.byref(self._sw), c._stream()), "gpd_swarm_forces")
+        self._dw_version = c.state_version           # (the forces belong to this state)
+
+    def _check_vectors(self, vectors):
         if vectors is not None and (vectors.device != self.device or vectors.dtype != torch.float32 or not vectors.is_contiguous()
                                     or tuple(vectors.shape) != (self.NUM_DRONES, 20)):
             raise ValueError(f"vectors must be a contiguous float32 ({self.NUM_DRONES}, 20) tensor on {self.device}")
-        with torch.cuda.device(self.device):
-            self._order, self._visit = self._visit, self._order      # ping-pong: last call's order is this call's visit order
-            rc = c.lib.gpd_downwash_global(ctypes.byref(c._params), _ptr(c.kin), c.ld, self.NUM_DRONES, self.cell, self.x0,
-                                           self.y0, self.nx, self.ny, self.z0, self.zbin, self.nz,
-                                           _ptr(self._visit) if self._have_visit else None,
-                                           _ptr(self._count), _ptr(self._start), _ptr(self._order), _ptr(self._sorted),
-                                           _ptr(self.dw_force), ctypes.byref(c._state) if vectors is not None else None,
-                                           _ptr(c.obs12) if vectors is not None else None, _ptr(vectors), c._stream())
-        _native.check(rc, "gpd_downwash_global")
-        self._have_visit = True
-        self._dw_version = c.state_version                           # (the forces belong to this state)
+
+    # ------------------------------------------------------------------------------------------
+    def downwash(self, vectors: torch.Tensor = None) -> torch.Tensor:
+        """Body-z downwash force of this rank's drones for the current positions -> [n] view (re-packs, exchanges, re-bins:
+        the from-scratch path a reset takes; collective when the world is shared).  `vectors`: an (n, 20) tensor that
+        receives the state vectors on the way."""
+        self._check_vectors(vectors)
+        self._pack(vectors)
+        self._exchange()
+        self._forces()
         return self.dw_force[:self.NUM_DRONES]
 
     def reset(self, seed=None, options=None):
@@ -127,45 +252,115 @@ class SwarmAviary:
 
     def _kernel_action(self, action) -> torch.Tensor:
         """What the step kernel is fed: the raw action itself (the kernel maps it to RPMs), or -- waypoint actions -- the
-        RPMs of the N embedded DSLPID controllers (`gpd_pid`, one launch)."""
-        N = self.NUM_DRONES
+        RPMs of the embedded DSLPID controllers (`gpd_pid`, one launch)."""
+        n = self.NUM_DRONES
         a = torch.as_tensor(action, dtype=torch.float32, device=self.device)
         if self.ctrl is None:
-            return a.reshape(N, 4)
-        k = self.core.kin[:, :N]
-        rpm, _, _ = self.ctrl.computeControl(self.CTRL_TIMESTEP, k[0:3].t(), k[3:7].t(), k[7:10].t(), None, a.reshape(N, 3))
+            return a.reshape(n, 4)
+        k = self.core.kin[:, :n]
+        rpm, _, _ = self.ctrl.computeControl(self.CTRL_TIMESTEP, k[0:3].t(), k[3:7].t(), k[7:10].t(), None, a.reshape(n, 3))
         return rpm
 
     def step(self, action):
-        """One control step = PYB_STEPS_PER_CTRL × { downwash of the snapshot, one physics sub-step }.
+        """One control step = PYB_STEPS_PER_CTRL × { one physics sub-step, [exchange,] downwash of the snapshot it left }.
 
         The forces a sub-step uses are computed right AFTER the sub-step before it, on the snapshot it left (the same
-        positions: `envs/BaseAviary.py:346-347, 785-811`), so that the pass that bins the drones also writes the state vectors
-        this method returns -- five dependent launches per step instead of six.  After a reset, a `set_state` or any other
-        change of the state behind this class's back (call `invalidate()` then), the first sub-step computes its own."""
+        positions: `envs/BaseAviary.py:346-347, 785-811`).  After a reset, a `set_state` or any other change of the state behind
+        this class's back (call `invalidate()` then -- on every rank of a shared world), the first sub-step computes its own."""
         rpm = self._kernel_action(action).contiguous()
-        if not (self.flags & PHYS_DW):
-            for _ in range(self.PYB_STEPS_PER_CTRL):
-                self.core.step(rpm)
-            self.step_counter += self.PYB_STEPS_PER_CTRL
-            return self.state_vectors(), -1, False, False, {"answer": 42}
         vectors = torch.empty((self.NUM_DRONES, 20), dtype=torch.float32, device=self.device)
+        dw = bool(self.flags & PHYS_DW)
         for s in range(self.PYB_STEPS_PER_CTRL):
-            if self._dw_version != self.core.state_version:
+            if dw and self._dw_version != self.core.state_version:
                 self.downwash()
-            self.core.step(rpm)
-            self.downwash(vectors if s == self.PYB_STEPS_PER_CTRL - 1 else None)
+            self._substep(rpm, vectors if s == self.PYB_STEPS_PER_CTRL - 1 else None)
+            if dw:
+                self._exchange()
+                self._forces()
         self.step_counter += self.PYB_STEPS_PER_CTRL
         return vectors, -1, False, False, {"answer": 42}
 
     def invalidate(self):
         """Tell the aviary that the state was changed without going through `reset()` / `core.set_state()` (e.g. by writing
-        into `core.kin`): the next step recomputes the downwash forces first."""
+        into `core.kin`): the next step re-packs, re-bins and recomputes the downwash forces first."""
         self._dw_version = -1
 
     def state_vectors(self) -> torch.Tensor:
-        """(N, 20) `_getDroneStateVector` rows (envs/BaseAviary.py:559-561)."""
+        """(n, 20) `_getDroneStateVector` rows (envs/BaseAviary.py:559-561)."""
         return self.core.state_vectors()
+
+    def downwash_oneshot(self) -> torch.Tensor:
+        """The forces through the C-ABI's one-call entry `gpd_downwash_global` (count + scan/scatter + force on the state block,
+        no persistent sort): single-rank worlds only; the cross-check of the persistent path."""
+        if self.WORLD_SIZE != 1:
+            raise ValueError("gpd_downwash_global works on one rank's state block")
+        c, n = self.core, self.NUM_DRONES
+        keys = self.nx * self.ny * self.nz
+        i32 = dict(dtype=torch.int32, device=self.device)
+        count, start, order = torch.zeros(2 * (keys + 1), **i32), torch.zeros(keys + 1, **i32), torch.zeros(n, **i32)
+        srt, out = torch.zeros((n, 4), dtype=torch.float32, device=self.device), torch.zeros(n, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = c.lib.gpd_downwash_global(ctypes.byref(c._params), _ptr(c.kin), c.ld, n, self.cell, self.x0, self.y0, self.nx, self.ny,
+                                           self.z0, self.zbin, self.nz, None, _ptr(count), _ptr(start), _ptr(order), _ptr(srt), _ptr(out),
+                                           None, None, None, c._stream())
+        _native.check(rc, "gpd_downwash_global")
+        return out
 
     def close(self):
         pass
+
+
+class LocalSwarmGroup:
+    """The ranks of ONE shared world inside one process (all on one device): the exchange is a device-to-device copy of every
+    rank's slab into every rank's position array.  What the bitwise tests run on a single-GPU box; a deployment runs one
+    process per GPU with `NativeSlabExchange` / `TorchSlabExchange` instead."""
+
+    def __init__(self, num_drones: int, world_size: int, **kw):
+        kw.pop("exchange", None)
+        self.ranks = [SwarmAviary(num_drones, world_size=world_size, rank=r, exchange=self._noop, **kw) for r in range(world_size)]
+        self.W = world_size
+
+    @staticmethod
+    def _noop(pos4, rank, slab):
+        raise RuntimeError("LocalSwarmGroup exchanges for all its ranks at once")
+
+    def _exchange(self):
+        for src in self.ranks:
+            sl = slice(src.RANK * src.slab, (src.RANK + 1) * src.slab)
+            for dst in self.ranks:
+                if dst is not src:
+                    dst.pos4[sl].copy_(src.pos4[sl])
+
+    def reset(self):
+        out = []
+        for e in self.ranks:
+            e.core.reset()
+            if e.ctrl is not None:
+                e.ctrl.reset()
+            e.step_counter = 0
+            v = torch.empty((e.NUM_DRONES, 20), dtype=torch.float32, device=e.device)
+            e._pack(v)
+            out.append(v)
+        self._exchange()
+        for e in self.ranks:
+            e._forces()
+        return torch.cat(out)
+
+    def step(self, action):
+        """`action`: the whole world's (N, A) actions -> the whole world's (N, 20) state vectors"""
+        a = torch.as_tensor(action, dtype=torch.float32, device=self.ranks[0].device)
+        rpm = [e._kernel_action(a[e.FIRST_DRONE:e.FIRST_DRONE + e.NUM_DRONES]).contiguous() for e in self.ranks]
+        vec = [torch.empty((e.NUM_DRONES, 20), dtype=torch.float32, device=e.device) for e in self.ranks]
+        S = self.ranks[0].PYB_STEPS_PER_CTRL
+        for s in range(S):
+            for e, r, v in zip(self.ranks, rpm, vec):
+                e._substep(r, v if s == S - 1 else None)
+            self._exchange()
+            for e in self.ranks:
+                e._forces()
+        for e in self.ranks:
+            e.step_counter += S
+        return torch.cat(vec)
+
+    def forces(self):
+        return torch.cat([e.dw_force[:e.NUM_DRONES] for e in self.ranks])

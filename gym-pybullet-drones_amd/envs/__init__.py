@@ -3,10 +3,11 @@ from .BaseRLAviary import BaseRLAviary
 from .CtrlAviary import CtrlAviary
 from .HoverAviary import HoverAviary
 from .MultiHoverAviary import MultiHoverAviary
-from .SwarmAviary import SwarmAviary
+from .SwarmAviary import LocalSwarmGroup, NativeSlabExchange, SwarmAviary, TorchSlabExchange, swarm_partition
 from .VelocityAviary import VelocityAviary
 from .VectorAviary import (GymVectorEnvAdapter, VecEnvAdapter, VectorAviary, VectorCtrlAviary, VectorHoverAviary, VectorMultiHoverAviary,
                            VectorVelocityAviary)
 
 __all__ = ["BaseAviary", "BaseRLAviary", "CtrlAviary", "HoverAviary", "MultiHoverAviary", "VelocityAviary", "VectorAviary",
-           "VectorCtrlAviary", "VectorHoverAviary", "VectorMultiHoverAviary", "VectorVelocityAviary", "VecEnvAdapter", "GymVectorEnvAdapter", "SwarmAviary"]
+           "VectorCtrlAviary", "VectorHoverAviary", "VectorMultiHoverAviary", "VectorVelocityAviary", "VecEnvAdapter", "GymVectorEnvAdapter", "SwarmAviary",
+           "LocalSwarmGroup", "NativeSlabExchange", "TorchSlabExchange", "swarm_partition"]

@@ -389,6 +389,81 @@ int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, i
                         const GpdState* vec_state, const float* vec_obs12, float* vec_out, void* stream);
 
 /*
+ * ONE aviary of any size, stepped by one or several ranks (GPUs): the persistent form of gpd_downwash_global.
+ *
+ * What changes against calling gpd_downwash_global before every gpd_step (count + scan/scatter + force + step = four
+ * dependent launches per physics sub-step):
+ *   - the physics sub-step kernel (gpd_swarm_step: gpd_step's arithmetic for single-drone lanes) ALSO writes the drone's new
+ *     position into a packed [rows][4] array, tracks how far it has moved since the drones were last binned, and (on request)
+ *     writes the drone's 20-float state vector: no separate pass over the drones after a step;
+ *   - the counting sort (gpd_swarm_bin) runs every few sub-steps only.  Between two binnings the force kernel
+ *     (gpd_swarm_forces) works on the STALE cell order but on CURRENT positions (slot -> row -> pos4), and widens its search
+ *     from 3x3 cells to (2R+1)x(2R+1), R = ceil((10 m + 2 dmax) / cell), dmax = the largest displacement of any
+ *     drone since the binning: two drones within 10 m of each other now were within 10 m + 2 dmax then, i.e. at most R cells
+ *     apart.  With cell = 10 m + a skin, R stays 1 until some drone has moved half the skin; whatever the drones do, every
+ *     pair the reference would sum (dz > 0, dxy < 10 m; envs/BaseAviary.py:785-811) is evaluated, on current positions, in
+ *     order-independent 64-bit fixed point: the forces are the ones gpd_downwash_global returns, bit for bit.  (R beyond 3,
+ *     or beyond the grid: the group sweeps every drone.)  A sub-step is then TWO launches: gpd_swarm_step, gpd_swarm_forces;
+ *   - several ranks share one world: rank r owns the rows [r*slab, (r+1)*slab) -- its own_count drones, then rows without a
+ *     drone (non-finite x), the LAST meta_rows rows of the slab being the rank's meta rows (NaN, NaN, NaN, w): workgroup b of
+ *     gpd_swarm_step stores the largest squared displacement of its 256 drones in the w of meta row b -- plain stores, the
+ *     force kernel takes the maximum.  After
+ *     gpd_swarm_step every rank all-gathers its slab IN PLACE (gpd_allgather_obs(comm, pos4 + rank*slab*4, pos4, slab*4):
+ *     16 bytes per drone, the one collective per sub-step), bins ALL rows when a binning is due (every rank the same
+ *     sub-steps), and evaluates the forces of ITS drones only (workgroups of the sorted array without a drone of the rank
+ *     exit at once).  Sums are integers: a world stepped by 1, 2 or 8 ranks follows the same trajectory bit for bit.
+ *
+ * The force of own drone i lands in dw_force[i]: pass it to gpd_swarm_step as state.dw_force (GPD_PHYS_DW).
+ */
+typedef struct GpdSwarm {
+    int32_t n_rows;        /* rows of pos4 = world_size * slab */
+    int32_t slab;          /* rows per rank (>= own_count + meta_rows: the last meta_rows are its meta rows) */
+    int32_t world_size, rank;
+    int32_t own_count;     /* drones of this rank: rows rank*slab .. rank*slab + own_count - 1 */
+    int32_t nx, ny, nz;    /* grid: cells per side (>= 3 each), height bins per cell (1: none); nx*ny*nz <= 65536 */
+    float cell, x0, y0;    /* cell size [m] (>= 10), lower-left corner of the (periodic) grid */
+    float z0, zbin;        /* height bins as in gpd_downwash_global (ordering only) */
+    int32_t meta_rows;     /* >= ceil(max own_count / 256), the same on every rank: one row per workgroup of gpd_swarm_step */
+    float* pos4;           /* [n_rows][4] x, y, z, - of every row (meta rows: w = a partial dmax^2) */
+    float* bin_pos;        /* [n_rows][4] x, y, z, - of every row at the last binning */
+    int32_t* cell_count;   /* [2 (nx*ny*nz + 1)] counts | cursors: ZERO before the first binning (left zeroed by every call) */
+    int32_t* cell_start;   /* [nx*ny*nz + 1] */
+    int32_t* order;        /* [n_rows] sorted slot -> row, written by gpd_swarm_bin, read by gpd_swarm_forces: ONE buffer, always that
+                              of the latest binning (a captured hipGraph of sub-steps replays correctly whatever ran in between) */
+    const int32_t* visit;  /* [n_rows] or NULL: the order gpd_swarm_bin visits the rows in -- any permutation gives the same forces;
+                              the previous binning's order makes neighbouring lanes share a cell (one atomic per run of equal
+                              cells).  Must alias neither `order` nor `visit_out` ... */
+    int32_t* visit_out;    /* ... [n_rows] or NULL: gpd_swarm_bin writes a second copy of `order` here -- hand it in as `visit` next
+                              time and the old `visit` buffer as `visit_out` (ping-pong; which of the two holds the newer copy
+                              does not matter for correctness) */
+    int32_t* slot_key;     /* [n_rows] sort key (cell*nz + bin) of every sorted slot */
+    float* dw_force;       /* [>= own_count] out: body-z downwash force of own drone i (envs/BaseAviary.py:805-811) */
+    /* world_size == 1 only (both NULL otherwise): the positions ALSO by sorted slot, kept current by gpd_swarm_step, so that the
+     * force kernel reads its candidates as contiguous stretches instead of through order[] (a rank that holds the whole world
+     * needs no exchange in row order) */
+    int32_t* slot_of;      /* [n_rows] row -> sorted slot (-1: no finite position), written by gpd_swarm_bin */
+    float* pos_sorted;     /* [n_rows][4] */
+} GpdSwarm;
+
+/* One physics sub-step of the rank's own_count drones (state / cfg as for gpd_step: drones_per_env = 1, num_envs = own_count,
+ * substeps = 1, task NONE, no auto-reset; act_type RPM, RAW_RPM or DIRECT_RPM; state.dw_force = swarm.dw_force with
+ * GPD_PHYS_DW), plus: pos4 rows of the rank, the rank's dmax^2, and -- vec_out != NULL -- the [own_count][20] state vectors
+ * of gpd_state_vectors.  Replaces the body of BaseAviary.step's sub-step loop for one world (envs/BaseAviary.py:346-372). */
+/* sizeof(GpdSwarm), for a binding to verify its mirror (gpd_struct_sizes covers the three structs of ABI 1). */
+int gpd_sizeof_swarm(void);
+
+int gpd_swarm_step(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, const GpdSwarm* swarm,
+                   const float* action, float* obs12, float* vec_out, void* stream);
+/* After a reset / any outside change of the state: pos4 rows of the rank (and its drone-less rows and meta row) from
+ * state.kin, dmax^2 = 0, optionally the state vectors.  Follow it with the all-gather, gpd_swarm_bin and gpd_swarm_forces. */
+int gpd_swarm_pack(const GpdState* state, const GpdSwarm* swarm, const float* obs12, float* vec_out, void* stream);
+/* Counting sort of ALL rows by grid cell from pos4 (rows with a non-finite position take no part): order, slot_key,
+ * cell_start, bin_xy; every rank's dmax^2 (in this rank's copy of pos4) back to 0. */
+int gpd_swarm_bin(const GpdSwarm* swarm, void* stream);
+/* Downwash forces of the rank's drones for the positions in pos4 -> dw_force. */
+int gpd_swarm_forces(const GpdParams* params, const GpdSwarm* swarm, void* stream);
+
+/*
  * Masked reset.  Replaces BaseAviary.reset/_housekeeping (envs/BaseAviary.py:220-255, 451-477)
  * for the envs whose mask byte is non-zero (mask == NULL: all).  Sets pos/quat to init_pose,
  * vel, rpy_rates, last_rpm and step_counter to zero and writes the initial obs12 rows.  As in

@@ -164,3 +164,31 @@ class CAviary:
                              _ptr(self.INIT_XYZS), _ptr(self.INIT_QUAT), _ptr(self.obs), _ptr(self.reward),
                              _ptr(self.terminated), _ptr(self.truncated), _ptr(self.term_obs))
         assert rc == 0
+
+
+def downwash_all_pairs(urdf_path, xyz, drone_model="cf2x", threads=1):
+    """`BaseAviary._downwash` for ONE aviary of any size (the reference's O(n^2) loop, float64 C): body-z force per drone."""
+    L = lib()
+    p = make_params(UrdfConstants(urdf_path, drone_model))
+    pos = np.ascontiguousarray(np.asarray(xyz, dtype=np.float64).reshape(-1, 3))
+    out = np.zeros(len(pos))
+    L.orc_set_threads(threads)
+    try:
+        rc = L.orc_downwash_all_pairs(ctypes.byref(p), len(pos), _ptr(pos), _ptr(out))
+    finally:
+        L.orc_set_threads(1)
+    assert rc == 0
+    return out
+
+
+def swarm_substep_seconds(xyz, threads=1, budget_s=10.0, urdf_path=None):
+    """Seconds per all-pairs downwash pass over the drones at `xyz` (what dominates a sub-step of one large world on the CPU),
+    averaged over the passes that fit `budget_s` -> (seconds, passes)."""
+    import time
+    urdf_path = urdf_path or os.path.join(os.path.dirname(_HERE), "gym-pybullet-drones_amd", "assets", "cf2x.urdf")
+    downwash_all_pairs(urdf_path, xyz[:256], threads=threads)          # (page in)
+    reps, t0 = 0, time.perf_counter()
+    while reps == 0 or time.perf_counter() - t0 < budget_s:
+        downwash_all_pairs(urdf_path, xyz, threads=threads)
+        reps += 1
+    return (time.perf_counter() - t0) / reps, reps

@@ -315,6 +315,29 @@ int orc_step(const OrcParams* P, const OrcCfg* C, double* pos, double* quat, dou
     return 0;
 }
 
+/* BaseAviary._downwash (envs/BaseAviary.py:785-811) for ONE aviary of n drones, any n: the reference's all-pairs loop, body-z
+ * force of every drone from the drones above it.  pos [n][3], out [n].  (The per-aviary path above stops at 256 drones.) */
+int orc_downwash_all_pairs(const OrcParams* P, int n, const double* pos, double* out) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+#endif
+    for (int i = 0; i < n; ++i) {
+        double f = 0;
+        for (int j = 0; j < n; ++j) {
+            const double dz = pos[3 * j + 2] - pos[3 * i + 2];
+            const double dx = pos[3 * j] - pos[3 * i], dy = pos[3 * j + 1] - pos[3 * i + 1];
+            const double dxy = sqrt(dx * dx + dy * dy);
+            if (dz > 0 && dxy < 10) {
+                const double ratio = P->prop_radius / (4.0 * dz);
+                const double alpha = P->dw_coeff[0] * ratio * ratio, beta = P->dw_coeff[1] * dz + P->dw_coeff[2];
+                f += -alpha * exp(-0.5 * (dxy / beta) * (dxy / beta));
+            }
+        }
+        out[i] = f;
+    }
+    return 0;
+}
+
 /* standalone batched DSLPIDControl.computeControl: arrays [n][3]/[n][4], pid [n][9] */
 int orc_pid(const OrcParams* P, double dt, int n, const double* pos, const double* quat, const double* vel,
             const double* tpos, const double* trpy, const double* tvel, const double* trates, double* pid, double* rpm,

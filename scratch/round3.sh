@@ -41,6 +41,22 @@ mask)
     timeout 200 python bench.py --steps $k --warmup 5 --split $c --cu-mask --no-cpu-baseline --no-second-leg 2>gpurun_out/r03_bench_rollout${k}_split${c}_cumask.err | tail -1 > gpurun_out/r03_bench_rollout${k}_split${c}_cumask.json
     show "rollout$k split $c cu-mask" gpurun_out/r03_bench_rollout${k}_split${c}_cumask.json
   done; done ;;
+swarmtests)
+  timeout 900 python -m pytest tests/test_gpu_surface.py -m gpu -q -x -k "swarm or world or stale or hipgraph" > gpurun_out/pytest_r03_swarm.log 2>&1; echo "pytest swarm rc $?"; grep -E "^(FAILED|ERROR)|Error|assert" gpurun_out/pytest_r03_swarm.log | head -20; tail -3 gpurun_out/pytest_r03_swarm.log | cut -c1-300 ;;
+swarm)
+  for cfg in "10.0 1" "10.5 4" "10.5 8" "10.5 16" "11.0 16"; do set -- $cfg
+    GPD_SWARM_CELL=$1 GPD_SWARM_REBIN=$2 timeout 300 python bench.py --workload swarm65536_ext_240hz --steps 240 --warmup 24 --no-cpu-baseline 2>gpurun_out/r03_swarm_c$1_m$2.err | tail -1 > gpurun_out/r03_swarm_c$1_m$2.json
+    show "swarm65536 cell $1 rebin $2" gpurun_out/r03_swarm_c$1_m$2.json
+  done ;;
+swarmdbg)
+  timeout 300 python scratch/debug_swarm3.py > gpurun_out/r03_debug_swarm3.txt 2>&1; echo "rc $?"; grep -v Warning gpurun_out/r03_debug_swarm3.txt | cut -c1-260 ;;
+swarmprof)
+  for cfg in "10.0 1" "10.5 8"; do set -- $cfg
+    (cd /tmp && export TMPDIR=/tmp && GPD_SWARM_CELL=$1 GPD_SWARM_REBIN=$2 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_swarm_c$1_m$2 -o p -- python $GRAFT_REPO_ROOT/bench.py --workload swarm65536_ext_240hz --steps 256 --warmup 64 --min-time 0.05 --no-cpu-baseline > /dev/null 2>&1)
+    f=$(find gpurun_out/prof_swarm_c$1_m$2 -name "*kernel_stats.csv" | head -1); echo "== cell $1 rebin $2: $f"; head -12 $f | cut -c1-200
+  done ;;
+swarm1m)
+  timeout 600 python bench.py --workload swarm1m_ext_240hz --steps 256 --warmup 16 --no-cpu-baseline 2>gpurun_out/r03_bench_swarm1m.err | tail -1 > gpurun_out/r03_bench_swarm1m_ext_240hz.json; show swarm1m gpurun_out/r03_bench_swarm1m_ext_240hz.json ;;
 configs)
   for w in hover4096_240hz hover65536_ext_240hz hover65536_240hz_history hover65536_30hz_history; do
     timeout 400 python bench.py --workload $w 2>gpurun_out/r03_bench_$w.err | tail -1 > gpurun_out/r03_bench_$w.json; show $w gpurun_out/r03_bench_$w.json

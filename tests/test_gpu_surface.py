@@ -322,7 +322,9 @@ def test_swarm_downwash_is_order_independent_and_matches_the_workgroup_path(gpu_
     # of equal cells): same forces, and `order` stays a permutation
     for _ in range(3):
         assert torch.equal(a.downwash(), fa)
-        assert torch.equal(torch.sort(a._order.long()).values, torch.arange(N, device=gpu_device))
+        # (the rows of the packed position array: the N drones + the rank's meta row)
+        assert torch.equal(torch.sort(a._order.long()).values, torch.arange(N + 1, device=gpu_device))
+    assert torch.equal(a.downwash_oneshot(), fa)              # ... and the C-ABI's one-call entry, gpd_downwash_global
     v = VectorCtrlAviary(1, N, initial_xyzs=xyz, physics=Physics.PYB_DW, ctrl_freq=240, device=gpu_device)
     rpm = torch.full((N, 4), float(a.HOVER_RPM), device=gpu_device)
     for _ in range(5):
@@ -409,3 +411,119 @@ def test_swarm_downwash_outside_the_grid_box(gpu_device):
     ref = orc.downwash_force_all()[0]
     np.testing.assert_allclose(f, ref, rtol=3e-3, atol=1e-7)
     assert (np.abs(ref) > 1e-4).mean() > 0.1                # (only the lower layer feels a wake, and only under a close neighbour)
+
+
+def _layered_scene(rng, N, jitter=0.3):
+    """12 layers 1 m apart, a 4 m lattice per layer with jitter, the lattices aligned (drones DO fly in each other's wake)"""
+    sites = np.array([(x, y) for x in np.arange(-28, 29, 4.0) for y in np.arange(-18, 19, 4.0)])     # 15 x 10
+    idx = rng.permutation(len(sites) * 12)[:N]
+    layer, site = idx // len(sites), idx % len(sites)
+    xyz = np.concatenate([sites[site] + rng.uniform(-jitter, jitter, size=(N, 2)), (1.0 + 1.0 * layer)[:, None]], axis=1)
+    return xyz, rng.uniform(-0.05, 0.05, size=(N, 3))
+
+
+@pytest.mark.parametrize("W", [2, 3, 8])
+def test_one_world_shared_by_several_ranks_is_bitwise_the_single_rank_world(gpu_device, W):
+    """ONE world sharded across ranks.  Rank r owns a block of drones, steps them, the ranks
+    all-gather their positions (here: the in-process exchange of `LocalSwarmGroup`, W ranks on one device), every rank bins
+    all positions and evaluates the downwash of its own drones.  The force sums are 64-bit fixed point, hence the demand:
+    the sharded world follows the single-rank trajectory BIT FOR BIT -- state vectors and forces, every step, with every
+    add-on term and the ground plane on, blocks of unequal size (N not a multiple of W), two sub-steps per control step,
+    and different re-binning schedules on the two sides."""
+    from gym_pybullet_drones_amd.envs import LocalSwarmGroup, SwarmAviary, swarm_partition
+    from gym_pybullet_drones_amd.utils.enums import Physics
+    rng = np.random.default_rng(100 + W)
+    N = 1501
+    xyz, rpy = _layered_scene(rng, N)
+    kw = dict(initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.PYB_GND_DRAG_DW, pyb_freq=240, ctrl_freq=120, device=gpu_device)
+    one = SwarmAviary(N, rebin_every=1, **kw)
+    grp = LocalSwarmGroup(N, W, rebin_every=5, **kw)
+    per, slab, counts = swarm_partition(N, W)
+    assert [e.NUM_DRONES for e in grp.ranks] == counts and sum(counts) == N and len(set(counts)) > 1
+    v1, _ = one.reset()
+    vw = grp.reset()
+    assert torch.equal(v1, vw) and torch.equal(one.dw_force[:N], grp.forces())
+    assert float(one.dw_force[:N].abs().max()) > 1e-3
+    for k in range(12):
+        rpm = torch.as_tensor((one.HOVER_RPM * (1 + 0.05 * rng.uniform(-1, 1, size=(N, 4)))).astype(np.float32), device=gpu_device)
+        v1, *_ = one.step(rpm)
+        vw = grp.step(rpm)
+        assert torch.equal(v1, vw), k
+        assert torch.equal(one.dw_force[:N], grp.forces()), k
+    # every rank holds every drone's position after the exchange, and only its own drones' forces
+    for e in grp.ranks:
+        assert torch.equal(e.pos4[:, :3].isfinite().all(dim=1).sum(), torch.tensor(N, device=gpu_device))
+
+
+def test_stale_cell_order_stays_exact_when_drones_outrun_the_skin(gpu_device):
+    """Between two binnings the force kernel searches the STALE cell order with a radius that follows the largest displacement
+    since the binning (R = ceil((10 m + 2 dmax) / cell); beyond R = 3 a group sweeps every drone).  Drones given lateral
+    velocities of up to 40 m/s (and a few at 600 m/s) cross several 10 m cells within the 30 sub-steps of this test while one
+    side never re-bins: forces and trajectories stay those of the side that re-bins before every force evaluation, bit for
+    bit -- and those of the float64 all-pairs loop."""
+    from conftest import urdf
+    from gym_pybullet_drones_amd.envs import SwarmAviary
+    from gym_pybullet_drones_amd.utils.enums import Physics
+    from oracle import c_oracle
+    rng = np.random.default_rng(77)
+    N = 1200
+    xyz, rpy = _layered_scene(rng, N)
+    kw = dict(initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.PYB_DW, device=gpu_device, pyb_like=False, cell=10.0)
+    fresh, stale = SwarmAviary(N, rebin_every=1, **kw), SwarmAviary(N, rebin_every=10 ** 6, **kw)
+    vel = rng.uniform(-40, 40, size=(N, 2))
+    vel[:5] = rng.uniform(-600, 600, size=(5, 2))
+    for e in (fresh, stale):
+        e.reset()
+        kin = e.core.kin[:, :N].clone()
+        kin[7:9] = torch.as_tensor(vel.T, dtype=torch.float32, device=gpu_device)
+        e.core.set_state(kin=kin)
+    rpm = torch.full((N, 4), float(fresh.HOVER_RPM), device=gpu_device)
+    for k in range(30):
+        a, *_ = fresh.step(rpm)
+        b, *_ = stale.step(rpm)
+        assert torch.equal(a, b), k
+        assert torch.equal(fresh.dw_force, stale.dw_force), k
+        if k in (0, 9, 29):
+            ref = c_oracle.downwash_all_pairs(urdf("cf2x"), stale.core.kin[0:3, :N].t().cpu().numpy().astype(np.float64))
+            np.testing.assert_allclose(stale.dw_force[:N].cpu().numpy().astype(np.float64), ref, rtol=3e-3, atol=1e-7)
+    assert stale._since_bin == 30 and fresh._since_bin == 0
+    moved = (stale.core.kin[0:2, :N].t().cpu().numpy() - xyz[:, :2])
+    assert np.abs(moved).max() > 30.0                       # several cells
+
+
+@pytest.mark.parametrize("rebin", [3, 16])
+def test_swarm_steps_captured_in_a_hipgraph_replay_like_eager_steps(gpu_device, rebin):
+    """A captured hipGraph of swarm steps bakes in WHICH sub-steps re-bin; replayed after eager calls that re-binned on a
+    schedule of their own (a reset between two replays), it must still follow the eager trajectory bit for bit: `order` is one
+    buffer that always belongs to the latest binning, whatever ran in between."""
+    from gym_pybullet_drones_amd.envs import SwarmAviary
+    from gym_pybullet_drones_amd.utils.enums import Physics
+    rng = np.random.default_rng(5)
+    N = 900
+    xyz, rpy = _layered_scene(rng, N)
+    kw = dict(initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.PYB_GND_DRAG_DW, device=gpu_device, rebin_every=rebin)
+    a, b = SwarmAviary(N, **kw), SwarmAviary(N, **kw)
+    rpm = torch.as_tensor((a.HOVER_RPM * (1 + 0.02 * rng.uniform(-1, 1, size=(20, N, 4)))).astype(np.float32), device=gpu_device)
+    for e in (a, b):
+        e.reset()
+        for k in range(5):
+            e.step(rpm[k])
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    stream = torch.cuda.Stream(gpu_device)
+    stream.wait_stream(torch.cuda.current_stream(gpu_device))
+    with torch.cuda.stream(stream):
+        with torch.cuda.graph(g, stream=stream):
+            for k in range(20):
+                vb, *_ = b.step(rpm[k])
+    torch.cuda.current_stream(gpu_device).wait_stream(stream)
+    for rep in range(3):
+        a.reset(); b.reset()                       # (eager: re-bins, out of step with the schedule the graph has baked in)
+        if rep == 2:
+            a.step(rpm[0]); b.step(rpm[0])         # ... and an eager step, so that the two sides' host counters differ from capture time
+        for k in range(20):
+            va, *_ = a.step(rpm[k])
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(va, vb) and torch.equal(a.core.kin, b.core.kin), rep
+        assert torch.equal(a.dw_force, b.dw_force), rep
