@@ -57,7 +57,8 @@ class GpdSwarm(ctypes.Structure):
                 ("pos4", ctypes.c_void_p), ("bin_pos", ctypes.c_void_p), ("cell_count", ctypes.c_void_p),
                 ("cell_start", ctypes.c_void_p), ("order", ctypes.c_void_p), ("visit", ctypes.c_void_p), ("visit_out", ctypes.c_void_p),
                 ("slot_key", ctypes.c_void_p), ("dw_force", ctypes.c_void_p), ("slot_of", ctypes.c_void_p),
-                ("pos_sorted", ctypes.c_void_p)]
+                ("pos_sorted", ctypes.c_void_p), ("pair_list", ctypes.c_void_p), ("pair_nb", ctypes.c_void_p),
+                ("list_ok", ctypes.c_void_p), ("list_cap", ctypes.c_int32), ("list_delta", ctypes.c_float)]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -121,7 +122,7 @@ _SIGNATURES = {
                                       ctypes.POINTER(GpdSwarm), _P, _P, _P, _P]),
     "gpd_swarm_pack": (ctypes.c_int, [ctypes.POINTER(GpdState), ctypes.POINTER(GpdSwarm), _P, _P, _P]),
     "gpd_swarm_bin": (ctypes.c_int, [ctypes.POINTER(GpdSwarm), _P]),
-    "gpd_swarm_forces": (ctypes.c_int, [ctypes.POINTER(GpdParams), ctypes.POINTER(GpdSwarm), _P]),
+    "gpd_swarm_forces": (ctypes.c_int, [ctypes.POINTER(GpdParams), ctypes.POINTER(GpdSwarm), ctypes.c_int32, _P]),
     "gpd_reset": (ctypes.c_int, [ctypes.POINTER(GpdState), _P, ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_int32,
                                  ctypes.c_int32, _P, _P]),
     "gpd_pid": (ctypes.c_int, [ctypes.POINTER(GpdParams), _P, ctypes.c_int64, ctypes.c_float, _P, _P, _P, _P, _P, _P,

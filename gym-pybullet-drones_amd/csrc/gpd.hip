@@ -2083,6 +2083,7 @@ struct DwBinOut {
     int* slot_key;         // [n] sort key of every sorted slot
     int* slot_of;          // [n] or NULL: row -> sorted slot (rows without a finite position: -1)
     int* visit_out;        // [n] or NULL: a second copy of `order`, for the NEXT binning to visit the rows in
+    int* list_ok;          // [ceil(n / 64)] or NULL: the groups' wake lists belong to the previous binning: all back to 0
     float4* bin_pos;       // [n] x, y, z of every row at this binning
     float* pos4_w;         // pos4 as floats: the w of every rank's meta rows (the last meta_rows of its slab) goes back to 0
     int slab, world, meta_rows;
@@ -2123,6 +2124,7 @@ __global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const DwPos src, in
     if (B.pos4_w && blockIdx.x == 0)                       // every rank bins on the same sub-steps: all displacements restart
         for (int k = threadIdx.x; k < B.world * B.meta_rows; k += kBlock)
             B.pos4_w[(static_cast<size_t>(k / B.meta_rows + 1) * B.slab - B.meta_rows + k % B.meta_rows) * 4 + 3] = 0.0f;
+    if (B.list_ok && i < (n + 63) / 64) B.list_ok[i] = 0;
     int c = -1 - lane, d = 0;
     float x = 0.0f, y = 0.0f, z = 0.0f;
     if (i < n) {
@@ -2216,7 +2218,25 @@ struct DwWorld {
     int slab, world, meta_rows;
     float cell;
 };
-__global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, const DwGrid G, const DwWorld Wd,
+// Wake lists (GpdSwarm): what survives phase A changes little from one sub-step to the next -- drones move centimetres, the
+// model's reach is metres.  The force launch right after a binning (MODE 1, "build") runs phase A with a margin -- a pair is
+// kept if it COULD pass the exact tests once both drones have moved up to `delta` in any direction -- and writes every batch it
+// evaluates to a per-wave list in HBM (the queue entries: 6 bits lane, 10 bits candidate slot of the tile; tiles are
+// reproducible: same stale `start` / `order`, same runs).  The launches until the next binning (MODE 2, "replay") skip phases A
+// and Q: load the tile (current positions), read the batches back, evaluate -- the same exact tests and integer sums.  Valid
+// while no drone is further than delta from where it was binned (dmax, the quantity the search radius follows; delta is what
+// keeps R = 1: just under half the skin cell - 10 m) and the group's list did not overflow; otherwise the launch sweeps as if
+// there were no lists.  MODE 0: no lists (gpd_downwash_global, or none allocated).
+constexpr int kDwMaxTiles = 16;                            // per row segment sequence of a group; more: no list for the group
+struct DwLists {
+    unsigned short* list;  // [groups][4 waves][cap * 64] queue entries, batch-major; 0xffff: no pair in this lane of the batch
+    unsigned short* nb;    // [groups][4 waves][kDwMaxTiles] batches per tile
+    int* ok;               // [groups] 1: the group's list is complete for the current binning
+    int cap;               // batches per wave
+    float delta;           // the displacement the lists allow for
+};
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, const DwGrid G, const DwWorld Wd, const DwLists Ls,
                                                            const int* __restrict__ start, const int* __restrict__ order,
                                                            const float4* __restrict__ sorted, float* __restrict__ dw_out,
                                                            int* __restrict__ cursor) {
@@ -2250,19 +2270,25 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
     const int c_first = key_at(base) / nz, c_last = key_at(min(base + 63, sorted_n - 1)) / nz;
     // search radius in cells
     int R = 1;
+    float d2 = 0.0f;                                       // dmax^2
     if (Wd.meta) {
-        // dmax^2: the largest of the step kernel's per-workgroup maxima (one meta row each, every rank's)
-        float d2 = 0.0f;
+        // the largest of the step kernel's per-workgroup maxima (one meta row each, every rank's)
         const int tot = Wd.world * Wd.meta_rows;
-        for (int k = threadIdx.x; k < tot; k += kBlock)
-            d2 = fmaxf(d2, Wd.meta[static_cast<size_t>(k / Wd.meta_rows + 1) * Wd.slab - Wd.meta_rows + k % Wd.meta_rows].w);
+        auto meta_w = [&](int k) { return Wd.meta[static_cast<size_t>(k / Wd.meta_rows + 1) * Wd.slab - Wd.meta_rows + k % Wd.meta_rows].w; };
+        if (tot <= 1024) {                                 // few: every wave reads them all (no LDS round, no barrier)
+            for (int k = lane; k < tot; k += 64) d2 = fmaxf(d2, meta_w(k));
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, off));
-        float* const red = reinterpret_cast<float*>(pre);      // (free until the first segment)
-        if (lane == 0) red[wave] = d2;
-        __syncthreads();
-        d2 = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        __syncthreads();
+            for (int off = 32; off > 0; off >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, off));
+        } else {
+            for (int k = threadIdx.x; k < tot; k += kBlock) d2 = fmaxf(d2, meta_w(k));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, off));
+            float* const red = reinterpret_cast<float*>(pre);      // (free until the first segment)
+            if (lane == 0) red[wave] = d2;
+            __syncthreads();
+            d2 = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            __syncthreads();
+        }
         if (d2 > 0.0f) {                                   // (rounded up: a wider search is still exact, a narrower one is not)
             const float reach = 10.0f + 2.0002f * sqrtf(d2) + 2.0e-6f;
             const float cells = ceilf(reach / Wd.cell * 1.000001f);
@@ -2270,6 +2296,14 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
         }
         R = __builtin_amdgcn_readfirstlane(R);
     }
+    // replay this group's wake list?  (uniform for the workgroup)
+    const bool replay = MODE == 2 && R == 1 && d2 <= Ls.delta * Ls.delta && Ls.ok[blockIdx.x] != 0;
+    unsigned short* const my_list = MODE ? Ls.list + (static_cast<size_t>(blockIdx.x) * (kBlock / 64) + wave) * Ls.cap * 64 : nullptr;
+    unsigned short* const my_nb = MODE ? Ls.nb + (static_cast<size_t>(blockIdx.x) * (kBlock / 64) + wave) * kDwMaxTiles : nullptr;
+    int lb = 0, tcount = 0;                                // batches recorded / replayed so far; tiles so far
+    bool rec_ok = true;                                    // (build) the list is complete so far
+    const float m2 = MODE == 1 ? 2.0f * Ls.delta : 0.0f;   // (build) what two drones can have closed in on each other
+    const float c2 = MODE == 1 ? cut * fabsf(P.dw_coeff[1]) * m2 : 0.0f;      // ... and what that adds to sqrt(80.02) |beta|
     const bool sweep_all = R > kDwMaxR;                    // the group's candidates: every sorted drone, one run
     const int nrows = sweep_all ? 0 : min(2 * R + 1, ny);
     my_sums[lane] = 0ull;                                  // sum of contributions in units of 2^-30 N: order-independent
@@ -2279,8 +2313,28 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
         const int cxa = cs - cy * nx, w = ce - cs + 1 + 2 * R;     // columns cxa - R .. cxb + R, periodic
         const bool active = own && my_cell >= cs && my_cell <= ce;
         const float mez = active ? me.z : 3.0e38f;         // (switched off: nothing is above it)
-        __syncthreads();                                   // (the previous segment's tiles are done with run0 / pre)
+        const bool fast = R == 1 && !sweep_all;            // the usual case: three rows, six runs, all in registers, no barrier
+        int run0r[6], prer[7];
         const int nruns = sweep_all ? 1 : 2 * nrows;
+        if (fast) {
+            prer[0] = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int row = ((cy + r - 1 + ny) % ny) * nx;
+                int a0, a1, b1c;                           // run A: cells a0 .. a1; run B (the wrapped part): cells 0 .. b1c, or empty
+                if (w >= nx) { a0 = 0; a1 = nx - 1; b1c = -1; }
+                else {
+                    const int a = (cxa - 1 + nx) % nx;
+                    a0 = a; a1 = min(a + w - 1, nx - 1);
+                    b1c = a + w - 1 - nx;                  // (< 0: no wrap)
+                }
+                run0r[2 * r] = start[(row + a0) * nz];
+                prer[2 * r + 1] = prer[2 * r] + (start[(row + a1 + 1) * nz] - run0r[2 * r]);
+                run0r[2 * r + 1] = start[row * nz];
+                prer[2 * r + 2] = prer[2 * r + 1] + (b1c >= 0 ? start[(row + b1c + 1) * nz] - run0r[2 * r + 1] : 0);
+            }
+        } else {
+        __syncthreads();                                   // (the previous segment's tiles are done with run0 / pre)
         if (static_cast<int>(threadIdx.x) < nruns) {       // run q: row q >> 1, part A (up to the end of the row) or B (the wrapped rest)
             const int q = threadIdx.x;
             int first = 0, len = sorted_n;
@@ -2307,12 +2361,18 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
             for (int q = 0; q < nruns; ++q) pre[q + 1] += pre[q];
         }
         __syncthreads();
-        const int total = pre[nruns];
+        }
+        const int total = fast ? prer[6] : pre[nruns];
         const fp2 mx = splat(me.x), my = splat(me.y), mz = splat(mez);
         int pending = 0;                                   // pairs in this wave's queue (wave-uniform)
         // one queued pair: the exact tests and the model (:798-808), added to the drone's sum
         // (called by ALL lanes -- ds_bpermute reads nothing from a lane that is masked off -- with `valid` false where there is no pair)
         auto evaluate = [&](unsigned e, bool valid) {
+            if (MODE == 1) {                               // build: the batch goes to the list as it is evaluated
+                if (rec_ok && lb < Ls.cap) my_list[static_cast<size_t>(lb) * 64 + lane] = static_cast<unsigned short>(valid ? e : 0xffffu);
+                else rec_ok = false;
+                ++lb;
+            }
             const int dl = static_cast<int>(e >> 10), ci = static_cast<int>(e & 1023u);
             const float px = __shfl(me.x, dl), py = __shfl(me.y, dl), pz = __shfl(me.z, dl);
             const float dz = tz[ci] - pz;
@@ -2339,21 +2399,40 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
                 }
             }
         };
-        for (int v0 = 0; v0 < total; v0 += kDwTile) {
-            const int cnt = min(kDwTile, total - v0);
+        // (a tile holds kDwTile - 1 candidates: the entry "lane 63, slot 1023" never occurs and 0xffff can mark an empty lane)
+        for (int v0 = 0; v0 < total; v0 += kDwTile - 1) {
+            const int cnt = min(kDwTile - 1, total - v0);
             const int chunks = (cnt + kDwChunk - 1) / kDwChunk;
             __syncthreads();
             for (int j = threadIdx.x; j < chunks * kDwChunk; j += kBlock) {
                 float4 o = make_float4(0.0f, 0.0f, -3.0e38f, 0.0f);        // (padding of the last chunk: below everything)
                 if (j < cnt) {
                     const int v = v0 + j;                  // position in the concatenated list -> run q, element src
-                    int src = run0[0] + v;
-                    for (int q = 1; q < nruns; ++q) src = (v >= pre[q]) ? run0[q] + (v - pre[q]) : src;
+                    int src;
+                    if (fast) {
+                        src = run0r[0] + v;
+#pragma unroll
+                        for (int q = 1; q < 6; ++q) src = (v >= prer[q]) ? run0r[q] + (v - prer[q]) : src;
+                    } else {
+                        src = run0[0] + v;
+                        for (int q = 1; q < nruns; ++q) src = (v >= pre[q]) ? run0[q] + (v - pre[q]) : src;
+                    }
                     o = pos_at(src);
                 }
                 tx[j] = o.x; ty[j] = o.y; tz[j] = o.z;
             }
             __syncthreads();
+            if (replay) {                                              // the batches this wave evaluated on this tile at the build
+                const int nbt = tcount < kDwMaxTiles ? my_nb[tcount] : 0;
+                for (int b = 0; b < nbt; ++b) {
+                    const unsigned e = my_list[static_cast<size_t>(lb + b) * 64 + lane];
+                    evaluate(e, e != 0xffffu);
+                }
+                lb += nbt;
+                ++tcount;
+                continue;
+            }
+            const int tile_b0 = lb;
             for (int ch = wave; ch < chunks; ch += kBlock / 64) {       // this wave's share of the candidates
                 const int j0 = ch * kDwChunk;
                 uint32_t mask = 0;                                     // candidate j0 + j of the chunk -> bit 31 - j
@@ -2362,12 +2441,22 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
                     const fp2 ox = *reinterpret_cast<const fp2*>(&tx[j0 + j]), oy = *reinterpret_cast<const fp2*>(&ty[j0 + j]),
                               oz = *reinterpret_cast<const fp2*>(&tz[j0 + j]);
                     const fp2 ddx = ox - mx, ddy = oy - my, below = mz - oz;       // below < 0: the candidate is above
-                    const fp2 d2 = fma2(ddy, ddy, ddx * ddx);
+                    const fp2 dd2 = fma2(ddy, ddy, ddx * ddx);
                     const fp2 bs = fma2(b1, below, b0);                            // sqrt(80.02) beta(dz)
-                    const fp2 lim = bs * bs;
-                    const fp2 q = d2 - fp2{fminf(lim.x, 100.01f), fminf(lim.y, 100.01f)};
-                    mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(q.x) & __float_as_uint(below.x), 31);
-                    mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(q.y) & __float_as_uint(below.y), 31);
+                    if (MODE == 1) {
+                        // with the margin: the candidate may come up to m2 closer in height and in the plane, |beta| may grow by
+                        // DW2 m2:  dxy < min(10, sqrt(80.02) (|beta| + DW2 m2)) + m2  and  dz > -m2
+                        const float tx_ = fminf(fabsf(bs.x) + c2, 10.0005f) + m2, ty_ = fminf(fabsf(bs.y) + c2, 10.0005f) + m2;
+                        const fp2 q = dd2 - fp2{tx_ * tx_, ty_ * ty_};
+                        const fp2 bm = below - splat(m2);
+                        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(q.x) & __float_as_uint(bm.x), 31);
+                        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(q.y) & __float_as_uint(bm.y), 31);
+                    } else {
+                        const fp2 lim = bs * bs;
+                        const fp2 q = dd2 - fp2{fminf(lim.x, 100.01f), fminf(lim.y, 100.01f)};
+                        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(q.x) & __float_as_uint(below.x), 31);
+                        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(q.y) & __float_as_uint(below.y), 31);
+                    }
                 }
                 const int mine = __builtin_popcount(mask);
                 const int upto = wave_inclusive_scan(mine);
@@ -2394,8 +2483,20 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
                 for (int b = 0; b < nb; ++b) { const int k = b + lane * nb; evaluate(k < pending ? my_queue[k] : 0u, k < pending); }
             }
             pending = 0;
+            if (MODE == 1) {
+                if (tcount < kDwMaxTiles) { if (lane == 0) my_nb[tcount] = static_cast<unsigned short>(lb - tile_b0); }
+                else rec_ok = false;
+            }
+            ++tcount;
         }
         cs = ce + 1;
+    }
+    if (MODE == 1) {                                       // the group's list counts only if all four waves completed theirs
+        int* const okf = reinterpret_cast<int*>(pre);
+        __syncthreads();
+        if (lane == 0) okf[wave] = rec_ok ? 1 : 0;
+        __syncthreads();
+        if (threadIdx.x == 0) Ls.ok[blockIdx.x] = okf[0] & okf[1] & okf[2] & okf[3];
     }
     __syncthreads();
     if (wave == 0 && own) {                                // add up the four waves' shares
@@ -2516,18 +2617,45 @@ __global__ __launch_bounds__(kBlock) void gpd_swarm_step_kernel(const GpdParams 
     env_step<false, true, false, 4, ACT, true>(P, C, flags, 1, L, act, tgx, tgy, tgz, false, S.kin, ip[0], ip[1], ip[2], ip[3], ip[4],
                                                ip[5], ip[6], nullptr, nullptr, c, out);
     swarm_tail(O, L.active, L.n, c.k.px, c.k.py, c.k.pz);
-    if (!L.active) return;
-    store_obs12(obs12, L.n, out.o[0], out.o[1], out.o[2], out.o[3], out.o[4], out.o[5], out.o[6], out.o[7], out.o[8],
-                out.o[9], out.o[10], out.o[11]);
-    if (O.vec_out) {                                       // BaseAviary._getDroneStateVector (envs/BaseAviary.py:541-561)
-        float4* w = reinterpret_cast<float4*>(O.vec_out + static_cast<size_t>(L.n) * 20);
-        const Kin& k = c.k;
-        w[0] = make_float4(k.px, k.py, k.pz, k.qx);
-        w[1] = make_float4(k.qy, k.qz, k.qw, out.o[3]);
-        w[2] = make_float4(out.o[4], out.o[5], k.vx, k.vy);
-        w[3] = make_float4(k.vz, out.o[9], out.o[10], out.o[11]);
-        w[4] = make_float4(c.l0, c.l1, c.l2, c.l3);
+    // observation rows (48 B) and state vectors (80 B, BaseAviary._getDroneStateVector, envs/BaseAviary.py:541-561): a lane's row
+    // is a strided piece of cache lines, a wave's 64 rows are one contiguous block -- transposed through LDS and stored as
+    // 1 KiB bursts (the wave's own LDS instructions execute in order: no barrier between its writes and its reads)
+    __shared__ __attribute__((aligned(16))) float4 sh_rows[kBlock * 5];
+    const int wave0 = threadIdx.x & ~63, lane = threadIdx.x & 63;
+    const uint32_t n0 = n_raw - static_cast<uint32_t>(lane);               // first drone of this wave
+    const uint32_t rows = n0 < N ? (N - n0 < 64u ? N - n0 : 64u) : 0u;
+    const Kin& k = c.k;
+    auto burst = [&](float* dst_rows, int F4) {            // F4 float4 per row; the wave's rows start at dst_rows
+        float4* patch = sh_rows + wave0 * 5;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < F4; ++j) {
+            const int idx = j * 64 + lane;
+            const float4 v = patch[idx];
+            if (static_cast<uint32_t>(idx) < rows * F4) {
+                f4v wv = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(wv, reinterpret_cast<f4v*>(dst_rows) + idx);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    {
+        float4* mine = sh_rows + wave0 * 5 + lane * 3;
+        mine[0] = make_float4(out.o[0], out.o[1], out.o[2], out.o[3]);
+        mine[1] = make_float4(out.o[4], out.o[5], out.o[6], out.o[7]);
+        mine[2] = make_float4(out.o[8], out.o[9], out.o[10], out.o[11]);
+        burst(obs12 + static_cast<size_t>(n0) * 12, 3);
     }
+    if (O.vec_out) {
+        float4* mine = sh_rows + wave0 * 5 + lane * 5;
+        mine[0] = make_float4(k.px, k.py, k.pz, k.qx);
+        mine[1] = make_float4(k.qy, k.qz, k.qw, out.o[3]);
+        mine[2] = make_float4(out.o[4], out.o[5], k.vx, k.vy);
+        mine[3] = make_float4(k.vz, out.o[9], out.o[10], out.o[11]);
+        mine[4] = make_float4(c.l0, c.l1, c.l2, c.l3);
+        burst(O.vec_out + static_cast<size_t>(n0) * 20, 5);
+    }
+    if (!L.active) return;
     store_carry<false>(S, L, c);
 }
 
@@ -3019,7 +3147,7 @@ int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, i
                            nullptr, nullptr);
     }
     int32_t* const cursors = cell_count + keys + 1;       // second half of cell_count: the scatter's per-key cursors
-    const DwBinOut B{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, n};
+    const DwBinOut B{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, n};
     if (keys <= kDwScanMax) {
         hipLaunchKernelGGL(dwg_scatter_kernel<true>, grid, dim3(kBlock), 0, st, src, n, G, visit_order, cell_count, cursors,
                            cell_start, order, reinterpret_cast<float4*>(sorted_xyzc), dw_out, B);
@@ -3029,8 +3157,8 @@ int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, i
                            cell_start, order, reinterpret_cast<float4*>(sorted_xyzc), dw_out, B);
     }
     const DwWorld Wd{nullptr, nullptr, nullptr, 0, n, 0, 0, 0, cell};
-    hipLaunchKernelGGL(dwg_force_kernel, dim3(static_cast<unsigned>((n + 63) / 64)), dim3(kBlock), 0, st, *params, G, Wd, cell_start,
-                       order, reinterpret_cast<const float4*>(sorted_xyzc), dw_out, cell_count);
+    hipLaunchKernelGGL(dwg_force_kernel<0>, dim3(static_cast<unsigned>((n + 63) / 64)), dim3(kBlock), 0, st, *params, G, Wd, DwLists{},
+                       cell_start, order, reinterpret_cast<const float4*>(sorted_xyzc), dw_out, cell_count);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gpd_downwash_global launch");
     return 0;
@@ -3112,7 +3240,7 @@ int gpd_swarm_bin(const GpdSwarm* w, void* stream) {
     const DwPos src{nullptr, 0, reinterpret_cast<const float4*>(w->pos4)};
     hipLaunchKernelGGL(dwg_count_kernel<false>, grid, dim3(kBlock), 0, st, src, n, G, w->visit, w->cell_count, GpdState{}, nullptr, nullptr);
     int32_t* const cursors = w->cell_count + keys + 1;
-    const DwBinOut B{w->slot_key, w->slot_of, w->visit_out, reinterpret_cast<float4*>(w->bin_pos), w->pos4, w->slab, w->world_size, w->meta_rows, w->rank * w->slab, w->own_count};
+    const DwBinOut B{w->slot_key, w->slot_of, w->visit_out, w->list_ok, reinterpret_cast<float4*>(w->bin_pos), w->pos4, w->slab, w->world_size, w->meta_rows, w->rank * w->slab, w->own_count};
     float4* const srt = reinterpret_cast<float4*>(w->pos_sorted);
     if (keys <= kDwScanMax) {
         hipLaunchKernelGGL(dwg_scatter_kernel<true>, grid, dim3(kBlock), 0, st, src, n, G, w->visit, w->cell_count, cursors,
@@ -3127,15 +3255,23 @@ int gpd_swarm_bin(const GpdSwarm* w, void* stream) {
     return 0;
 }
 
-int gpd_swarm_forces(const GpdParams* params, const GpdSwarm* w, void* stream) {
+int gpd_swarm_forces(const GpdParams* params, const GpdSwarm* w, int32_t build_lists, void* stream) {
     if (!params) return fail(GPD_EINVAL, "gpd_swarm_forces: NULL params");
     if (int rc = swarm_args("gpd_swarm_forces", w, true)) return rc;
     if (!w->dw_force) return fail(GPD_EINVAL, "gpd_swarm_forces: NULL dw_force");
+    const bool lists = w->pair_list != nullptr;
+    if (lists && (!w->pair_nb || !w->list_ok || w->list_cap < 1 || !(w->list_delta >= 0.0f)))
+        return fail(GPD_EINVAL, "gpd_swarm_forces: pair_list needs pair_nb, list_ok, list_cap >= 1 and list_delta >= 0");
     const DwGrid G{1.0f / w->cell, w->x0, w->y0, w->nx, w->ny, w->z0, w->nz > 1 ? 1.0f / w->zbin : 0.0f, w->nz};
     const float4* const p4 = reinterpret_cast<const float4*>(w->pos4);
     const DwWorld Wd{w->pos_sorted ? nullptr : p4, w->slot_key, p4, w->rank * w->slab, w->own_count, w->slab, w->world_size, w->meta_rows, w->cell};
-    hipLaunchKernelGGL(dwg_force_kernel, dim3(static_cast<unsigned>((w->n_rows + 63) / 64)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                       *params, G, Wd, w->cell_start, w->order, reinterpret_cast<const float4*>(w->pos_sorted), w->dw_force, w->cell_count);
+    const DwLists Ls{w->pair_list, w->pair_nb, w->list_ok, w->list_cap, w->list_delta};
+    const dim3 grid(static_cast<unsigned>((w->n_rows + 63) / 64));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float4* const srt = reinterpret_cast<const float4*>(w->pos_sorted);
+    if (!lists) hipLaunchKernelGGL(dwg_force_kernel<0>, grid, dim3(kBlock), 0, st, *params, G, Wd, Ls, w->cell_start, w->order, srt, w->dw_force, w->cell_count);
+    else if (build_lists) hipLaunchKernelGGL(dwg_force_kernel<1>, grid, dim3(kBlock), 0, st, *params, G, Wd, Ls, w->cell_start, w->order, srt, w->dw_force, w->cell_count);
+    else hipLaunchKernelGGL(dwg_force_kernel<2>, grid, dim3(kBlock), 0, st, *params, G, Wd, Ls, w->cell_start, w->order, srt, w->dw_force, w->cell_count);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gpd_swarm_forces launch");
     return 0;

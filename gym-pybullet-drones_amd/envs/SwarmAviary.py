@@ -94,7 +94,8 @@ class SwarmAviary:
     def __init__(self, num_drones: int, drone_model: DroneModel = DroneModel.CF2X, initial_xyzs=None, initial_rpys=None,
                  physics: Physics = Physics.PYB_DW, pyb_freq: int = 240, ctrl_freq: int = 240, act="raw_rpm",
                  world_min=None, world_max=None, cell: float = 10.5, zbin: float = 1.0, nz: int = 1, device=None,
-                 pyb_like: bool = None, world_size: int = 1, rank: int = 0, exchange=None, rebin_every: int = None):
+                 pyb_like: bool = None, world_size: int = 1, rank: int = 0, exchange=None, rebin_every: int = None,
+                 wake_lists: bool = True, list_cap: int = 48):
         if pyb_freq % ctrl_freq != 0:
             raise ValueError("[ERROR] in SwarmAviary.__init__(), pyb_freq is not divisible by ctrl_freq.")
         if act not in ("raw_rpm", ActionType.RPM, ActionType.PID):
@@ -151,11 +152,13 @@ class SwarmAviary:
         self.z0 = float(xyz_all[:, 2].min() - self.zbin)
         self.nz = int(max(1, min(nz, 65536 // cells)))
         # How often the drones are re-binned.  Between two binnings the search radius is R = ceil((10 m + 2 dmax) / cell) cells
-        # (dmax: the largest lateral displacement since the binning), so the skin cell - 10 m buys sub-steps with R = 1:
-        # with no skin every sub-step re-bins (R = 1 always, the round-2 behaviour); otherwise every 8th by default -- 0.25 m of
-        # lateral travel in 1/30 s is 7.5 m/s, the airframe's top speed (MAX_SPEED_KMH = 30); faster drones widen the search
-        # for a few sub-steps, they never break it.
-        self.rebin_every = int(rebin_every) if rebin_every is not None else (1 if self.cell <= 10.0 else 8)
+        # (dmax: the largest displacement since the binning) and the wake lists hold while dmax <= list_delta = 0.49 skin, so the
+        # skin cell - 10 m buys cheap sub-steps: with no skin every sub-step re-bins (R = 1 always, no lists: the round-2
+        # behaviour); otherwise every 16th by default -- with the default 0.5 m skin a drone slower than 3.7 m/s stays inside
+        # list_delta for 1/15 s; faster ones make the launches sweep (and, beyond half the skin, widen the search) until the
+        # next binning, they never break anything.  Measured at 65 536 drones (profiles/r03_swarm_*): 51 us per sub-step with a
+        # binning every sub-step, 34.7 / 30.1 / 27.5 with one every 4th / 8th / 16th.
+        self.rebin_every = int(rebin_every) if rebin_every is not None else (1 if self.cell <= 10.0 else 16)
         if self.rebin_every < 1:
             raise ValueError("rebin_every must be >= 1")
         i32 = dict(dtype=torch.int32, device=dev)
@@ -175,6 +178,15 @@ class SwarmAviary:
         self.dw_force = torch.zeros(self.core.ld, dtype=torch.float32, device=dev)
         if self.flags & PHYS_DW:
             self.core._state.dw_force = self.dw_force.data_ptr()
+        # Wake lists: the pairs the force launch after a binning evaluates (with a margin of `list_delta` per drone), replayed by
+        # the launches until the next binning instead of sweeping all candidates.  Pointless without a skin (every sub-step bins).
+        groups = (self.n_rows + 63) // 64
+        self.list_delta = 0.49 * (self.cell - 10.0)
+        self.wake_lists = bool(wake_lists) and self.rebin_every > 1 and self.list_delta > 0
+        u16 = dict(dtype=torch.int16, device=dev)
+        self._pair_list = torch.zeros((groups, 4, int(list_cap) * 64), **u16) if self.wake_lists else None
+        self._pair_nb = torch.zeros((groups, 4, 16), **u16) if self.wake_lists else None
+        self._list_ok = torch.zeros(groups, **i32) if self.wake_lists else None
         self._sw = _native.GpdSwarm(n_rows=self.n_rows, slab=self.slab, world_size=self.WORLD_SIZE, rank=self.RANK, own_count=n,
                                     nx=self.nx, ny=self.ny, nz=self.nz, cell=self.cell, x0=self.x0, y0=self.y0, z0=self.z0,
                                     zbin=self.zbin, meta_rows=self.slab - self.per, pos4=self.pos4.data_ptr(), bin_pos=self._bin_pos.data_ptr(),
@@ -183,7 +195,11 @@ class SwarmAviary:
                                     slot_key=self._slot_key.data_ptr(),
                                     dw_force=self.dw_force.data_ptr(),
                                     slot_of=self._slot_of.data_ptr() if self._slot_of is not None else None,
-                                    pos_sorted=self._pos_sorted.data_ptr() if self._pos_sorted is not None else None)
+                                    pos_sorted=self._pos_sorted.data_ptr() if self._pos_sorted is not None else None,
+                                    pair_list=self._pair_list.data_ptr() if self.wake_lists else None,
+                                    pair_nb=self._pair_nb.data_ptr() if self.wake_lists else None,
+                                    list_ok=self._list_ok.data_ptr() if self.wake_lists else None,
+                                    list_cap=int(list_cap), list_delta=self.list_delta)
         self.step_counter = 0
         self._since_bin = 0                          # sub-steps since the last binning
         self._dw_version = -1                        # core.state_version the forces in dw_force were computed for
@@ -213,14 +229,16 @@ class SwarmAviary:
     def _forces(self):
         """(binning when one is due,) the downwash forces of this rank's drones for the positions in pos4"""
         c = self.core
+        binned = False
         with torch.cuda.device(self.device):
             if self._since_bin >= self.rebin_every:
+                binned = True
                 self._visit_in, self._visit_out = self._visit_out, self._visit_in      # the last binning's copy is this one's visit order
                 self._sw.visit = self._visit_in.data_ptr()
                 self._sw.visit_out = self._visit_out.data_ptr()
                 _native.check(c.lib.gpd_swarm_bin(ctypes.byref(self._sw), c._stream()), "gpd_swarm_bin")
                 self._since_bin = 0
-            _native.check(c.lib.gpd_swarm_forces(ctypes.byref(c._params), ctypes.byref(self._sw), c._stream()), "gpd_swarm_forces")
+            _native.check(c.lib.gpd_swarm_forces(ctypes.byref(c._params), ctypes.byref(self._sw), int(binned), c._stream()), "gpd_swarm_forces")
         self._dw_version = c.state_version           # (the forces belong to this state)
 
     def _check_vectors(self, vectors):

@@ -443,6 +443,16 @@ typedef struct GpdSwarm {
      * needs no exchange in row order) */
     int32_t* slot_of;      /* [n_rows] row -> sorted slot (-1: no finite position), written by gpd_swarm_bin */
     float* pos_sorted;     /* [n_rows][4] */
+    /* Wake lists (optional: pair_list NULL = none).  The force launch right after a binning (build_lists != 0) keeps every pair
+     * that could pass the model's tests once both drones have moved up to list_delta, and writes the pairs it evaluates to
+     * pair_list; the launches until the next binning read them back instead of sweeping all candidates -- as long as no drone is
+     * further than list_delta from where it was binned (otherwise they sweep as if there were no lists: still exact).
+     * list_delta: just under (cell - 10 m) / 2, e.g. 0.49 (cell - 10). */
+    uint16_t* pair_list;   /* [ceil(n_rows / 64)][4][list_cap * 64] */
+    uint16_t* pair_nb;     /* [ceil(n_rows / 64)][4][16] */
+    int32_t* list_ok;      /* [ceil(n_rows / 64)] */
+    int32_t list_cap;      /* batches of 64 pairs per wavefront (a group of 64 drones has four); a group that needs more sweeps */
+    float list_delta;
 } GpdSwarm;
 
 /* One physics sub-step of the rank's own_count drones (state / cfg as for gpd_step: drones_per_env = 1, num_envs = own_count,
@@ -460,8 +470,9 @@ int gpd_swarm_pack(const GpdState* state, const GpdSwarm* swarm, const float* ob
 /* Counting sort of ALL rows by grid cell from pos4 (rows with a non-finite position take no part): order, slot_key,
  * cell_start, bin_xy; every rank's dmax^2 (in this rank's copy of pos4) back to 0. */
 int gpd_swarm_bin(const GpdSwarm* swarm, void* stream);
-/* Downwash forces of the rank's drones for the positions in pos4 -> dw_force. */
-int gpd_swarm_forces(const GpdParams* params, const GpdSwarm* swarm, void* stream);
+/* Downwash forces of the rank's drones for the positions in pos4 -> dw_force.  build_lists: non-zero on the call that follows a
+ * gpd_swarm_bin (ignored without wake lists). */
+int gpd_swarm_forces(const GpdParams* params, const GpdSwarm* swarm, int32_t build_lists, void* stream);
 
 /*
  * Masked reset.  Replaces BaseAviary.reset/_housekeeping (envs/BaseAviary.py:220-255, 451-477)

@@ -42,7 +42,7 @@ mask)
     show "rollout$k split $c cu-mask" gpurun_out/r03_bench_rollout${k}_split${c}_cumask.json
   done; done ;;
 swarmtests)
-  timeout 900 python -m pytest tests/test_gpu_surface.py -m gpu -q -x -k "swarm or world or stale or hipgraph" > gpurun_out/pytest_r03_swarm.log 2>&1; echo "pytest swarm rc $?"; grep -E "^(FAILED|ERROR)|Error|assert" gpurun_out/pytest_r03_swarm.log | head -20; tail -3 gpurun_out/pytest_r03_swarm.log | cut -c1-300 ;;
+  timeout 900 python -m pytest tests/test_gpu_surface.py -m gpu -q -x -k "swarm or world or stale or hipgraph or wake" > gpurun_out/pytest_r03_swarm.log 2>&1; echo "pytest swarm rc $?"; grep -E "^(FAILED|ERROR)|Error|assert" gpurun_out/pytest_r03_swarm.log | head -20; tail -3 gpurun_out/pytest_r03_swarm.log | cut -c1-300 ;;
 swarm)
   for cfg in "10.0 1" "10.5 4" "10.5 8" "10.5 16" "11.0 16"; do set -- $cfg
     GPD_SWARM_CELL=$1 GPD_SWARM_REBIN=$2 timeout 300 python bench.py --workload swarm65536_ext_240hz --steps 240 --warmup 24 --no-cpu-baseline 2>gpurun_out/r03_swarm_c$1_m$2.err | tail -1 > gpurun_out/r03_swarm_c$1_m$2.json

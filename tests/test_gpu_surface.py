@@ -527,3 +527,39 @@ def test_swarm_steps_captured_in_a_hipgraph_replay_like_eager_steps(gpu_device, 
         torch.cuda.synchronize()
         assert torch.equal(va, vb) and torch.equal(a.core.kin, b.core.kin), rep
         assert torch.equal(a.dw_force, b.dw_force), rep
+
+
+@pytest.mark.parametrize("variant", ["lists", "overflowing lists", "outrun lists"])
+def test_wake_lists_replay_the_pairs_of_the_last_binning_exactly(gpu_device, variant):
+    """Between two binnings the force launches replay the pairs the launch after the binning evaluated (kept with a margin of
+    `list_delta` per drone) instead of sweeping all candidates.  Same forces and trajectories, bit for bit, as a twin that bins
+    before every force evaluation (no lists at all) -- also when most groups' lists overflow their capacity (those groups sweep),
+    and when drones move further than `list_delta` between two binnings (every group sweeps, with the radius of
+    `test_stale_cell_order_stays_exact_when_drones_outrun_the_skin`)."""
+    from gym_pybullet_drones_amd.envs import SwarmAviary
+    from gym_pybullet_drones_amd.utils.enums import Physics
+    rng = np.random.default_rng(31)
+    N = 1700
+    xyz, rpy = _layered_scene(rng, N)
+    kw = dict(initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.PYB_GND_DRAG_DW, device=gpu_device, cell=10.5)
+    ref = SwarmAviary(N, rebin_every=1, **kw)
+    env = SwarmAviary(N, rebin_every=12, list_cap=1 if variant == "overflowing lists" else 48, **kw)
+    assert env.wake_lists and not ref.wake_lists and 0.2 < env.list_delta < 0.25
+    for e in (ref, env):
+        e.reset()
+        if variant == "outrun lists":              # 6 m/s sideways: 0.245 m -- list_delta -- after ten sub-steps
+            kin = e.core.kin[:, :N].clone()
+            kin[7] = 6.0
+            e.core.set_state(kin=kin)
+    rpm = torch.as_tensor((ref.HOVER_RPM * (1 + 0.02 * rng.uniform(-1, 1, size=(N, 4)))).astype(np.float32), device=gpu_device)
+    for k in range(30):
+        a, *_ = ref.step(rpm)
+        b, *_ = env.step(rpm)
+        assert torch.equal(a, b), k
+        assert torch.equal(ref.dw_force, env.dw_force), k
+    ok = env._list_ok[:(N + 63) // 64].float().mean().item()
+    assert float(ref.dw_force[:N].abs().max()) > 1e-3
+    if variant == "lists":
+        assert ok == 1.0                            # every group replays
+    elif variant == "overflowing lists":
+        assert ok < 0.5                             # most groups evaluate more than one batch per wave: they sweep
