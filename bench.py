@@ -56,6 +56,8 @@ WORKLOADS = {
     "hover65536_30hz": dict(E=65536, D=1, phys=0, ctrl=30, act="rpm", task="hover"),
     "hover4096_240hz": dict(E=4096, D=1, phys=0, ctrl=240, act="rpm", task="hover"),
     "hover65536_ext_240hz": dict(E=65536, D=1, phys=7, ctrl=240, act="rpm", task="hover"),
+    # the headline with terminal observations kept (what VecEnvAdapter / GymVectorEnvAdapter need): the store-wave kernel
+    "hover65536_240hz_termobs": dict(E=65536, D=1, phys=0, ctrl=240, act="rpm", task="hover", term_obs=True),
     "stack8x8192_ext_240hz": dict(E=8192, D=8, phys=7, ctrl=240, act="rpm", task="multihover"),
     "multihover2x16384_240hz": dict(E=16384, D=2, phys=4, ctrl=240, act="rpm", task="multihover"),
     "hover65536_pid_240hz": dict(E=65536, D=1, phys=0, ctrl=240, act="pid", task="hover"),
@@ -123,7 +125,8 @@ def make_env(w, device, seed, E=None, world=1, rank=0, exchange=None):
     rpy = rng.uniform(-0.1, 0.1, size=(E, D, 3))
     env = VectorAviary(E, D, initial_xyzs=xyz, initial_rpys=rpy, physics=w["phys"], pyb_freq=240,
                        ctrl_freq=w["ctrl"], act=ActionType(w["act"]), task=w["task"], auto_reset=True,
-                       track_rpm=bool(w["phys"] & 2), full_obs=w.get("full_obs", False), device=device)
+                       track_rpm=bool(w["phys"] & 2), full_obs=w.get("full_obs", False), keep_terminal_obs=bool(w.get("term_obs")),
+                       device=device)
     if w.get("policy"):
         from gym_pybullet_drones_amd.policy import MlpPolicy
         hist = env.ACTION_BUFFER_SIZE * env.ACT_DIM if w.get("full_obs") else 0
@@ -565,7 +568,7 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
     kernel = "gpd_rollout_policy_kernel" if (mode == "rollout" and getattr(envs[0], "bench_policy", None) is not None) else \
         "dwg_force_kernel (+ gpd_swarm_step_kernel; a binning every few sub-steps)" if hasattr(envs[0], "pos4") else \
         "gpd_step_kernel" if mode != "rollout" else \
-        ("gpd_rollout1_kernel" if core.D & (core.D - 1) == 0 and core.D <= 64 else "gpd_rollout_kernel")
+        ("gpd_rollout1_kernel" if core.D & (core.D - 1) == 0 and core.D <= 64 and core.term_obs12 is None else "gpd_rollout_kernel")
     return {
         "K": K, "W": W, "repeats": repeats, "timed_steps": timed_steps, "ev_s": ev_s, "wall_s": wall_s,
         "value": n_total * core.S * timed_steps / ev_s, "value_wall": n_total * core.S * timed_steps / wall_s,

@@ -57,9 +57,12 @@ swarmprof)
   done ;;
 swarm1m)
   timeout 600 python bench.py --workload swarm1m_ext_240hz --steps 256 --warmup 16 --no-cpu-baseline 2>gpurun_out/r03_bench_swarm1m.err | tail -1 > gpurun_out/r03_bench_swarm1m_ext_240hz.json; show swarm1m gpurun_out/r03_bench_swarm1m_ext_240hz.json ;;
+profile) timeout 1500 python scratch/profile_r03.py quick > gpurun_out/profile_r03.log 2>&1; tail -30 gpurun_out/profile_r03.log | cut -c1-300 ;;
+profile-full) timeout 2400 python scratch/profile_r03.py > gpurun_out/profile_r03.log 2>&1; tail -40 gpurun_out/profile_r03.log | cut -c1-300 ;;
 configs)
-  for w in hover4096_240hz hover65536_ext_240hz hover65536_240hz_history hover65536_30hz_history; do
-    timeout 400 python bench.py --workload $w 2>gpurun_out/r03_bench_$w.err | tail -1 > gpurun_out/r03_bench_$w.json; show $w gpurun_out/r03_bench_$w.json
+  for w in hover4096_240hz hover65536_ext_240hz hover65536_240hz_termobs hover65536_240hz_history hover65536_30hz_history swarm65536_ext_240hz; do
+    extra=""; case $w in swarm*) extra="--steps 240 --warmup 24" ;; esac
+    timeout 400 python bench.py --workload $w $extra 2>gpurun_out/r03_bench_$w.err | tail -1 > gpurun_out/r03_bench_$w.json; show $w gpurun_out/r03_bench_$w.json
   done ;;
 *) echo "unknown stage $what" ;;
 esac

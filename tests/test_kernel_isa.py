@@ -165,17 +165,23 @@ def test_no_kernel_saves_a_half_overwritten_argument_tuple(gpd_asm, policy_asm):
     assert n >= 130, n
 
 
-def test_swarm_force_kernel_tests_pairs_packed_and_evaluates_them_compacted(gpd_asm):
-    """dwg_force_kernel: phase A is packed and branch-free (v_pk_* + v_and + v_alignbit, no compare in
-    the sweep), the compaction is a DPP prefix sum into an LDS queue of 16-bit pairs, the evaluation gathers its drone by
-    ds_bpermute and adds 64-bit integers with LDS atomics; no scratch, at most 128 VGPRs (four workgroups per CU)."""
-    body, meta = _kernel(gpd_asm, "dwg_force_kernel")
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_swarm_force_kernel_tests_pairs_packed_and_evaluates_them_compacted(gpd_asm, mode):
+    """dwg_force_kernel<MODE> (MODE 0: no wake lists, 1: the launch after a binning builds them, 2: the
+    launches in between replay them): phase A is packed and branch-free (v_pk_* + v_and + v_alignbit, no compare in the sweep;
+    the build's margins add scalar min / abs, still no branch), the compaction is a DPP prefix sum into an LDS queue of 16-bit
+    pairs, the evaluation gathers its drone by ds_bpermute and adds 64-bit integers with LDS atomics; the build writes its
+    batches as 16-bit stores, the replay reads them back; no scratch, at most 128 VGPRs (four workgroups per CU)."""
+    body, meta = _kernel(gpd_asm, f"dwg_force_kernelILi{mode}E")
     assert re.search(r"ScratchSize: 0\b", meta)
     assert int(re.search(r"; NumVgprs: (\d+)", meta).group(1)) <= 128
     ops = Counter(op for op, _ in _ops(body))
+    sites = 3 if mode == 2 else 2                          # evaluate() call sites: full batches, the flush (, the replay)
     assert ops["v_alignbit_b32"] >= 16 and ops["v_pk_fma_f32"] >= 8 and ops["v_pk_add_f32"] >= 24
-    assert ops["v_mov_b32_dpp"] == 6 and ops["ds_write_b16"] >= 1 and ops["ds_bpermute_b32"] == 6 and ops["ds_add_u64"] == 2
-    assert ops["v_exp_f32_e32"] == 2 and not [op for op in ops if op.startswith("scratch_")]      # (the model: two evaluate() sites)
+    # (12 more ds_bpermute: the two wave reductions of the displacement maxima)
+    assert ops["v_mov_b32_dpp"] == 6 and ops["ds_write_b16"] >= 1 and ops["ds_bpermute_b32"] == 3 * sites + 12 and ops["ds_add_u64"] == sites
+    assert ops["v_exp_f32_e32"] == sites and not [op for op in ops if op.startswith("scratch_")]
+    assert (ops["global_store_short"] >= 2) == (mode == 1) and (ops["global_load_ushort"] >= 1) == (mode == 2), ops
     # the sweep: from the first alignbit to the last, only packed arithmetic, bit operations, LDS reads and their waits
     first = next(i for i, l in enumerate(body) if "v_alignbit_b32" in l)
     last = max(i for i, l in enumerate(body) if "v_alignbit_b32" in l)
