@@ -437,7 +437,7 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
     gathers = {}
     if mode == "rollout" and gather is not None:
         for n in sorted(sizes):             # one larger collective per rollout; every length shares the ONE communicator of `gather`
-            gathers[n] = gather.sized(n * core.N)
+            gathers[n] = gather.sized(n * core.N * 12)
 
     # rollout mode with --split C: sub-batch c is an independent chain of launches on stream c -- no join inside the timed
     # region (the aviaries share nothing), so one chain's kernel boundary and straggler tail hide under the others' steady state
