@@ -48,6 +48,8 @@ swarm)
     GPD_SWARM_CELL=$1 GPD_SWARM_REBIN=$2 timeout 300 python bench.py --workload swarm65536_ext_240hz --steps 240 --warmup 24 --no-cpu-baseline 2>gpurun_out/r03_swarm_c$1_m$2.err | tail -1 > gpurun_out/r03_swarm_c$1_m$2.json
     show "swarm65536 cell $1 rebin $2" gpurun_out/r03_swarm_c$1_m$2.json
   done ;;
+swarm1mdbg)
+  timeout 300 python scratch/debug_swarm1m.py > gpurun_out/r03_debug_swarm1m.txt 2>&1; echo "rc $?"; grep -v Warning gpurun_out/r03_debug_swarm1m.txt | cut -c1-200 | tail -40 ;;
 swarmdbg)
   timeout 300 python scratch/debug_swarm3.py > gpurun_out/r03_debug_swarm3.txt 2>&1; echo "rc $?"; grep -v Warning gpurun_out/r03_debug_swarm3.txt | cut -c1-260 ;;
 swarmprof)

@@ -44,6 +44,17 @@ def test_bench_two_ranks_named_config5_workload(gpu_device):
     assert j["one_launch_per_step"]["value"] > 0 and j["one_launch_per_step"]["roofline"]["kernel"] == "gpd_step_kernel"
 
 
+def test_bench_two_ranks_share_one_swarm_world(gpu_device):
+    """ONE world of 65 536 drones shared by two ranks (both on device 0, positions exchanged through torch.distributed / gloo --
+    the test hook; on a node RCCL carries them): rank r steps its block of drones, all-gathers, evaluates its own forces."""
+    j = _bench(["--workload", "swarm65536_ext_240hz", "--mode", "eager", "--steps", "24", "--warmup", "4", "--min-time", "0.02",
+                "--no-cpu-baseline"], 2, 29543)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["total_drones"] == 65536
+    sw = j["config"]["swarm"]
+    assert sw["ranks"] == 2 and sw["total_drones"] == 65536 and "torch.distributed" in sw["note"]
+    assert j["value"] > 1e5 and j["steps"] == 24
+
+
 def test_native_allgather_one_rank_and_inside_a_graph(gpu_device):
     from gym_pybullet_drones_amd import dist as gdist
     from gym_pybullet_drones_amd.envs import VectorHoverAviary
