@@ -762,7 +762,7 @@ def main():
             "repeats": m["repeats"], "timed_steps": m["timed_steps"], "timed_region_ms": m["ev_s"] * 1e3,
             "wall_ms_per_step": m["wall_s"] * 1e3 / m["timed_steps"], "value_wall": m["value_wall"],
             "config": {"workload": args.workload, "envs_per_gpu": w["E"], "drones_per_env": D,
-                       "total_drones": n_total, "physics": "DYN" + "".join(n for b, n in ((1, "+GND"), (2, "+DRAG"), (4, "+DW"), (8, "+GROUND_PLANE")) if core.physics_flags & b),
+                       "total_drones": n_total, "physics": "DYN" + "".join(n for b, n in ((1, "+GND"), (2, "+DRAG"), (4, "+DW"), (8, "+GROUND_PLANE"), (16, "+BULLET_DAMPING")) if core.physics_flags & b),
                        "physics_flags": core.physics_flags,
                        "pyb_freq": 240, "ctrl_freq": w["ctrl"], "substeps_per_step": S, "action": w["act"],
                        "task": w["task"], "auto_reset": True, "mode": args.mode, "launch": launch, "split": len(envs),
