@@ -14,7 +14,8 @@ large-world counterpart, built on the `GpdSwarm` entries of t
 * the counting sort by grid cell (`gpd_swarm_bin`) runs every `rebin_every` sub-steps only; in between the force kernel
   searches the stale cell order with current positions and a radius that grows with the tracked displacement — every pair the
   reference would sum is evaluated whatever the drones do, in order-independent 64-bit fixed point;
-* `world_size` ranks share one world: rank r owns a contiguous block of drones, and after every sub-step the ranks all-gather
+* `world_size` ranks share one world: rank r owns a block of drones (by default a stripe of the world: the drones are dealt in
+  the cell order of their initial positions; `GLOBAL_IDS`), and after every sub-step the ranks all-gather
   their 16 bytes per drone (`exchange`: RCCL through the C-ABI's `gpd_allgather_obs`, or `torch.distributed`) — the one
   collective of a sub-step.  Every rank bins all positions and evaluates the forces of its own drones; the sums are integers,
   so a world stepped by 1, 2 or 8 ranks follows the same trajectory bit for bit.
@@ -95,7 +96,7 @@ class SwarmAviary:
                  physics: Physics = Physics.PYB_DW, pyb_freq: int = 240, ctrl_freq: int = 240, act="raw_rpm",
                  world_min=None, world_max=None, cell: float = 10.5, zbin: float = 1.0, nz: int = 1, device=None,
                  pyb_like: bool = None, world_size: int = 1, rank: int = 0, exchange=None, rebin_every: int = None,
-                 wake_lists: bool = True, list_cap: int = 48):
+                 wake_lists: bool = True, list_cap: int = 48, partition: str = "spatial"):
         if pyb_freq % ctrl_freq != 0:
             raise ValueError("[ERROR] in SwarmAviary.__init__(), pyb_freq is not divisible by ctrl_freq.")
         if act not in ("raw_rpm", ActionType.RPM, ActionType.PID):
@@ -121,8 +122,25 @@ class SwarmAviary:
             initial_xyzs = P.default_init_xyzs(N)
         xyz_all = np.asarray(initial_xyzs, dtype=np.float64).reshape(N, 3)            # the WHOLE world (every rank passes the same)
         rpy_all = np.zeros((N, 3)) if initial_rpys is None else np.asarray(initial_rpys, dtype=np.float64).reshape(N, 3)
-        own = slice(self.FIRST_DRONE, self.FIRST_DRONE + n)
-        xyz, rpy = xyz_all[own].reshape(n, 1, 3), rpy_all[own].reshape(n, 1, 3)
+        # Which drones a rank owns.  Forces and trajectories do not depend on it (integer sums: bit for bit the same), the WORK a
+        # rank does does: its force launch runs the groups of 64 sorted drones that hold one of ITS drones.  "spatial" (default):
+        # the drones are dealt in the row-major cell order of their INITIAL positions, so a rank's block is a stripe of the world
+        # and ~1/W of the groups (a swarm that mixes thoroughly in flight degrades towards "index"); "index": block r = drones
+        # r*per ... in the caller's numbering -- with a spatially random numbering every group holds drones of every rank and
+        # every rank runs every group (1/W of its lanes busy).  `GLOBAL_IDS[i]` is the caller's index of this rank's drone i.
+        if partition not in ("spatial", "index"):
+            raise ValueError("partition must be 'spatial' or 'index'")
+        self.cell = float(cell)
+        if not self.cell >= 10.0:
+            raise ValueError("cell must be >= 10 m (the downwash model's lateral cut-off)")
+        if partition == "spatial" and self.WORLD_SIZE > 1:
+            lo_xy = xyz_all[:, :2].min(axis=0)
+            cxy = np.floor((xyz_all[:, :2] - lo_xy) / self.cell).astype(np.int64)
+            order_all = np.lexsort((np.arange(N), cxy[:, 0], cxy[:, 1]))             # by cell row, then column, then index (stable)
+        else:
+            order_all = np.arange(N)
+        self.GLOBAL_IDS = np.ascontiguousarray(order_all[self.FIRST_DRONE:self.FIRST_DRONE + n])
+        xyz, rpy = xyz_all[self.GLOBAL_IDS].reshape(n, 1, 3), rpy_all[self.GLOBAL_IDS].reshape(n, 1, 3)
         self.INIT_XYZS, self.INIT_RPYS = xyz[:, 0], rpy[:, 0]
         # the kernel runs n single-drone lanes, one physics sub-step per launch.  The action -> RPM mapping is the kernel's own
         # (GPD_ACT_RAW_RPM: clip to [0, MAX_RPM], envs/CtrlAviary.py:140; GPD_ACT_RPM: HOVER_RPM (1 + 0.05 a),
@@ -135,9 +153,6 @@ class SwarmAviary:
         self.flags = self.core.physics_flags
         self.ctrl = DSLPIDControlBatch(n, drone_model, device=dev) if act == ActionType.PID else None
         # ---- downwash grid (the same on every rank: laid over the whole world) --------------------
-        self.cell = float(cell)
-        if not self.cell >= 10.0:
-            raise ValueError("cell must be >= 10 m (the downwash model's lateral cut-off)")
         lo = xyz_all[:, :2].min(axis=0) - 2 * self.cell if world_min is None else np.asarray(world_min, dtype=np.float64)
         hi = xyz_all[:, :2].max(axis=0) + 2 * self.cell if world_max is None else np.asarray(world_max, dtype=np.float64)
         self.x0, self.y0 = float(lo[0]), float(lo[1])
@@ -337,6 +352,9 @@ class LocalSwarmGroup:
         kw.pop("exchange", None)
         self.ranks = [SwarmAviary(num_drones, world_size=world_size, rank=r, exchange=self._noop, **kw) for r in range(world_size)]
         self.W = world_size
+        dev = self.ranks[0].device
+        self._ids = [torch.as_tensor(e.GLOBAL_IDS, dtype=torch.long, device=dev) for e in self.ranks]
+        self._all_ids = torch.cat(self._ids)
 
     @staticmethod
     def _noop(pos4, rank, slab):
@@ -362,12 +380,18 @@ class LocalSwarmGroup:
         self._exchange()
         for e in self.ranks:
             e._forces()
-        return torch.cat(out)
+        return self._global(torch.cat(out))
+
+    def _global(self, per_rank: torch.Tensor) -> torch.Tensor:
+        """rows in rank order (rank 0's drones, rank 1's ...) -> rows in the caller's drone order"""
+        out = torch.empty_like(per_rank)
+        out[self._all_ids] = per_rank
+        return out
 
     def step(self, action):
         """`action`: the whole world's (N, A) actions -> the whole world's (N, 20) state vectors"""
         a = torch.as_tensor(action, dtype=torch.float32, device=self.ranks[0].device)
-        rpm = [e._kernel_action(a[e.FIRST_DRONE:e.FIRST_DRONE + e.NUM_DRONES]).contiguous() for e in self.ranks]
+        rpm = [e._kernel_action(a[ids]).contiguous() for e, ids in zip(self.ranks, self._ids)]
         vec = [torch.empty((e.NUM_DRONES, 20), dtype=torch.float32, device=e.device) for e in self.ranks]
         S = self.ranks[0].PYB_STEPS_PER_CTRL
         for s in range(S):
@@ -378,7 +402,7 @@ class LocalSwarmGroup:
                 e._forces()
         for e in self.ranks:
             e.step_counter += S
-        return torch.cat(vec)
+        return self._global(torch.cat(vec))
 
     def forces(self):
-        return torch.cat([e.dw_force[:e.NUM_DRONES] for e in self.ranks])
+        return self._global(torch.cat([e.dw_force[:e.NUM_DRONES] for e in self.ranks]))

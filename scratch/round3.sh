@@ -50,6 +50,8 @@ swarm)
   done ;;
 swarm1mdbg)
   timeout 300 python scratch/debug_swarm1m.py > gpurun_out/r03_debug_swarm1m.txt 2>&1; echo "rc $?"; grep -v Warning gpurun_out/r03_debug_swarm1m.txt | cut -c1-200 | tail -40 ;;
+partition)
+  timeout 600 python scratch/swarm_partition_cost.py > gpurun_out/r03_swarm_partition_cost.txt 2>&1; echo "rc $?"; grep -v "Warning\|SwarmAviary(\|amdgpu.ids" gpurun_out/r03_swarm_partition_cost.txt | cut -c1-200 ;;
 swarmdbg)
   timeout 300 python scratch/debug_swarm3.py > gpurun_out/r03_debug_swarm3.txt 2>&1; echo "rc $?"; grep -v Warning gpurun_out/r03_debug_swarm3.txt | cut -c1-260 ;;
 swarmprof)

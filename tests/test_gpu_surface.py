@@ -422,8 +422,8 @@ def _layered_scene(rng, N, jitter=0.3):
     return xyz, rng.uniform(-0.05, 0.05, size=(N, 3))
 
 
-@pytest.mark.parametrize("W", [2, 3, 8])
-def test_one_world_shared_by_several_ranks_is_bitwise_the_single_rank_world(gpu_device, W):
+@pytest.mark.parametrize("W,partition", [(2, "spatial"), (3, "index"), (8, "spatial"), (8, "index")])
+def test_one_world_shared_by_several_ranks_is_bitwise_the_single_rank_world(gpu_device, W, partition):
     """ONE world sharded across ranks.  Rank r owns a block of drones, steps them, the ranks
     all-gather their positions (here: the in-process exchange of `LocalSwarmGroup`, W ranks on one device), every rank bins
     all positions and evaluates the downwash of its own drones.  The force sums are 64-bit fixed point, hence the demand:
@@ -437,8 +437,15 @@ def test_one_world_shared_by_several_ranks_is_bitwise_the_single_rank_world(gpu_
     xyz, rpy = _layered_scene(rng, N)
     kw = dict(initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.PYB_GND_DRAG_DW, pyb_freq=240, ctrl_freq=120, device=gpu_device)
     one = SwarmAviary(N, rebin_every=1, **kw)
-    grp = LocalSwarmGroup(N, W, rebin_every=5, **kw)
+    grp = LocalSwarmGroup(N, W, rebin_every=5, partition=partition, **kw)
     per, slab, counts = swarm_partition(N, W)
+    ids = np.concatenate([e.GLOBAL_IDS for e in grp.ranks])
+    assert sorted(ids.tolist()) == list(range(N))                        # every drone has exactly one owner
+    if partition == "index":
+        assert np.array_equal(ids, np.arange(N))
+    else:       # stripes: a rank's drones sit in few rows of cells; the groups of 64 sorted drones that hold one of them are ~1/W of all
+        rows = [np.unique(np.floor((xyz[e.GLOBAL_IDS, 1] - xyz[:, 1].min()) / 10.5)).size for e in grp.ranks]
+        assert max(rows) <= -(-6 // W) + 2, rows
     assert [e.NUM_DRONES for e in grp.ranks] == counts and sum(counts) == N and len(set(counts)) > 1
     v1, _ = one.reset()
     vw = grp.reset()
