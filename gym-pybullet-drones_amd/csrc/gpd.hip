@@ -2423,10 +2423,19 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
             }
             __syncthreads();
             if (replay) {                                              // the batches this wave evaluated on this tile at the build
+                // four batches' entries are requested before the first is evaluated: one at a time, each evaluation waited a
+                // full memory round trip for its 128 bytes (SQ_WAIT_ANY 68 % of the wave's cycles, profiles/r03_swarm_counters.txt)
                 const int nbt = tcount < kDwMaxTiles ? my_nb[tcount] : 0;
-                for (int b = 0; b < nbt; ++b) {
-                    const unsigned e = my_list[static_cast<size_t>(lb + b) * 64 + lane];
-                    evaluate(e, e != 0xffffu);
+                const unsigned short* const lp = my_list + static_cast<size_t>(lb) * 64 + lane;
+                for (int b = 0; b < nbt; b += 4) {
+                    const unsigned e0 = lp[static_cast<size_t>(b) * 64];
+                    const unsigned e1 = b + 1 < nbt ? lp[static_cast<size_t>(b + 1) * 64] : 0xffffu;
+                    const unsigned e2 = b + 2 < nbt ? lp[static_cast<size_t>(b + 2) * 64] : 0xffffu;
+                    const unsigned e3 = b + 3 < nbt ? lp[static_cast<size_t>(b + 3) * 64] : 0xffffu;
+                    evaluate(e0, e0 != 0xffffu);
+                    if (b + 1 < nbt) evaluate(e1, e1 != 0xffffu);
+                    if (b + 2 < nbt) evaluate(e2, e2 != 0xffffu);
+                    if (b + 3 < nbt) evaluate(e3, e3 != 0xffffu);
                 }
                 lb += nbt;
                 ++tcount;

@@ -172,7 +172,7 @@ class SwarmAviary:
         # behaviour); otherwise every 16th by default -- with the default 0.5 m skin a drone slower than 3.7 m/s stays inside
         # list_delta for 1/15 s; faster ones make the launches sweep (and, beyond half the skin, widen the search) until the
         # next binning, they never break anything.  Measured at 65 536 drones (profiles/r03_swarm_*): 51 us per sub-step with a
-        # binning every sub-step, 34.7 / 30.1 / 27.5 with one every 4th / 8th / 16th.
+        # binning every sub-step, 34.7 / 30.1 / 27.5 with one every 4th / 8th / 16th (25.7 with the replay's list reads four batches ahead).
         self.rebin_every = int(rebin_every) if rebin_every is not None else (1 if self.cell <= 10.0 else 16)
         if self.rebin_every < 1:
             raise ValueError("rebin_every must be >= 1")

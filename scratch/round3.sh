@@ -59,6 +59,11 @@ swarmprof)
     (cd /tmp && export TMPDIR=/tmp && GPD_SWARM_CELL=$1 GPD_SWARM_REBIN=$2 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_swarm_c$1_m$2 -o p -- python $GRAFT_REPO_ROOT/bench.py --workload swarm65536_ext_240hz --steps 256 --warmup 64 --min-time 0.05 --no-cpu-baseline > /dev/null 2>&1)
     f=$(find gpurun_out/prof_swarm_c$1_m$2 -name "*kernel_stats.csv" | head -1); echo "== cell $1 rebin $2: $f"; head -12 $f | cut -c1-200
   done ;;
+swarm2)
+  for cfg in "10.25 8" "10.25 16" "10.5 16" "10.5 32" "10.75 32" "11.0 32"; do set -- $cfg
+    GPD_SWARM_CELL=$1 GPD_SWARM_REBIN=$2 timeout 300 python bench.py --workload swarm65536_ext_240hz --steps 240 --warmup 24 --no-cpu-baseline 2>gpurun_out/r03_swarm_c$1_m$2.err | tail -1 > gpurun_out/r03_swarm_c$1_m$2.json
+    show "swarm65536 cell $1 rebin $2" gpurun_out/r03_swarm_c$1_m$2.json
+  done ;;
 swarm1m)
   timeout 600 python bench.py --workload swarm1m_ext_240hz --steps 256 --warmup 16 --no-cpu-baseline 2>gpurun_out/r03_bench_swarm1m.err | tail -1 > gpurun_out/r03_bench_swarm1m_ext_240hz.json; show swarm1m gpurun_out/r03_bench_swarm1m_ext_240hz.json ;;
 profile) timeout 1500 python scratch/profile_r03.py quick > gpurun_out/profile_r03.log 2>&1; tail -30 gpurun_out/profile_r03.log | cut -c1-300 ;;
