@@ -64,6 +64,11 @@ swarm2)
     GPD_SWARM_CELL=$1 GPD_SWARM_REBIN=$2 timeout 300 python bench.py --workload swarm65536_ext_240hz --steps 240 --warmup 24 --no-cpu-baseline 2>gpurun_out/r03_swarm_c$1_m$2.err | tail -1 > gpurun_out/r03_swarm_c$1_m$2.json
     show "swarm65536 cell $1 rebin $2" gpurun_out/r03_swarm_c$1_m$2.json
   done ;;
+regress)
+  for w in hover65536_30hz hover65536_pid_240hz stack8x8192_ext_240hz multihover2x16384_240hz hover4m_240hz; do
+    extra=""; case $w in hover4m*) extra="--steps 256 --warmup 64" ;; esac
+    timeout 400 python bench.py --workload $w $extra --no-cpu-baseline 2>gpurun_out/r03_bench_$w.err | tail -1 > gpurun_out/r03_bench_$w.json; show $w gpurun_out/r03_bench_$w.json
+  done ;;
 swarm1m)
   timeout 600 python bench.py --workload swarm1m_ext_240hz --steps 256 --warmup 16 --no-cpu-baseline 2>gpurun_out/r03_bench_swarm1m.err | tail -1 > gpurun_out/r03_bench_swarm1m_ext_240hz.json; show swarm1m gpurun_out/r03_bench_swarm1m_ext_240hz.json ;;
 profile) timeout 1500 python scratch/profile_r03.py quick > gpurun_out/profile_r03.log 2>&1; tail -30 gpurun_out/profile_r03.log | cut -c1-300 ;;
