@@ -2297,7 +2297,8 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
         R = __builtin_amdgcn_readfirstlane(R);
     }
     // replay this group's wake list?  (uniform for the workgroup)
-    const bool replay = MODE == 2 && R == 1 && d2 <= Ls.delta * Ls.delta && Ls.ok[blockIdx.x] != 0;
+    // (0.98: dmax <= 0.99 delta -- the build's margin test is evaluated in fp32, a pair exactly on its boundary must not matter)
+    const bool replay = MODE == 2 && R == 1 && d2 <= 0.98f * (Ls.delta * Ls.delta) && Ls.ok[blockIdx.x] != 0;
     unsigned short* const my_list = MODE ? Ls.list + (static_cast<size_t>(blockIdx.x) * (kBlock / 64) + wave) * Ls.cap * 64 : nullptr;
     unsigned short* const my_nb = MODE ? Ls.nb + (static_cast<size_t>(blockIdx.x) * (kBlock / 64) + wave) * kDwMaxTiles : nullptr;
     int lb = 0, tcount = 0;                                // batches recorded / replayed so far; tiles so far
