@@ -321,6 +321,7 @@ def parity_check(w, env, actions, K, POOL, max_steps=256):
     osl = {"pos": slice(0, 3), "rpy": slice(3, 6), "vel": slice(6, 9), "ang_v": slice(9, 12)}
     scale = {g: 1.0 for g in list(sl) + list(osl)}
     obs_err = {g: 0.0 for g in osl}
+    first_err = {}
     alive = np.ones(E, dtype=bool)                  # aviaries whose flags agreed in every step so far
     rew_err, checked, n_done = 0.0, 0, 0
     c_oracle.lib().orc_set_threads(min(host_threads(), c_oracle.lib().orc_max_threads()))
@@ -340,7 +341,10 @@ def parity_check(w, env, actions, K, POOL, max_steps=256):
                 o64 = orc.obs.reshape(N, 12)
                 for g, s_ in osl.items():
                     scale[g] = max(scale[g], float(np.abs(o64[:, s_]).max()))
-                    obs_err[g] = max(obs_err[g], float(np.abs(obs[k][m][:, s_] - o64[m][:, s_]).max()) if m.any() else 0.0)
+                    e_ = float(np.abs(obs[k][m][:, s_] - o64[m][:, s_]).max()) if m.any() else 0.0
+                    obs_err[g] = max(obs_err[g], e_)
+                    if checked == 0:
+                        first_err[g] = e_
                 if alive.any():
                     rew_err = max(rew_err, float(np.abs(rew[k][alive].astype(np.float64) - orc.reward[alive]).max()))
                 k64 = np.concatenate([orc.pos.reshape(N, 3), orc.quat.reshape(N, 4), orc.vel.reshape(N, 3), orc.rpy_rates.reshape(N, 3)], axis=1)
@@ -359,6 +363,11 @@ def parity_check(w, env, actions, K, POOL, max_steps=256):
         res[g] = float(np.abs(kin32[m][:, sl[g]] - k64[m][:, sl[g]]).max() / scale[g])
         worst = max(worst, res[g])
     res["obs_every_step"] = {g: obs_err[g] / scale[g] for g in osl}
+    res["obs_first_step"] = {g: first_err.get(g, 0.0) / scale[g] for g in osl}
+    if D > 1 and core.physics_flags & 4:
+        res["note"] = ("drones flying in each other's wake: the reference's downwash model is ill-conditioned there (alpha ~ 1/dz^2, "
+                       "exp(-(dxy/beta)^2/2) with |beta| ~ 0.06 m) -- single steps agree (obs_first_step; tests/test_gpu_parity.py), "
+                       "trajectories of the closest pairs separate in any finite precision (DESIGN.md section 4)")
     res["flag_mismatch_frac"] = float(1.0 - alive.mean())
     res["reward_max_abs"] = rew_err
     res["max"] = worst
