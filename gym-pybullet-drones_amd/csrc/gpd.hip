@@ -2302,7 +2302,9 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
     unsigned short* const my_list = MODE ? Ls.list + (static_cast<size_t>(blockIdx.x) * (kBlock / 64) + wave) * Ls.cap * 64 : nullptr;
     unsigned short* const my_nb = MODE ? Ls.nb + (static_cast<size_t>(blockIdx.x) * (kBlock / 64) + wave) * kDwMaxTiles : nullptr;
     int lb = 0, tcount = 0;                                // batches recorded / replayed so far; tiles so far
-    bool rec_ok = true;                                    // (build) the list is complete so far
+    // (build) the list is complete so far -- and only a build on the binning's own positions counts (a caller that builds later
+    // gets no lists rather than lists whose margin was measured from somewhere else)
+    bool rec_ok = R == 1 && d2 == 0.0f;
     const float m2 = MODE == 1 ? 2.0f * Ls.delta : 0.0f;   // (build) what two drones can have closed in on each other
     const float c2 = MODE == 1 ? cut * fabsf(P.dw_coeff[1]) * m2 : 0.0f;      // ... and what that adds to sqrt(80.02) |beta|
     const bool sweep_all = R > kDwMaxR;                    // the group's candidates: every sorted drone, one run

@@ -54,6 +54,15 @@ def swarm_partition(num_drones: int, world_size: int):
     return per, per + -(-per // 256), counts
 
 
+def swarm_spatial_order(xyz, cell: float) -> np.ndarray:
+    """The order `partition="spatial"` deals the drones to the ranks in: row-major over the cells (of size `cell`, anchored at the
+    lowest x / y) of their INITIAL positions, the caller's index breaking ties -- a rank's contiguous block of it is a stripe of
+    the world.  Returns a permutation of `range(len(xyz))`."""
+    xyz = np.asarray(xyz, dtype=np.float64).reshape(-1, 3)
+    cxy = np.floor((xyz[:, :2] - xyz[:, :2].min(axis=0)) / cell).astype(np.int64)
+    return np.lexsort((np.arange(len(xyz)), cxy[:, 0], cxy[:, 1]))
+
+
 class TorchSlabExchange:
     """The all-gather of the ranks' position slabs through `torch.distributed` (RCCL with the "nccl" backend; with gloo the
     slabs are staged through host memory: CPU tests and the single-device test hook)."""
@@ -133,12 +142,7 @@ class SwarmAviary:
         self.cell = float(cell)
         if not self.cell >= 10.0:
             raise ValueError("cell must be >= 10 m (the downwash model's lateral cut-off)")
-        if partition == "spatial" and self.WORLD_SIZE > 1:
-            lo_xy = xyz_all[:, :2].min(axis=0)
-            cxy = np.floor((xyz_all[:, :2] - lo_xy) / self.cell).astype(np.int64)
-            order_all = np.lexsort((np.arange(N), cxy[:, 0], cxy[:, 1]))             # by cell row, then column, then index (stable)
-        else:
-            order_all = np.arange(N)
+        order_all = swarm_spatial_order(xyz_all, self.cell) if partition == "spatial" and self.WORLD_SIZE > 1 else np.arange(N)
         self.GLOBAL_IDS = np.ascontiguousarray(order_all[self.FIRST_DRONE:self.FIRST_DRONE + n])
         xyz, rpy = xyz_all[self.GLOBAL_IDS].reshape(n, 1, 3), rpy_all[self.GLOBAL_IDS].reshape(n, 1, 3)
         self.INIT_XYZS, self.INIT_RPYS = xyz[:, 0], rpy[:, 0]

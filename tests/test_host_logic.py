@@ -223,6 +223,15 @@ def test_swarm_partition_and_slab_exchange_world_size_2():
         swarm_partition(9, 4)                   # blocks of 3: the fourth rank would own nothing
     with pytest.raises(ValueError):
         swarm_partition(3, 4)
+    # the spatial deal: a permutation, row-major over the cells of the initial positions, index order inside a cell
+    from gym_pybullet_drones_amd.envs.SwarmAviary import swarm_spatial_order
+    rng = np.random.default_rng(0)
+    xyz = np.concatenate([rng.uniform(0, 42, size=(500, 2)), np.ones((500, 1))], axis=1)
+    o = swarm_spatial_order(xyz, 10.5)
+    assert sorted(o.tolist()) == list(range(500))
+    cx, cy = np.floor((xyz[o, 0] - xyz[:, 0].min()) / 10.5), np.floor((xyz[o, 1] - xyz[:, 1].min()) / 10.5)
+    key = cy * 100 + cx
+    assert np.all(np.diff(key) >= 0) and np.all(np.diff(o)[np.diff(key) == 0] > 0)
     port = 29500 + os.getpid() % 2000
     mp.spawn(_slab_exchange_worker, args=(2, port), nprocs=2, join=True)
 
