@@ -288,3 +288,28 @@ def test_the_timed_workload_of_bench_py_against_the_c_oracle(gpu_device, workloa
     assert res["reward_max_abs"] < 1e-3, res
     if w["D"] == 1 and not w["phys"]:
         assert res["episodes_ended_in_window"] > w["E"] // 4, res
+
+
+def test_swarm_of_65536_drones_forces_and_a_second_of_flight(gpu_device):
+    """ONE world at bench size (`swarm65536_ext_240hz`): after 48 steps through the persistent path (a binning every 16th
+    sub-step, stale cell order, wake lists) the forces of all 65 536 drones against the float64 all-pairs loop of the reference
+    (`BaseAviary._downwash`, 4.3e9 pairs in C) on the same positions -- bench.py's `swarm_parity_check`, the block its swarm
+    lines carry -- and the trajectory bit for bit that of a twin that bins before every force evaluation."""
+    import bench
+    w = bench.WORKLOADS["swarm65536_ext_240hz"]
+    env = bench.make_env(w, gpu_device, seed=1000)
+    from gym_pybullet_drones_amd.envs import SwarmAviary
+    from gym_pybullet_drones_amd.utils.enums import Physics
+    twin = SwarmAviary(w["D"], initial_xyzs=env.INIT_XYZS, initial_rpys=env.INIT_RPYS, physics=Physics.PYB_GND_DRAG_DW, pyb_freq=240,
+                       ctrl_freq=240, act="raw_rpm", device=gpu_device, cell=env.cell, rebin_every=1)
+    acts = bench.make_actions(w, env, gpu_device, seed=2000, pool=8)
+    va, _ = env.reset()
+    vb, _ = twin.reset()
+    for k in range(48):
+        va, *_ = env.step(acts[k % 8])
+        vb, *_ = twin.step(acts[k % 8])
+    assert torch.equal(va, vb) and torch.equal(env.dw_force, twin.dw_force)
+    assert env.wake_lists and float(env._list_ok.float().mean()) > 0.99
+    res = bench.swarm_parity_check(env)
+    print(res)
+    assert res["ok"] and res["drones_with_a_force"] > 30000, res
