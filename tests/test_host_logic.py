@@ -257,3 +257,68 @@ def _slab_exchange_worker(rank, world, port):
             assert float(pos4[(r + 1) * slab - 1, 3]) == 0.5 + r
     finally:
         dist.destroy_process_group()
+
+
+def _stub_rccl(tmp):
+    """tests/stubs/rccl_stub.c (a stand-in for librccl.so that moves host memory between processes) -> a shared object"""
+    out = os.path.join(str(tmp), "librccl_stub.so")
+    subprocess.run(["gcc", "-O1", "-shared", "-fPIC", os.path.join(REPO, "tests", "stubs", "rccl_stub.c"), "-o", out, "-lpthread", "-lrt"], check=True)
+    return out
+
+
+def _comm_worker(rank, world, stub, idfile):
+    """one rank of the C-ABI's collective glue: unique id (rank 0) -> init -> count -> all-gather (out of place, and in place like
+    the position slabs of a shared swarm world) -> destroy"""
+    import time
+    os.environ["GPD_RCCL_LIB"] = stub
+    from gym_pybullet_drones_amd import _native
+    L = _native.lib()
+    ident = (ctypes.c_uint8 * _native.COMM_ID_BYTES)()
+    if rank == 0:
+        _native.check(L.gpd_comm_unique_id(ident), "gpd_comm_unique_id")
+        with open(idfile + ".tmp", "wb") as f:
+            f.write(bytes(ident))
+        os.rename(idfile + ".tmp", idfile)
+    else:
+        for _ in range(2000):
+            if os.path.exists(idfile):
+                break
+            time.sleep(0.005)
+        ident = (ctypes.c_uint8 * _native.COMM_ID_BYTES).from_buffer_copy(open(idfile, "rb").read())
+    comm = ctypes.c_void_p()
+    _native.check(L.gpd_comm_init(ctypes.byref(comm), ident, rank, world), "gpd_comm_init")
+    n = ctypes.c_int32(0)
+    _native.check(L.gpd_comm_count(comm, ctypes.byref(n)), "gpd_comm_count")
+    assert n.value == world
+    rows = 5
+    shard = (np.arange(rows * 12, dtype=np.float32) + 1000 * rank).reshape(rows, 12)
+    full = np.zeros((world * rows, 12), dtype=np.float32)
+    for _ in range(3):                           # (one communicator, several calls, two counts: what bench.py's gathers do)
+        _native.check(L.gpd_allgather_obs(comm, shard.ctypes.data_as(ctypes.c_void_p), full.ctypes.data_as(ctypes.c_void_p), rows * 12, None),
+                      "gpd_allgather_obs")
+        for r in range(world):
+            assert np.array_equal(full[r * rows:(r + 1) * rows], (np.arange(rows * 12, dtype=np.float32) + 1000 * r).reshape(rows, 12))
+    # in place: every rank's slab already sits at its place in the receive buffer (gpd.h, GpdSwarm)
+    slab = 7
+    pos4 = np.full((world * slab, 4), np.nan, dtype=np.float32)
+    pos4[rank * slab:(rank + 1) * slab] = np.arange(slab * 4, dtype=np.float32).reshape(slab, 4) + 100 * rank
+    send = ctypes.c_void_p(pos4.ctypes.data + rank * slab * 16)
+    _native.check(L.gpd_allgather_obs(comm, send, pos4.ctypes.data_as(ctypes.c_void_p), slab * 4, None), "gpd_allgather_obs (in place)")
+    for r in range(world):
+        assert np.array_equal(pos4[r * slab:(r + 1) * slab], np.arange(slab * 4, dtype=np.float32).reshape(slab, 4) + 100 * r)
+    # argument errors come back as codes, not crashes
+    assert L.gpd_allgather_obs(comm, None, full.ctypes.data_as(ctypes.c_void_p), 12, None) == _native.GPD_EINVAL
+    assert L.gpd_comm_count(None, ctypes.byref(n)) == _native.GPD_EINVAL
+    _native.check(L.gpd_comm_destroy(comm), "gpd_comm_destroy")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_comm_glue_with_several_ranks_over_a_stub_rccl(tmp_path, world):
+    """The C-ABI's multi-rank entries (`gpd_comm_unique_id / _init / _count`, `gpd_allgather_obs`, `gpd_comm_destroy`) with
+    rank > 0 and world_size > 1 -- which no single-GPU box can run against RCCL itself (it refuses two ranks on one device):
+    `GPD_RCCL_LIB` points libgpd.so's dlopen at tests/stubs/rccl_stub.c, a stand-in that moves HOST buffers between processes
+    through shared memory.  What it pins: the id hand-over, init on every rank, ONE communicator serving several calls and
+    counts, the shard order of the gathered tensor, the in-place form the swarm slabs use, and the error codes."""
+    import torch.multiprocessing as mp
+    stub = _stub_rccl(tmp_path)
+    mp.spawn(_comm_worker, args=(world, stub, os.path.join(str(tmp_path), "id.bin")), nprocs=world, join=True)
