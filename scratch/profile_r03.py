@@ -107,6 +107,11 @@ for key, wl, mode, kern, spl in PMC:
             open(os.path.join(OUT, tag + ".csv"), "w").write("\n".join(keep) + "\n")
     summary["pmc"][key] = rec
 json.dump(summary, open(os.path.join(OUT, "summary.json"), "w"), indent=1)
+# the raw per-dispatch traces are tens of MB per pass (gpurun copies back 64 MiB at most): keep the extracted summaries only
+import shutil
+for d in glob.glob(os.path.join(OUT, "*")):
+    if os.path.isdir(d):
+        shutil.rmtree(d, ignore_errors=True)
 for key, rec in summary["pmc"].items():
     print(key, {k: (round(v["mean_per_dispatch"], 1) if isinstance(v, dict) else v) for k, v in rec.items()})
 for tag, rows in summary["traces"].items():
