@@ -58,7 +58,8 @@ class GpdSwarm(ctypes.Structure):
                 ("cell_start", ctypes.c_void_p), ("order", ctypes.c_void_p), ("visit", ctypes.c_void_p), ("visit_out", ctypes.c_void_p),
                 ("slot_key", ctypes.c_void_p), ("dw_force", ctypes.c_void_p), ("slot_of", ctypes.c_void_p),
                 ("pos_sorted", ctypes.c_void_p), ("pair_list", ctypes.c_void_p), ("pair_nb", ctypes.c_void_p),
-                ("list_ok", ctypes.c_void_p), ("list_cap", ctypes.c_int32), ("list_delta", ctypes.c_float)]
+                ("list_ok", ctypes.c_void_p), ("list_cap", ctypes.c_int32), ("list_delta", ctypes.c_float),
+                ("drift", ctypes.c_void_p), ("total_drones", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -2085,7 +2085,8 @@ struct DwBinOut {
     int* visit_out;        // [n] or NULL: a second copy of `order`, for the NEXT binning to visit the rows in
     int* list_ok;          // [ceil(n / 64)] or NULL: the groups' wake lists belong to the previous binning: all back to 0
     float4* bin_pos;       // [n] x, y, z of every row at this binning
-    float* pos4_w;         // pos4 as floats: the w of every rank's meta rows (the last meta_rows of its slab) goes back to 0
+    float* pos4_w;         // pos4 as floats: the sums and maxima in every rank's meta rows (the last meta_rows of its slab) go back to 0
+    float* drift;          // [2] ... and so does the common drift
     int slab, world, meta_rows;
     int own_lo, own_cnt;   // rows whose force lands in dw_out[row - own_lo]
 };
@@ -2121,9 +2122,13 @@ __global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const DwPos src, in
         if (blockIdx.x == 0) for (int k = t; k <= keys; k += kBlock) start_g[k] = lstart[k];
     }
     auto start = [&](int k) { if constexpr (FUSED) return lstart[k]; else return start_g[k]; };
-    if (B.pos4_w && blockIdx.x == 0)                       // every rank bins on the same sub-steps: all displacements restart
-        for (int k = threadIdx.x; k < B.world * B.meta_rows; k += kBlock)
-            B.pos4_w[(static_cast<size_t>(k / B.meta_rows + 1) * B.slab - B.meta_rows + k % B.meta_rows) * 4 + 3] = 0.0f;
+    if (B.pos4_w && blockIdx.x == 0) {                     // every rank bins on the same sub-steps: all displacements restart
+        for (int k = threadIdx.x; k < B.world * B.meta_rows; k += kBlock) {
+            float* row = B.pos4_w + (static_cast<size_t>(k / B.meta_rows + 1) * B.slab - B.meta_rows + k % B.meta_rows) * 4;
+            row[1] = 0.0f; row[2] = 0.0f; row[3] = 0.0f;
+        }
+        if (B.drift && threadIdx.x < 2) B.drift[threadIdx.x] = 0.0f;
+    }
     if (B.list_ok && i < (n + 63) / 64) B.list_ok[i] = 0;
     int c = -1 - lane, d = 0;
     float x = 0.0f, y = 0.0f, z = 0.0f;
@@ -2217,6 +2222,8 @@ struct DwWorld {
     int own_lo, own_cnt;   // rows this launch produces forces for (dw_out[row - own_lo])
     int slab, world, meta_rows;
     float cell;
+    float* drift;          // [2] out (workgroup 0): the mean lateral displacement of all drones, for the NEXT sub-step's step kernel
+    float inv_total;       // 1 / drones in the world
 };
 // Wake lists (GpdSwarm): what survives phase A changes little from one sub-step to the next -- drones move centimetres, the
 // model's reach is metres.  The force launch right after a binning (MODE 1, "build") runs phase A with a margin -- a pair is
@@ -2248,10 +2255,30 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
     const int keys = nx * ny * nz;
     // the sort's per-key counters / cursors are done with: leave them zeroed for the next binning (no memset node per call)
     for (int k = blockIdx.x * kBlock + threadIdx.x; k < 2 * (keys + 1); k += gridDim.x * kBlock) cursor[k] = 0;   // (counts | cursors)
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    if (Wd.drift && blockIdx.x == 0) {
+        // the swarm's common drift for the next sub-step (see swarm_tail): the sum of the workgroups' displacement sums, in an
+        // order that depends on nothing but the layout -- every rank arrives at the same two floats
+        float sx = 0.0f, sy = 0.0f;
+        const int tot = Wd.world * Wd.meta_rows;
+        for (int k = threadIdx.x; k < tot; k += kBlock) {
+            const float4 m = Wd.meta[static_cast<size_t>(k / Wd.meta_rows + 1) * Wd.slab - Wd.meta_rows + k % Wd.meta_rows];
+            sx += m.y; sy += m.z;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); }
+        float* const red = reinterpret_cast<float*>(pre);
+        if (lane == 0) { red[2 * wave] = sx; red[2 * wave + 1] = sy; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            Wd.drift[0] = (((red[0] + red[2]) + red[4]) + red[6]) * Wd.inv_total;
+            Wd.drift[1] = (((red[1] + red[3]) + red[5]) + red[7]) * Wd.inv_total;
+        }
+        __syncthreads();
+    }
     const int sorted_n = start[keys];                      // drones with a finite position (the others: force 0, set by the sort)
     const int base = 64 * blockIdx.x;
     if (base >= sorted_n) return;
-    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int s = base + lane;
     const bool have = s < sorted_n;
     const int my_row = have ? order[s] : -1;
@@ -2577,35 +2604,49 @@ __global__ __launch_bounds__(kBlock) void gpd_state20_kernel(const GpdState S, c
 struct SwarmOut {
     float4* pos4_own;          // pos4 + rank * slab: row i = own drone i
     const float4* bin_pos_own; // bin_pos + rank * slab
-    float* dmax2;              // the w of the rank's first meta row (workgroup b's: 4 b floats on)
+    float* meta_own;           // the rank's first meta row as floats (workgroup b's row: 4 b floats on)
     const int* slot_of_own;    // slot_of + rank * slab, or NULL
     float4* pos_sorted;        // [n_rows] current positions by sorted slot (with slot_of)
+    const float* drift;        // [2] the swarm's common lateral drift since the binning, as of the previous sub-step
     float* vec_out;            // [n][20] or NULL
 };
-// the drone's new position for the next launch (by row; by sorted slot when this rank holds the whole world), and how far it
-// is from where it was binned: the workgroup's maximum goes to the workgroup's own meta row -- a plain store (1024 wavefronts
-// updating ONE word with atomics cost 13 us: atomics on one address are served one after the other; the force kernel, which
-// needs the maximum over all of them, reads a few hundred words instead)
+// The drone's new position for the next launch (by row; by sorted slot when this rank holds the whole world), and how far it is
+// from where it was binned -- RELATIVE TO THE SWARM'S COMMON DRIFT: what the stale cell order and the wake lists tolerate is a
+// change of the drones' positions relative to each other; a translation all drones share (a swarm in transit) changes no pair.
+// `drift` is the mean lateral displacement of all drones as of the previous sub-step (the force launch in between computes it
+// from the sums below and every workgroup of every rank reads the same two floats: ANY common vector keeps the bound exact, a
+// good one keeps it small).  The workgroup's largest residual and its displacement sums go to the workgroup's own meta row --
+// plain stores (1024 wavefronts updating ONE word with atomics cost 13 us: atomics on one address are served one after the
+// other; the force kernel, which needs the maximum over all of them, reads a few hundred words instead).
 __device__ __forceinline__ void swarm_tail(const SwarmOut& O, bool active, uint32_t n, float px, float py, float pz) {
-    __shared__ float wg_max[kBlock / 64];
-    float d2 = 0.0f;
+    __shared__ float wg_red[kBlock / 64][3];
+    const float cx = O.drift[0], cy = O.drift[1];
+    float d2 = 0.0f, sx = 0.0f, sy = 0.0f;
     if (active) {
         O.pos4_own[n] = make_float4(px, py, pz, 0.0f);
         if (O.slot_of_own) { const int slot = O.slot_of_own[n]; if (slot >= 0) O.pos_sorted[slot] = make_float4(px, py, pz, 0.0f); }
         const float4 b = O.bin_pos_own[n];
         const float dx = px - b.x, dy = py - b.y, dz = pz - b.z;
-        d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-        d2 = d2 == d2 ? d2 : 0.0f;                            // (a drone without a finite position takes no part in the sort)
+        const float ex = dx - cx, ey = dy - cy;
+        d2 = fmaf(dz, dz, fmaf(ey, ey, ex * ex));
+        const bool fin = d2 == d2 && d2 < 3.0e38f;             // (a drone without a finite position takes no part in the sort)
+        d2 = d2 == d2 ? d2 : 0.0f;
+        sx = fin ? dx : 0.0f; sy = fin ? dy : 0.0f;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, off));
-    if ((threadIdx.x & 63) == 0) wg_max[threadIdx.x >> 6] = d2;
+    for (int off = 32; off > 0; off >>= 1) {
+        d2 = fmaxf(d2, __shfl_xor(d2, off));
+        sx += __shfl_xor(sx, off);
+        sy += __shfl_xor(sy, off);
+    }
+    if ((threadIdx.x & 63) == 0) { wg_red[threadIdx.x >> 6][0] = d2; wg_red[threadIdx.x >> 6][1] = sx; wg_red[threadIdx.x >> 6][2] = sy; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        float m = wg_max[0];
+        float m = wg_red[0][0], tx = wg_red[0][1], ty = wg_red[0][2];
 #pragma unroll
-        for (int k = 1; k < kBlock / 64; ++k) m = fmaxf(m, wg_max[k]);
-        O.dmax2[4 * blockIdx.x] = m;
+        for (int k = 1; k < kBlock / 64; ++k) { m = fmaxf(m, wg_red[k][0]); tx += wg_red[k][1]; ty += wg_red[k][2]; }
+        float* row = O.meta_own + 4 * blockIdx.x;           // (x stays non-finite: "no drone in this row")
+        row[1] = tx; row[2] = ty; row[3] = m;
     }
 }
 template <int ACT>
@@ -2682,7 +2723,7 @@ __global__ __launch_bounds__(kBlock) void gpd_swarm_pack_kernel(const GpdState S
         pos4_own[i] = make_float4(S.kin[i], S.kin[S.ld + i], S.kin[2 * S.ld + i], 0.0f);
         if (vec_out) state20_row(S, obs12, vec_out, i);
     } else {
-        pos4_own[i] = make_float4(nan, nan, nan, 0.0f);
+        pos4_own[i] = make_float4(nan, 0.0f, 0.0f, 0.0f);     // (a non-finite x is what says "no drone"; meta rows: sums and maximum 0)
     }
 }
 
@@ -3159,7 +3200,7 @@ int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, i
                            nullptr, nullptr);
     }
     int32_t* const cursors = cell_count + keys + 1;       // second half of cell_count: the scatter's per-key cursors
-    const DwBinOut B{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, n};
+    const DwBinOut B{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, n};
     if (keys <= kDwScanMax) {
         hipLaunchKernelGGL(dwg_scatter_kernel<true>, grid, dim3(kBlock), 0, st, src, n, G, visit_order, cell_count, cursors,
                            cell_start, order, reinterpret_cast<float4*>(sorted_xyzc), dw_out, B);
@@ -3168,7 +3209,7 @@ int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, i
         hipLaunchKernelGGL(dwg_scatter_kernel<false>, grid, dim3(kBlock), 0, st, src, n, G, visit_order, cell_count, cursors,
                            cell_start, order, reinterpret_cast<float4*>(sorted_xyzc), dw_out, B);
     }
-    const DwWorld Wd{nullptr, nullptr, nullptr, 0, n, 0, 0, 0, cell};
+    const DwWorld Wd{nullptr, nullptr, nullptr, 0, n, 0, 0, 0, cell, nullptr, 0.0f};
     hipLaunchKernelGGL(dwg_force_kernel<0>, dim3(static_cast<unsigned>((n + 63) / 64)), dim3(kBlock), 0, st, *params, G, Wd, DwLists{},
                        cell_start, order, reinterpret_cast<const float4*>(sorted_xyzc), dw_out, cell_count);
     e = hipGetLastError();
@@ -3187,7 +3228,8 @@ static int swarm_args(const char* who, const GpdSwarm* w, bool sorted_buffers) {
     if (w->slot_of && w->world_size != 1) return bad(GPD_EINVAL, "positions by sorted slot (slot_of / pos_sorted) need the whole world on this rank");
     if (static_cast<int64_t>(w->slab) * w->world_size != w->n_rows) return bad(GPD_EINVAL, "n_rows must be world_size * slab");
     if (w->n_rows > (1 << 26)) return bad(GPD_ERANGE, "more than 2^26 rows");
-    if (!w->pos4 || !w->bin_pos) return bad(GPD_EINVAL, "NULL pos4 / bin_pos");
+    if (!w->pos4 || !w->bin_pos || !w->drift) return bad(GPD_EINVAL, "NULL pos4 / bin_pos / drift");
+    if (w->total_drones < 1 || w->total_drones > w->n_rows) return bad(GPD_EINVAL, "need 1 <= total_drones <= n_rows");
     if (sorted_buffers) {
         if (!w->cell_count || !w->cell_start || !w->order || !w->slot_key) return bad(GPD_EINVAL, "NULL cell_count / cell_start / order / slot_key");
         if (w->visit && (w->visit == w->order || w->visit == w->visit_out)) return bad(GPD_EINVAL, "visit must alias neither order nor visit_out (ping-pong visit / visit_out)");
@@ -3214,8 +3256,8 @@ int gpd_swarm_step(const GpdParams* params, const GpdState* state, const GpdStep
     if ((cfg->physics_flags & GPD_PHYS_DRAG) && !state->last_rpm) return bad(GPD_EINVAL, "GPD_PHYS_DRAG needs state.last_rpm");
     const size_t lo = static_cast<size_t>(swarm->rank) * swarm->slab;
     const SwarmOut O{reinterpret_cast<float4*>(swarm->pos4) + lo, reinterpret_cast<const float4*>(swarm->bin_pos) + lo,
-                     swarm->pos4 + (lo + swarm->slab - swarm->meta_rows) * 4 + 3, swarm->slot_of ? swarm->slot_of + lo : nullptr,
-                     reinterpret_cast<float4*>(swarm->pos_sorted), vec_out};
+                     swarm->pos4 + (lo + swarm->slab - swarm->meta_rows) * 4, swarm->slot_of ? swarm->slot_of + lo : nullptr,
+                     reinterpret_cast<float4*>(swarm->pos_sorted), swarm->drift, vec_out};
     const dim3 grid(static_cast<unsigned>((cfg->num_envs + kBlock - 1) / kBlock));
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (cfg->act_type) {
@@ -3252,7 +3294,7 @@ int gpd_swarm_bin(const GpdSwarm* w, void* stream) {
     const DwPos src{nullptr, 0, reinterpret_cast<const float4*>(w->pos4)};
     hipLaunchKernelGGL(dwg_count_kernel<false>, grid, dim3(kBlock), 0, st, src, n, G, w->visit, w->cell_count, GpdState{}, nullptr, nullptr);
     int32_t* const cursors = w->cell_count + keys + 1;
-    const DwBinOut B{w->slot_key, w->slot_of, w->visit_out, w->list_ok, reinterpret_cast<float4*>(w->bin_pos), w->pos4, w->slab, w->world_size, w->meta_rows, w->rank * w->slab, w->own_count};
+    const DwBinOut B{w->slot_key, w->slot_of, w->visit_out, w->list_ok, reinterpret_cast<float4*>(w->bin_pos), w->pos4, w->drift, w->slab, w->world_size, w->meta_rows, w->rank * w->slab, w->own_count};
     float4* const srt = reinterpret_cast<float4*>(w->pos_sorted);
     if (keys <= kDwScanMax) {
         hipLaunchKernelGGL(dwg_scatter_kernel<true>, grid, dim3(kBlock), 0, st, src, n, G, w->visit, w->cell_count, cursors,
@@ -3276,7 +3318,8 @@ int gpd_swarm_forces(const GpdParams* params, const GpdSwarm* w, int32_t build_l
         return fail(GPD_EINVAL, "gpd_swarm_forces: pair_list needs pair_nb, list_ok, list_cap >= 1 and list_delta >= 0");
     const DwGrid G{1.0f / w->cell, w->x0, w->y0, w->nx, w->ny, w->z0, w->nz > 1 ? 1.0f / w->zbin : 0.0f, w->nz};
     const float4* const p4 = reinterpret_cast<const float4*>(w->pos4);
-    const DwWorld Wd{w->pos_sorted ? nullptr : p4, w->slot_key, p4, w->rank * w->slab, w->own_count, w->slab, w->world_size, w->meta_rows, w->cell};
+    const DwWorld Wd{w->pos_sorted ? nullptr : p4, w->slot_key, p4, w->rank * w->slab, w->own_count, w->slab, w->world_size, w->meta_rows, w->cell,
+                     w->drift, 1.0f / static_cast<float>(w->total_drones)};
     const DwLists Ls{w->pair_list, w->pair_nb, w->list_ok, w->list_cap, w->list_delta};
     const dim3 grid(static_cast<unsigned>((w->n_rows + 63) / 64));
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -12,8 +12,9 @@ large-world counterpart, built on the `GpdSwarm` entries of t
   binned, and — on the last sub-step — the `(n, 20)` state vectors) and `gpd_swarm_forces` (downwash of the NEXT sub-step on
   the snapshot this one left);
 * the counting sort by grid cell (`gpd_swarm_bin`) runs every `rebin_every` sub-steps only; in between the force kernel
-  searches the stale cell order with current positions and a radius that grows with the tracked displacement — every pair the
-  reference would sum is evaluated whatever the drones do, in order-independent 64-bit fixed point;
+  searches the stale cell order with current positions and a radius that grows with the tracked displacement (measured against
+  the swarm's common drift: a swarm in transit counts as standing still) — every pair the reference would sum is evaluated
+  whatever the drones do, in order-independent 64-bit fixed point;
 * `world_size` ranks share one world: rank r owns a block of drones (by default a stripe of the world: the drones are dealt in
   the cell order of their initial positions; `GLOBAL_IDS`), and after every sub-step the ranks all-gather
   their 16 bytes per drone (`exchange`: RCCL through the C-ABI's `gpd_allgather_obs`, or `torch.distributed`) — the one
@@ -212,6 +213,7 @@ class SwarmAviary:
         self._pair_list = torch.zeros((groups, 4, int(list_cap) * 64), **u16) if self.wake_lists else None
         self._pair_nb = torch.zeros((groups, 4, 16), **u16) if self.wake_lists else None
         self._list_ok = torch.zeros(groups, **i32) if self.wake_lists else None
+        self._drift = torch.zeros(4, dtype=torch.float32, device=dev)          # the swarm's common lateral drift since the binning
         self._sw = _native.GpdSwarm(n_rows=self.n_rows, slab=self.slab, world_size=self.WORLD_SIZE, rank=self.RANK, own_count=n,
                                     nx=self.nx, ny=self.ny, nz=self.nz, cell=self.cell, x0=self.x0, y0=self.y0, z0=self.z0,
                                     zbin=self.zbin, meta_rows=self.slab - self.per, pos4=self.pos4.data_ptr(), bin_pos=self._bin_pos.data_ptr(),
@@ -224,7 +226,7 @@ class SwarmAviary:
                                     pair_list=self._pair_list.data_ptr() if self.wake_lists else None,
                                     pair_nb=self._pair_nb.data_ptr() if self.wake_lists else None,
                                     list_ok=self._list_ok.data_ptr() if self.wake_lists else None,
-                                    list_cap=int(list_cap), list_delta=self.list_delta)
+                                    list_cap=int(list_cap), list_delta=self.list_delta, drift=self._drift.data_ptr(), total_drones=N)
         self.step_counter = 0
         self._since_bin = 0                          # sub-steps since the last binning
         self._dw_version = -1                        # core.state_version the forces in dw_force were computed for

@@ -405,9 +405,9 @@ int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, i
  *     order-independent 64-bit fixed point: the forces are the ones gpd_downwash_global returns, bit for bit.  (R beyond 3,
  *     or beyond the grid: the group sweeps every drone.)  A sub-step is then TWO launches: gpd_swarm_step, gpd_swarm_forces;
  *   - several ranks share one world: rank r owns the rows [r*slab, (r+1)*slab) -- its own_count drones, then rows without a
- *     drone (non-finite x), the LAST meta_rows rows of the slab being the rank's meta rows (NaN, NaN, NaN, w): workgroup b of
- *     gpd_swarm_step stores the largest squared displacement of its 256 drones in the w of meta row b -- plain stores, the
- *     force kernel takes the maximum.  After
+ *     drone (non-finite x), the LAST meta_rows rows of the slab being the rank's meta rows (NaN, sum dx, sum dy, w): workgroup b
+ *     of gpd_swarm_step stores the largest squared displacement of its 256 drones in the w of meta row b (and their summed
+ *     lateral displacements in y, z) -- plain stores, the force kernel takes the maximum.  After
  *     gpd_swarm_step every rank all-gathers its slab IN PLACE (gpd_allgather_obs(comm, pos4 + rank*slab*4, pos4, slab*4):
  *     16 bytes per drone, the one collective per sub-step), bins ALL rows when a binning is due (every rank the same
  *     sub-steps), and evaluates the forces of ITS drones only (workgroups of the sorted array without a drone of the rank
@@ -453,6 +453,12 @@ typedef struct GpdSwarm {
     int32_t* list_ok;      /* [ceil(n_rows / 64)] */
     int32_t list_cap;      /* batches of 64 pairs per wavefront (a group of 64 drones has four); a group that needs more sweeps */
     float list_delta;
+    /* "Displacement" above is measured relative to the swarm's COMMON lateral drift since the binning (a translation all drones
+     * share changes no pair: a swarm in transit keeps R = 1 and its wake lists).  gpd_swarm_forces computes the drift -- the mean
+     * lateral displacement of all drones, from per-workgroup sums in the meta rows (y, z) -- for the next gpd_swarm_step. */
+    float* drift;          /* [2] device floats, zero before the first call (gpd_swarm_bin zeroes them) */
+    int32_t total_drones;  /* drones of the whole world (all ranks) */
+    int32_t pad_;
 } GpdSwarm;
 
 /* One physics sub-step of the rank's own_count drones (state / cfg as for gpd_step: drones_per_env = 1, num_envs = own_count,

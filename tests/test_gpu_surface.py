@@ -536,13 +536,15 @@ def test_swarm_steps_captured_in_a_hipgraph_replay_like_eager_steps(gpu_device, 
         assert torch.equal(a.dw_force, b.dw_force), rep
 
 
-@pytest.mark.parametrize("variant", ["lists", "overflowing lists", "outrun lists"])
+@pytest.mark.parametrize("variant", ["lists", "overflowing lists", "outrun lists", "in transit"])
 def test_wake_lists_replay_the_pairs_of_the_last_binning_exactly(gpu_device, variant):
     """Between two binnings the force launches replay the pairs the launch after the binning evaluated (kept with a margin of
     `list_delta` per drone) instead of sweeping all candidates.  Same forces and trajectories, bit for bit, as a twin that bins
     before every force evaluation (no lists at all) -- also when most groups' lists overflow their capacity (those groups sweep),
-    and when drones move further than `list_delta` between two binnings (every group sweeps, with the radius of
-    `test_stale_cell_order_stays_exact_when_drones_outrun_the_skin`)."""
+    and when drones move further than `list_delta` RELATIVE TO EACH OTHER between two binnings (every group sweeps, with the
+    radius of `test_stale_cell_order_stays_exact_when_drones_outrun_the_skin`).  A swarm in transit -- every drone at 6 m/s the
+    same way -- keeps its lists: displacement is measured against the swarm's common drift, the tracked residual stays a
+    fraction of `list_delta` while every drone has moved several times that."""
     from gym_pybullet_drones_amd.envs import SwarmAviary
     from gym_pybullet_drones_amd.utils.enums import Physics
     rng = np.random.default_rng(31)
@@ -554,16 +556,26 @@ def test_wake_lists_replay_the_pairs_of_the_last_binning_exactly(gpu_device, var
     assert env.wake_lists and not ref.wake_lists and 0.2 < env.list_delta < 0.25
     for e in (ref, env):
         e.reset()
-        if variant == "outrun lists":              # 6 m/s sideways: 0.245 m -- list_delta -- after ten sub-steps
+        if variant in ("outrun lists", "in transit"):      # 6 m/s sideways: 0.245 m -- list_delta -- after ten sub-steps
             kin = e.core.kin[:, :N].clone()
             kin[7] = 6.0
+            if variant == "outrun lists":                   # ... half of them the other way
+                kin[7, ::2] = -6.0
             e.core.set_state(kin=kin)
     rpm = torch.as_tensor((ref.HOVER_RPM * (1 + 0.02 * rng.uniform(-1, 1, size=(N, 4)))).astype(np.float32), device=gpu_device)
+    checked_drift = False
     for k in range(30):
         a, *_ = ref.step(rpm)
         b, *_ = env.step(rpm)
         assert torch.equal(a, b), k
         assert torch.equal(ref.dw_force, env.dw_force), k
+        if variant in ("outrun lists", "in transit") and env._since_bin == env.rebin_every - 1:      # (just before a binning)
+            true_d2 = float(((env.pos4[:N, :3] - env._bin_pos[:N, :3]) ** 2).sum(dim=1).max())
+            tracked = float(env.pos4[N:, 3].max())
+            assert true_d2 > env.list_delta ** 2             # (every drone is further from where it was binned than the lists allow)
+            assert (tracked < 0.25 * env.list_delta ** 2) == (variant == "in transit"), (tracked, true_d2)
+            checked_drift = True
+    assert checked_drift == (variant in ("outrun lists", "in transit"))
     ok = env._list_ok[:(N + 63) // 64].float().mean().item()
     assert float(ref.dw_force[:N].abs().max()) > 1e-3
     if variant == "lists":
