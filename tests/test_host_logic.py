@@ -322,3 +322,19 @@ def test_comm_glue_with_several_ranks_over_a_stub_rccl(tmp_path, world):
     import torch.multiprocessing as mp
     stub = _stub_rccl(tmp_path)
     mp.spawn(_comm_worker, args=(world, stub, os.path.join(str(tmp_path), "id.bin")), nprocs=world, join=True)
+
+
+def test_header_is_plain_c_and_a_c_program_links(tmp_path):
+    """include/gpd.h is the drop-in boundary: plain C (C11, -pedantic, no warnings), and a C program built against it links
+    libgpd.so, finds the struct sizes of the header in the library and gets an error code (not a crash) for a NULL call --
+    `examples/c/abi_check.c`, no GPU needed."""
+    from gym_pybullet_drones_amd import _native
+    _native.lib()
+    exe = os.path.join(str(tmp_path), "abi_check")
+    res = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(REPO, "include"),
+                          os.path.join(REPO, "examples", "c", "abi_check.c"), "-o", exe, "-L", _native.CSRC, "-lgpd",
+                          "-Wl,-rpath," + _native.CSRC], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    run = subprocess.run([exe], capture_output=True, text=True)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "ABI 6" in run.stdout and "-> -1:" in run.stdout
