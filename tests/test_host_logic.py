@@ -338,3 +338,55 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "ABI 6" in run.stdout and "-> -1:" in run.stdout
+
+
+def test_swarm_entries_reject_bad_arguments_before_touching_a_device():
+    """The `GpdSwarm` entries validate their arguments before the first HIP call: codes and messages, no crash, no GPU needed."""
+    from gym_pybullet_drones_amd import _native
+    from gym_pybullet_drones_amd.params import DroneParams
+    from gym_pybullet_drones_amd.utils.enums import DroneModel
+    L = _native.lib()
+    P = DroneParams(DroneModel.CF2X).to_struct(pid_model=DroneModel.CF2X)
+    buf = (ctypes.c_float * 4096)()
+    ptr = ctypes.cast(buf, ctypes.c_void_p).value
+    ok = dict(n_rows=80, slab=40, world_size=2, rank=1, own_count=30, nx=3, ny=3, nz=1, cell=10.5, x0=0.0, y0=0.0, z0=0.0, zbin=1.0,
+              meta_rows=1, pos4=ptr, bin_pos=ptr, cell_count=ptr, cell_start=ptr, order=ptr, visit=None, visit_out=ptr + 1024,
+              slot_key=ptr, dw_force=ptr, slot_of=None, pos_sorted=None, pair_list=None, pair_nb=None, list_ok=None, list_cap=0,
+              list_delta=0.0, drift=ptr, total_drones=60)
+
+    def rc(entry, **change):
+        sw = _native.GpdSwarm(**{**ok, **change})
+        if entry == "bin":
+            return L.gpd_swarm_bin(ctypes.byref(sw), None)
+        return L.gpd_swarm_forces(ctypes.byref(P), ctypes.byref(sw), 0, None)
+
+    for entry in ("bin", "forces"):
+        assert rc(entry, cell=9.0) == _native.GPD_EINVAL and b"cell must be >= 10" in L.gpd_last_error()
+        assert rc(entry, n_rows=81) == _native.GPD_EINVAL                    # != world_size * slab
+        assert rc(entry, rank=2) == _native.GPD_EINVAL
+        assert rc(entry, own_count=40) == _native.GPD_EINVAL                 # no room for the meta rows
+        assert rc(entry, meta_rows=0) == _native.GPD_EINVAL
+        assert rc(entry, nx=2) == _native.GPD_ERANGE and rc(entry, nx=300, ny=300) == _native.GPD_ERANGE
+        assert rc(entry, pos4=None) == _native.GPD_EINVAL and rc(entry, drift=None) == _native.GPD_EINVAL
+        assert rc(entry, total_drones=0) == _native.GPD_EINVAL
+        assert rc(entry, visit=ptr) == _native.GPD_EINVAL                    # aliases order
+        assert rc(entry, slot_of=ptr) == _native.GPD_EINVAL                  # ... comes with pos_sorted
+        assert rc(entry, slot_of=ptr, pos_sorted=ptr) == _native.GPD_EINVAL  # ... and only when this rank holds the whole world
+    assert rc("forces", pair_list=ptr) == _native.GPD_EINVAL                 # lists need pair_nb / list_ok / list_cap
+    assert L.gpd_swarm_forces(None, ctypes.byref(_native.GpdSwarm(**ok)), 0, None) == _native.GPD_EINVAL
+    # gpd_swarm_step: the step configuration it accepts
+    st = _native.GpdState(kin=ptr, last_rpm=ptr, pid=None, step_counter=ptr, ld=64)
+    cfg = dict(num_envs=30, drones_per_env=1, act_type=5, substeps=1, physics_flags=7, pyb_dt=1 / 240, ctrl_dt=1 / 240, inv_ctrl_dt=240.0,
+               lanes_per_wave=64, task=0, xy_bound=1.5, z_bound=2.0, tilt_bound=0.4, term_dist=1e-4, trunc_counter=1920, target_per_env=0,
+               init_per_env=0, auto_reset=0)
+    sw = _native.GpdSwarm(**ok)
+
+    def step_rc(**change):
+        c = _native.GpdStepCfg(**{**cfg, **change})
+        return L.gpd_swarm_step(ctypes.byref(P), ctypes.byref(st), ctypes.byref(c), ctypes.byref(sw), ptr, ptr, None, None)
+
+    assert step_rc(substeps=2) == _native.GPD_ENOTSUP and step_rc(auto_reset=1) == _native.GPD_ENOTSUP and step_rc(task=1) == _native.GPD_ENOTSUP
+    assert step_rc(act_type=1) == _native.GPD_ENOTSUP                        # waypoints: gpd_pid first
+    assert step_rc(num_envs=31) == _native.GPD_EINVAL and step_rc(drones_per_env=2) == _native.GPD_EINVAL
+    assert step_rc(physics_flags=64) == _native.GPD_EINVAL
+    assert L.gpd_swarm_pack(None, ctypes.byref(sw), None, None, None) == _native.GPD_EINVAL
