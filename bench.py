@@ -486,16 +486,17 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
     indep = mode == "rollout" and len(envs) > 1
     if indep:
         if getattr(args, "cu_mask", False):
-            # every chain on a stream restricted to its own XCDs (hipExtStreamCreateWithCUMask; mask bit i = CU i/8 of XCD i%8,
-            # the KFD's layout for multi-XCC parts): without it the dispatchers of two queues place their workgroups on the
-            # same CUs from CU 0 on, and the chains share SIMDs instead of splitting the chip
+            # every chain on a stream restricted to its own CUs (hipExtStreamCreateWithCUMask).  Chain c takes the mask bits
+            # c*256/C .. (c+1)*256/C - 1: scratch/exp_r03/place.hip shows that two such halves are disjoint sets of 128 CUs,
+            # 16 in every XCD (profiles/r03_stream_placement.txt) -- the "bit i = CU i/8 of XCD i%8" layout the first version
+            # of this option assumed changes nothing against plain streams, where two 128-workgroup kernels share 21 CUs
             hip = ctypes.CDLL("libamdhip64.so")
             C = len(envs)
             side = []
             for c in range(C):
                 words = (ctypes.c_uint32 * 8)()
                 for i in range(256):
-                    if (i % 8) * C // 8 == c:
+                    if i * C // 256 == c:
                         words[i // 32] |= 1 << (i % 32)
                 h = ctypes.c_void_p()
                 rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words)
@@ -533,6 +534,27 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
             main.wait_stream(stream)
             graphs[n] = g
 
+    # --rollout-graph P (experiment): P passes of the rollout schedule -- every chain of a --split -- captured in ONE hipGraph
+    # (fork behind the capture stream, join before its end) and replayed: no host launch cost in the timed region, which at
+    # 20 steps per launch and two or more chains is what the plain --split figures measure (9 us of host time per launch)
+    pass_graph, P = None, int(getattr(args, "rollout_graph", 0) or 0)
+    if mode == "rollout" and P > 0 and gather is None:
+        cap = torch.cuda.Stream(device)
+        cap.wait_stream(main)
+        with torch.cuda.stream(cap):
+            pass_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(pass_graph, stream=cap):
+                if indep:
+                    for s_ in side:
+                        s_.wait_stream(cap)
+                for _ in range(P):
+                    for n in groups_of(K, POOL):
+                        one_rollout(n)
+                if indep:
+                    for s_ in side:
+                        cap.wait_stream(s_)
+        main.wait_stream(cap)
+
     def run(k):
         for e in envs:
             if getattr(e, "reset_each_pass", False):
@@ -561,8 +583,19 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
         if indep:             # fork: the other chains start behind ev0 ...
             for s_ in side:
                 s_.wait_event(ev0)
-        for _ in range(reps):
-            run(K)
+        if indep and getattr(args, "stagger", False):
+            # chains forked at the same instant with launches of the same length stay in lock step: their kernel boundaries
+            # coincide and hide nothing.  Chain c starts with a launch of c/C of the schedule's steps (inside the timed
+            # region, its steps NOT counted).
+            for c, (e, a) in enumerate(zip(envs, actions)):
+                if c:
+                    launch_rollout(e, a, max(1, min(K, POOL) * c // len(envs)))
+        if pass_graph is not None and reps % P == 0:
+            for _ in range(reps // P):
+                pass_graph.replay()
+        else:
+            for _ in range(reps):
+                run(K)
         if indep:             # ... and ev1 sits behind the last launch of EVERY chain (one join, after the last step)
             for s_ in side:
                 main.wait_stream(s_)
@@ -574,10 +607,16 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
         return (gdist.max_over_ranks(ev0.elapsed_time(ev1) * 1e-3, device=device),
                 gdist.max_over_ranks(t1 - t0, device=device))
 
+    if indep and getattr(args, "stagger", False):
+        for c, (e, a) in enumerate(zip(envs, actions)):
+            if c:
+                launch_rollout(e, a, max(1, min(K, POOL) * c // len(envs)))      # (allocates that length's buffers)
     run(W)                                          # W untimed warm-up steps, as requested
     run(K)                                          # + one untimed pass of the schedule itself
     cal, _ = timed(1)                               # calibration pass (untimed in the result): how long is one schedule?
     repeats = int(min(max(1, math.ceil(args.min_time / max(cal, 1e-7))), 1 << 20))
+    if pass_graph is not None:
+        repeats = max(P, (repeats + P - 1) // P * P)
     ev_s, wall_s = timed(repeats)
     timed_steps = K * repeats
     # roofline of the dominant kernel: algorithmic bytes of all launches of the timed region / its HIP-event time
@@ -681,6 +720,9 @@ def main():
     ap.add_argument("--split", type=int, default=1,
                     help="C sub-batches of E/C aviaries as C independent chains on C streams: rollout mode -- C concurrent rollout launches, "
                          "no join inside the timed region; graph/eager -- C chains of single-step launches")
+    ap.add_argument("--stagger", action="store_true", help="rollout --split C: chain c starts c/C of a launch late (experiment)")
+    ap.add_argument("--rollout-graph", type=int, default=0,
+                    help="experiment: rollout mode -- capture this many passes of the schedule (all chains of a --split) in one hipGraph")
     ap.add_argument("--cu-mask", action="store_true", help="rollout --split C: chain c runs on a stream restricted to its own 8/C XCDs")
     ap.add_argument("--no-parity", action="store_true", help="skip the replay of one schedule through the float64 C oracle")
     ap.add_argument("--allgather", action="store_true", help="all-gather the obs shards over RCCL")
@@ -813,6 +855,8 @@ def main():
                        "physics_flags": core.physics_flags,
                        "pyb_freq": 240, "ctrl_freq": w["ctrl"], "substeps_per_step": S, "action": w["act"],
                        "task": w["task"], "auto_reset": True, "mode": args.mode, "launch": launch, "split": len(envs),
+                       **({"rollout_graph_passes": args.rollout_graph} if args.rollout_graph else {}),
+                       **({"staggered_chains": True} if args.stagger and len(envs) > 1 else {}),
                        "full_obs": w.get("full_obs", False), "policy": "MlpPolicy 64x64 tanh, in the kernel (rollout) / torch between steps (graph)" if w.get("policy") else None,
                        "obs_allgather": want_gather, "allgather_impl": impl, "allgather_note": gather_note,
                        "n_ranks_seen_by_rccl": ranks_seen,

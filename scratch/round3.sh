@@ -36,6 +36,16 @@ split)
     timeout 200 python bench.py --steps $k --warmup 5 --split $c --no-cpu-baseline --no-second-leg 2>gpurun_out/r03_bench_rollout${k}_split$c.err | tail -1 > gpurun_out/r03_bench_rollout${k}_split$c.json
     show "rollout$k split $c" gpurun_out/r03_bench_rollout${k}_split$c.json
   done; done ;;
+splitgraph)
+  for k in 20 64; do for c in 1 2 4; do
+    timeout 200 python bench.py --steps $k --warmup 5 --split $c --rollout-graph 8 --no-parity --no-cpu-baseline --no-second-leg 2>gpurun_out/r03_bench_rollout${k}_split${c}_graph.err | tail -1 > gpurun_out/r03_bench_rollout${k}_split${c}_graph.json
+    show "rollout$k split $c, 8 passes per hipGraph" gpurun_out/r03_bench_rollout${k}_split${c}_graph.json
+  done; done ;;
+mask2)
+  for k in 20 64; do for c in 2 4; do
+    timeout 200 python bench.py --steps $k --warmup 5 --split $c --cu-mask --no-parity --no-cpu-baseline --no-second-leg 2>gpurun_out/r03_bench_rollout${k}_split${c}_cumask2.err | tail -1 > gpurun_out/r03_bench_rollout${k}_split${c}_cumask2.json
+    show "rollout$k split $c cu-mask (blocked bits)" gpurun_out/r03_bench_rollout${k}_split${c}_cumask2.json
+  done; done ;;
 mask)
   for k in 20 64; do for c in 2 4 8; do
     timeout 200 python bench.py --steps $k --warmup 5 --split $c --cu-mask --no-cpu-baseline --no-second-leg 2>gpurun_out/r03_bench_rollout${k}_split${c}_cumask.err | tail -1 > gpurun_out/r03_bench_rollout${k}_split${c}_cumask.json
