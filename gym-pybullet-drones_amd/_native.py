@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(CSRC, "libgpd.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # Two translation units (csrc/gpd.hip, csrc/gpd_policy.hip = the same source with GPD_POLICY_TU defined), one library:
 #   -mllvm -amdgpu-sched-strategy=max-ilp for the step / rollout kernels: it interleaves independent dependency chains, which
@@ -59,7 +59,7 @@ class GpdSwarm(ctypes.Structure):
                 ("slot_key", ctypes.c_void_p), ("dw_force", ctypes.c_void_p), ("slot_of", ctypes.c_void_p),
                 ("pos_sorted", ctypes.c_void_p), ("pair_list", ctypes.c_void_p), ("pair_nb", ctypes.c_void_p),
                 ("list_ok", ctypes.c_void_p), ("list_cap", ctypes.c_int32), ("list_delta", ctypes.c_float),
-                ("drift", ctypes.c_void_p), ("total_drones", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+                ("drift", ctypes.c_void_p), ("total_drones", ctypes.c_int32), ("list_adapt", ctypes.c_int32)]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -2086,9 +2086,11 @@ struct DwBinOut {
     int* list_ok;          // [ceil(n / 64)] or NULL: the groups' wake lists belong to the previous binning: all back to 0
     float4* bin_pos;       // [n] x, y, z of every row at this binning
     float* pos4_w;         // pos4 as floats: the sums and maxima in every rank's meta rows (the last meta_rows of its slab) go back to 0
-    float* drift;          // [2] ... and so does the common drift
+    float* drift;          // [4] ... and so does the common drift [0..1]; [2]: the margin of the wake lists of THIS binning (below)
     int slab, world, meta_rows;
     int own_lo, own_cnt;   // rows whose force lands in dw_out[row - own_lo]
+    float list_delta;      // the largest margin the skin allows
+    int list_adapt;        // 1: the margin follows the displacement the interval that ends here has seen
 };
 template <bool FUSED>
 __global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const DwPos src, int n, const DwGrid G,
@@ -2123,11 +2125,31 @@ __global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const DwPos src, in
     }
     auto start = [&](int k) { if constexpr (FUSED) return lstart[k]; else return start_g[k]; };
     if (B.pos4_w && blockIdx.x == 0) {                     // every rank bins on the same sub-steps: all displacements restart
+        __shared__ float dmax_red[kBlock / 64];
+        float d2 = 0.0f;                                   // ... the largest one of the interval that ends here first
         for (int k = threadIdx.x; k < B.world * B.meta_rows; k += kBlock) {
             float* row = B.pos4_w + (static_cast<size_t>(k / B.meta_rows + 1) * B.slab - B.meta_rows + k % B.meta_rows) * 4;
+            d2 = fmaxf(d2, row[3]);
             row[1] = 0.0f; row[2] = 0.0f; row[3] = 0.0f;
         }
-        if (B.drift && threadIdx.x < 2) B.drift[threadIdx.x] = 0.0f;
+        if (B.drift) {
+            // The wake lists' margin: a pair is listed if it could pass the model's tests after both drones have moved `delta`,
+            // and a list is replayed while no drone has.  The skin allows 0.49 (cell - 10 m) -- at 10.5 m, 0.245 m and 40 % more
+            // pairs than the exact tests keep; a swarm that moved 5 mm between the last two binnings (relative to its common
+            // drift) needs nothing like it.  Three times what the ending interval saw, at least a centimetre, at most what the
+            // skin allows; a swarm that then moves further than that sweeps until the next binning (exact either way).
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, off));
+            if (lane == 0) dmax_red[threadIdx.x >> 6] = d2;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float m = dmax_red[0];
+#pragma unroll
+                for (int k = 1; k < kBlock / 64; ++k) m = fmaxf(m, dmax_red[k]);
+                B.drift[0] = 0.0f; B.drift[1] = 0.0f;
+                B.drift[2] = B.list_adapt ? fminf(B.list_delta, fmaxf(0.01f, 3.0f * sqrtf(m))) : B.list_delta;
+            }
+        }
     }
     if (B.list_ok && i < (n + 63) / 64) B.list_ok[i] = 0;
     int c = -1 - lane, d = 0;
@@ -2222,8 +2244,9 @@ struct DwWorld {
     int own_lo, own_cnt;   // rows this launch produces forces for (dw_out[row - own_lo])
     int slab, world, meta_rows;
     float cell;
-    float* drift;          // [2] out (workgroup 0): the mean lateral displacement of all drones, for the NEXT sub-step's step kernel
+    float* drift;          // [2] out (the extra workgroup): the mean lateral displacement of all drones, for the NEXT sub-step's step kernel
     float inv_total;       // 1 / drones in the world
+    int n_slots;           // entries of `order` / `sorted` / `slot_key` (what a slot index may be clamped to)
 };
 // Wake lists (GpdSwarm): what survives phase A changes little from one sub-step to the next -- drones move centimetres, the
 // model's reach is metres.  The force launch right after a binning (MODE 1, "build") runs phase A with a margin -- a pair is
@@ -2251,19 +2274,24 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
     __shared__ unsigned short queue[kBlock / 64][kDwQueue];
     __shared__ unsigned long long sums[kBlock / 64][64];
     __shared__ int run0[kDwMaxRuns], pre[kDwMaxRuns + 1];  // first element of each candidate run; prefix sums of the run lengths
+#if defined(GPD_EXP_TS) && defined(GPD_EXP_TSF)
+    const unsigned long long tf0 = wall_clock64();
+    unsigned long long tf1 = 0, tf2 = 0, tf3 = 0;
+#endif
     const int nx = G.nx, ny = G.ny, nz = G.nz;
     const int keys = nx * ny * nz;
     // the sort's per-key counters / cursors are done with: leave them zeroed for the next binning (no memset node per call)
     for (int k = blockIdx.x * kBlock + threadIdx.x; k < 2 * (keys + 1); k += gridDim.x * kBlock) cursor[k] = 0;   // (counts | cursors)
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    if (Wd.drift && blockIdx.x == 0) {
+    if (Wd.drift && blockIdx.x == gridDim.x - 1) {
+        // (an EXTRA workgroup behind those of the sorted array: workgroup 0 used to do this in front of its own share, and with
+        // all workgroups resident at once the launch lasts as long as its slowest one)
         // the swarm's common drift for the next sub-step (see swarm_tail): the sum of the workgroups' displacement sums, in an
         // order that depends on nothing but the layout -- every rank arrives at the same two floats
         float sx = 0.0f, sy = 0.0f;
-        const int tot = Wd.world * Wd.meta_rows;
-        for (int k = threadIdx.x; k < tot; k += kBlock) {
-            const float4 m = Wd.meta[static_cast<size_t>(k / Wd.meta_rows + 1) * Wd.slab - Wd.meta_rows + k % Wd.meta_rows];
-            sx += m.y; sy += m.z;
+        for (int r = 0; r < Wd.world; ++r) {               // (rank by rank: no division by a run-time meta_rows per element)
+            const float4* const mr = Wd.meta + (static_cast<size_t>(r + 1) * Wd.slab - Wd.meta_rows);
+            for (int k = threadIdx.x; k < Wd.meta_rows; k += kBlock) { const float4 m = mr[k]; sx += m.y; sy += m.z; }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); }
@@ -2274,14 +2302,48 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
             Wd.drift[0] = (((red[0] + red[2]) + red[4]) + red[6]) * Wd.inv_total;
             Wd.drift[1] = (((red[1] + red[3]) + red[5]) + red[7]) * Wd.inv_total;
         }
-        __syncthreads();
+        return;
     }
-    const int sorted_n = start[keys];                      // drones with a finite position (the others: force 0, set by the sort)
+    // Everything the set-up needs from memory is requested HERE, before the first decision that depends on any of it: the
+    // workgroup's early exits used to sit between the loads (drones sorted -> slot's row -> positions, keys, maxima, list
+    // header: four dependent trips to memory, 3.2 of a replay launch's 15 us, profiles/r03_force_timeline.txt); slot indices
+    // are clamped so that a workgroup which is about to leave reads valid memory.
     const int base = 64 * blockIdx.x;
-    if (base >= sorted_n) return;
     const int s = base + lane;
+    const int sc = min(s, Wd.n_slots - 1);
+    auto key_at = [&](int slot) { return Wd.slot_key ? Wd.slot_key[slot] : __float_as_int(sorted[slot].w); };
+    auto pos_at = [&](int slot) { return Wd.pos4 ? Wd.pos4[order[slot]] : sorted[slot]; };
+    const int sorted_n = start[keys];                      // drones with a finite position (the others: force 0, set by the sort)
+    int row_l = order[sc];
+    int key_l = key_at(sc);
+    float4 me_l = Wd.pos4 ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : sorted[sc];
+    // dmax^2: the largest of the step kernel's per-workgroup maxima (one meta row each, every rank's)
+    // (rank by rank: an index k -> (rank, row) split would be two divisions by a run-time meta_rows per element)
+    float d2 = 0.0f;
+    const int tot = Wd.world * Wd.meta_rows;
+    const bool few = tot <= 1024;                          // few: every wave reads them all (no LDS round, no barrier)
+    if (Wd.meta) {
+        for (int r = 0; r < Wd.world; ++r) {
+            const float4* const mr = Wd.meta + (static_cast<size_t>(r + 1) * Wd.slab - Wd.meta_rows);
+            for (int k = few ? lane : static_cast<int>(threadIdx.x); k < Wd.meta_rows; k += few ? 64 : kBlock) d2 = fmaxf(d2, mr[k].w);
+        }
+    }
+    // (replay) whether the group's list is complete, this wave's batches on the first tile
+    unsigned short* const my_list = MODE ? Ls.list + (static_cast<size_t>(blockIdx.x) * (kBlock / 64) + wave) * Ls.cap * 64 : nullptr;
+    unsigned short* const my_nb = MODE ? Ls.nb + (static_cast<size_t>(blockIdx.x) * (kBlock / 64) + wave) * kDwMaxTiles : nullptr;
+    int list_ok = 0, nb0 = 0;
+    float delta = Ls.delta;                                // the lists' margin: what gpd_swarm_bin chose for this binning
+    if (MODE && Wd.drift) delta = Wd.drift[2];
+    if (MODE == 2) {
+        list_ok = Ls.ok[blockIdx.x];
+        nb0 = my_nb[0];
+    }
+    // (the loads above are all in flight; this is where they are waited for, together)
+    asm volatile("" : "+v"(row_l), "+v"(key_l), "+v"(me_l.x), "+v"(me_l.y), "+v"(me_l.z), "+v"(d2), "+v"(list_ok), "+v"(nb0), "+v"(delta));
+    list_ok = __builtin_amdgcn_readfirstlane(list_ok); nb0 = __builtin_amdgcn_readfirstlane(nb0);
+    if (base >= sorted_n) return;
     const bool have = s < sorted_n;
-    const int my_row = have ? order[s] : -1;
+    const int my_row = have ? row_l : -1;
     const bool own = have && my_row >= Wd.own_lo && my_row < Wd.own_lo + Wd.own_cnt;
     if (__builtin_amdgcn_ballot_w64(own) == 0) return;     // (the four waves hold the same 64 slots: the whole workgroup leaves)
     unsigned short* const my_queue = queue[wave];
@@ -2289,25 +2351,18 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
     const float kr = 0.25f * P.prop_radius;
     const float cut = 8.9454f;                             // sqrt(80.02): arg < 40  <=>  dxy^2 < 80 beta^2
     const fp2 b1 = splat(-P.dw_coeff[1] * cut), b0 = splat(P.dw_coeff[2] * cut);
-    auto key_at = [&](int slot) { return Wd.slot_key ? Wd.slot_key[slot] : __float_as_int(sorted[slot].w); };
-    auto pos_at = [&](int slot) { return Wd.pos4 ? Wd.pos4[order[slot]] : sorted[slot]; };
     float4 me = make_float4(0.0f, 0.0f, 3.0e38f, 0.0f);
-    if (own) me = Wd.pos4 ? Wd.pos4[my_row] : sorted[s];
-    const int my_cell = own ? key_at(s) / nz : -1;
-    const int c_first = key_at(base) / nz, c_last = key_at(min(base + 63, sorted_n - 1)) / nz;
+    if (own) me = Wd.pos4 ? Wd.pos4[my_row] : me_l;
+    // (key -> cell: nz = 1 for every grid SwarmAviary builds -- no division by a run-time value then)
+    auto cell_of = [&](int key) { return nz == 1 ? key : key / nz; };
+    const int my_cell = own ? cell_of(key_l) : -1;
     // search radius in cells
     int R = 1;
-    float d2 = 0.0f;                                       // dmax^2
     if (Wd.meta) {
-        // the largest of the step kernel's per-workgroup maxima (one meta row each, every rank's)
-        const int tot = Wd.world * Wd.meta_rows;
-        auto meta_w = [&](int k) { return Wd.meta[static_cast<size_t>(k / Wd.meta_rows + 1) * Wd.slab - Wd.meta_rows + k % Wd.meta_rows].w; };
-        if (tot <= 1024) {                                 // few: every wave reads them all (no LDS round, no barrier)
-            for (int k = lane; k < tot; k += 64) d2 = fmaxf(d2, meta_w(k));
+        if (few) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, off));
         } else {
-            for (int k = threadIdx.x; k < tot; k += kBlock) d2 = fmaxf(d2, meta_w(k));
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, off));
             float* const red = reinterpret_cast<float*>(pre);      // (free until the first segment)
@@ -2325,14 +2380,18 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
     }
     // replay this group's wake list?  (uniform for the workgroup)
     // (0.98: dmax <= 0.99 delta -- the build's margin test is evaluated in fp32, a pair exactly on its boundary must not matter)
-    const bool replay = MODE == 2 && R == 1 && d2 <= 0.98f * (Ls.delta * Ls.delta) && Ls.ok[blockIdx.x] != 0;
-    unsigned short* const my_list = MODE ? Ls.list + (static_cast<size_t>(blockIdx.x) * (kBlock / 64) + wave) * Ls.cap * 64 : nullptr;
-    unsigned short* const my_nb = MODE ? Ls.nb + (static_cast<size_t>(blockIdx.x) * (kBlock / 64) + wave) * kDwMaxTiles : nullptr;
+    const bool replay = MODE == 2 && R == 1 && d2 <= 0.98f * (delta * delta) && list_ok != 0;
+    // the group's first and last cell: the keys of its first and last sorted slot, which two of its lanes hold already
+    const int c_first = cell_of(__builtin_amdgcn_readlane(key_l, 0));
+    const int c_last = cell_of(__builtin_amdgcn_readlane(key_l, __builtin_amdgcn_readfirstlane(min(63, sorted_n - 1 - base))));
+#if defined(GPD_EXP_TS) && defined(GPD_EXP_TSF)
+    if (MODE == 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tf1 = wall_clock64(); }
+#endif
     int lb = 0, tcount = 0;                                // batches recorded / replayed so far; tiles so far
     // (build) the list is complete so far -- and only a build on the binning's own positions counts (a caller that builds later
     // gets no lists rather than lists whose margin was measured from somewhere else)
     bool rec_ok = R == 1 && d2 == 0.0f;
-    const float m2 = MODE == 1 ? 2.0f * Ls.delta : 0.0f;   // (build) what two drones can have closed in on each other
+    const float m2 = MODE == 1 ? 2.0f * delta : 0.0f;      // (build) what two drones can have closed in on each other
     const float c2 = MODE == 1 ? cut * fabsf(P.dw_coeff[1]) * m2 : 0.0f;      // ... and what that adds to sqrt(80.02) |beta|
     const bool sweep_all = R > kDwMaxR;                    // the group's candidates: every sorted drone, one run
     const int nrows = sweep_all ? 0 : min(2 * R + 1, ny);
@@ -2350,11 +2409,13 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
             prer[0] = 0;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                const int row = ((cy + r - 1 + ny) % ny) * nx;
+                int gy = cy + r - 1;                       // (one period at most: no modulo)
+                gy = gy < 0 ? gy + ny : gy >= ny ? gy - ny : gy;
+                const int row = gy * nx;
                 int a0, a1, b1c;                           // run A: cells a0 .. a1; run B (the wrapped part): cells 0 .. b1c, or empty
                 if (w >= nx) { a0 = 0; a1 = nx - 1; b1c = -1; }
                 else {
-                    const int a = (cxa - 1 + nx) % nx;
+                    const int a = cxa > 0 ? cxa - 1 : nx - 1;
                     a0 = a; a1 = min(a + w - 1, nx - 1);
                     b1c = a + w - 1 - nx;                  // (< 0: no wrap)
                 }
@@ -2433,6 +2494,20 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
         for (int v0 = 0; v0 < total; v0 += kDwTile - 1) {
             const int cnt = min(kDwTile - 1, total - v0);
             const int chunks = (cnt + kDwChunk - 1) / kDwChunk;
+            // (replay) the batches this wave evaluated on this tile at the build: the first four are requested BEFORE the tile is
+            // staged -- their addresses depend on nothing the staging produces, and the wave would otherwise wait a full memory
+            // round trip for 128 bytes behind the barrier (SQ_WAIT_ANY 68 % of the wave's cycles, profiles/r03_swarm_counters.txt)
+            int nbt = 0;
+            const unsigned short* lp = nullptr;
+            unsigned e0 = 0xffffu, e1 = 0xffffu, e2 = 0xffffu, e3 = 0xffffu;
+            if (replay) {
+                nbt = tcount == 0 ? nb0 : tcount < kDwMaxTiles ? my_nb[tcount] : 0;
+                lp = my_list + static_cast<size_t>(lb) * 64 + lane;
+                if (0 < nbt) e0 = lp[0];
+                if (1 < nbt) e1 = lp[64];
+                if (2 < nbt) e2 = lp[128];
+                if (3 < nbt) e3 = lp[192];
+            }
             __syncthreads();
             for (int j = threadIdx.x; j < chunks * kDwChunk; j += kBlock) {
                 float4 o = make_float4(0.0f, 0.0f, -3.0e38f, 0.0f);        // (padding of the last chunk: below everything)
@@ -2452,20 +2527,22 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
                 tx[j] = o.x; ty[j] = o.y; tz[j] = o.z;
             }
             __syncthreads();
-            if (replay) {                                              // the batches this wave evaluated on this tile at the build
-                // four batches' entries are requested before the first is evaluated: one at a time, each evaluation waited a
-                // full memory round trip for its 128 bytes (SQ_WAIT_ANY 68 % of the wave's cycles, profiles/r03_swarm_counters.txt)
-                const int nbt = tcount < kDwMaxTiles ? my_nb[tcount] : 0;
-                const unsigned short* const lp = my_list + static_cast<size_t>(lb) * 64 + lane;
+#if defined(GPD_EXP_TS) && defined(GPD_EXP_TSF)
+            if (MODE == 2 && tf2 == 0) tf2 = wall_clock64();
+#endif
+            if (replay) {
+                // ... and the next four are requested before the current four are evaluated
                 for (int b = 0; b < nbt; b += 4) {
-                    const unsigned e0 = lp[static_cast<size_t>(b) * 64];
-                    const unsigned e1 = b + 1 < nbt ? lp[static_cast<size_t>(b + 1) * 64] : 0xffffu;
-                    const unsigned e2 = b + 2 < nbt ? lp[static_cast<size_t>(b + 2) * 64] : 0xffffu;
-                    const unsigned e3 = b + 3 < nbt ? lp[static_cast<size_t>(b + 3) * 64] : 0xffffu;
+                    const unsigned short* const np = lp + static_cast<size_t>(b + 4) * 64;
+                    const unsigned f0 = b + 4 < nbt ? np[0] : 0xffffu;
+                    const unsigned f1 = b + 5 < nbt ? np[64] : 0xffffu;
+                    const unsigned f2 = b + 6 < nbt ? np[128] : 0xffffu;
+                    const unsigned f3 = b + 7 < nbt ? np[192] : 0xffffu;
                     evaluate(e0, e0 != 0xffffu);
                     if (b + 1 < nbt) evaluate(e1, e1 != 0xffffu);
                     if (b + 2 < nbt) evaluate(e2, e2 != 0xffffu);
                     if (b + 3 < nbt) evaluate(e3, e3 != 0xffffu);
+                    e0 = f0; e1 = f1; e2 = f2; e3 = f3;
                 }
                 lb += nbt;
                 ++tcount;
@@ -2537,7 +2614,17 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
         __syncthreads();
         if (threadIdx.x == 0) Ls.ok[blockIdx.x] = okf[0] & okf[1] & okf[2] & okf[3];
     }
+#if defined(GPD_EXP_TS) && defined(GPD_EXP_TSF)
+    if (MODE == 2) tf3 = wall_clock64();
+#endif
     __syncthreads();
+#if defined(GPD_EXP_TS) && defined(GPD_EXP_TSF)
+    if (MODE == 2 && threadIdx.x == 0 && blockIdx.x < 4096) {
+        const unsigned int slot = gpd_ts_cnt[blockIdx.x]++ & 7u;
+        unsigned long long* o = gpd_ts + (static_cast<size_t>(slot) * 4096 + blockIdx.x) * 4;
+        o[0] = tf0; o[1] = tf1; o[2] = tf2; o[3] = tf3;
+    }
+#endif
     if (wave == 0 && own) {                                // add up the four waves' shares
         unsigned long long sum = 0;
 #pragma unroll
@@ -2618,14 +2705,22 @@ struct SwarmOut {
 // good one keeps it small).  The workgroup's largest residual and its displacement sums go to the workgroup's own meta row --
 // plain stores (1024 wavefronts updating ONE word with atomics cost 13 us: atomics on one address are served one after the
 // other; the force kernel, which needs the maximum over all of them, reads a few hundred words instead).
-__device__ __forceinline__ void swarm_tail(const SwarmOut& O, bool active, uint32_t n, float px, float py, float pz) {
+struct SwarmIn { float4 b; float cx, cy; int slot; };     // what the tail needs from memory, requested with the state's loads
+__device__ __forceinline__ SwarmIn swarm_head(const SwarmOut& O, bool active, uint32_t n) {
+    SwarmIn I;
+    I.cx = O.drift[0]; I.cy = O.drift[1];
+    I.b = active ? O.bin_pos_own[n] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    I.slot = (active && O.slot_of_own) ? O.slot_of_own[n] : -1;
+    return I;
+}
+__device__ __forceinline__ void swarm_tail(const SwarmOut& O, const SwarmIn& I, bool active, uint32_t n, float px, float py, float pz) {
     __shared__ float wg_red[kBlock / 64][3];
-    const float cx = O.drift[0], cy = O.drift[1];
+    const float cx = I.cx, cy = I.cy;
     float d2 = 0.0f, sx = 0.0f, sy = 0.0f;
     if (active) {
         O.pos4_own[n] = make_float4(px, py, pz, 0.0f);
-        if (O.slot_of_own) { const int slot = O.slot_of_own[n]; if (slot >= 0) O.pos_sorted[slot] = make_float4(px, py, pz, 0.0f); }
-        const float4 b = O.bin_pos_own[n];
+        if (I.slot >= 0) O.pos_sorted[I.slot] = make_float4(px, py, pz, 0.0f);
+        const float4 b = I.b;
         const float dx = px - b.x, dy = py - b.y, dz = pz - b.z;
         const float ex = dx - cx, ey = dy - cy;
         d2 = fmaf(dz, dz, fmaf(ey, ey, ex * ex));
@@ -2664,12 +2759,13 @@ __global__ __launch_bounds__(kBlock) void gpd_swarm_step_kernel(const GpdParams 
     Carry c;
     float tgx, tgy, tgz, ip[7];
     const float4 act = load_action<4>(action, L.n);
+    const SwarmIn I = swarm_head(O, L.active, L.n);        // (one trip to memory with the state's loads instead of one behind the step)
     load_carry<false, true>(S, C, flags, L, S.kin, S.kin, c, tgx, tgy, tgz, ip);     // (no task, no reset: readable dummies)
     c.roll = c.pitch = c.yaw = 0.0f;
     StepOut out;
     env_step<false, true, false, 4, ACT, true>(P, C, flags, 1, L, act, tgx, tgy, tgz, false, S.kin, ip[0], ip[1], ip[2], ip[3], ip[4],
                                                ip[5], ip[6], nullptr, nullptr, c, out);
-    swarm_tail(O, L.active, L.n, c.k.px, c.k.py, c.k.pz);
+    swarm_tail(O, I, L.active, L.n, c.k.px, c.k.py, c.k.pz);
     // observation rows (48 B) and state vectors (80 B, BaseAviary._getDroneStateVector, envs/BaseAviary.py:541-561): a lane's row
     // is a strided piece of cache lines, a wave's 64 rows are one contiguous block -- transposed through LDS and stored as
     // 1 KiB bursts (the wave's own LDS instructions execute in order: no barrier between its writes and its reads)
@@ -3200,7 +3296,7 @@ int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, i
                            nullptr, nullptr);
     }
     int32_t* const cursors = cell_count + keys + 1;       // second half of cell_count: the scatter's per-key cursors
-    const DwBinOut B{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, n};
+    const DwBinOut B{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, n, 0.0f, 0};
     if (keys <= kDwScanMax) {
         hipLaunchKernelGGL(dwg_scatter_kernel<true>, grid, dim3(kBlock), 0, st, src, n, G, visit_order, cell_count, cursors,
                            cell_start, order, reinterpret_cast<float4*>(sorted_xyzc), dw_out, B);
@@ -3209,7 +3305,7 @@ int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, i
         hipLaunchKernelGGL(dwg_scatter_kernel<false>, grid, dim3(kBlock), 0, st, src, n, G, visit_order, cell_count, cursors,
                            cell_start, order, reinterpret_cast<float4*>(sorted_xyzc), dw_out, B);
     }
-    const DwWorld Wd{nullptr, nullptr, nullptr, 0, n, 0, 0, 0, cell, nullptr, 0.0f};
+    const DwWorld Wd{nullptr, nullptr, nullptr, 0, n, 0, 0, 0, cell, nullptr, 0.0f, n};
     hipLaunchKernelGGL(dwg_force_kernel<0>, dim3(static_cast<unsigned>((n + 63) / 64)), dim3(kBlock), 0, st, *params, G, Wd, DwLists{},
                        cell_start, order, reinterpret_cast<const float4*>(sorted_xyzc), dw_out, cell_count);
     e = hipGetLastError();
@@ -3294,7 +3390,8 @@ int gpd_swarm_bin(const GpdSwarm* w, void* stream) {
     const DwPos src{nullptr, 0, reinterpret_cast<const float4*>(w->pos4)};
     hipLaunchKernelGGL(dwg_count_kernel<false>, grid, dim3(kBlock), 0, st, src, n, G, w->visit, w->cell_count, GpdState{}, nullptr, nullptr);
     int32_t* const cursors = w->cell_count + keys + 1;
-    const DwBinOut B{w->slot_key, w->slot_of, w->visit_out, w->list_ok, reinterpret_cast<float4*>(w->bin_pos), w->pos4, w->drift, w->slab, w->world_size, w->meta_rows, w->rank * w->slab, w->own_count};
+    const DwBinOut B{w->slot_key, w->slot_of, w->visit_out, w->list_ok, reinterpret_cast<float4*>(w->bin_pos), w->pos4, w->drift, w->slab, w->world_size, w->meta_rows, w->rank * w->slab, w->own_count,
+                     w->pair_list ? w->list_delta : 0.0f, w->list_adapt != 0};
     float4* const srt = reinterpret_cast<float4*>(w->pos_sorted);
     if (keys <= kDwScanMax) {
         hipLaunchKernelGGL(dwg_scatter_kernel<true>, grid, dim3(kBlock), 0, st, src, n, G, w->visit, w->cell_count, cursors,
@@ -3319,9 +3416,9 @@ int gpd_swarm_forces(const GpdParams* params, const GpdSwarm* w, int32_t build_l
     const DwGrid G{1.0f / w->cell, w->x0, w->y0, w->nx, w->ny, w->z0, w->nz > 1 ? 1.0f / w->zbin : 0.0f, w->nz};
     const float4* const p4 = reinterpret_cast<const float4*>(w->pos4);
     const DwWorld Wd{w->pos_sorted ? nullptr : p4, w->slot_key, p4, w->rank * w->slab, w->own_count, w->slab, w->world_size, w->meta_rows, w->cell,
-                     w->drift, 1.0f / static_cast<float>(w->total_drones)};
+                     w->drift, 1.0f / static_cast<float>(w->total_drones), w->n_rows};
     const DwLists Ls{w->pair_list, w->pair_nb, w->list_ok, w->list_cap, w->list_delta};
-    const dim3 grid(static_cast<unsigned>((w->n_rows + 63) / 64));
+    const dim3 grid(static_cast<unsigned>((w->n_rows + 63) / 64) + 1u);        // (+ the workgroup that computes the drift)
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float4* const srt = reinterpret_cast<const float4*>(w->pos_sorted);
     if (!lists) hipLaunchKernelGGL(dwg_force_kernel<0>, grid, dim3(kBlock), 0, st, *params, G, Wd, Ls, w->cell_start, w->order, srt, w->dw_force, w->cell_count);

@@ -106,7 +106,8 @@ class SwarmAviary:
                  physics: Physics = Physics.PYB_DW, pyb_freq: int = 240, ctrl_freq: int = 240, act="raw_rpm",
                  world_min=None, world_max=None, cell: float = 10.5, zbin: float = 1.0, nz: int = 1, device=None,
                  pyb_like: bool = None, world_size: int = 1, rank: int = 0, exchange=None, rebin_every: int = None,
-                 wake_lists: bool = True, list_cap: int = 48, partition: str = "spatial", expected_speed: float = None):
+                 wake_lists: bool = True, list_cap: int = 48, partition: str = "spatial", expected_speed: float = None,
+                 adaptive_lists: bool = True):
         if pyb_freq % ctrl_freq != 0:
             raise ValueError("[ERROR] in SwarmAviary.__init__(), pyb_freq is not divisible by ctrl_freq.")
         if act not in ("raw_rpm", ActionType.RPM, ActionType.PID):
@@ -209,6 +210,11 @@ class SwarmAviary:
         groups = (self.n_rows + 63) // 64
         self.list_delta = 0.49 * (self.cell - 10.0)
         self.wake_lists = bool(wake_lists) and self.rebin_every > 1 and self.list_delta > 0
+        # adaptive_lists: `list_delta` is the most the skin allows; every binning then picks the margin of ITS lists from how
+        # far the drones moved (relative to the swarm's drift) since the previous one -- three times that, at least 1 cm.  A
+        # hovering swarm lists 34 pairs per drone instead of 47 at cell = 10.5 m; a swarm that outruns the guess sweeps (exactly)
+        # until the next binning.  False: always the full margin.
+        self.adaptive_lists = bool(adaptive_lists)
         u16 = dict(dtype=torch.int16, device=dev)
         self._pair_list = torch.zeros((groups, 4, int(list_cap) * 64), **u16) if self.wake_lists else None
         self._pair_nb = torch.zeros((groups, 4, 16), **u16) if self.wake_lists else None
@@ -226,7 +232,8 @@ class SwarmAviary:
                                     pair_list=self._pair_list.data_ptr() if self.wake_lists else None,
                                     pair_nb=self._pair_nb.data_ptr() if self.wake_lists else None,
                                     list_ok=self._list_ok.data_ptr() if self.wake_lists else None,
-                                    list_cap=int(list_cap), list_delta=self.list_delta, drift=self._drift.data_ptr(), total_drones=N)
+                                    list_cap=int(list_cap), list_delta=self.list_delta, drift=self._drift.data_ptr(), total_drones=N,
+                                    list_adapt=int(bool(adaptive_lists)))
         self.step_counter = 0
         self._since_bin = 0                          # sub-steps since the last binning
         self._dw_version = -1                        # core.state_version the forces in dw_force were computed for

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GPD_ABI_VERSION 6
+#define GPD_ABI_VERSION 7
 
 /* DroneModel (utils/enums.py:3-8) */
 enum { GPD_MODEL_CF2X = 0, GPD_MODEL_CF2P = 1, GPD_MODEL_RACE = 2 };
@@ -456,9 +456,14 @@ typedef struct GpdSwarm {
     /* "Displacement" above is measured relative to the swarm's COMMON lateral drift since the binning (a translation all drones
      * share changes no pair: a swarm in transit keeps R = 1 and its wake lists).  gpd_swarm_forces computes the drift -- the mean
      * lateral displacement of all drones, from per-workgroup sums in the meta rows (y, z) -- for the next gpd_swarm_step. */
-    float* drift;          /* [2] device floats, zero before the first call (gpd_swarm_bin zeroes them) */
+    float* drift;          /* [4] device floats, zero before the first call: [0..1] the drift (gpd_swarm_bin zeroes them), [2] the
+                              margin of the wake lists of the current binning (gpd_swarm_bin sets it, below), [3] reserved */
     int32_t total_drones;  /* drones of the whole world (all ranks) */
-    int32_t pad_;
+    int32_t list_adapt;    /* (ABI 7) 0: the lists' margin is list_delta.  1: gpd_swarm_bin chooses it for each binning from the
+                              displacement the interval that ends there has seen -- min(list_delta, max(1 cm, 3 dmax)): a swarm
+                              that hovers lists hardly more pairs than the exact tests keep (at cell = 10.5 m the full margin
+                              lists 40 % more); one that moves further than expected sweeps until the next binning.  Exact
+                              either way. */
 } GpdSwarm;
 
 /* One physics sub-step of the rank's own_count drones (state / cfg as for gpd_step: drones_per_env = 1, num_envs = own_count,

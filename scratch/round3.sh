@@ -69,6 +69,11 @@ swarmprof)
     (cd /tmp && export TMPDIR=/tmp && GPD_SWARM_CELL=$1 GPD_SWARM_REBIN=$2 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_swarm_c$1_m$2 -o p -- python $GRAFT_REPO_ROOT/bench.py --workload swarm65536_ext_240hz --steps 256 --warmup 64 --min-time 0.05 --no-cpu-baseline > /dev/null 2>&1)
     f=$(find gpurun_out/prof_swarm_c$1_m$2 -name "*kernel_stats.csv" | head -1); echo "== cell $1 rebin $2: $f"; head -12 $f | cut -c1-200
   done ;;
+swarmq)   # the swarm line + the kernel times of the same command (default cell / rebin)
+  timeout 300 python bench.py --workload swarm65536_ext_240hz --steps 240 --warmup 24 --no-cpu-baseline 2>gpurun_out/r03_swarmq.err | tail -1 > gpurun_out/r03_swarmq.json
+  show "swarm65536" gpurun_out/r03_swarmq.json
+  (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_swarmq -o p -- python $GRAFT_REPO_ROOT/bench.py --workload swarm65536_ext_240hz --steps 256 --warmup 64 --min-time 0.05 --no-cpu-baseline --no-parity > /dev/null 2>&1)
+  f=$(find gpurun_out/prof_swarmq -name "*kernel_stats.csv" | head -1); head -8 $f | cut -c1-160; cp $f gpurun_out/r03_swarmq_kernel_stats.csv; rm -rf gpurun_out/prof_swarmq ;;
 swarm2)
   for cfg in "10.25 8" "10.25 16" "10.5 16" "10.5 32" "10.75 32" "11.0 32"; do set -- $cfg
     GPD_SWARM_CELL=$1 GPD_SWARM_REBIN=$2 timeout 300 python bench.py --workload swarm65536_ext_240hz --steps 240 --warmup 24 --no-cpu-baseline 2>gpurun_out/r03_swarm_c$1_m$2.err | tail -1 > gpurun_out/r03_swarm_c$1_m$2.json

@@ -536,15 +536,18 @@ def test_swarm_steps_captured_in_a_hipgraph_replay_like_eager_steps(gpu_device, 
         assert torch.equal(a.dw_force, b.dw_force), rep
 
 
+@pytest.mark.parametrize("adaptive", [True, False], ids=["margin follows the motion", "full margin"])
 @pytest.mark.parametrize("variant", ["lists", "overflowing lists", "outrun lists", "in transit"])
-def test_wake_lists_replay_the_pairs_of_the_last_binning_exactly(gpu_device, variant):
+def test_wake_lists_replay_the_pairs_of_the_last_binning_exactly(gpu_device, variant, adaptive):
     """Between two binnings the force launches replay the pairs the launch after the binning evaluated (kept with a margin of
     `list_delta` per drone) instead of sweeping all candidates.  Same forces and trajectories, bit for bit, as a twin that bins
     before every force evaluation (no lists at all) -- also when most groups' lists overflow their capacity (those groups sweep),
     and when drones move further than `list_delta` RELATIVE TO EACH OTHER between two binnings (every group sweeps, with the
     radius of `test_stale_cell_order_stays_exact_when_drones_outrun_the_skin`).  A swarm in transit -- every drone at 6 m/s the
     same way -- keeps its lists: displacement is measured against the swarm's common drift, the tracked residual stays a
-    fraction of `list_delta` while every drone has moved several times that."""
+    fraction of `list_delta` while every drone has moved several times that.  `adaptive`: every binning picks the margin of its
+    lists from the displacement the interval before it saw (1 cm ... `list_delta`), or always `list_delta`: the lists differ,
+    the forces do not."""
     from gym_pybullet_drones_amd.envs import SwarmAviary
     from gym_pybullet_drones_amd.utils.enums import Physics
     rng = np.random.default_rng(31)
@@ -552,7 +555,7 @@ def test_wake_lists_replay_the_pairs_of_the_last_binning_exactly(gpu_device, var
     xyz, rpy = _layered_scene(rng, N)
     kw = dict(initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.PYB_GND_DRAG_DW, device=gpu_device, cell=10.5)
     ref = SwarmAviary(N, rebin_every=1, **kw)
-    env = SwarmAviary(N, rebin_every=12, list_cap=1 if variant == "overflowing lists" else 48, **kw)
+    env = SwarmAviary(N, rebin_every=12, list_cap=1 if variant == "overflowing lists" else 48, adaptive_lists=adaptive, **kw)
     assert env.wake_lists and not ref.wake_lists and 0.2 < env.list_delta < 0.25
     for e in (ref, env):
         e.reset()
@@ -576,6 +579,11 @@ def test_wake_lists_replay_the_pairs_of_the_last_binning_exactly(gpu_device, var
             assert (tracked < 0.25 * env.list_delta ** 2) == (variant == "in transit"), (tracked, true_d2)
             checked_drift = True
     assert checked_drift == (variant in ("outrun lists", "in transit"))
+    margin = float(env._drift[2])                   # what the last binning chose
+    if not adaptive or variant == "outrun lists":
+        assert margin == np.float32(env.list_delta)
+    else:                                           # hovering, or all in transit together: centimetres relative to the drift
+        assert 0.01 <= margin < 0.5 * env.list_delta, margin
     ok = env._list_ok[:(N + 63) // 64].float().mean().item()
     assert float(ref.dw_force[:N].abs().max()) > 1e-3
     if variant == "lists":

@@ -337,7 +337,7 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path):
     assert res.returncode == 0, res.stderr
     run = subprocess.run([exe], capture_output=True, text=True)
     assert run.returncode == 0, run.stdout + run.stderr
-    assert "ABI 6" in run.stdout and "-> -1:" in run.stdout
+    assert "ABI 7" in run.stdout and "-> -1:" in run.stdout
 
 
 def test_swarm_entries_reject_bad_arguments_before_touching_a_device():
@@ -352,7 +352,7 @@ def test_swarm_entries_reject_bad_arguments_before_touching_a_device():
     ok = dict(n_rows=80, slab=40, world_size=2, rank=1, own_count=30, nx=3, ny=3, nz=1, cell=10.5, x0=0.0, y0=0.0, z0=0.0, zbin=1.0,
               meta_rows=1, pos4=ptr, bin_pos=ptr, cell_count=ptr, cell_start=ptr, order=ptr, visit=None, visit_out=ptr + 1024,
               slot_key=ptr, dw_force=ptr, slot_of=None, pos_sorted=None, pair_list=None, pair_nb=None, list_ok=None, list_cap=0,
-              list_delta=0.0, drift=ptr, total_drones=60)
+              list_delta=0.0, drift=ptr, total_drones=60, list_adapt=1)
 
     def rc(entry, **change):
         sw = _native.GpdSwarm(**{**ok, **change})
