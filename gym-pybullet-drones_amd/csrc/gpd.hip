@@ -2270,8 +2270,16 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
                                                            const int* __restrict__ start, const int* __restrict__ order,
                                                            const float4* __restrict__ sorted, float* __restrict__ dw_out,
                                                            int* __restrict__ cursor) {
-    __shared__ __attribute__((aligned(16))) float tx[kDwTile], ty[kDwTile], tz[kDwTile];
-    __shared__ unsigned short queue[kBlock / 64][kDwQueue];
+    // one LDS block: the tile's x / y / z planes, then the four waves' queues.  A group that REPLAYS its list queues nothing, and
+    // the queues' 18 KiB hold a second tile (planes at kDwTileB, same spacing): two tiles staged behind one barrier -- the 3 % of
+    // the groups with more than 1023 candidates were what a replay launch waited for (profiles/r03_force_timeline.txt)
+    constexpr int kDwTileB = 3 * kDwTile;                  // floats: where the second tile's x plane starts
+    static_assert((kBlock / 64) * kDwQueue * 2 >= 3 * kDwTile * 4, "the queues hold a second tile");
+    __shared__ __attribute__((aligned(16))) float lds_tile[3 * kDwTile + (kBlock / 64) * kDwQueue / 2];
+    float* const tx = lds_tile;
+    float* const ty = lds_tile + kDwTile;
+    float* const tz = lds_tile + 2 * kDwTile;
+    unsigned short (*const queue)[kDwQueue] = reinterpret_cast<unsigned short (*)[kDwQueue]>(lds_tile + 3 * kDwTile);
     __shared__ unsigned long long sums[kBlock / 64][64];
     __shared__ int run0[kDwMaxRuns], pre[kDwMaxRuns + 1];  // first element of each candidate run; prefix sums of the run lengths
 #if defined(GPD_EXP_TS) && defined(GPD_EXP_TSF)
@@ -2458,7 +2466,7 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
         int pending = 0;                                   // pairs in this wave's queue (wave-uniform)
         // one queued pair: the exact tests and the model (:798-808), added to the drone's sum
         // (called by ALL lanes -- ds_bpermute reads nothing from a lane that is masked off -- with `valid` false where there is no pair)
-        auto evaluate = [&](unsigned e, bool valid) {
+        auto evaluate = [&](unsigned e, bool valid, int org = 0) {         // org: 0, or kDwTileB for a pair of the second tile
             if (MODE == 1) {                               // build: the batch goes to the list as it is evaluated
                 if (rec_ok && lb < Ls.cap) my_list[static_cast<size_t>(lb) * 64 + lane] = static_cast<unsigned short>(valid ? e : 0xffffu);
                 else rec_ok = false;
@@ -2466,8 +2474,8 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
             }
             const int dl = static_cast<int>(e >> 10), ci = static_cast<int>(e & 1023u);
             const float px = __shfl(me.x, dl), py = __shfl(me.y, dl), pz = __shfl(me.z, dl);
-            const float dz = tz[ci] - pz;
-            const float ddx = tx[ci] - px, ddy = ty[ci] - py;
+            const float dz = tz[org + ci] - pz;
+            const float ddx = tx[org + ci] - px, ddy = ty[org + ci] - py;
             const float dxy2 = fmaf(ddy, ddy, ddx * ddx);
             if (valid && dz > 0.0f && dxy2 < 100.0f) {     // dz > 0 and dxy < 10 m  (:800-801)
                 const float ratio = kr * fast_rcp(dz);
@@ -2491,61 +2499,69 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
             }
         };
         // (a tile holds kDwTile - 1 candidates: the entry "lane 63, slot 1023" never occurs and 0xffff can mark an empty lane)
-        for (int v0 = 0; v0 < total; v0 += kDwTile - 1) {
+        for (int v0 = 0; v0 < total;) {
             const int cnt = min(kDwTile - 1, total - v0);
             const int chunks = (cnt + kDwChunk - 1) / kDwChunk;
+            const int cnt2 = replay ? min(kDwTile - 1, total - v0 - cnt) : 0;   // (replay) the tile after this one comes along
             // (replay) the batches this wave evaluated on this tile at the build: the first four are requested BEFORE the tile is
             // staged -- their addresses depend on nothing the staging produces, and the wave would otherwise wait a full memory
             // round trip for 128 bytes behind the barrier (SQ_WAIT_ANY 68 % of the wave's cycles, profiles/r03_swarm_counters.txt)
-            int nbt = 0;
+            int nbt = 0, nbt1 = 0;                         // batches on this tile; on the two tiles together
             const unsigned short* lp = nullptr;
             unsigned e0 = 0xffffu, e1 = 0xffffu, e2 = 0xffffu, e3 = 0xffffu;
             if (replay) {
                 nbt = tcount == 0 ? nb0 : tcount < kDwMaxTiles ? my_nb[tcount] : 0;
+                nbt1 = nbt + ((cnt2 > 0 && tcount + 1 < kDwMaxTiles) ? my_nb[tcount + 1] : 0);
                 lp = my_list + static_cast<size_t>(lb) * 64 + lane;
-                if (0 < nbt) e0 = lp[0];
-                if (1 < nbt) e1 = lp[64];
-                if (2 < nbt) e2 = lp[128];
-                if (3 < nbt) e3 = lp[192];
+                if (0 < nbt1) e0 = lp[0];
+                if (1 < nbt1) e1 = lp[64];
+                if (2 < nbt1) e2 = lp[128];
+                if (3 < nbt1) e3 = lp[192];
             }
+            auto source = [&](int v) {                     // position in the concatenated list -> run q, element src
+                int src;
+                if (fast) {
+                    src = run0r[0] + v;
+#pragma unroll
+                    for (int q = 1; q < 6; ++q) src = (v >= prer[q]) ? run0r[q] + (v - prer[q]) : src;
+                } else {
+                    src = run0[0] + v;
+                    for (int q = 1; q < nruns; ++q) src = (v >= pre[q]) ? run0[q] + (v - pre[q]) : src;
+                }
+                return src;
+            };
             __syncthreads();
             for (int j = threadIdx.x; j < chunks * kDwChunk; j += kBlock) {
                 float4 o = make_float4(0.0f, 0.0f, -3.0e38f, 0.0f);        // (padding of the last chunk: below everything)
-                if (j < cnt) {
-                    const int v = v0 + j;                  // position in the concatenated list -> run q, element src
-                    int src;
-                    if (fast) {
-                        src = run0r[0] + v;
-#pragma unroll
-                        for (int q = 1; q < 6; ++q) src = (v >= prer[q]) ? run0r[q] + (v - prer[q]) : src;
-                    } else {
-                        src = run0[0] + v;
-                        for (int q = 1; q < nruns; ++q) src = (v >= pre[q]) ? run0[q] + (v - pre[q]) : src;
-                    }
-                    o = pos_at(src);
-                }
+                if (j < cnt) o = pos_at(source(v0 + j));
                 tx[j] = o.x; ty[j] = o.y; tz[j] = o.z;
+            }
+            for (int j = threadIdx.x; j < cnt2; j += kBlock) {
+                const float4 o = pos_at(source(v0 + cnt + j));
+                tx[kDwTileB + j] = o.x; ty[kDwTileB + j] = o.y; tz[kDwTileB + j] = o.z;
             }
             __syncthreads();
 #if defined(GPD_EXP_TS) && defined(GPD_EXP_TSF)
             if (MODE == 2 && tf2 == 0) tf2 = wall_clock64();
 #endif
+            v0 += cnt + cnt2;
             if (replay) {
                 // ... and the next four are requested before the current four are evaluated
-                for (int b = 0; b < nbt; b += 4) {
+                auto org_of = [&](int b) { return b < nbt ? 0 : kDwTileB; };
+                for (int b = 0; b < nbt1; b += 4) {
                     const unsigned short* const np = lp + static_cast<size_t>(b + 4) * 64;
-                    const unsigned f0 = b + 4 < nbt ? np[0] : 0xffffu;
-                    const unsigned f1 = b + 5 < nbt ? np[64] : 0xffffu;
-                    const unsigned f2 = b + 6 < nbt ? np[128] : 0xffffu;
-                    const unsigned f3 = b + 7 < nbt ? np[192] : 0xffffu;
-                    evaluate(e0, e0 != 0xffffu);
-                    if (b + 1 < nbt) evaluate(e1, e1 != 0xffffu);
-                    if (b + 2 < nbt) evaluate(e2, e2 != 0xffffu);
-                    if (b + 3 < nbt) evaluate(e3, e3 != 0xffffu);
+                    const unsigned f0 = b + 4 < nbt1 ? np[0] : 0xffffu;
+                    const unsigned f1 = b + 5 < nbt1 ? np[64] : 0xffffu;
+                    const unsigned f2 = b + 6 < nbt1 ? np[128] : 0xffffu;
+                    const unsigned f3 = b + 7 < nbt1 ? np[192] : 0xffffu;
+                    evaluate(e0, e0 != 0xffffu, org_of(b));
+                    if (b + 1 < nbt1) evaluate(e1, e1 != 0xffffu, org_of(b + 1));
+                    if (b + 2 < nbt1) evaluate(e2, e2 != 0xffffu, org_of(b + 2));
+                    if (b + 3 < nbt1) evaluate(e3, e3 != 0xffffu, org_of(b + 3));
                     e0 = f0; e1 = f1; e2 = f2; e3 = f3;
                 }
-                lb += nbt;
-                ++tcount;
+                lb += nbt1;
+                tcount += cnt2 > 0 ? 2 : 1;
                 continue;
             }
             const int tile_b0 = lb;
