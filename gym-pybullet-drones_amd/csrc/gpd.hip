@@ -344,13 +344,15 @@ __device__ __forceinline__ void substep(const GpdParams& P, float h, uint32_t fl
     float f0 = g[0], f1 = g[1], f2 = g[2], f3 = g[3];      // thrust deviations (ground effect adds to them)
     if (EXT && (flags & GPD_PHYS_GND)) {
         // per-rotor extra thrust (:739-743): KF*rpm_i^2 * coeff * (r/(4 h_i))^2, h_i = world z of rotor i, clipped
+        // (the four rotors as two packed pairs: the same operations in the same order per rotor, half the issue slots)
         float e[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float hz = fmaf(R.r21, P.prop_y[i], fmaf(R.r20, P.prop_x[i], k.pz));
-            hz = fmaxf(hz, P.gnd_eff_h_clip);
-            const float ratio = (0.25f * P.prop_radius) * fast_rcp(hz);
-            e[i] = (P.hover_thrust + g[i]) * P.gnd_eff_coeff * (ratio * ratio);
+        for (int i = 0; i < 4; i += 2) {
+            fp2 hz = fma2(splat(R.r21), fp2{P.prop_y[i], P.prop_y[i + 1]}, fma2(splat(R.r20), fp2{P.prop_x[i], P.prop_x[i + 1]}, splat(k.pz)));
+            hz = fp2{fmaxf(hz.x, P.gnd_eff_h_clip), fmaxf(hz.y, P.gnd_eff_h_clip)};
+            const fp2 ratio = splat(0.25f * P.prop_radius) * fp2{fast_rcp(hz.x), fast_rcp(hz.y)};
+            const fp2 ei = ((splat(P.hover_thrust) + fp2{g[i], g[i + 1]}) * splat(P.gnd_eff_coeff)) * (ratio * ratio);
+            e[i] = ei.x; e[i + 1] = ei.y;
         }
         // |roll| < pi/2 and |pitch| < pi/2 on Bullet's Euler extraction (:742), without the atan2/asin:
         // pitch = asin(sarg) is inside (-pi/2, pi/2) off the gimbal branches and exactly +-pi/2 on them;
