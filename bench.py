@@ -700,6 +700,15 @@ def attach_counters(roof, key, m, core, clock_ghz):
             if clock_ghz:
                 issue["measured_clock_ghz"] = clock_ghz
                 issue["frac_at_measured_clock"] = waves_per_simd * slots * 4 / (clock_ghz * 1e3) / m["us_per_step"]
+            if waves_per_simd == 1:
+                # ONE wave on a SIMD does not issue every 4 cycles: profiles/r01_issue_microbench.txt measures 4.5 cycles per
+                # instruction with four independent chains and 5.4 for a dependent chain (two waves per SIMD issue twice that).
+                # At the headline size (1024 waves on 1024 SIMDs) that interval, not the 4-cycle figure, is the floor.
+                ck = clock_ghz or PEAK_CLOCK_GHZ
+                lo, hi = slots * 4.5 / (ck * 1e3), slots * 5.4 / (ck * 1e3)
+                issue["lone_wave"] = {"cycles_per_slot": [4.5, 5.4], "clock_ghz": ck, "floor_us": [lo, hi],
+                                      "frac": [lo / m["us_per_step"], hi / m["us_per_step"]],
+                                      "source": "profiles/r01_issue_microbench.txt (scratch/issue.hip)"}
     hbm_floor = roof["bytes_per_launch"] / roof["env_steps_per_launch"] / (HBM_PEAK_GBS * 1e3)     # us per env step
     roof["floor_us"] = hbm_floor
     if issue is not None:
