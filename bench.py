@@ -61,6 +61,12 @@ WORKLOADS = {
     "stack8x8192_ext_240hz": dict(E=8192, D=8, phys=7, ctrl=240, act="rpm", task="multihover"),
     "multihover2x16384_240hz": dict(E=16384, D=2, phys=4, ctrl=240, act="rpm", task="multihover"),
     "hover65536_pid_240hz": dict(E=65536, D=1, phys=0, ctrl=240, act="pid", task="hover"),
+    # config 2 at the reference's 30 Hz control, and the closed-loop (ActionType.PID) run of every config
+    "hover4096_30hz": dict(E=4096, D=1, phys=0, ctrl=30, act="rpm", task="hover"),
+    "hover4096_pid_240hz": dict(E=4096, D=1, phys=0, ctrl=240, act="pid", task="hover"),
+    "hover65536_ext_pid_240hz": dict(E=65536, D=1, phys=7, ctrl=240, act="pid", task="hover"),
+    "stack8x8192_ext_pid_240hz": dict(E=8192, D=8, phys=7, ctrl=240, act="pid", task="multihover"),
+    "multihover2x16384_pid_240hz": dict(E=16384, D=2, phys=4, ctrl=240, act="pid", task="multihover"),
     "hover65536_240hz_fullobs": dict(E=65536, D=1, phys=0, ctrl=240, act="rpm", task="hover", full_obs=True),
     "hover65536_30hz_fullobs": dict(E=65536, D=1, phys=0, ctrl=30, act="rpm", task="hover", full_obs=True),
     # ... and with the action ring only ("lazy": the history tail stays a strided view of the ring the step kernel pushes into)

@@ -93,6 +93,10 @@ configs)
     extra=""; case $w in swarm*) extra="--steps 240 --warmup 24" ;; esac
     timeout 400 python bench.py --workload $w $extra 2>gpurun_out/r03_bench_$w.err | tail -1 > gpurun_out/r03_bench_$w.json; show $w gpurun_out/r03_bench_$w.json
   done ;;
+configs2)   # config 2 at 30 Hz and the closed-loop run of every config
+  for w in hover4096_30hz hover4096_pid_240hz hover65536_ext_pid_240hz stack8x8192_ext_pid_240hz multihover2x16384_pid_240hz; do
+    timeout 400 python bench.py --workload $w 2>gpurun_out/r03_bench_$w.err | tail -1 > gpurun_out/r03_bench_$w.json; show $w gpurun_out/r03_bench_$w.json
+  done ;;
 *) echo "unknown stage $what" ;;
 esac
 done
