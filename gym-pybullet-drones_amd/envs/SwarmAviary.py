@@ -64,6 +64,10 @@ def swarm_spatial_order(xyz, cell: float) -> np.ndarray:
     return np.lexsort((np.arange(len(xyz)), cxy[:, 0], cxy[:, 1]))
 
 
+import contextlib
+_NO_GUARD = contextlib.nullcontext()
+
+
 class TorchSlabExchange:
     """The all-gather of the ranks' position slabs through `torch.distributed` (RCCL with the "nccl" backend; with gloo the
     slabs are staged through host memory: CPU tests and the single-device test hook)."""
@@ -247,13 +251,27 @@ class SwarmAviary:
         _native.check(rc, "gpd_swarm_pack")
         self._since_bin = self.rebin_every           # (forces a binning)
 
+    def _refs(self):
+        """ctypes references of the four structs and the address of the observation block: built once (an eager sub-step is three
+        C calls; the host side of each is what an eager loop waits for)"""
+        r = self.__dict__.get("_ref_cache")
+        if r is None:
+            c = self.core
+            r = self._ref_cache = (ctypes.byref(c._params), ctypes.byref(c._state), ctypes.byref(c._cfg), ctypes.byref(self._sw), _ptr(c.obs12))
+        return r
+
+    def _guard(self):
+        """the device guard, or nothing when this world's device is the current one already"""
+        return _NO_GUARD if torch.cuda.current_device() == self.device.index else torch.cuda.device(self.device)
+
     def _substep(self, rpm, vectors=None):
         c = self.core
         c.state_version += 1
-        with torch.cuda.device(self.device):
-            rc = c.lib.gpd_swarm_step(ctypes.byref(c._params), ctypes.byref(c._state), ctypes.byref(c._cfg), ctypes.byref(self._sw),
-                                      _ptr(rpm), _ptr(c.obs12), _ptr(vectors), c._stream())
-        _native.check(rc, "gpd_swarm_step")
+        r = self._refs()
+        with self._guard():
+            rc = c.lib.gpd_swarm_step(r[0], r[1], r[2], r[3], _ptr(rpm), r[4], _ptr(vectors), c._stream())
+        if rc:
+            _native.check(rc, "gpd_swarm_step")
         self._since_bin += 1
 
     def _exchange(self):
@@ -264,15 +282,19 @@ class SwarmAviary:
         """(binning when one is due,) the downwash forces of this rank's drones for the positions in pos4"""
         c = self.core
         binned = False
-        with torch.cuda.device(self.device):
+        r = self._refs()
+        with self._guard():
+            stream = c._stream()
             if self._since_bin >= self.rebin_every:
                 binned = True
                 self._visit_in, self._visit_out = self._visit_out, self._visit_in      # the last binning's copy is this one's visit order
                 self._sw.visit = self._visit_in.data_ptr()
                 self._sw.visit_out = self._visit_out.data_ptr()
-                _native.check(c.lib.gpd_swarm_bin(ctypes.byref(self._sw), c._stream()), "gpd_swarm_bin")
+                _native.check(c.lib.gpd_swarm_bin(r[3], stream), "gpd_swarm_bin")
                 self._since_bin = 0
-            _native.check(c.lib.gpd_swarm_forces(ctypes.byref(c._params), ctypes.byref(self._sw), int(binned), c._stream()), "gpd_swarm_forces")
+            rc = c.lib.gpd_swarm_forces(r[0], r[3], int(binned), stream)
+            if rc:
+                _native.check(rc, "gpd_swarm_forces")
         self._dw_version = c.state_version           # (the forces belong to this state)
 
     def _check_vectors(self, vectors):

@@ -19,3 +19,18 @@ for _ in range(n): core.step(a)
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 print("host time per core.step() %.2f us" % ((t1 - t0) / n * 1e6))
+# ONE world of 65 536 drones stepped eagerly (three C calls per sub-step)
+import bench
+sw = bench.make_env(bench.WORKLOADS["swarm65536_ext_240hz"], torch.device("cuda:0"), seed=1000)
+act = torch.full((sw.NUM_DRONES, 4), float(sw.HOVER_RPM), device="cuda:0")
+sw.reset()
+for _ in range(50): sw.step(act)
+torch.cuda.synchronize()
+sw.reset(); torch.cuda.synchronize()
+n = 200
+t0 = time.perf_counter()
+for _ in range(n): sw.step(act)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("SwarmAviary(65536): host time per eager step() %.2f us (incl. GPU drain %.2f us)" % ((t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6))
