@@ -1507,7 +1507,7 @@ __device__ __forceinline__ bf16x8 as_frag(uint32_t a, uint32_t b, uint32_t c, ui
 }
 // tanh(x) = 2 / (1 + exp(-2x)) - 1: v_exp_f32 + v_rcp_f32 (1 ulp each) and three plain operations, no sign handling (x -> -inf:
 // exp -> inf, rcp -> 0, result -1; x -> +inf: exp -> 0, result 1); absolute error ~1.5e-7
-__device__ __forceinline__ float fast_tanh(float x) {
+[[maybe_unused]] __device__ __forceinline__ float fast_tanh(float x) {
     const float t = __builtin_amdgcn_exp2f(x * -2.88539008177792681472f);            // exp(-2x) = 2^(-2 log2(e) x)
     return fmaf(2.0f, fast_rcp(1.0f + t), -1.0f);
 }
@@ -3569,7 +3569,7 @@ int gpd_clock_probe(double* shader_ghz, double* ns_per_fma, void* stream) {
         if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
-    hipFree(d);
+    (void)hipFree(d);
     if (e != hipSuccess) return hip_fail(e, "gpd_clock_probe");
     if (h[1] == 0) return fail(GPD_ENOTSUP, "gpd_clock_probe: the wall clock did not advance");
     const double secs = static_cast<double>(h[1]) / (static_cast<double>(wall_khz) * 1e3);
