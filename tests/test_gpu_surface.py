@@ -537,7 +537,7 @@ def test_swarm_steps_captured_in_a_hipgraph_replay_like_eager_steps(gpu_device, 
 
 
 @pytest.mark.parametrize("adaptive", [True, False], ids=["margin follows the motion", "full margin"])
-@pytest.mark.parametrize("variant", ["lists", "overflowing lists", "outrun lists", "in transit"])
+@pytest.mark.parametrize("variant", ["lists", "overflowing lists", "outrun lists", "in transit", "one fast drone"])
 def test_wake_lists_replay_the_pairs_of_the_last_binning_exactly(gpu_device, variant, adaptive):
     """Between two binnings the force launches replay the pairs the launch after the binning evaluated (kept with a margin of
     `list_delta` per drone) instead of sweeping all candidates.  Same forces and trajectories, bit for bit, as a twin that bins
@@ -547,7 +547,8 @@ def test_wake_lists_replay_the_pairs_of_the_last_binning_exactly(gpu_device, var
     same way -- keeps its lists: displacement is measured against the swarm's common drift, the tracked residual stays a
     fraction of `list_delta` while every drone has moved several times that.  `adaptive`: every binning picks the margin of its
     lists from the displacement the interval before it saw (1 cm ... `list_delta`), or always `list_delta`: the lists differ,
-    the forces do not."""
+    the forces do not.  ONE drone crossing the hovering swarm at 3 m/s outruns an adapted margin within a sub-step (every group
+    sweeps until the next binning, whose margin then follows that drone up to what the skin allows) -- same bits."""
     from gym_pybullet_drones_amd.envs import SwarmAviary
     from gym_pybullet_drones_amd.utils.enums import Physics
     rng = np.random.default_rng(31)
@@ -564,6 +565,10 @@ def test_wake_lists_replay_the_pairs_of_the_last_binning_exactly(gpu_device, var
             kin[7] = 6.0
             if variant == "outrun lists":                   # ... half of them the other way
                 kin[7, ::2] = -6.0
+            e.core.set_state(kin=kin)
+        if variant == "one fast drone":                    # 3 m/s: 0.15 m in twelve sub-steps, inside the skin, beyond an adapted margin
+            kin = e.core.kin[:, :N].clone()
+            kin[7, 5] = 3.0
             e.core.set_state(kin=kin)
     rpm = torch.as_tensor((ref.HOVER_RPM * (1 + 0.02 * rng.uniform(-1, 1, size=(N, 4)))).astype(np.float32), device=gpu_device)
     checked_drift = False
@@ -582,6 +587,8 @@ def test_wake_lists_replay_the_pairs_of_the_last_binning_exactly(gpu_device, var
     margin = float(env._drift[2])                   # what the last binning chose
     if not adaptive or variant == "outrun lists":
         assert margin == np.float32(env.list_delta)
+    elif variant == "one fast drone":               # the margin follows the fastest drone
+        assert margin > 0.1
     else:                                           # hovering, or all in transit together: centimetres relative to the drift
         assert 0.01 <= margin < 0.5 * env.list_delta, margin
     ok = env._list_ok[:(N + 63) // 64].float().mean().item()
