@@ -181,6 +181,22 @@ def downwash_all_pairs(urdf_path, xyz, drone_model="cf2x", threads=1):
     return out
 
 
+def downwash_some(urdf_path, xyz, receivers, drone_model="cf2x", threads=1):
+    """`downwash_all_pairs` for the drones `receivers` (indices) only: every drone is a source, a sample of them receivers."""
+    L = lib()
+    p = make_params(UrdfConstants(urdf_path, drone_model))
+    pos = np.ascontiguousarray(np.asarray(xyz, dtype=np.float64).reshape(-1, 3))
+    recv = np.ascontiguousarray(np.asarray(receivers, dtype=np.int32))
+    out = np.zeros(len(recv))
+    L.orc_set_threads(threads)
+    try:
+        rc = L.orc_downwash_some(ctypes.byref(p), len(pos), _ptr(pos), len(recv), _ptr(recv), _ptr(out))
+    finally:
+        L.orc_set_threads(1)
+    assert rc == 0
+    return out
+
+
 def swarm_substep_seconds(xyz, threads=1, budget_s=10.0, urdf_path=None):
     """Seconds per all-pairs downwash pass over the drones at `xyz` (what dominates a sub-step of one large world on the CPU),
     averaged over the passes that fit `budget_s` -> (seconds, passes)."""

@@ -338,6 +338,31 @@ int orc_downwash_all_pairs(const OrcParams* P, int n, const double* pos, double*
     return 0;
 }
 
+/* The same loop for m of the n drones only (recv [m]: their indices; out [m]): every source, a sample of the receivers --
+ * what a bounded check of a world of 10^6 drones runs (the full loop is 10^12 pair tests). */
+int orc_downwash_some(const OrcParams* P, int n, const double* pos, int m, const int* recv, double* out) {
+    for (int k = 0; k < m; ++k) if (recv[k] < 0 || recv[k] >= n) return -1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+#endif
+    for (int k = 0; k < m; ++k) {
+        const int i = recv[k];
+        double f = 0;
+        for (int j = 0; j < n; ++j) {
+            const double dz = pos[3 * j + 2] - pos[3 * i + 2];
+            const double dx = pos[3 * j] - pos[3 * i], dy = pos[3 * j + 1] - pos[3 * i + 1];
+            const double dxy = sqrt(dx * dx + dy * dy);
+            if (dz > 0 && dxy < 10) {
+                const double ratio = P->prop_radius / (4.0 * dz);
+                const double alpha = P->dw_coeff[0] * ratio * ratio, beta = P->dw_coeff[1] * dz + P->dw_coeff[2];
+                f += -alpha * exp(-0.5 * (dxy / beta) * (dxy / beta));
+            }
+        }
+        out[k] = f;
+    }
+    return 0;
+}
+
 /* standalone batched DSLPIDControl.computeControl: arrays [n][3]/[n][4], pid [n][9] */
 int orc_pid(const OrcParams* P, double dt, int n, const double* pos, const double* quat, const double* vel,
             const double* tpos, const double* trpy, const double* tvel, const double* trates, double* pid, double* rpm,

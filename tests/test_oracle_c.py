@@ -63,3 +63,23 @@ def test_c_auto_reset():
         if k == 241:
             assert trunc.all() and (c.step_counter == 0).all()
             np.testing.assert_allclose(obs[:, 0, :3], c.INIT_XYZS[:, 0])
+
+
+def test_all_pairs_downwash_for_a_sample_of_receivers_is_the_full_loop_restricted():
+    """`orc_downwash_some` (every drone a source, some of them receivers: bench.py's bounded check of a world of 10^6 drones)
+    returns the entries of `orc_downwash_all_pairs` bit for bit, on any thread count; bad indices are refused."""
+    import ctypes
+    from conftest import urdf
+    from oracle import c_oracle
+    rng = np.random.default_rng(5)
+    xyz = rng.uniform([-20, -20, 0.5], [20, 20, 6.0], size=(1500, 3))
+    full = c_oracle.downwash_all_pairs(urdf("cf2x"), xyz, threads=2)
+    assert (np.abs(full) > 1e-6).mean() > 0.3
+    recv = rng.choice(1500, 300, replace=False)
+    for th in (1, 3):
+        np.testing.assert_array_equal(c_oracle.downwash_some(urdf("cf2x"), xyz, recv, threads=th), full[recv])
+    p = c_oracle.make_params(c_oracle.UrdfConstants(urdf("cf2x"), "cf2x"))
+    pos = np.ascontiguousarray(xyz)
+    bad = np.array([0, 1500], dtype=np.int32)
+    out = np.zeros(2)
+    assert c_oracle.lib().orc_downwash_some(ctypes.byref(p), 1500, c_oracle._ptr(pos), 2, c_oracle._ptr(bad), c_oracle._ptr(out)) == -1
