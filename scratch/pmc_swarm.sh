@@ -4,7 +4,7 @@ mkdir -p gpurun_out/pmc_swarm
 cd /tmp && export TMPDIR=/tmp
 for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_swarm/$tag -o p -- python $GRAFT_REPO_ROOT/bench.py --workload swarm65536_ext_240hz --mode eager --steps 96 --warmup 16 --min-time 0.001 --no-cpu-baseline > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_swarm/$tag -o p -- python $GRAFT_REPO_ROOT/bench.py --workload swarm65536_ext_240hz --mode eager --steps 96 --warmup 16 --min-time 0.001 --no-cpu-baseline --no-parity > /dev/null 2>&1
   echo "$tag rc $?"
 done
 cd $GRAFT_REPO_ROOT
