@@ -2332,12 +2332,15 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
     float d2 = 0.0f;
     const int tot = Wd.world * Wd.meta_rows;
     const bool few = tot <= 1024;                          // few: every wave reads them all (no LDS round, no barrier)
-    if (Wd.meta) {
+    auto read_maxima = [&]() {
         for (int r = 0; r < Wd.world; ++r) {
             const float4* const mr = Wd.meta + (static_cast<size_t>(r + 1) * Wd.slab - Wd.meta_rows);
             for (int k = few ? lane : static_cast<int>(threadIdx.x); k < Wd.meta_rows; k += few ? 64 : kBlock) d2 = fmaxf(d2, mr[k].w);
         }
-    }
+    };
+    // (many of them -- a world of 10^6 drones, or shared by many ranks -- and they are read behind the early exits instead: 7 of 8
+    // groups of a rank of eight hold none of its drones, and were reading 64 rows per lane before they found out)
+    if (Wd.meta && few) read_maxima();
     // (replay) whether the group's list is complete, this wave's batches on the first tile
     unsigned short* const my_list = MODE ? Ls.list + (static_cast<size_t>(blockIdx.x) * (kBlock / 64) + wave) * Ls.cap * 64 : nullptr;
     unsigned short* const my_nb = MODE ? Ls.nb + (static_cast<size_t>(blockIdx.x) * (kBlock / 64) + wave) * kDwMaxTiles : nullptr;
@@ -2369,6 +2372,7 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
     // search radius in cells
     int R = 1;
     if (Wd.meta) {
+        if (!few) read_maxima();
         if (few) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, off));
