@@ -479,10 +479,11 @@ int gpd_swarm_step(const GpdParams* params, const GpdState* state, const GpdStep
  * state.kin, dmax^2 = 0, optionally the state vectors.  Follow it with the all-gather, gpd_swarm_bin and gpd_swarm_forces. */
 int gpd_swarm_pack(const GpdState* state, const GpdSwarm* swarm, const float* obs12, float* vec_out, void* stream);
 /* Counting sort of ALL rows by grid cell from pos4 (rows with a non-finite position take no part): order, slot_key,
- * cell_start, bin_xy; every rank's dmax^2 (in this rank's copy of pos4) back to 0. */
+ * cell_start, bin_pos; every rank's dmax^2 and displacement sums (in this rank's copy of pos4) and drift[0..1] back to 0;
+ * drift[2] = the margin of the wake lists of this binning (list_adapt: from the largest dmax^2 found there before the reset). */
 int gpd_swarm_bin(const GpdSwarm* swarm, void* stream);
-/* Downwash forces of the rank's drones for the positions in pos4 -> dw_force.  build_lists: non-zero on the call that follows a
- * gpd_swarm_bin (ignored without wake lists). */
+/* Downwash forces of the rank's drones for the positions in pos4 -> dw_force, and drift[0..1] for the next gpd_swarm_step.
+ * build_lists: non-zero on the call that follows a gpd_swarm_bin (ignored without wake lists). */
 int gpd_swarm_forces(const GpdParams* params, const GpdSwarm* swarm, int32_t build_lists, void* stream);
 
 /*
