@@ -19,8 +19,10 @@ shutil.copy(f"{SRC}/summary.json", "profiles/r03_summary.json")
 for f in glob.glob("gpurun_out/r03_bench_*.json"):
     if os.path.getsize(f):
         shutil.copy(f, "profiles/" + os.path.basename(f))
-for f in glob.glob("gpurun_out/r03_*.txt"):
-    shutil.copy(f, "profiles/" + os.path.basename(f))
+# (only the text files that are copied as they come; the others in profiles/ are curated -- before / after in one file, renamed)
+for name in ("r03_smoke_diag.txt", "r03_swarm_partition_cost.txt"):
+    if os.path.exists("gpurun_out/" + name):
+        shutil.copy("gpurun_out/" + name, "profiles/" + name)
 
 
 def avg_ns(tag, frag):
