@@ -266,13 +266,18 @@ def test_multihover_131072x2_reward_is_sum_of_hover_rewards(gpu_device):
 
 
 @pytest.mark.parametrize("workload,K,steps", [("hover65536_240hz", 20, 240), ("hover65536_240hz", 64, 128),
-                                              ("hover65536_ext_240hz", 20, 120), ("multihover2x16384_240hz", 20, 120)])
+                                              ("hover65536_ext_240hz", 20, 120), ("multihover2x16384_240hz", 20, 120),
+                                              # config 2 at 30 Hz, and the closed-loop (ActionType.PID) runs
+                                              ("hover4096_30hz", 64, 128), ("hover65536_pid_240hz", 20, 120),
+                                              ("hover65536_ext_pid_240hz", 20, 120), ("multihover2x16384_pid_240hz", 20, 120)])
 def test_the_timed_workload_of_bench_py_against_the_c_oracle(gpu_device, workload, K, steps):
     """What bench.py TIMES, not a gentler stand-in: 65 536 HoverAviaries at 240 Hz, U(-1, 1) RPM actions that change every step,
     same-step auto-reset on, through `gpd_rollout` with K steps per launch (K = 20: the driver's `--steps 20`) -- replayed
     through the float64 C oracle from the device's own state by bench.py's `parity_check` (the block the bench line carries).
     SURVEY.md section 8(d)'s metric, every field group below 1e-4; episodes do end inside the window (tilt / box truncation:
-    the reset path is exercised), and the aviaries whose flags flip within rounding of a threshold stay a handful."""
+    the reset path is exercised), and the aviaries whose flags flip within rounding of a threshold stay a handful.  The other
+    cases: the same for the workloads of the other BASELINE configs, open loop and with DSLPID closing the loop in the kernel
+    (waypoints around TARGET_POS that change every step)."""
     import bench
     w = bench.WORKLOADS[workload]
     env = bench.make_env(w, gpu_device, seed=1000)
