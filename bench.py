@@ -582,6 +582,8 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
                 for i in range(n):
                     one_step(i)
 
+    per_rank_s = []
+
     def timed(reps):
         torch.cuda.synchronize()
         if world > 1:
@@ -614,7 +616,9 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
         if world > 1:
             torch.distributed.barrier()
         t1 = time.perf_counter()
-        return (gdist.max_over_ranks(ev0.elapsed_time(ev1) * 1e-3, device=device),
+        mine = ev0.elapsed_time(ev1) * 1e-3
+        per_rank_s[:] = gdist.gather_floats(mine, device=device)       # (this rank's own event time, from every rank)
+        return (gdist.max_over_ranks(mine, device=device),
                 gdist.max_over_ranks(t1 - t0, device=device))
 
     if indep and getattr(args, "stagger", False):
@@ -664,6 +668,7 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
         "K": K, "W": W, "repeats": repeats, "timed_steps": timed_steps, "ev_s": ev_s, "wall_s": wall_s,
         "value": n_total * core.S * timed_steps / ev_s, "value_wall": n_total * core.S * timed_steps / wall_s,
         "env_steps_per_s": n_total * timed_steps / ev_s, "us_per_step": ev_s * 1e6 / timed_steps,
+        "per_gpu": [n_rank * core.S * timed_steps / t for t in per_rank_s],
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "achievable": HBM_ACHIEVABLE_GBS,
                      "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS, "traffic": None, "kernel": kernel,
@@ -726,7 +731,7 @@ def attach_counters(roof, key, m, core, clock_ghz):
     return issue
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4096)
@@ -750,22 +755,199 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-leg", action="store_true",
                     help="skip the extra one-launch-per-step measurement reported next to the rollout headline")
-    args = ap.parse_args()
+    ap.add_argument("--scale-suite", action="store_true",
+                    help="after the headline, also run the multi-GPU configurations of BASELINE.json in the same job and report them "
+                         "under `suite` (default with --gpus > 1 and the default workload; --no-suite turns it off)")
+    ap.add_argument("--no-suite", action="store_true")
+    ap.add_argument("--suite-timeout", type=float, default=300.0,
+                    help="seconds the suite may take before the headline line is printed without it")
+    ap.add_argument("--no-hbm-leg", action="store_true",
+                    help="skip the `hbm_saturating` block (hover4m_240hz: a working set the 256 MiB Infinity Cache cannot hold)")
+    args = ap.parse_args(argv)
     if args.steps < 1 or args.warmup < 0:
         ap.error("--steps must be >= 1 and --warmup >= 0")
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    return args
 
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no torchrun around it: start the N ranks ourselves (one process per GPU,
+    `torch.distributed.run` on 127.0.0.1 and a free port) with the very same arguments, pass rank 0's ONE JSON line through,
+    and exit with the job's return code.  A node with fewer than N devices is an error, not a silent smaller run (the
+    GPD_BENCH_SINGLE_DEVICE test hook puts every rank on device 0)."""
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus and not os.environ.get("GPD_BENCH_SINGLE_DEVICE"):
+        print(f"[bench] --gpus {args.gpus} but this node shows {have} device(s): refusing to report a smaller run as {args.gpus} GPUs",
+              file=sys.stderr)
+        raise SystemExit(2)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", GPD_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_threads() // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr)
+    sys.stderr.flush()
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+class Job:
+    """What every workload of one bench.py process shares: the process group, this rank's device."""
+    def __init__(self, args):
+        from gym_pybullet_drones_amd import dist as gdist
+        # (GPD_DIST_BACKEND / GPD_BENCH_SINGLE_DEVICE: test hooks -- run the multi-rank code path with gloo on one GPU)
+        self.backend = os.environ.get("GPD_DIST_BACKEND", "nccl")
+        self.rank, self.world, self.local = gdist.init_from_env(self.backend if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+        if args.gpus != self.world:
+            # (reached only when a launcher set WORLD_SIZE to something else than --gpus: the line reports what really ran)
+            if self.rank == 0:
+                print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={self.world}: reporting {self.world}", file=sys.stderr)
+            args.gpus = self.world
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+        self.device = torch.device("cuda", self.local if self.world > 1 and not os.environ.get("GPD_BENCH_SINGLE_DEVICE") else 0)
+        torch.cuda.set_device(self.device)
+        # what the collective library itself says the job spans: an all-reduce of ones over the process group (RCCL with the
+        # "nccl" backend), before anything is timed -- a job that fell apart into one-rank worlds shows here
+        self.ranks_in_group = None
+        if self.world > 1:
+            one = torch.ones(1, dtype=torch.float32, device=self.device if self.backend == "nccl" else None)
+            torch.distributed.all_reduce(one)
+            self.ranks_in_group = int(one.item())
+        # ... and the C-ABI's own communicator (gpd_comm_*: ncclCommInitRank / ncclCommCount), created once per process; every
+        # rank takes the same branch when it fails anywhere (the native collectives then fall back to torch.distributed together)
+        self.native_ranks_seen, self.native_note = None, None
+        if self.world > 1 and self.backend == "nccl":
+            err = None
+            try:
+                self.native_ranks_seen = gdist.NativeComm.shared(device=self.device).ranks_seen
+            except Exception as e:      # noqa: BLE001 -- reported in the JSON line
+                err = f"{type(e).__name__}: {e}"[:300]
+            if not gdist.all_ranks_ok(err is None, device=self.device):
+                self.native_ranks_seen, self.native_note = None, f"no native RCCL communicator ({err or 'failed on another rank'})"
+                if gdist.NativeComm._shared is not None:
+                    gdist.NativeComm._shared.close()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, argv)
+    job = Job(args)
+    suite = (args.scale_suite or (job.world > 1 and args.workload == "hover65536_240hz")) and not args.no_suite
+    out = run_workload(args, job)
+    if args.workload == "hover65536_240hz" and not args.no_hbm_leg:
+        hbm_leg(args, job, out)
+    if suite:
+        run_suite(args, job, out)
+    if job.rank == 0:
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if job.world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def hbm_leg(args, job, out):
+    """The headline's working set (99 MB per 20-step launch, re-used by every launch) fits the 256 MiB Infinity Cache, and the
+    FETCH_SIZE / WRITE_SIZE counters count L2 -> fabric requests whether HBM or the cache serves them: "of the HBM roofline"
+    next to it is a fabric-side rate.  This leg puts a number beside it that the cache cannot serve: the same kernel, the same
+    schedule, 4 194 304 drones per GPU (13.9 GB of observation rows per 64-step launch, 218 MB of state)."""
+    a = argparse.Namespace(**vars(args))
+    a.workload, a.no_cpu_baseline, a.no_second_leg, a.split, a.allgather = "hover4m_240hz", True, True, 1, False
+    a.min_time = min(args.min_time, 0.1)
+    try:
+        r = run_workload(a, job)
+    except Exception as e:          # noqa: BLE001 -- reported; the headline survives
+        r = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if job.rank == 0:
+        if "error" in r:
+            out["hbm_saturating"] = r
+            return
+        roof = r["roofline"]
+        out["hbm_saturating"] = {
+            "workload": "hover4m_240hz", "drones_per_gpu": 4194304, "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+            "timed_steps": r["timed_steps"], "kernel": roof["kernel"], "env_steps_per_launch": roof["env_steps_per_launch"],
+            "bytes_per_launch": roof["bytes_per_launch"], "achieved": roof["achieved"], "peak": roof["peak"], "unit_bw": "GB/s",
+            "frac": roof["frac"], "frac_of_achievable": roof["frac_of_achievable"], "traffic": roof.get("traffic"),
+            "parity": {k: r["parity"].get(k) for k in ("checked_steps", "max", "tolerance", "ok", "flag_mismatch_frac", "error") if k in r.get("parity", {})},
+            "note": "working set of one launch >> the 256 MiB Infinity Cache: this rate is served by HBM"}
+        out["roofline"]["traffic_scope"] = ("the headline's working set (%.0f MB per launch, re-used by every launch) is Infinity-Cache "
+                                            "resident: achieved / traffic are fabric-side rates; see hbm_saturating for the HBM-served figure"
+                                            % (out["roofline"]["bytes_per_launch"] / 1e6))
+
+
+#: the multi-GPU configurations of BASELINE.json (configs 4 and 5) and the one strong-scaling workload, per GPU
+SUITE = ("hover65536x8_allgather", "multihover2x16384x8", "swarm1m_ext_240hz")
+
+
+def run_suite(args, job, out):
+    """The other multi-GPU lines in the same job, compact, under out["suite"].  A watchdog bounds the whole suite: when it
+    fires, rank 0 prints the headline line it already holds (the suite entry says what happened) and every rank leaves -- a
+    hang in a collective of a workload that has never met this node must not cost the headline."""
+    import threading
+    results = {}
+    if job.rank == 0:
+        out["suite"] = results
+    done = threading.Event()
+
+    def watchdog():
+        if done.wait(args.suite_timeout):
+            return
+        if job.rank == 0:
+            results["error"] = f"suite not finished after {args.suite_timeout:.0f} s: line printed without the rest"
+            print(json.dumps(out))
+            sys.stdout.flush()
+        os._exit(0)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        for name in SUITE:
+            a = argparse.Namespace(**vars(args))
+            a.workload, a.no_cpu_baseline, a.no_hbm_leg, a.split = name, True, True, 1
+            a.no_parity = a.no_parity or bool(WORKLOADS[name].get("swarm"))       # (the O(N^2) float64 loop over a million drones: minutes)
+            a.allgather = False
+            if WORKLOADS[name].get("swarm"):
+                a.mode, a.no_second_leg = "graph", True
+                a.steps, a.warmup = min(args.steps, 64), min(args.warmup, 8)
+            t0 = time.perf_counter()
+            try:
+                r = run_workload(a, job)
+            except Exception as e:          # noqa: BLE001 -- reported; the headline survives
+                r = {"error": f"{type(e).__name__}: {e}"[:300]}
+            ok = __import__("gym_pybullet_drones_amd.dist", fromlist=["x"]).all_ranks_ok(r is None or "error" not in r, device=job.device)
+            if job.rank == 0:
+                if "error" in r or not ok:
+                    results[name] = {"error": r.get("error", "failed on another rank")}
+                else:
+                    keep = ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "per_gpu", "timed_steps", "value_wall")
+                    c = {k: r[k] for k in keep if k in r}
+                    c["roofline"] = {k: r["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "env_steps_per_launch")}
+                    c["config"] = {k: r["config"].get(k) for k in ("workload", "total_drones", "obs_allgather", "allgather_impl", "allgather_note",
+                                                                   "n_ranks_seen_by_rccl", "ranks_in_process_group", "swarm", "launch", "mode")}
+                    for k in ("one_launch_per_step", "parity", "without_allgather"):
+                        if k in r:
+                            c[k] = r[k] if k != "one_launch_per_step" else {q: r[k][q] for q in ("value", "us_per_step", "launch")}
+                    c["wall_s"] = time.perf_counter() - t0
+                    results[name] = c
+            if not ok:
+                break
+    finally:
+        done.set()
+
+
+def run_workload(args, job):
+    """Measure ONE workload on every rank of the job; rank 0 gets the JSON object, the others None."""
     from gym_pybullet_drones_amd import dist as gdist
-    # (GPD_DIST_BACKEND / GPD_BENCH_SINGLE_DEVICE: test hooks -- run the multi-rank code path with gloo on one GPU)
-    backend = os.environ.get("GPD_DIST_BACKEND", "nccl")
-    rank, world, local = gdist.init_from_env(backend if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
-    if args.gpus != world:
-        if rank == 0:
-            print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run", file=sys.stderr)
-        args.gpus = world
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    device = torch.device("cuda", local if world > 1 and not os.environ.get("GPD_BENCH_SINGLE_DEVICE") else 0)
-    torch.cuda.set_device(device)
-
+    backend, rank, world, device = job.backend, job.rank, job.world, job.device
     w = WORKLOADS[args.workload]
     want_gather = bool(args.allgather or w.get("allgather"))
     POOL = 64      # env steps per rollout launch / per captured hipGraph
@@ -831,6 +1013,12 @@ def main():
         if w.get("policy") or w.get("full_obs"):
             raise SystemExit("--split: plain obs12 workloads only (no policy / history rows)")
         envs, actions = build(args.split)
+    plain = None
+    if gather is not None and len(envs) == 1:
+        # BASELINE config 4 asks for both: first the same schedule WITHOUT the collective
+        plain = measure(args.mode, args, envs, actions, None, device, world, POOL)
+        for e in envs:
+            e.reset()
     m = measure(args.mode, args, envs, actions, gather if len(envs) == 1 else None, device, world, POOL)
 
     parity = None
@@ -878,13 +1066,25 @@ def main():
                        **({"staggered_chains": True} if args.stagger and len(envs) > 1 else {}),
                        "full_obs": w.get("full_obs", False), "policy": "MlpPolicy 64x64 tanh, in the kernel (rollout) / torch between steps (graph)" if w.get("policy") else None,
                        "obs_allgather": want_gather, "allgather_impl": impl, "allgather_note": gather_note,
-                       "n_ranks_seen_by_rccl": ranks_seen,
+                       "n_ranks_seen_by_rccl": ranks_seen if ranks_seen is not None else job.native_ranks_seen,
+                       "ranks_in_process_group": job.ranks_in_group, "process_group_backend": backend if world > 1 else None,
+                       **({"native_comm_note": job.native_note} if job.native_note else {}),
+                       "launcher": "bench.py self-launch (torch.distributed.run)" if os.environ.get("GPD_BENCH_SELF_LAUNCHED") else
+                                   ("torch.distributed.run" if world > 1 else "single process"),
                        "env_steps_per_s": m["env_steps_per_s"],
                        **({"swarm": {"total_drones": envs[0].TOTAL_DRONES, "ranks": envs[0].WORLD_SIZE, "cell_m": envs[0].cell,
                                      "grid": [envs[0].nx, envs[0].ny], "rebin_every": envs[0].rebin_every, "note": "; ".join(swarm_note) or None}}
                           if w.get("swarm") else {})},
             "roofline": m["roofline"],
+            "per_gpu": {"unit": "drone-steps/s", "values": m["per_gpu"], "min": min(m["per_gpu"]), "max": max(m["per_gpu"]),
+                        "note": "every rank's own units / its own HIP-event time of the same timed region; `value` uses the slowest rank's time"},
         }
+        if plain is not None:
+            out["without_allgather"] = {"value": plain["value"], "unit": "drone-steps/s", "us_per_step": plain["us_per_step"],
+                                        "per_gpu": plain["per_gpu"], "frac": plain["roofline"]["frac"]}
+            per_step = 12 * 4 * core.N
+            out["allgather"] = {"bytes_per_rank_per_env_step": per_step, "bytes_per_collective": per_step * m["roofline"]["env_steps_per_launch"] if args.mode == "rollout" else per_step,
+                                "us_per_step_added": m["us_per_step"] - plain["us_per_step"]}
         key_launch = "rollout64" if args.mode == "rollout" else args.mode
         issue = attach_counters(out["roofline"], f"{args.workload}:{key_launch}", m, core, clock_ghz)
         if issue is not None:
@@ -904,10 +1104,8 @@ def main():
             out["parity"] = parity
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = swarm_cpu_baseline(w, envs[0]) if w.get("swarm") else cpu_baseline(w, phys=core.physics_flags)
-        print(json.dumps(out))
-    if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+        return out
+    return None
 
 
 if __name__ == "__main__":

@@ -127,13 +127,22 @@ class NativeComm:
         ident = (ctypes.c_uint8 * _native.COMM_ID_BYTES)()
         blob = [None]
         self.comm = None
+        self.group = group
         with torch.cuda.device(self.device):
             if self.rank == 0:
-                _native.check(self.lib.gpd_comm_unique_id(ident), "gpd_comm_unique_id")
-                blob[0] = bytes(ident)
+                # a failure here (no RCCL on this box) must still reach the other ranks, which sit in the broadcast below:
+                # rank 0 broadcasts the error text instead of the id and EVERY rank raises (callers then agree on a
+                # fallback with all_ranks_ok instead of dead-locking between a broadcast and an all-reduce)
+                try:
+                    _native.check(self.lib.gpd_comm_unique_id(ident), "gpd_comm_unique_id")
+                    blob[0] = bytes(ident)
+                except Exception as e:      # noqa: BLE001
+                    blob[0] = f"rank 0: {type(e).__name__}: {e}"
             if self.world > 1:
                 dist.broadcast_object_list(blob, src=0, group=group)
-                ident = (ctypes.c_uint8 * _native.COMM_ID_BYTES).from_buffer_copy(blob[0])
+            if isinstance(blob[0], str):
+                raise _native.GpdError(blob[0])
+            ident = (ctypes.c_uint8 * _native.COMM_ID_BYTES).from_buffer_copy(blob[0])
             comm = ctypes.c_void_p()
             _native.check(self.lib.gpd_comm_init(ctypes.byref(comm), ident, self.rank, self.world), "gpd_comm_init")
             self.comm = comm
@@ -146,7 +155,12 @@ class NativeComm:
         """The process-wide communicator (created on first use; collective: every rank must call it)."""
         if cls._shared is None or cls._shared.comm is None:
             cls._shared = cls(device=device, group=group)
-        return cls._shared
+        have = cls._shared
+        if (device is not None and torch.device(device) != have.device and torch.device(device).index is not None) or \
+                (group is not None and group is not have.group):
+            raise ValueError(f"the process-wide communicator lives on {have.device} / group {have.group}: a second device or group "
+                             f"needs its own NativeComm(device=..., group=...)")
+        return have
 
     def close(self):
         if getattr(self, "comm", None):
@@ -215,3 +229,14 @@ def max_over_ranks(value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device if _backend() != "gloo" else None)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_floats(value: float, device=None) -> list:
+    """`value` of every rank, in rank order, on every rank (per-GPU figures next to the whole-job one)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    w = dist.get_world_size()
+    t = torch.zeros(w, dtype=torch.float64, device=device if _backend() != "gloo" else None)
+    t[dist.get_rank()] = value
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.tolist()]

@@ -63,3 +63,60 @@ def test_counter_profiles_scale_with_the_launch(tmp_path, monkeypatch):
     # no profile for this key: nothing is invented
     roof = {"env_steps_per_launch": 1.0, "bytes_per_launch": 1.0e6}
     assert bench.attach_counters(roof, "other:graph", m, _Core, None) is None and roof.get("traffic") is None
+
+
+# ---- `python bench.py --gpus N` starts its N ranks itself -------------------------------------------------
+def test_self_launch_builds_a_torchrun_job_with_the_same_arguments(monkeypatch):
+    import subprocess
+    import torch
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 0)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    argv = ["--gpus", "4", "--steps", "20", "--warmup", "5"]
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(bench.parse_args(argv), argv)
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(os.path.join(REPO, "bench.py"))
+    assert cmd[i + 1:] == argv                                   # the ranks see exactly what the caller typed
+    assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["GPD_BENCH_SELF_LAUNCHED"] == "1"
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_self_launch_refuses_to_call_a_smaller_run_n_gpus(monkeypatch, capsys):
+    import torch
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.delenv("GPD_BENCH_SINGLE_DEVICE", raising=False)
+    argv = ["--gpus", "8"]
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(bench.parse_args(argv), argv)
+    assert e.value.code == 2 and "refusing" in capsys.readouterr().err
+
+
+def test_gpus_n_without_torchrun_never_runs_one_rank_silently():
+    """The driver's command form on a box without N devices: a loud non-zero exit, no JSON line claiming anything."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GPD_BENCH_SINGLE_DEVICE")}
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                         cwd=REPO, env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("this box really has two devices")
+    assert res.returncode == 2 and not [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert "--gpus 2" in res.stderr and "refusing" in res.stderr
+
+
+def test_suite_names_are_workloads_and_cover_baseline_configs_4_and_5():
+    assert set(bench.SUITE) <= set(bench.WORKLOADS)
+    assert "hover65536x8_allgather" in bench.SUITE and "multihover2x16384x8" in bench.SUITE and "swarm1m_ext_240hz" in bench.SUITE
+    a = bench.parse_args([])
+    assert a.gpus == 1 and not a.scale_suite and not a.no_suite and a.suite_timeout > 0

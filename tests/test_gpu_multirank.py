@@ -26,6 +26,44 @@ def _bench(args, world, port, timeout=900):
     return json.loads(lines[0])
 
 
+def _bench_self(args, timeout=1200):
+    """`python bench.py --gpus 2 ...` the way the driver types it -- NO torch.distributed.run around it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(GPD_DIST_BACKEND="gloo", GPD_BENCH_SINGLE_DEVICE="1")
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"] + args, cwd=REPO, env=env, capture_output=True,
+                         text=True, timeout=timeout)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]          # ONE JSON line, whatever ran
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_launches_its_two_ranks_itself(gpu_device):
+    j = _bench_self(["--steps", "20", "--warmup", "5", "--min-time", "0.05", "--no-cpu-baseline", "--no-suite", "--no-hbm-leg"])
+    assert j["n_gpus"] == 2 and j["config"]["total_drones"] == 2 * 65536 and j["steps"] == 20 and j["warmup"] == 5
+    assert j["config"]["ranks_in_process_group"] == 2 and "self-launch" in j["config"]["launcher"]
+    pg = j["per_gpu"]["values"]
+    assert len(pg) == 2 and all(v > 1e8 for v in pg) and j["value"] <= sum(pg) * 1.0001
+    assert j["metric"].startswith("env steps/sec (whole node), HoverAviary N=65536")
+
+
+def test_bench_gpus_2_default_run_carries_the_suite_and_the_hbm_leg(gpu_device):
+    """What the driver's SCALE run gets from one command: the headline, the HBM-saturating leg beside it, and BASELINE configs 4
+    and 5 plus the shared 1M-drone world under `suite`."""
+    j = _bench_self(["--steps", "20", "--warmup", "5", "--min-time", "0.05", "--no-cpu-baseline"], timeout=2400)
+    assert j["n_gpus"] == 2 and j["config"]["workload"] == "hover65536_240hz"
+    h = j["hbm_saturating"]
+    assert h["workload"] == "hover4m_240hz" and h["bytes_per_launch"] > 4 * 256 * 2 ** 20 and 0.2 < h["frac"] < 1.1
+    su = j["suite"]
+    assert "error" not in su, su
+    ag = su["hover65536x8_allgather"]
+    assert ag["config"]["obs_allgather"] is True and ag["without_allgather"]["value"] >= ag["value"] * 0.5 and ag["n_gpus"] == 2
+    mh = su["multihover2x16384x8"]
+    assert mh["config"]["total_drones"] == 2 * 2 * 16384 and mh["value"] > 1e8
+    sw = su["swarm1m_ext_240hz"]
+    assert sw["scaling"] == "strong" and sw["config"]["swarm"]["ranks"] == 2 and sw["config"]["total_drones"] == 1048576
+
+
 def test_bench_two_ranks_with_obs_allgather(gpu_device):
     j = _bench(["--steps", "64", "--warmup", "8", "--allgather", "--min-time", "0.02", "--no-second-leg", "--no-cpu-baseline"], 2, 29541)
     assert j["n_gpus"] == 2 and j["config"]["total_drones"] == 2 * 65536 and j["config"]["obs_allgather"] is True
