@@ -2149,7 +2149,9 @@ __global__ __launch_bounds__(kBlock) void dwg_scatter_kernel(const DwPos src, in
 #pragma unroll
                 for (int k = 1; k < kBlock / 64; ++k) m = fmaxf(m, dmax_red[k]);
                 B.drift[0] = 0.0f; B.drift[1] = 0.0f;
-                B.drift[2] = B.list_adapt ? fminf(B.list_delta, fmaxf(0.01f, 3.0f * sqrtf(m))) : B.list_delta;
+                // (m == 0 exactly: nothing has moved -- the binning right after a pack / reset, where the interval that "ended" says
+                // nothing about the one that starts: the full margin, not the 1 cm floor a swarm faster than 0.15 m/s outruns at once)
+                B.drift[2] = (B.list_adapt && m > 0.0f) ? fminf(B.list_delta, fmaxf(0.01f, 3.0f * sqrtf(m))) : B.list_delta;
             }
         }
     }
@@ -2747,7 +2749,9 @@ __device__ __forceinline__ void swarm_tail(const SwarmOut& O, const SwarmIn& I, 
         const float ex = dx - cx, ey = dy - cy;
         d2 = fmaf(dz, dz, fmaf(ey, ey, ex * ex));
         const bool fin = d2 == d2 && d2 < 3.0e38f;             // (a drone without a finite position takes no part in the sort)
-        d2 = d2 == d2 ? d2 : 0.0f;
+        // (NaN AND +-inf: a non-finite position fails every pair test, it needs no search radius -- an infinite d2 would be the
+        // workgroup's maximum, push R beyond kDwMaxR and turn every group of every rank into an O(N^2) sweep until the next binning)
+        d2 = fin ? d2 : 0.0f;
         sx = fin ? dx : 0.0f; sy = fin ? dy : 0.0f;
     }
 #pragma unroll

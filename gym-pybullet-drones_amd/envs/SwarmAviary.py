@@ -42,17 +42,23 @@ def _ptr(t):
 
 
 def swarm_partition(num_drones: int, world_size: int):
-    """How one world of `num_drones` is dealt to `world_size` ranks: `(per, slab, counts)` — rank r owns the drones
-    `r*per .. r*per + counts[r] - 1` (contiguous blocks of `per = ceil(N / W)`), which sit in the rows `r*slab ..` of the packed
-    position array; `slab = per + meta` rows per rank, the last `meta = ceil(per / 256)` being the rank's meta rows (one per
-    workgroup of the step kernel; `include/gpd.h`, `GpdSwarm`)."""
+    """How one world of `num_drones` is dealt to `world_size` ranks: `(per, slab, counts)` -- balanced contiguous blocks (sizes
+    differ by at most one: the first `N mod W` ranks own `per = ceil(N / W)` drones, the others one fewer; rank r's first drone is
+    `swarm_first_drone(N, W, r)`), which sit in the rows `r*slab ..` of the packed position array; `slab = per + meta` rows per
+    rank, the same on every rank, the last `meta = ceil(per / 256)` being the rank's meta rows (one per workgroup of the step
+    kernel; `include/gpd.h`, `GpdSwarm`).  Any N >= W works."""
     if num_drones < world_size:
-        raise ValueError("every rank needs at least one drone")
-    per = -(-num_drones // world_size)
-    counts = [max(0, min(per, num_drones - r * per)) for r in range(world_size)]
-    if min(counts) == 0:
-        raise ValueError(f"{num_drones} drones do not fill {world_size} ranks (blocks of {per}): every rank needs at least one drone")
+        raise ValueError(f"{num_drones} drones cannot be shared by {world_size} ranks: every rank needs at least one drone")
+    base, rem = divmod(num_drones, world_size)
+    per = base + (1 if rem else 0)
+    counts = [base + (1 if r < rem else 0) for r in range(world_size)]
     return per, per + -(-per // 256), counts
+
+
+def swarm_first_drone(num_drones: int, world_size: int, rank: int) -> int:
+    """Index (in the order the drones are dealt in) of the first drone of `rank` under `swarm_partition`."""
+    base, rem = divmod(num_drones, world_size)
+    return rank * base + min(rank, rem)
 
 
 def swarm_spatial_order(xyz, cell: float) -> np.ndarray:
@@ -123,7 +129,7 @@ class SwarmAviary:
         self.TOTAL_DRONES = N = int(num_drones)
         self.WORLD_SIZE, self.RANK, self.exchange = int(world_size), int(rank), exchange
         self.per, self.slab, counts = swarm_partition(N, self.WORLD_SIZE)
-        self.FIRST_DRONE = self.RANK * self.per                  # global index of this rank's first drone
+        self.FIRST_DRONE = swarm_first_drone(N, self.WORLD_SIZE, self.RANK)       # global index of this rank's first drone
         self.NUM_DRONES = n = counts[self.RANK]                  # drones of THIS rank
         self.n_rows = self.slab * self.WORLD_SIZE
         self.DRONE_MODEL, self.PHYSICS, self.ACT_TYPE = drone_model, physics, act

@@ -120,7 +120,12 @@ def warn_if_pyb(physics) -> None:
                   f"explicit Physics.DYN integrator (envs/BaseAviary.py:815-877 of the reference) is used instead"
                   + (", with the " + "/".join(n for b, n in ((1, "ground-effect"), (2, "drag"), (4, "downwash")) if physics.flags & b)
                      + " model(s) evaluated inside it" if physics.flags else "")
-                  + ".  Trajectories follow the reference's Physics.DYN, not its Physics.PYB.", UserWarning, stacklevel=3)
+                  + (".  On top of it this package adds two models the reference's Physics.DYN does NOT have, standing in for what Bullet "
+                     "does in Physics.PYB*: a ground plane at z = 0 (GPD_PHYS_GROUND) and Bullet's default multibody damping of 0.04 "
+                     "(GPD_PHYS_DAMP; restated from the Bullet sources, parity unpinned).  set_pyb_like(False) / GPD_PYB_LIKE=0 / "
+                     "pyb_like=False turn both off: trajectories then follow the reference's Physics.DYN exactly."
+                     if _pyb_like else ".  Trajectories follow the reference's Physics.DYN (pyb_like is off: no ground plane, no damping)."),
+                  UserWarning, stacklevel=3)
 
 
 #: physics add-on bits, mirrored in include/gpd.h

@@ -426,7 +426,11 @@ typedef struct GpdSwarm {
     int32_t meta_rows;     /* >= ceil(max own_count / 256), the same on every rank: one row per workgroup of gpd_swarm_step */
     float* pos4;           /* [n_rows][4] x, y, z, - of every row (meta rows: w = a partial dmax^2) */
     float* bin_pos;        /* [n_rows][4] x, y, z, - of every row at the last binning */
-    int32_t* cell_count;   /* [2 (nx*ny*nz + 1)] counts | cursors: ZERO before the first binning (left zeroed by every call) */
+    int32_t* cell_count;   /* [2 (nx*ny*nz + 1)] counts | cursors: ZERO before the first gpd_swarm_bin.  gpd_swarm_bin leaves the counts
+                              and cursors of its sort in it; the gpd_swarm_forces call that must follow every binning (build_lists
+                              or not) clears them again -- no memset per call.  Two gpd_swarm_bin calls WITHOUT a gpd_swarm_forces
+                              in between (re-pack + re-bin) need the caller to zero the array itself: the second sort would
+                              otherwise start from the first one's counts and scatter out of bounds */
     int32_t* cell_start;   /* [nx*ny*nz + 1] */
     int32_t* order;        /* [n_rows] sorted slot -> row, written by gpd_swarm_bin, read by gpd_swarm_forces: ONE buffer, always that
                               of the latest binning (a captured hipGraph of sub-steps replays correctly whatever ran in between) */
@@ -479,7 +483,7 @@ int gpd_swarm_step(const GpdParams* params, const GpdState* state, const GpdStep
  * state.kin, dmax^2 = 0, optionally the state vectors.  Follow it with the all-gather, gpd_swarm_bin and gpd_swarm_forces. */
 int gpd_swarm_pack(const GpdState* state, const GpdSwarm* swarm, const float* obs12, float* vec_out, void* stream);
 /* Counting sort of ALL rows by grid cell from pos4 (rows with a non-finite position take no part): order, slot_key,
- * cell_start, bin_pos; every rank's dmax^2 and displacement sums (in this rank's copy of pos4) and drift[0..1] back to 0;
+ * cell_start, bin_pos (cell_count must be zero on entry: see GpdSwarm -- every binning is followed by gpd_swarm_forces); every rank's dmax^2 and displacement sums (in this rank's copy of pos4) and drift[0..1] back to 0;
  * drift[2] = the margin of the wake lists of this binning (list_adapt: from the largest dmax^2 found there before the reset). */
 int gpd_swarm_bin(const GpdSwarm* swarm, void* stream);
 /* Downwash forces of the rank's drones for the positions in pos4 -> dw_force, and drift[0..1] for the next gpd_swarm_step.

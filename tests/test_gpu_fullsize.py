@@ -50,17 +50,18 @@ def test_config2_65536_hover_1920_physics_steps(gpu_device):
 
 
 def test_config3_stacks_of_8_all_force_terms(gpu_device):
-    """BASELINE config 3 (ii): 8192 aviaries x 8 stacked drones, GND|DRAG|DW, 0.25 s (60 physics steps).
+    """BASELINE config 3 (ii): 8192 aviaries x 8 stacked drones, GND|DRAG|DW, 0.25 s (60 physics steps), on THE scene bench.py
+    times (`bench.stack_scene`: workload stack8x8192_ext_240hz), against the tolerance.
 
     Short on purpose: among 65 536 drones with random tilts a few drift under their upper neighbour within
-    half a second, where the downwash Gaussian exp(-(dxy/beta)^2/2) with |beta| ~ 0.06 m has a relative
+    half a second, where the downwash Gaussian exp(-(dxy/beta)^2/2) with |beta| ~ 0.07 m has a relative
     condition number of (dxy/beta)^2 ~ 10-100 and its 1/dz^2 prefactor is ~3x the drone's weight; fp32 and
-    fp64 then separate by 1e-3..1e-2 m although every single step agrees to 1e-6 (one-step tests)."""
-    rng = np.random.default_rng(8192)
+    fp64 then separate by 1e-3..1e-2 m although every single step agrees to 1e-6 (one-step tests).  The 256-step horizon of
+    the bench is held against the float64 envelope instead (next test)."""
+    import bench
     E, D, S = 8192, 8, 1
-    xyz = rng.uniform(-0.02, 0.02, size=(E, D, 3)) + np.arange(D)[None, :, None] * np.array([0.12, 0.0, 0.3]) + \
-        np.array([0, 0, 0.8])
-    rpy = rng.uniform(-0.05, 0.05, size=(E, D, 3))
+    xyz, rpy = bench.stack_scene(np.random.default_rng(1000), E, D)            # (seed 1000: rank 0's aviaries in bench.make_env)
+    rng = np.random.default_rng(8192)
     orc = CAviary(urdf("cf2x"), "cf2x", E, D, initial_xyzs=xyz, initial_rpys=rpy, physics_flags=7, pyb_freq=240,
                   ctrl_freq=240, act="rpm", task="multihover")
     core = _core("cf2x", E, D, 7, S, "rpm", "multihover", xyz, rpy, gpu_device, target=orc.TARGET_POS)
@@ -71,6 +72,38 @@ def test_config3_stacks_of_8_all_force_terms(gpu_device):
         print(f"t={t:5d} " + " ".join(f"{g}={v:.2e}" for g, v in e.items()))
         assert max(e.values()) < 1e-4, (t, e)
     np.testing.assert_allclose(core.reward.cpu().numpy(), orc.reward, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("workload", ["stack8x8192_ext_240hz", "stack8x8192_ext_pid_240hz"])
+def test_stack8_downwash_stays_inside_the_float64_envelope(gpu_device, workload):
+    """The bench's OWN stack8 workload -- its scene, its random +-5 % RPM (or DSLPID waypoint) blocks, same-step auto-reset, its
+    64-step rollout launches -- for the bench's 256-step horizon, through the bench's own checker (`bench.parity_check`):
+    the fp32 HIP run against the float64 C oracle, AND against the envelope of a second float64 run nudged by half an fp32
+    ulp after every step.  Over 256 steps of random actions some drones cross a neighbour's wake, where the reference's model
+    amplifies any rounding; the claim that this, not a kernel defect, is what the plain tolerance sees is measured here:
+    median and 95th percentile of the fp32 error over the aviaries stay within 4x the float64-vs-float64 envelope at every
+    checkpoint (VERDICT r03, weak #1)."""
+    import bench
+    w = bench.WORKLOADS[workload]
+    env = bench.make_env(w, gpu_device, seed=1000)
+    acts = bench.make_actions(w, env, gpu_device, seed=2000, pool=64)
+    for n in (64, 64):                                   # (some history first, like the bench's timed region before its check)
+        bench.launch_rollout(env, acts, n)
+    _all_threads()
+    res = bench.parity_check(w, env, acts, 256, 64, max_steps=256)
+    e = res["envelope"]
+    for r in e["rows"]:
+        print("t=%3d %-5s median fp32 %.2e envelope %.2e | p95 fp32 %.2e envelope %.2e | max fp32 %.2e envelope %.2e | %d aviaries" % tuple(r))
+    print({k: res[k] for k in ("max", "flag_mismatch_frac", "ok", "ok_by", "episodes_ended_in_window")}, "ratio", e["ratio"], e["worst"])
+    assert res["checked_steps"] == 256 and len(e["rows"]) >= 4 * 16
+    assert e["ratio"] <= 4.0 and e["ok"] and res["ok"], e["worst"]
+    # the first steps are plain rounding on both sides ...
+    first = [r for r in e["rows"] if r[0] == 1]
+    assert all(r[4] < 2e-6 for r in first), first
+    # ... and the divergence the tolerance sees is there in float64 as well: the two float64 runs separate by more than the tolerance
+    # in their worst aviaries, or the fp32 run passed the tolerance outright
+    assert res["ok_by"] == "tolerance" or max(r[7] for r in e["rows"]) > 1e-4
+    assert e["flag_mismatch_frac_between_the_two_float64_runs"] < 0.05 and res["flag_mismatch_frac"] < 0.05
 
 
 def _all_threads():

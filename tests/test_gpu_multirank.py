@@ -55,7 +55,7 @@ def test_bench_gpus_2_default_run_carries_the_suite_and_the_hbm_leg(gpu_device):
     h = j["hbm_saturating"]
     assert h["workload"] == "hover4m_240hz" and h["bytes_per_launch"] > 4 * 256 * 2 ** 20 and 0.2 < h["frac"] < 1.1
     su = j["suite"]
-    assert "error" not in su, su
+    assert "error" not in su and not [n for n, r in su.items() if "error" in r], su
     ag = su["hover65536x8_allgather"]
     assert ag["config"]["obs_allgather"] is True and ag["without_allgather"]["value"] >= ag["value"] * 0.5 and ag["n_gpus"] == 2
     mh = su["multihover2x16384x8"]
