@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(CSRC, "libgpd.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # Two translation units (csrc/gpd.hip, csrc/gpd_policy.hip = the same source with GPD_POLICY_TU defined), one library:
 #   -mllvm -amdgpu-sched-strategy=max-ilp for the step / rollout kernels: it interleaves independent dependency chains, which
@@ -34,7 +34,7 @@ class GpdState(ctypes.Structure):
     _fields_ = [("kin", ctypes.c_void_p), ("last_rpm", ctypes.c_void_p), ("pid", ctypes.c_void_p),
                 ("step_counter", ctypes.c_void_p), ("ld", ctypes.c_int64), ("dw_force", ctypes.c_void_p),
                 ("act_ring", ctypes.c_void_p), ("ring_pos", ctypes.c_void_p), ("hist_len", ctypes.c_int32),
-                ("pad_", ctypes.c_int32)]
+                ("pad_", ctypes.c_int32), ("bad", ctypes.c_void_p)]
 
 
 class GpdStepCfg(ctypes.Structure):
@@ -111,7 +111,7 @@ _SIGNATURES = {
                                            ctypes.c_int64, _P]),
     "gpd_rollout_policy": (ctypes.c_int, [ctypes.POINTER(GpdParams), ctypes.POINTER(GpdState), ctypes.POINTER(GpdStepCfg), _P,
                                           ctypes.c_int32, _P, _P, _P, _P, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_int64, _P,
-                                          ctypes.POINTER(ctypes.c_float), _P, _P]),
+                                          ctypes.POINTER(ctypes.c_float), _P, _P, _P]),
     "gpd_hist_rows": (ctypes.c_int, [ctypes.POINTER(GpdState), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P]),
     "gpd_full_obs": (ctypes.c_int, [ctypes.POINTER(GpdState), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P,
                                     ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_int64, _P]),

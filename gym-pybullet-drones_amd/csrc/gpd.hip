@@ -77,7 +77,7 @@ std::string& gpd_detail_last_error();
 struct GpdPolicyLaunch {
     const GpdParams* params; const GpdState* state; const GpdStepCfg* cfg; const void* span; const GpdPolicy* policy;
     const float* obs12_in; const float* target_pos; const float* init_pose; float* actions_out; float* obs12; float* reward;
-    uint8_t* terminated; uint8_t* truncated; void* stream; unsigned grid; int hist;
+    uint8_t* terminated; uint8_t* truncated; void* stream; unsigned grid; int hist; float* term_obs12;
 };
 void gpd_detail_launch_policy_pid(const GpdPolicyLaunch& a);
 #ifndef GPD_POLICY_TU
@@ -840,6 +840,16 @@ __device__ __forceinline__ void store_carry(const GpdState& S, const Lane& L, co
     const uint32_t off4 = L.n * 4u;
     const Kin& k = c.k;
     if (L.d == 0) S.step_counter[L.env] = c.counter;
+    if (S.bad) {
+        // non-finite guard (include/gpd.h): a NaN or an infinity in any of the 13 floats makes the sum non-finite (inf - inf = NaN;
+        // finite values of this magnitude cannot overflow it)
+        const float sum = (((k.px + k.py) + (k.pz + k.qx)) + ((k.qy + k.qz) + (k.qw + k.vx))) + (((k.vy + k.vz) + (k.wx + k.wy)) + k.wz);
+        // (the DSLPID members need no check: every one of them passes a clip or is overwritten each step -- control/
+        // DSLPIDControl.py:191-193, 248-251 -- and v_max / v_min return the bound for a NaN where numpy's clip would propagate it.
+        // For the same reason a NaN SET-POINT never reaches the state: one step of saturated commands, then the controller
+        // recovers, where the reference's drone is gone for good.  tests/test_gpu_resume.py pins both behaviours.)
+        S.bad[L.n] = fabsf(sum) <= 3.4028234e38f ? 0 : 1;
+    }
     st_row<NT>(S.kin, ld, 0, off4, k.px); st_row<NT>(S.kin, ld, 1, off4, k.py); st_row<NT>(S.kin, ld, 2, off4, k.pz);
     st_row<NT>(S.kin, ld, 3, off4, k.qx); st_row<NT>(S.kin, ld, 4, off4, k.qy); st_row<NT>(S.kin, ld, 5, off4, k.qz);
     st_row<NT>(S.kin, ld, 6, off4, k.qw);
@@ -1538,7 +1548,7 @@ __device__ __forceinline__ void rollout_policy_body(
     const float* __restrict__ obs12_in, const float* __restrict__ target_pos, const float* __restrict__ init_pose,
     float* __restrict__ actions_out, float* __restrict__ obs12, float* __restrict__ reward, uint8_t* __restrict__ terminated,
     uint8_t* __restrict__ truncated, const float* __restrict__ noise, float* __restrict__ mean_out, const float sd0, const float sd1,
-    const float sd2, const float sd3) {
+    const float sd2, const float sd3, float* __restrict__ term_obs12) {
     constexpr int CAP = 16 * NK1 - 12;                       // history capacity in features
     constexpr int NP = 8 * NK1;                              // packed feature registers (two bf16 features each)
     constexpr bool HIST = NK1 > 1;
@@ -1791,6 +1801,12 @@ __device__ __forceinline__ void rollout_policy_body(
                 if (AW == 4) *reinterpret_cast<float4*>(ar) = make_float4(a[0], a[1], a[2], a[3]);
                 else { ar[0] = a[0]; if (AW == 3) { ar[1] = a[1]; ar[2] = a[2]; } }
             }
+            if (term_obs12 && out.reset) {                   // the last observation of the episode that ended in this step (SB3's
+                f4v* tr = reinterpret_cast<f4v*>(term_obs12 + t * obs_step + static_cast<size_t>(L.n) * 12);   // info["terminal_observation"])
+                tr[0] = f4v{out.to[0], out.to[1], out.to[2], out.to[3]};
+                tr[1] = f4v{out.to[4], out.to[5], out.to[6], out.to[7]};
+                tr[2] = f4v{out.to[8], out.to[9], out.to[10], out.to[11]};
+            }
             if (ring) {                                      // exact fp32 action into both halves of the double ring
                 float* r0 = S.act_ring + static_cast<size_t>(ring_q) * slot + static_cast<size_t>(L.n) * AW;
                 float* r1 = r0 + static_cast<size_t>(S.hist_len) * slot;
@@ -1810,9 +1826,9 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout_policy_kernel(
     const GpdParams P, const GpdState S, const GpdStepCfg C, const Span T, const GpdPolicy Pol,
     const float* __restrict__ obs12_in, const float* __restrict__ target_pos, const float* __restrict__ init_pose,
     float* __restrict__ actions_out, float* __restrict__ obs12, float* __restrict__ reward, uint8_t* __restrict__ terminated,
-    uint8_t* __restrict__ truncated) {
+    uint8_t* __restrict__ truncated, float* __restrict__ term_obs12) {
     rollout_policy_body<PID, AW, ACT, NK1, RELU, false>(P, S, C, T, Pol, obs12_in, target_pos, init_pose, actions_out, obs12, reward,
-                                                        terminated, truncated, nullptr, nullptr, 0.0f, 0.0f, 0.0f, 0.0f);
+                                                        terminated, truncated, nullptr, nullptr, 0.0f, 0.0f, 0.0f, 0.0f, term_obs12);
 }
 
 template <int AW, int ACT, int NK1, bool RELU>
@@ -1820,9 +1836,10 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout_policy_noise_kernel(
     const GpdParams P, const GpdState S, const GpdStepCfg C, const Span T, const GpdPolicy Pol,
     const float* __restrict__ obs12_in, const float* __restrict__ target_pos, const float* __restrict__ init_pose,
     float* __restrict__ actions_out, float* __restrict__ obs12, float* __restrict__ reward, uint8_t* __restrict__ terminated,
-    uint8_t* __restrict__ truncated, const float* __restrict__ noise, float* __restrict__ mean_out, const float4 sd) {
+    uint8_t* __restrict__ truncated, const float* __restrict__ noise, float* __restrict__ mean_out, const float4 sd,
+    float* __restrict__ term_obs12) {
     rollout_policy_body<false, AW, ACT, NK1, RELU, true>(P, S, C, T, Pol, obs12_in, target_pos, init_pose, actions_out, obs12, reward,
-                                                         terminated, truncated, noise, mean_out, sd.x, sd.y, sd.z, sd.w);
+                                                         terminated, truncated, noise, mean_out, sd.x, sd.y, sd.z, sd.w, term_obs12);
 }
 
 #ifndef GPD_POLICY_TU
@@ -3063,10 +3080,10 @@ void gpd_detail_launch_policy_pid(const GpdPolicyLaunch& a) {
     do {                                                                                                                            \
         if (a.policy->activation == 1)                                                                                              \
             hipLaunchKernelGGL((gpd_rollout_policy_kernel<true, AW_, ACT_, NK1_, true>), grid, dim3(kBlock), 0, st, *a.params, *a.state, *a.cfg, T, \
-                               *a.policy, a.obs12_in, a.target_pos, a.init_pose, a.actions_out, a.obs12, a.reward, a.terminated, a.truncated); \
+                               *a.policy, a.obs12_in, a.target_pos, a.init_pose, a.actions_out, a.obs12, a.reward, a.terminated, a.truncated, a.term_obs12); \
         else                                                                                                                        \
             hipLaunchKernelGGL((gpd_rollout_policy_kernel<true, AW_, ACT_, NK1_, false>), grid, dim3(kBlock), 0, st, *a.params, *a.state, *a.cfg, T, \
-                               *a.policy, a.obs12_in, a.target_pos, a.init_pose, a.actions_out, a.obs12, a.reward, a.terminated, a.truncated); \
+                               *a.policy, a.obs12_in, a.target_pos, a.init_pose, a.actions_out, a.obs12, a.reward, a.terminated, a.truncated, a.term_obs12); \
     } while (0)
     switch (a.cfg->act_type) {
         case GPD_ACT_VEL: if (a.hist) GPD_POL(4, GPD_ACT_VEL, 5); else GPD_POL(4, GPD_ACT_VEL, 1); break;
@@ -3141,7 +3158,7 @@ int gpd_rollout_policy(const GpdParams* params, const GpdState* state, const Gpd
                        int32_t num_steps, const float* obs12_in, const float* target_pos, const float* init_pose,
                        float* actions_out, float* obs12, int64_t obs_step_stride, float* reward, uint8_t* terminated,
                        uint8_t* truncated, int64_t env_step_stride, const float* noise, const float* action_std, float* mean_out,
-                       void* stream) {
+                       float* term_obs12, void* stream) {
     auto bad = [&](int code, const char* msg) { return fail(code, (std::string("gpd_rollout_policy: ") + msg).c_str()); };
     if ((noise != nullptr) != (action_std != nullptr)) return bad(GPD_EINVAL, "noise and action_std come together");
     if (mean_out && !noise) return bad(GPD_EINVAL, "mean_out is written by the sampling kernels only (pass noise)");
@@ -3185,10 +3202,10 @@ int gpd_rollout_policy(const GpdParams* params, const GpdState* state, const Gpd
     do {                                                                                                                            \
         if (policy->activation == 1)                                                                                                \
             hipLaunchKernelGGL((gpd_rollout_policy_kernel<PID_, AW_, ACT_, NK1_, true>), grid, dim3(kBlock), 0, st, *params, *state, c, T, \
-                               *policy, obs12_in, target_pos, init_pose, actions_out, obs12, reward, terminated, truncated);        \
+                               *policy, obs12_in, target_pos, init_pose, actions_out, obs12, reward, terminated, truncated, term_obs12); \
         else                                                                                                                        \
             hipLaunchKernelGGL((gpd_rollout_policy_kernel<PID_, AW_, ACT_, NK1_, false>), grid, dim3(kBlock), 0, st, *params, *state, c, T, \
-                               *policy, obs12_in, target_pos, init_pose, actions_out, obs12, reward, terminated, truncated);        \
+                               *policy, obs12_in, target_pos, init_pose, actions_out, obs12, reward, terminated, truncated, term_obs12); \
     } while (0)
 #define GPD_POLN(AW_, ACT_, NK1_)                                                                                                    \
     do {                                                                                                                            \
@@ -3197,11 +3214,11 @@ int gpd_rollout_policy(const GpdParams* params, const GpdState* state, const Gpd
         if (policy->activation == 1)                                                                                                \
             hipLaunchKernelGGL((gpd_rollout_policy_noise_kernel<AW_, ACT_, NK1_, true>), grid, dim3(kBlock), 0, st, *params, *state, c, \
                                T, *policy, obs12_in, target_pos, init_pose, actions_out, obs12, reward, terminated, truncated, noise, \
-                               mean_out, sd);                                                                                       \
+                               mean_out, sd, term_obs12);                                                                           \
         else                                                                                                                        \
             hipLaunchKernelGGL((gpd_rollout_policy_noise_kernel<AW_, ACT_, NK1_, false>), grid, dim3(kBlock), 0, st, *params, *state, c, \
                                T, *policy, obs12_in, target_pos, init_pose, actions_out, obs12, reward, terminated, truncated, noise, \
-                               mean_out, sd);                                                                                       \
+                               mean_out, sd, term_obs12);                                                                           \
     } while (0)
     if (noise) {                 // sampling: the RPM action types (the ones examples/learn.py and the reference's learn.py train)
         if (pid) return bad(GPD_ENOTSUP, "sampling (noise) is implemented for ActionType.RPM and ONE_D_RPM");
@@ -3210,7 +3227,7 @@ int gpd_rollout_policy(const GpdParams* params, const GpdState* state, const Gpd
     } else
     if (pid) {                   // (instantiated in the main unit, see GpdPolicyLaunch)
         const GpdPolicyLaunch a{params, state, &c, &T, policy, obs12_in, target_pos, init_pose, actions_out, obs12, reward, terminated,
-                                truncated, stream, grid.x, hist ? 1 : 0};
+                                truncated, stream, grid.x, hist ? 1 : 0, term_obs12};
         gpd_detail_launch_policy_pid(a);
     } else if (cfg->act_type == GPD_ACT_RPM) {      // NK1 = K-steps of layer 1: 16*NK1 >= 12 + history features
         if (hist) GPD_POL(false, 4, GPD_ACT_RPM, 5); else GPD_POL(false, 4, GPD_ACT_RPM, 1);

@@ -72,7 +72,7 @@ class SimCore:
                  episode_len_sec: float = 8.0, xy_bound: float = 1.5, z_bound: float = 2.0, tilt_bound: float = 0.4,
                  term_dist: float = 1e-4, auto_reset: bool = False, track_rpm: bool = True,
                  keep_terminal_obs: bool = False, device=None, gains: PIDGains = None, force_pid: bool = False,
-                 pyb_like: bool = None):
+                 pyb_like: bool = None, nan_guard: bool = False):
         if pyb_freq % ctrl_freq != 0:
             raise ValueError("[ERROR] pyb_freq is not divisible by ctrl_freq.")
         self.lib = _native.lib()                      # raises if the HIP extension is missing
@@ -137,10 +137,14 @@ class SimCore:
         self.init_pose = torch.tensor(pose, dtype=f32, device=dev).contiguous()
         self.set_target(target_pos)
 
+        # nan_guard: one byte per drone, rewritten by every call that stores the state: 1 = a NaN / infinity sits in the drone's
+        # kinematic state (GpdState.bad; the reference has no such check)
+        self.bad = torch.zeros((self.N,), dtype=torch.bool, device=dev) if nan_guard else None
         self._state = _native.GpdState(kin=self.kin.data_ptr(),
                                        last_rpm=self.last_rpm.data_ptr() if self.last_rpm is not None else None,
                                        pid=self.pid.data_ptr() if self.pid is not None else None,
-                                       step_counter=self.step_counter.data_ptr(), ld=self.ld)
+                                       step_counter=self.step_counter.data_ptr(), ld=self.ld,
+                                       bad=self.bad.data_ptr() if nan_guard else None)
         self._cfg = _native.GpdStepCfg(
             num_envs=self.E, drones_per_env=self.D, act_type=self.act_code, substeps=self.S,
             physics_flags=self.physics_flags, pyb_dt=1.0 / pyb_freq, ctrl_dt=1.0 / ctrl_freq,
@@ -295,8 +299,10 @@ class SimCore:
 
         Training rollouts: `noise` `[K,N,A]` (standard-normal draws, e.g. `torch.randn`) and `action_std` (A floats =
         exp(log_std)) make it `a_t = clip(mean_t + action_std * noise_t, -1, 1)`, SB3's collection loop; `mean_out`
-        `[K,N,A]` receives the unclipped means.  No terminal observations (`term_obs12` is not written: the adapters that
-        promise them step through `step()` / `rollout()`)."""
+        `[K,N,A]` receives the unclipped means.  With `keep_terminal_obs` the kernel also writes the last observation of every
+        episode that ends inside the launch: `terminal_observations(K)` returns the `[K,N,12]` block (rows of step t of the
+        aviaries that ended at step t; the flags say which), and `term_obs12` holds those of the last step -- what SB3's
+        `VecEnv` hands its PPO as `infos[i]["terminal_observation"]` (examples/learn.py:61-95)."""
         K = int(num_steps)
         if K < 1:
             raise ValueError("num_steps must be >= 1")
@@ -313,7 +319,7 @@ class SimCore:
             if mean_out is not None and (mean_out.device != self.device or mean_out.dtype != torch.float32 or not mean_out.is_contiguous()
                                          or mean_out.numel() != K * self.N * self.A):
                 raise ValueError("mean_out must be a contiguous float32 tensor like noise")
-        obs, rew, term, trunc, _ = self._rollout_buffers(K)
+        obs, rew, term, trunc, tobs = self._rollout_buffers(K)
         cache = self.__dict__.setdefault("_policy_actions", {})
         acts = None
         if want_actions:
@@ -327,13 +333,34 @@ class SimCore:
             rc = self.lib.gpd_rollout_policy(ctypes.byref(self._params), ctypes.byref(self._state), ctypes.byref(self._cfg),
                                              ctypes.byref(ps), K, _ptr(self.obs12), _ptr(self.target), _ptr(self.init_pose),
                                              _ptr(acts), _ptr(obs), self.N * 12, _ptr(rew), _ptr(term), _ptr(trunc), self.E,
-                                             _ptr(noise), std, _ptr(mean_out), self._stream())
+                                             _ptr(noise), std, _ptr(mean_out), _ptr(tobs), self._stream())
         _native.check(rc, "gpd_rollout_policy")
+        if tobs is not None:
+            self._latest_terminal(tobs, term, trunc, K)
         self.obs12.copy_(obs[K - 1])
         self.reward.copy_(rew[K - 1])
         self.terminated.copy_(term[K - 1])
         self.truncated.copy_(trunc[K - 1])
         return obs, rew, term, trunc, acts
+
+    def _latest_terminal(self, tobs, term, trunc, K):
+        """`term_obs12` after a K-step launch = what K single steps would have left: for every aviary the terminal observation
+        of the LAST step it ended in (aviaries that did not end keep what they held).  A few small torch kernels, off the
+        hot path (only with keep_terminal_obs)."""
+        done = term | trunc                                                             # [K, E]
+        last = (done.to(torch.int32) * torch.arange(1, K + 1, dtype=torch.int32, device=self.device).unsqueeze(1)).amax(dim=0)   # 0: never
+        W = self.D * 12
+        rows = tobs.view(K, self.E, W).gather(0, (last - 1).clamp(min=0).to(torch.int64).view(1, self.E, 1).expand(1, self.E, W))[0]
+        cur = self.term_obs12.view(self.E, W)
+        torch.where((last > 0).unsqueeze(1), rows, cur, out=cur)
+
+    def terminal_observations(self, K: int) -> torch.Tensor:
+        """`[K, N, 12]` terminal-observation block of the latest K-step `rollout()` / `rollout_policy()` (needs
+        `keep_terminal_obs`): row (t, n) is meaningful where aviary n ended at step t."""
+        buf = self.__dict__.get("_rollout_cache", {}).get(int(K))
+        if buf is None or buf[4] is None:
+            raise ValueError("no terminal observations: build with keep_terminal_obs=True and run a K-step rollout first")
+        return buf[4]
 
     # ---- action history / full KIN observation rows (envs/BaseRLAviary.py:65-67, 153-154, 187, 307-320) ----
     def enable_history(self, hist_len: int):
@@ -444,27 +471,48 @@ class SimCore:
         _native.check(rc, "gpd_state_vectors")
         return out
 
-    # ---- state access for tests / checkpointing (host <-> device copies, off the hot path) ---------
+    def bad_envs(self) -> torch.Tensor:
+        """[E] bool: aviaries with a non-finite kinematic state after the latest step / rollout (needs `nan_guard=True`).  A
+        device tensor -- `.any().item()` is the one host sync a training loop pays when it wants to stop on the first NaN."""
+        if self.bad is None:
+            raise ValueError("built without nan_guard=True")
+        return self.bad.view(self.E, self.D).any(dim=1)
+
+    # ---- checkpoint / resume (host <-> device copies, off the hot path) ------------------------------
+    #: everything a later step can depend on: the integrator state, the controllers' members, the last applied RPMs (drag), the
+    #: episode clocks, the latest observation rows and task outputs (a policy rollout starts from `obs12`), and -- with an action
+    #: history -- the ring with its positions (the reference's never-reset `action_buffer`, envs/BaseRLAviary.py:65-67)
+    _STATE_FIELDS = ("kin", "last_rpm", "pid", "step_counter", "obs12", "reward", "terminated", "truncated", "term_obs12",
+                     "act_ring", "ring_pos", "bad")
+
     def get_state(self) -> dict:
+        """Snapshot (device clones) of the complete simulator state: `set_state(**get_state())` later -- on this core or on
+        another one built with the same arguments -- continues bit for bit (same observations, history tails, rewards)."""
         n = self.N
-        out = {"kin": self.kin[:, :n].clone(), "step_counter": self.step_counter.clone()}
-        if self.last_rpm is not None:
-            out["last_rpm"] = self.last_rpm[:, :n].clone()
-        if self.pid is not None:
-            out["pid"] = self.pid[:, :n].clone()
+        out = {}
+        for name in self._STATE_FIELDS:
+            t = getattr(self, name, None)
+            if t is not None:
+                out[name] = (t[:, :n] if name in ("kin", "last_rpm", "pid") else t).clone()
         return out
 
-    def set_state(self, kin=None, last_rpm=None, pid=None, step_counter=None):
+    def set_state(self, kin=None, last_rpm=None, pid=None, step_counter=None, **rest):
+        """Overwrite the given parts of the state (tensors or arrays shaped like `get_state()`'s; absent or None: untouched)."""
         n = self.N
         self.state_version += 1
-        if kin is not None:
-            self.kin[:, :n].copy_(torch.as_tensor(kin, dtype=torch.float32))
-        if last_rpm is not None and self.last_rpm is not None:
-            self.last_rpm[:, :n].copy_(torch.as_tensor(last_rpm, dtype=torch.float32))
-        if pid is not None and self.pid is not None:
-            self.pid[:, :n].copy_(torch.as_tensor(pid, dtype=torch.float32))
-        if step_counter is not None:
-            self.step_counter.copy_(torch.as_tensor(step_counter, dtype=torch.int32))
+        given = dict(rest, kin=kin, last_rpm=last_rpm, pid=pid, step_counter=step_counter)
+        unknown = set(given) - set(self._STATE_FIELDS)
+        if unknown:
+            raise TypeError(f"set_state() got unknown state fields {sorted(unknown)}")
+        for name, v in given.items():
+            t = getattr(self, name, None)
+            if v is None or t is None:       # (a snapshot of a core with more optional parts than this one: the rest applies)
+                continue
+            dst = t[:, :n] if name in ("kin", "last_rpm", "pid") else t
+            src = torch.as_tensor(v, device=self.device)
+            if tuple(src.shape) != tuple(dst.shape):
+                raise ValueError(f"set_state: {name} has shape {tuple(src.shape)}, expected {tuple(dst.shape)}")
+            dst.copy_(src.to(dst.dtype))
 
     def bytes_per_step(self) -> int:
         """Algorithmic HBM bytes one `step()` moves (SURVEY.md §8d accounting)."""

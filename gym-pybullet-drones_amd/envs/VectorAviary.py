@@ -44,6 +44,7 @@ class VectorAviary:
                  keep_terminal_obs: bool = False,
                  track_rpm: bool = False,
                  pyb_like: bool = None,
+                 nan_guard: bool = False,
                  device=None):
         if obs != ObservationType.KIN:
             raise NotImplementedError("only ObservationType.KIN is on the MI355X hot path")
@@ -71,7 +72,7 @@ class VectorAviary:
                                    task=_TASKS[task], initial_xyzs=init, initial_rpys=initial_rpys,
                                    target_pos=target_pos, episode_len_sec=episode_len_sec, xy_bound=xy,
                                    auto_reset=auto_reset, track_rpm=track_rpm, keep_terminal_obs=keep_terminal_obs,
-                                   device=device, pyb_like=pyb_like)
+                                   device=device, pyb_like=pyb_like, nan_guard=nan_guard)
         self.device = self.core.device
         self.ACT_DIM = self.core.A
         self.INIT_XYZS, self.INIT_RPYS, self.TARGET_POS = self.core.INIT_XYZS, self.core.INIT_RPYS, self.core.TARGET_POS
@@ -164,6 +165,22 @@ class VectorAviary:
     def state_vectors(self) -> torch.Tensor:
         """(E, D, 20) `_getDroneStateVector`-ordered states (needs `track_rpm=True` for the RPM columns)."""
         return self.core.state_vectors().view(self.NUM_ENVS, self.NUM_DRONES, 20)
+
+    # ---- checkpoint / resume; non-finite guard (SURVEY.md section 5: both absent upstream) ----------------------
+    def get_state(self) -> dict:
+        """Complete snapshot (device clones): integrator state, controller members, episode clocks, latest observations and -- with
+        `full_obs` -- the action ring and its positions.  `set_state(get_state())` resumes bit for bit, history tails included."""
+        return self.core.get_state()
+
+    def set_state(self, state: dict):
+        self.core.set_state(**state)
+        if self.full_obs:                    # the materialised rows follow from obs12 + ring
+            self.core.history_rows()
+        return self._obs()
+
+    def bad_envs(self) -> torch.Tensor:
+        """[E] bool device tensor: aviaries whose state holds a NaN / infinity after the latest step (`nan_guard=True`)."""
+        return self.core.bad_envs()
 
     def close(self):
         pass

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GPD_ABI_VERSION 7
+#define GPD_ABI_VERSION 8
 
 /* DroneModel (utils/enums.py:3-8) */
 enum { GPD_MODEL_CF2X = 0, GPD_MODEL_CF2P = 1, GPD_MODEL_RACE = 2 };
@@ -159,6 +159,15 @@ typedef struct GpdState {
                               one sits.  Kept on the device so that a captured hipGraph of steps replays correctly */
     int32_t hist_len;      /* H = ctrl_freq // 2 (envs/BaseRLAviary.py:65); 0 with act_ring == NULL */
     int32_t pad_;
+    /* (ABI 8) Non-finite guard, optional: every call that writes the state back (gpd_step, gpd_rollout*, gpd_rollout_policy,
+     * gpd_swarm_step) also stores one byte per drone -- 1 if any of the drone's 13 kinematic floats is NaN or +-inf in the
+     * state it leaves behind, else 0.  The reference has no such check (a NaN action silently poisons `pos` / `quat` for the rest
+     * of the episode, envs/BaseAviary.py:831-877); a NaN position also never trips a truncation bound
+     * (every comparison is false), so without the flag a poisoned aviary runs on until the episode clock ends it.  (Deviation for
+     * garbage input, DSLPID action types only: a NaN set-point is absorbed by the controller's clips -- the hardware min/max return
+     * the bound where numpy's clip propagates the NaN -- so the drone sees one step of saturated commands and stays finite.)  Costs
+     * thirteen adds and a compare per drone and launch, outside the step loop. */
+    uint8_t* bad;          /* [N] or NULL */
 } GpdState;
 
 /* Per-call configuration of gpd_step */
@@ -312,7 +321,10 @@ typedef struct GpdPolicy {
  * With in_dim > 12 the action ring of `state` is read at the start, and EVERY step pushes its (clipped) action into both halves
  * of the ring and advances ring_pos by one (mod hist_len), exactly as gpd_step does: after the call the ring and ring_pos are what
  * num_steps gpd_step calls with the same actions would have left (history() / gpd_hist_rows / a following gpd_step continue
- * seamlessly).  No terminal observations are produced.
+ * seamlessly).
+ *   term_obs12   (ABI 8) NULL, or laid out like obs12 (same stride): with auto_reset, the rows of step t of the aviaries that ended
+ *                at step t receive the last observation of the finished episode -- SB3's info["terminal_observation"], which its
+ *                PPO bootstraps time-outs from (examples/learn.py:61-95 through `model.learn()`); other rows are left untouched.
  * GPD_ENOTSUP: drones_per_env > 1, hidden != 64, in_dim not one of the two forms, or a history longer than 17 actions of 4 or
  * 3 floats / 20 actions of 1 float (the reference's 30 Hz control: 15).
  */
@@ -320,7 +332,7 @@ int gpd_rollout_policy(const GpdParams* params, const GpdState* state, const Gpd
                        int32_t num_steps, const float* obs12_in, const float* target_pos, const float* init_pose,
                        float* actions_out, float* obs12, int64_t obs_step_stride, float* reward, uint8_t* terminated,
                        uint8_t* truncated, int64_t env_step_stride, const float* noise, const float* action_std, float* mean_out,
-                       void* stream);
+                       float* term_obs12, void* stream);
 
 /*
  * Full KIN observation rows with the action-history tail.  Replaces the row assembly of BaseRLAviary._computeObs

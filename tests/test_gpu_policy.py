@@ -100,6 +100,47 @@ def test_policy_rollout_is_bitwise_stepping_its_actions(gpu_device, act, ctrl, h
         assert torch.equal(a.history(), b.history())
 
 
+@pytest.mark.parametrize("act,ctrl,hist,sample", [("rpm", 30, True, False), ("rpm", 30, True, True), ("one_d_rpm", 240, False, False),
+                                                  ("pid", 30, True, False), ("vel", 48, False, False)])
+def test_policy_rollout_writes_the_terminal_observations_step_would(gpu_device, act, ctrl, hist, sample):
+    """SB3's PPO bootstraps a time-out from `infos[i]["terminal_observation"]` (the loop `model.learn()` runs around
+    examples/learn.py:61-95): the in-kernel collection loop hands them out too -- for every aviary that ends at step t of the
+    launch, row (t, aviary) of the terminal block is, bit for bit, what `gpd_step` writes for the same action; rows of aviaries
+    that did not end stay untouched; `term_obs12` afterwards holds what K single steps would have left.  The VecEnv-style
+    infos of a policy rollout are thereby reconstructible from its outputs alone."""
+    from gym_pybullet_drones_amd.policy import MlpPolicy
+    E, K = 777, 30
+    mode = "lazy" if hist else False
+    a, b = (_env(act, ctrl, mode, E, gpu_device, episode_len_sec=10.0 / ctrl, keep_terminal_obs=True) for _ in range(2))
+    A, H = a.ACT_DIM, ctrl // 2
+    pol = MlpPolicy.random(12 + (H * A if hist else 0), A, seed=5, gain=1.2, device=gpu_device)
+    kw = {}
+    if sample:
+        g = torch.Generator(device=gpu_device)
+        g.manual_seed(1)
+        kw = dict(noise=torch.randn((K, E, 1, A), generator=g, device=gpu_device), action_std=[0.5] * A)
+    sentinel = -123.0
+    a.core._rollout_buffers(K)[4].fill_(sentinel)
+    obs, rew, term, trunc, acts = a.rollout_policy(pol, K, **kw)
+    tob = a.core.terminal_observations(K).view(K, E, 1, 12)
+    done_any = torch.zeros(E, dtype=torch.bool, device=gpu_device)
+    for t in range(K):
+        o, r, te, tr, info = b.step(acts[t])
+        done = te | tr
+        assert torch.equal(te, term[t]) and torch.equal(tr, trunc[t]), t
+        assert torch.equal(tob[t][done], info["terminal_observation"][done]), t
+        assert bool((tob[t][~done] == sentinel).all()), t                     # nothing written where no episode ended
+        done_any |= done
+    assert int(done_any.sum()) > E // 2                                       # (short episodes: most aviaries ended at least once)
+    assert torch.equal(a.core.term_obs12, b.core.term_obs12)
+    # the VecEnv infos, rebuilt from the rollout's outputs alone
+    t_last = K - 1
+    idx = torch.nonzero(term[t_last] | trunc[t_last]).flatten()
+    for i in idx[:5].tolist():
+        info_i = {"terminal_observation": tob[t_last, i], "TimeLimit.truncated": bool(trunc[t_last, i] and not term[t_last, i])}
+        assert torch.equal(info_i["terminal_observation"], b.core.term_obs12.view(E, 1, 12)[i])
+
+
 def test_policy_closed_loop_against_the_float64_oracle(gpu_device):
     """`examples/learn.py:157-192` end to end: HoverAviary at the reference's 30 Hz, RPM actions, the policy sees the full
     row; fp32 HIP kernel vs float64 oracle aviary + float64 actor, 45 control steps (1.5 s)."""

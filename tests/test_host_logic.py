@@ -342,7 +342,7 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path):
     assert res.returncode == 0, res.stderr
     run = subprocess.run([exe], capture_output=True, text=True)
     assert run.returncode == 0, run.stdout + run.stderr
-    assert "ABI 7" in run.stdout and "-> -1:" in run.stdout
+    assert "ABI 8" in run.stdout and "-> -1:" in run.stdout
 
 
 def test_swarm_entries_reject_bad_arguments_before_touching_a_device():
