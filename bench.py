@@ -249,6 +249,10 @@ def cpu_baseline(w, budget_s=12.0, phys=None):
     except Exception as e:   # the C restatement is optional test infrastructure
         out.setdefault("c_port", {"error": str(e)[:200]})
     out["pybullet"] = pybullet_baseline()
+    if out["pybullet"].get("available"):        # the stated baseline itself was timed: it leads, the ports stay beside it
+        port = {k: out[k] for k in ("value", "unit", "cores", "kind", "sample")}
+        out.update({k: out["pybullet"][k] for k in ("value", "unit", "cores", "kind", "sample")})
+        out["port"] = port
     return out
 
 
@@ -271,7 +275,7 @@ def swarm_cpu_baseline(w, env, budget_s=10.0):
                       (f"; extrapolated to {N} drones by the pair count (x{(N / n) ** 2:.0f})" if n < N else "")}
 
 
-def swarm_parity_check(env):
+def swarm_parity_check(env, all_pos=None):
     """The swarm line's own parity figure: the downwash forces the timed path left in `dw_force` (stale cell order, wake lists
     and all) against the float64 all-pairs loop of the reference (oracle/gpd_oracle.c, all usable threads) on the positions of
     that very moment -- one snapshot of the whole world after the timed region (a multi-step replay through the O(N^2) loop
@@ -279,9 +283,17 @@ def swarm_parity_check(env):
     from oracle import c_oracle
     torch.cuda.synchronize()
     N, n = env.TOTAL_DRONES, env.NUM_DRONES
-    pos = env.pos4[:, :3].cpu().numpy().astype(np.float64)
-    rows = np.flatnonzero(np.isfinite(pos).all(axis=1))
-    if len(rows) != N:
+    if all_pos is not None:
+        # a world shared by several ranks: everybody's positions in the caller's drone order (SwarmAviary.all_positions(), gathered
+        # for this check -- with the halo exchange a rank holds its own neighbourhood only); this rank's drones are GLOBAL_IDS
+        pos = all_pos.cpu().numpy().astype(np.float64)
+        rows = np.arange(N)
+        mine_ids = np.asarray(env.GLOBAL_IDS)
+    else:
+        pos = env.pos4[:, :3].cpu().numpy().astype(np.float64)
+        rows = np.flatnonzero(np.isfinite(pos).all(axis=1))
+        mine_ids = None
+    if len(rows) != N or not np.isfinite(pos[rows]).all():
         return {"error": f"{N - len(rows)} drones without a finite position"}
     urdf = os.path.join(REPO, "gym-pybullet-drones_amd", "assets", "cf2x.urdf")
     th = min(host_threads(), c_oracle.lib().orc_max_threads())
@@ -291,7 +303,7 @@ def swarm_parity_check(env):
     cap = 131072
     pick = np.arange(n) if n <= cap else np.sort(np.random.default_rng(0).choice(n, cap, replace=False))
     t0 = time.perf_counter()
-    mine = c_oracle.downwash_some(urdf, pos[rows], first + pick, threads=th)
+    mine = c_oracle.downwash_some(urdf, pos[rows], (first + pick) if mine_ids is None else mine_ids[pick], threads=th)
     dt = time.perf_counter() - t0
     got = env.dw_force[:n].cpu().numpy().astype(np.float64)[pick]
     scale = max(float(np.abs(mine).max()), 1e-12)
@@ -304,28 +316,35 @@ def swarm_parity_check(env):
                     "relative condition number of ~30 against them: individual forces agree to ~1e-3 of themselves, all to < 1e-4 of the largest"}
 
 
-def pybullet_baseline(budget_s=8.0):
-    """The reference's REAL CPU path (BASELINE config 1: `HoverAviary()` defaults, Physics.PYB through Bullet's own
-    integrator, envs/BaseAviary.py:679-711), timed when a box has `pybullet` + the reference package installed.  This
-    image has neither (no network): the leg then reports why."""
+def pybullet_baseline(budget_s=20.0, steps=2420):
+    """The reference's REAL CPU path, BASELINE config 1 as SURVEY.md section 8(d) spells it out: `HoverAviary()` with its defaults
+    (Physics.PYB through Bullet's own integrator, envs/BaseAviary.py:679-711; 30 Hz control / 240 Hz physics), ActionType.ONE_D_RPM,
+    actions a ~ U(-1, 1) of shape (1, 1), 2 420 `step()` calls = ten 8-second episodes (cut short by `budget_s`).  Timed when a box
+    has `pybullet` AND the reference package installed (`import gym_pybullet_drones`); this image has neither and no network:
+    the leg then reports why.  Nothing here reads /root/reference."""
     try:
         import pybullet  # noqa: F401
         from gym_pybullet_drones.envs.HoverAviary import HoverAviary as RefHover
+        from gym_pybullet_drones.utils.enums import ActionType as RefAct
     except Exception as e:
         return {"available": False, "why": f"{type(e).__name__}: {e}"[:160]}
-    env = RefHover(gui=False)
+    env = RefHover(gui=False, act=RefAct.ONE_D_RPM)
     env.reset(seed=0)
     rng = np.random.default_rng(0)
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        _, _, term, trunc, _ = env.step(rng.uniform(-1, 1, size=env.action_space.shape).astype(np.float32))
+    n, episodes, t0 = 0, 0, time.perf_counter()
+    while n < steps and time.perf_counter() - t0 < budget_s:
+        _, _, term, trunc, _ = env.step(rng.uniform(-1, 1, size=(1, 1)).astype(np.float32))
         if term or trunc:
             env.reset()
+            episodes += 1
         n += 1
     dt = time.perf_counter() - t0
+    S = int(env.PYB_STEPS_PER_CTRL)
     env.close()
-    return {"available": True, "value": n * env.PYB_STEPS_PER_CTRL / dt, "unit": "drone-steps/s", "cores": 1, "kind": "reference",
-            "sample": f"{n} env.step() of the reference's HoverAviary() (Physics.PYB, 30 Hz control / 240 Hz physics) in {dt:.1f}s"}
+    return {"available": True, "value": n * S / dt, "unit": "drone-steps/s", "cores": 1, "kind": "reference",
+            "env_steps_per_s": n / dt,
+            "sample": f"{n} env.step() ({episodes} episodes ended) of the reference's HoverAviary() -- Physics.PYB, ONE_D_RPM, 30 Hz control / "
+                      f"240 Hz physics, S = {S} -- in {dt:.1f}s on 1 host core (pybullet {getattr(pybullet, '__version__', '?')})"}
 
 
 def parity_check(w, env, actions, K, POOL, max_steps=256):
@@ -1028,17 +1047,24 @@ def run_workload(args, job):
         if w.get("swarm"):      # ONE world: the same scene on every rank, rank r takes its block of drones
             exch = None
             if world > 1:
-                from gym_pybullet_drones_amd.envs import NativeSlabExchange, TorchSlabExchange
+                # GPD_SWARM_EXCHANGE=halo (default): blocks from the neighbouring stripes only (gpd_p2p_group: grouped ncclSend /
+                # ncclRecv; torch.distributed's batched P2P where the native communicator is missing); =allgather: every position to
+                # every rank (gpd_allgather_obs in place), the round-3 exchange
+                from gym_pybullet_drones_amd.envs import NativeHaloExchange, NativeSlabExchange, TorchHaloExchange, TorchSlabExchange
+                kind = os.environ.get("GPD_SWARM_EXCHANGE", "halo")
+                margin = float(os.environ.get("GPD_SWARM_HALO_MARGIN", "2.0"))
+                native, torch_ = (NativeHaloExchange, TorchHaloExchange) if kind == "halo" else (NativeSlabExchange, TorchSlabExchange)
                 err = None
                 try:
-                    exch = NativeSlabExchange(device=device) if backend == "nccl" else None
+                    exch = (native(margin=margin, device=device) if kind == "halo" else native(device=device)) if backend == "nccl" else None
                 except Exception as e:      # noqa: BLE001
                     err = f"{type(e).__name__}: {e}"[:200]
                 if not gdist.all_ranks_ok(exch is not None, device=device):
-                    exch = TorchSlabExchange()
-                    swarm_note.append(f"position exchange through torch.distributed ({err or 'no native RCCL communicator'})")
+                    exch = torch_(margin=margin) if kind == "halo" else torch_()
+                    swarm_note.append(f"position exchange ({kind}) through torch.distributed ({err or 'no native RCCL communicator'})")
                 else:
-                    swarm_note.append(f"position exchange: gpd_allgather_obs in place, {exch.nc.ranks_seen} ranks seen by RCCL")
+                    swarm_note.append(f"position exchange ({kind}): " + ("gpd_p2p_group, grouped ncclSend / ncclRecv" if kind == "halo" else "gpd_allgather_obs in place") +
+                                      f", {exch.nc.ranks_seen} ranks seen by RCCL")
             envs = [make_env(w, device, seed=1000, world=world, rank=rank, exchange=exch)]
             acts = [make_actions(w, envs[0], device, seed=2000 + rank * 16, pool=POOL)]
             return envs, acts
@@ -1091,9 +1117,12 @@ def run_workload(args, job):
     m = measure(args.mode, args, envs, actions, gather if len(envs) == 1 else None, device, world, POOL)
 
     parity = None
+    all_pos = None
+    if not args.no_parity and w.get("swarm") and envs[0].flags & 4 and world > 1:
+        all_pos = envs[0].all_positions()          # (collective: a rank of a halo-exchanging world holds its neighbourhood only)
     if rank == 0 and not args.no_parity and w.get("swarm") and envs[0].flags & 4:
         try:
-            parity = swarm_parity_check(envs[0])
+            parity = swarm_parity_check(envs[0], all_pos)
         except Exception as e:          # noqa: BLE001
             parity = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0 and not args.no_parity and args.mode == "rollout" and not w.get("policy") and not w.get("swarm"):
@@ -1142,7 +1171,12 @@ def run_workload(args, job):
                                    ("torch.distributed.run" if world > 1 else "single process"),
                        "env_steps_per_s": m["env_steps_per_s"],
                        **({"swarm": {"total_drones": envs[0].TOTAL_DRONES, "ranks": envs[0].WORLD_SIZE, "cell_m": envs[0].cell,
-                                     "grid": [envs[0].nx, envs[0].ny], "rebin_every": envs[0].rebin_every, "note": "; ".join(swarm_note) or None}}
+                                     "grid": [envs[0].nx, envs[0].ny], "rebin_every": envs[0].rebin_every, "note": "; ".join(swarm_note) or None,
+                                     "exchange": None if world == 1 else ("halo" if getattr(envs[0].exchange, "halo", False) else "allgather"),
+                                     "exchange_bytes_sent_per_rank_per_substep": None if world == 1 else
+                                     (envs[0].exchange.bytes_per_substep if getattr(envs[0].exchange, "halo", False) else envs[0].slab * 16),
+                                     "exchange_bytes_received_allgather": None if world == 1 else (world - 1) * envs[0].slab * 16,
+                                     "halo_plans_made": getattr(envs[0].exchange, "plans_made", None)}}
                           if w.get("swarm") else {})},
             "roofline": m["roofline"],
             "per_gpu": {"unit": "drone-steps/s", "values": m["per_gpu"], "min": min(m["per_gpu"]), "max": max(m["per_gpu"]),

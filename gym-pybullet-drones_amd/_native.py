@@ -48,6 +48,11 @@ class GpdStepCfg(ctypes.Structure):
                 ("init_per_env", ctypes.c_int32), ("auto_reset", ctypes.c_int32)]
 
 
+class GpdP2P(ctypes.Structure):
+    """mirror of `struct GpdP2P` (one block of gpd_p2p_group)"""
+    _fields_ = [("peer", ctypes.c_int32), ("pad_", ctypes.c_int32), ("ptr", ctypes.c_void_p), ("count", ctypes.c_int64)]
+
+
 class GpdSwarm(ctypes.Structure):
     """mirror of `struct GpdSwarm`"""
     _fields_ = [("n_rows", ctypes.c_int32), ("slab", ctypes.c_int32), ("world_size", ctypes.c_int32), ("rank", ctypes.c_int32),
@@ -135,6 +140,7 @@ _SIGNATURES = {
     "gpd_comm_count": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int32)]),
     "gpd_comm_destroy": (ctypes.c_int, [_P]),
     "gpd_allgather_obs": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, _P]),
+    "gpd_p2p_group": (ctypes.c_int, [_P, ctypes.POINTER(GpdP2P), ctypes.c_int32, ctypes.POINTER(GpdP2P), ctypes.c_int32, _P]),
     "gpd_clock_probe": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _P]),
 }
 COMM_ID_BYTES = 128

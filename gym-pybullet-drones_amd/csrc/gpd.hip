@@ -2898,6 +2898,11 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    // (optional: only gpd_p2p_group needs them -- a library without them still serves the all-gather)
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
 };
@@ -2921,6 +2926,10 @@ Rccl& rccl() {
         r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.handle, "ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.handle, "ncclGroupEnd"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(r.handle, "ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(r.handle, "ncclRecv"));
         if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.CommCount || !r.AllGather || !r.GetErrorString) {
             dlclose(r.handle);
             r.handle = nullptr;
@@ -3565,6 +3574,30 @@ int gpd_allgather_obs(void* comm, const float* shard, float* full, size_t count,
     ncclResult_t e = rccl().AllGather(shard, full, count, ncclFloat32, static_cast<ncclComm_t>(comm),
                                       static_cast<hipStream_t>(stream));
     if (e != ncclSuccess) return rccl_fail(e, "ncclAllGather");
+    return 0;
+}
+
+int gpd_p2p_group(void* comm, const GpdP2P* sends, int32_t n_sends, const GpdP2P* recvs, int32_t n_recvs, void* stream) {
+    if (!comm || (n_sends > 0 && !sends) || (n_recvs > 0 && !recvs) || n_sends < 0 || n_recvs < 0)
+        return fail(GPD_EINVAL, "gpd_p2p_group: NULL comm / operation list");
+    if (int rc = need_rccl("gpd_p2p_group")) return rc;
+    Rccl& R = rccl();
+    if (!R.GroupStart || !R.GroupEnd || !R.Send || !R.Recv) return fail(GPD_ENOTSUP, "gpd_p2p_group: this RCCL has no ncclSend / ncclRecv / ncclGroup*");
+    for (int i = 0; i < n_sends; ++i) if (!sends[i].ptr || sends[i].count <= 0 || sends[i].peer < 0) return fail(GPD_EINVAL, "gpd_p2p_group: bad send operation");
+    for (int i = 0; i < n_recvs; ++i) if (!recvs[i].ptr || recvs[i].count <= 0 || recvs[i].peer < 0) return fail(GPD_EINVAL, "gpd_p2p_group: bad receive operation");
+    if (n_sends + n_recvs == 0) return 0;
+    ncclComm_t c = static_cast<ncclComm_t>(comm);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ncclResult_t e = R.GroupStart();
+    if (e != ncclSuccess) return rccl_fail(e, "ncclGroupStart");
+    ncclResult_t first = ncclSuccess;
+    for (int i = 0; i < n_sends && first == ncclSuccess; ++i)
+        first = R.Send(sends[i].ptr, static_cast<size_t>(sends[i].count), ncclFloat32, sends[i].peer, c, st);
+    for (int i = 0; i < n_recvs && first == ncclSuccess; ++i)
+        first = R.Recv(recvs[i].ptr, static_cast<size_t>(recvs[i].count), ncclFloat32, recvs[i].peer, c, st);
+    e = R.GroupEnd();                                  // (always closed, also after a failed enqueue)
+    if (first != ncclSuccess) return rccl_fail(first, "ncclSend / ncclRecv");
+    if (e != ncclSuccess) return rccl_fail(e, "ncclGroupEnd");
     return 0;
 }
 

@@ -108,6 +108,224 @@ class NativeSlabExchange:
         _native.check(rc, "gpd_allgather_obs")
 
 
+# ---- halo exchange: a rank's neighbours' border drones instead of every position -------------------------------------------
+#: lateral cut-off of the reference's downwash model (envs/BaseAviary.py:801: `delta_xy < 10`)
+DW_LATERAL_CUTOFF = 10.0
+
+
+class HaloPlan:
+    """Which of a rank's drones every other rank needs, and where the blocks it receives go.
+
+    The ranks hold stripes of the world (`partition="spatial"`: blocks of the row-major cell order, i.e. bands in y), and a
+    drone feels only drones within 10 m laterally (envs/BaseAviary.py:798-811).  Rank d therefore needs, of rank s's drones,
+    those whose y lies within `reach = 10 m + margin` of the y-interval its own drones occupy -- for stripes: blocks from the two
+    neighbouring ranks, nothing from the others.  The plan is made whenever the drones are re-binned (and after a reset) from
+    CURRENT positions, in three phases separated by two tiny all-gathers (3 floats, then W counts per rank):
+        phase1  this rank's y-interval (+ whether the PREVIOUS plan's margin held)            -> [lo, hi, violated]
+        phase2  from everybody's intervals: the rows of this rank every other rank needs      -> counts [W]
+        phase3  from everybody's counts: send offsets, receive places; the rest of every other rank's rows is marked empty
+    Between two plans the SAME rows travel every sub-step (`gather()` packs them; `sends` / `recvs` say where the blocks go), so
+    row j of rank s's region is the same drone until the next plan -- what the stale-cell-order search of the force kernel
+    needs.  A halo row has no identity beyond that: received blocks are stored compactly at the start of the sender's region
+    of `pos4`, and the force sums are integers, so the forces are the all-gather path's bit for bit.
+
+    Exactness: a pair within 10 m NOW was within 10 m + d_i + d_j in y at plan time (d = |y now - y at plan time|), so the plan
+    covers every pair while every drone has moved less than margin / 2 in y since the plan.  `phase1` of the next plan checks
+    that for the interval that ends (every rank learns of a violation anywhere and raises): results are exact, or the run
+    stops and says which knob to turn (`halo_margin`, `rebin_every`).  The plan also sends every rank's meta rows (the per-
+    workgroup displacement maxima and sums the force kernel derives its search radius and the common drift from) to every
+    other rank: meta_rows x 16 bytes per pair."""
+
+    def __init__(self, margin: float):
+        if not margin > 0:
+            raise ValueError("halo margin must be positive")
+        self.margin = float(margin)
+        self.reach = DW_LATERAL_CUTOFF + self.margin
+        self.ready = False
+        self.y_plan = None
+
+    def _own(self, env):
+        r0 = env.RANK * env.slab
+        return env.pos4[r0:r0 + env.NUM_DRONES]
+
+    def phase1(self, env) -> torch.Tensor:
+        own = self._own(env)
+        y = own[:, 1]
+        fin = torch.isfinite(own[:, :3]).all(dim=1)
+        lo = torch.where(fin, y, torch.full_like(y, 3.0e38)).min()
+        hi = torch.where(fin, y, torch.full_like(y, -3.0e38)).max()
+        if self.y_plan is not None:
+            moved = ((y - self.y_plan).abs() > 0.5 * self.margin) & fin & self.fin_plan
+            viol = moved.any().to(torch.float32)
+        else:
+            viol = torch.zeros((), dtype=torch.float32, device=y.device)
+        self._y, self._fin = y, fin
+        return torch.stack([lo, hi, viol])
+
+    def phase2(self, env, bounds: torch.Tensor) -> torch.Tensor:
+        """`bounds`: [W, 3] of phase1, every rank's row -> float counts [W] (rows of mine rank d needs; 0 for myself)"""
+        if bool((bounds[:, 2] > 0).any().item()):
+            who = torch.nonzero(bounds[:, 2] > 0).flatten().tolist()
+            self.ready = False
+            raise RuntimeError(f"halo exchange: drones of rank(s) {who} moved more than margin / 2 = {0.5 * self.margin:g} m in y since the last "
+                               f"plan -- the halo may have missed pairs; results since the last binning are not guaranteed.  Use a larger "
+                               f"halo_margin, a smaller rebin_every, or exchange='allgather'.")
+        y, fin = self._y, self._fin
+        lo, hi = bounds[:, 0:1] - self.reach, bounds[:, 1:2] + self.reach
+        self._masks = (y.unsqueeze(0) >= lo) & (y.unsqueeze(0) <= hi) & fin.unsqueeze(0)
+        self._masks[env.RANK] = False
+        return self._masks.sum(dim=1).to(torch.float32)
+
+    def phase3(self, env, counts: torch.Tensor):
+        """`counts`: [W, W] of phase2 (row s = what rank s sends to each rank).  Builds the plan; marks the rows of the other
+        ranks that will not be received as empty."""
+        W, r, slab, meta = env.WORLD_SIZE, env.RANK, env.slab, env.slab - env.per
+        c = counts.to(torch.int64).cpu()
+        self.send_cnt, self.recv_cnt = c[r].tolist(), c[:, r].tolist()
+        own = self._own(env)
+        idx = [torch.nonzero(self._masks[p]).flatten() for p in range(W) if self.send_cnt[p] > 0]
+        self.idx = torch.cat(idx) if idx else torch.zeros(0, dtype=torch.int64, device=own.device)
+        assert int(self.idx.numel()) == sum(self.send_cnt)
+        self.sendbuf = torch.empty((max(1, int(self.idx.numel())), 4), dtype=torch.float32, device=own.device)
+        v = env.pos4.view(W, slab, 4)
+        self.sends, self.recvs, off = [], [], 0
+        meta_own = v[r, slab - meta:]
+        for p in range(W):
+            if p == r:
+                continue
+            if self.send_cnt[p]:
+                self.sends.append((p, self.sendbuf[off:off + self.send_cnt[p]]))
+                off += self.send_cnt[p]
+            self.sends.append((p, meta_own))
+            if self.recv_cnt[p]:
+                self.recvs.append((p, v[p, :self.recv_cnt[p]]))
+            self.recvs.append((p, v[p, slab - meta:]))
+            v[p, self.recv_cnt[p]:slab - meta] = float("nan")          # rows without a drone (a non-finite x: include/gpd.h)
+        self.y_plan, self.fin_plan = self._y.clone(), self._fin.clone()
+        self._masks = None
+        self.bytes_sent = (int(self.idx.numel()) + (W - 1) * meta) * 16
+        self.bytes_allgather = (W - 1) * slab * 16                     # what the in-place all-gather makes this rank receive
+        self.ready = True
+
+    def gather(self, env):
+        """pack the rows of the plan into the send buffer (one gather kernel per sub-step)"""
+        if self.idx.numel():
+            torch.index_select(self._own(env), 0, self.idx, out=self.sendbuf[:self.idx.numel()])
+
+
+class _HaloExchange:
+    """Plan (when a binning is due and the stream is not being captured) + move the blocks; subclasses are the transports."""
+    halo = True
+
+    def __init__(self, margin: float = 2.0):
+        self.plan = HaloPlan(margin)
+        self.plans_made = 0
+
+    # transport hooks ------------------------------------------------------------------------------
+    def _allgather_small(self, t: torch.Tensor) -> torch.Tensor:        # [k] on the device -> [W, k]
+        raise NotImplementedError
+
+    def _move(self, env):
+        raise NotImplementedError
+
+    def _plan_changed(self, env):
+        pass
+
+    def exchange(self, env, replan: bool):
+        P = self.plan
+        capturing = env.pos4.is_cuda and torch.cuda.is_current_stream_capturing()
+        if (replan or not P.ready) and not capturing:
+            bounds = self._allgather_small(P.phase1(env))
+            counts = self._allgather_small(P.phase2(env, bounds))
+            P.phase3(env, counts)
+            self.plans_made += 1
+            self._plan_changed(env)
+        elif not P.ready:
+            raise RuntimeError("halo exchange: no plan yet -- run one eager step (or reset()) before capturing a hipGraph")
+        P.gather(env)
+        self._move(env)
+
+    def check(self, env):
+        """Collective: raises on every rank if any drone has outrun the margin since the last plan (what the next plan would
+        find): call it after replaying a captured graph, whose plan is the one made before the capture."""
+        bounds = self._allgather_small(self.plan.phase1(env))
+        if bool((bounds[:, 2] > 0).any().item()):
+            self.plan.phase2(env, bounds)
+
+    @property
+    def bytes_per_substep(self):
+        return self.plan.bytes_sent if self.plan.ready else None
+
+
+class TorchHaloExchange(_HaloExchange):
+    """The halo blocks as `torch.distributed` point-to-point operations in one batch (`batch_isend_irecv`: RCCL's grouped
+    ncclSend / ncclRecv with the "nccl" backend; with gloo -- CPU tests, the single-device test hook -- device blocks are staged
+    through host memory)."""
+
+    def __init__(self, margin: float = 2.0, group=None):
+        super().__init__(margin)
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.stage = dist.get_backend(group) == "gloo"
+
+    def _allgather_small(self, t):
+        W = self.dist.get_world_size(self.group)
+        if self.stage:
+            out = torch.empty((W, t.numel()), dtype=t.dtype)
+            self.dist.all_gather_into_tensor(out, t.detach().cpu().reshape(1, -1).contiguous(), group=self.group)
+            return out.to(t.device)
+        out = torch.empty((W, t.numel()), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out, t.reshape(1, -1).contiguous(), group=self.group)
+        return out
+
+    def _move(self, env):
+        P, d = self.plan, self.dist
+        ops, landing = [], []
+        for p, blk in P.sends:
+            ops.append(d.P2POp(d.isend, blk.cpu().contiguous() if self.stage else blk, p, group=self.group))
+        for p, blk in P.recvs:
+            buf = torch.empty(blk.shape, dtype=blk.dtype) if self.stage else blk
+            landing.append((blk, buf))
+            ops.append(d.P2POp(d.irecv, buf, p, group=self.group))
+        for w in d.batch_isend_irecv(ops):
+            w.wait()
+        if self.stage:
+            for blk, buf in landing:
+                blk.copy_(buf)
+
+
+class NativeHaloExchange(_HaloExchange):
+    """The halo blocks through the C-ABI: `gpd_p2p_group` -- ncclSend / ncclRecv of RCCL in one group on the process's one
+    communicator (`dist.NativeComm`), asynchronous on the current stream, capturable in a hipGraph with the sub-step that
+    produced the positions.  The two tiny all-gathers of a plan go through `gpd_allgather_obs` on the same communicator."""
+
+    def __init__(self, margin: float = 2.0, comm=None, device=None):
+        super().__init__(margin)
+        from ..dist import NativeComm
+        self.nc = comm if comm is not None else NativeComm.shared(device=device)
+
+    def _allgather_small(self, t):
+        out = torch.empty((self.nc.world, t.numel()), dtype=torch.float32, device=t.device)
+        src = t.to(torch.float32).contiguous()
+        with torch.cuda.device(t.device):
+            rc = self.nc.lib.gpd_allgather_obs(self.nc.comm, _ptr(src), _ptr(out), src.numel(),
+                                               ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream))
+        _native.check(rc, "gpd_allgather_obs (halo plan)")
+        return out
+
+    def _plan_changed(self, env):
+        P = self.plan
+        mk = lambda ops: (_native.GpdP2P * max(1, len(ops)))(*[_native.GpdP2P(peer=p, ptr=b.data_ptr(), count=b.numel()) for p, b in ops])  # noqa: E731
+        self._S, self._R = mk(P.sends), mk(P.recvs)
+
+    def _move(self, env):
+        P = self.plan
+        with torch.cuda.device(env.device):
+            rc = self.nc.lib.gpd_p2p_group(self.nc.comm, self._S, len(P.sends), self._R, len(P.recvs),
+                                           ctypes.c_void_p(torch.cuda.current_stream(env.device).cuda_stream))
+        _native.check(rc, "gpd_p2p_group")
+
+
 class SwarmAviary:
     """One world, `num_drones` drones, explicit integrator + the selected force models over the whole swarm; this object holds
     the drones of rank `rank` of `world_size`."""
@@ -161,6 +379,7 @@ class SwarmAviary:
         if not self.cell >= 10.0:
             raise ValueError("cell must be >= 10 m (the downwash model's lateral cut-off)")
         order_all = swarm_spatial_order(xyz_all, self.cell) if partition == "spatial" and self.WORLD_SIZE > 1 else np.arange(N)
+        self._deal_order = order_all                             # position in the deal -> the caller's drone index
         self.GLOBAL_IDS = np.ascontiguousarray(order_all[self.FIRST_DRONE:self.FIRST_DRONE + n])
         xyz, rpy = xyz_all[self.GLOBAL_IDS].reshape(n, 1, 3), rpy_all[self.GLOBAL_IDS].reshape(n, 1, 3)
         self.INIT_XYZS, self.INIT_RPYS = xyz[:, 0], rpy[:, 0]
@@ -282,7 +501,29 @@ class SwarmAviary:
 
     def _exchange(self):
         if self.WORLD_SIZE > 1:
-            self.exchange(self.pos4, self.RANK, self.slab)
+            if getattr(self.exchange, "halo", False):       # blocks from the neighbouring stripes (re-planned with every binning)
+                self.exchange.exchange(self, replan=self._since_bin >= self.rebin_every)
+            else:                                           # every position to every rank
+                self.exchange(self.pos4, self.RANK, self.slab)
+
+    def all_positions(self) -> torch.Tensor:
+        """(TOTAL_DRONES, 3) positions of the WHOLE world in the caller's drone order, on every rank -- a collective through
+        `torch.distributed` (diagnostics / checks: a rank of a halo-exchanging world holds only its own and its neighbours'
+        border drones)."""
+        own = torch.full((self.per, 3), float("nan"), dtype=torch.float32, device=self.device)
+        own[:self.NUM_DRONES] = self.core.kin[0:3, :self.NUM_DRONES].t()
+        if self.WORLD_SIZE == 1:
+            return own[:self.NUM_DRONES].clone()
+        import torch.distributed as dist
+        stage = dist.get_backend() == "gloo"
+        out = torch.empty((self.WORLD_SIZE * self.per, 3), dtype=torch.float32, device=None if stage else self.device)
+        dist.all_gather_into_tensor(out, own.cpu() if stage else own)
+        out = out.to(self.device).view(self.WORLD_SIZE, self.per, 3)
+        _, _, counts = swarm_partition(self.TOTAL_DRONES, self.WORLD_SIZE)
+        rows = torch.cat([out[r, :counts[r]] for r in range(self.WORLD_SIZE)])          # the order the drones were dealt in
+        res = torch.empty_like(rows)
+        res[torch.as_tensor(self._deal_order, dtype=torch.long, device=self.device)] = rows
+        return res
 
     def _forces(self):
         """(binning when one is due,) the downwash forces of this rank's drones for the positions in pos4"""
@@ -395,10 +636,15 @@ class LocalSwarmGroup:
     rank's slab into every rank's position array.  What the bitwise tests run on a single-GPU box; a deployment runs one
     process per GPU with `NativeSlabExchange` / `TorchSlabExchange` instead."""
 
-    def __init__(self, num_drones: int, world_size: int, **kw):
-        kw.pop("exchange", None)
+    def __init__(self, num_drones: int, world_size: int, exchange: str = "allgather", halo_margin: float = 2.0, **kw):
+        if exchange not in ("allgather", "halo"):
+            raise ValueError("exchange must be 'allgather' or 'halo'")
         self.ranks = [SwarmAviary(num_drones, world_size=world_size, rank=r, exchange=self._noop, **kw) for r in range(world_size)]
         self.W = world_size
+        # "halo": every rank plans (HaloPlan, the same three phases a multi-process world runs, the two all-gathers being a
+        # torch.stack here) and receives only its neighbours' border drones
+        self.plans = [HaloPlan(halo_margin) for _ in self.ranks] if exchange == "halo" else None
+        self.plans_made = 0
         dev = self.ranks[0].device
         self._ids = [torch.as_tensor(e.GLOBAL_IDS, dtype=torch.long, device=dev) for e in self.ranks]
         self._all_ids = torch.cat(self._ids)
@@ -408,11 +654,40 @@ class LocalSwarmGroup:
         raise RuntimeError("LocalSwarmGroup exchanges for all its ranks at once")
 
     def _exchange(self):
+        if self.plans is not None:
+            return self._exchange_halo()
         for src in self.ranks:
             sl = slice(src.RANK * src.slab, (src.RANK + 1) * src.slab)
             for dst in self.ranks:
                 if dst is not src:
                     dst.pos4[sl].copy_(src.pos4[sl])
+
+    def _exchange_halo(self):
+        e0 = self.ranks[0]
+        if e0._since_bin >= e0.rebin_every or not self.plans[0].ready:
+            bounds = torch.stack([P.phase1(e) for P, e in zip(self.plans, self.ranks)])
+            counts = torch.stack([P.phase2(e, bounds) for P, e in zip(self.plans, self.ranks)])
+            for P, e in zip(self.plans, self.ranks):
+                P.phase3(e, counts)
+            self.plans_made += 1
+        for P, e in zip(self.plans, self.ranks):
+            P.gather(e)
+        for d, P in enumerate(self.plans):              # rank d's k-th receive from s <- rank s's k-th send to d
+            for s_rank in range(self.W):
+                if s_rank == d:
+                    continue
+                out = [b for p, b in self.plans[s_rank].sends if p == d]
+                inn = [b for p, b in P.recvs if p == s_rank]
+                assert len(out) == len(inn)
+                for a, b in zip(out, inn):
+                    b.copy_(a)
+
+    @property
+    def bytes_per_substep(self):
+        """bytes every rank sends per sub-step: halo blocks + meta rows (halo), or what the all-gather moves"""
+        if self.plans is not None:
+            return [P.bytes_sent for P in self.plans] if self.plans[0].ready else None
+        return [(self.W - 1) * e.slab * 16 for e in self.ranks]
 
     def reset(self):
         out = []

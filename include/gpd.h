@@ -562,6 +562,28 @@ int gpd_comm_destroy(void* comm);
 int gpd_allgather_obs(void* comm, const float* shard, float* full, size_t count, void* stream);
 
 /*
+ * (ABI 8) Point-to-point exchange of float blocks between the ranks of a communicator, all operations of one call in ONE RCCL
+ * group (ncclGroupStart, ncclSend / ncclRecv per block, ncclGroupEnd): the HALO exchange of a world shared by several ranks.
+ * The reference's `_downwash` reads every other drone's position from the process's own arrays (envs/BaseAviary.py:798-811,
+ * `self.pos[j]`); a rank of a sharded world needs the positions of the drones within the model's 10 m lateral cut-off (plus
+ * a margin) of its own -- with the ranks holding stripes of the world, blocks from its two neighbours instead of the
+ * all-gather of every position (gpd_allgather_obs in place; 16 B x every drone per sub-step).  xGMI is point to point: every
+ * block travels over the one link between its two GPUs.
+ *   sends / recvs   the operations: `count` floats at `ptr` to / from rank `peer`.  Several blocks between the same pair of
+ *                   ranks are matched in the order they are listed (RCCL's rule); every send needs its receive on the peer,
+ *                   in a call of its own made at the same point of the program.  Device pointers; asynchronous on `stream`,
+ *                   capturable in a hipGraph.
+ * GPD_ENOTSUP when RCCL (or its point-to-point entries) cannot be resolved.
+ */
+typedef struct GpdP2P {
+    int32_t peer;          /* rank of the other side */
+    int32_t pad_;
+    void* ptr;             /* device pointer (send: read, receive: written) */
+    int64_t count;         /* floats */
+} GpdP2P;
+int gpd_p2p_group(void* comm, const GpdP2P* sends, int32_t n_sends, const GpdP2P* recvs, int32_t n_recvs, void* stream);
+
+/*
  * Diagnostics for the measurement harness (bench.py's issue roofline): runs a dependent v_fma_f32 chain at one wave per
  * SIMD and reports the shader clock it ran at [GHz] (shader-clock cycles / constant-rate wall-clock time) and, optionally,
  * the time per dependent FMA [ns].  Synchronous (it waits for `stream`).

@@ -128,10 +128,10 @@ def test_native_allgather_one_rank_and_inside_a_graph(gpu_device):
     ag.close()
 
 
-def _swarm_rank(rank, world, port, out_dir, N):
+def _swarm_rank(rank, world, port, out_dir, N, halo=False):
     """one PROCESS = one rank of a shared swarm world (both on device 0; positions exchanged through torch.distributed / gloo)"""
     import torch.distributed as dist
-    from gym_pybullet_drones_amd.envs import SwarmAviary, TorchSlabExchange
+    from gym_pybullet_drones_amd.envs import SwarmAviary, TorchHaloExchange, TorchSlabExchange
     from gym_pybullet_drones_amd.utils.enums import Physics
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -139,19 +139,23 @@ def _swarm_rank(rank, world, port, out_dir, N):
         dev = torch.device("cuda:0")
         d = np.load(os.path.join(out_dir, "scene.npz"))
         env = SwarmAviary(N, initial_xyzs=d["xyz"], initial_rpys=d["rpy"], physics=Physics.PYB_GND_DRAG_DW, pyb_freq=240, ctrl_freq=120,
-                          device=dev, world_size=world, rank=rank, exchange=TorchSlabExchange(), rebin_every=4)
+                          device=dev, world_size=world, rank=rank, exchange=TorchHaloExchange(margin=1.0) if halo else TorchSlabExchange(),
+                          rebin_every=4)
         ids = torch.as_tensor(env.GLOBAL_IDS, dtype=torch.long, device=dev)
         rpm = torch.as_tensor(d["rpm"], device=dev)
         vec, _ = env.reset()
         for k in range(rpm.shape[0]):
             vec, *_ = env.step(rpm[k][ids])
         torch.cuda.synchronize()
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), ids=env.GLOBAL_IDS, vec=vec.cpu().numpy(), force=env.dw_force[:env.NUM_DRONES].cpu().numpy())
+        everything = env.all_positions()            # (collective: the whole world's positions on every rank, whatever the exchange)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), ids=env.GLOBAL_IDS, vec=vec.cpu().numpy(), force=env.dw_force[:env.NUM_DRONES].cpu().numpy(),
+                 everything=everything.cpu().numpy(), sent=np.array(getattr(env.exchange, "bytes_per_substep", 0) or 0))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_processes_share_one_swarm_world_bitwise(gpu_device, tmp_path):
+@pytest.mark.parametrize("halo", [False, True])
+def test_two_processes_share_one_swarm_world_bitwise(gpu_device, tmp_path, halo):
     """The multi-PROCESS form of the sharded world (what a node runs, one process per GPU): two processes, each holding its
     stripe of the drones, exchanging position slabs through torch.distributed every sub-step.  State vectors and forces of all
     drones after 10 control steps, bit for bit those of one process holding the whole world."""
@@ -167,7 +171,7 @@ def test_two_processes_share_one_swarm_world_bitwise(gpu_device, tmp_path):
     one = SwarmAviary(N, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.PYB_GND_DRAG_DW, pyb_freq=240, ctrl_freq=120, device=gpu_device)
     rpm = (one.HOVER_RPM * (1 + 0.03 * rng.uniform(-1, 1, size=(10, N, 4)))).astype(np.float32)
     np.savez(os.path.join(str(tmp_path), "scene.npz"), xyz=xyz, rpy=rpy, rpm=rpm)
-    mp.spawn(_swarm_rank, args=(2, 29551, str(tmp_path), N), nprocs=2, join=True)
+    mp.spawn(_swarm_rank, args=(2, 29551 + int(halo), str(tmp_path), N, halo), nprocs=2, join=True)
     v1, _ = one.reset()
     for k in range(10):
         v1, *_ = one.step(torch.as_tensor(rpm[k], device=gpu_device))
@@ -176,5 +180,7 @@ def test_two_processes_share_one_swarm_world_bitwise(gpu_device, tmp_path):
     for r in range(2):
         d = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
         assert np.array_equal(d["vec"], v1[d["ids"]]) and np.array_equal(d["force"], f1[d["ids"]]), r
+        assert np.array_equal(d["everything"], v1[:, :3])                 # SwarmAviary.all_positions(): the caller's drone order
+        assert (int(d["sent"]) > 0) == halo
         seen[d["ids"]] = True
     assert seen.all() and np.abs(f1).max() > 1e-3

@@ -311,6 +311,29 @@ def _comm_worker(rank, world, stub, idfile):
     _native.check(L.gpd_allgather_obs(comm, send, pos4.ctypes.data_as(ctypes.c_void_p), slab * 4, None), "gpd_allgather_obs (in place)")
     for r in range(world):
         assert np.array_equal(pos4[r * slab:(r + 1) * slab], np.arange(slab * 4, dtype=np.float32).reshape(slab, 4) + 100 * r)
+    # grouped point-to-point (gpd_p2p_group: the halo exchange): rank r sends two blocks of different sizes to every other rank --
+    # 3 + r + 2 p floats, then 2 -- and the blocks of a pair arrive in the order they were listed
+    def block(src, dst, k):
+        n = 3 + src + 2 * dst if k == 0 else 2
+        return (np.arange(n, dtype=np.float32) + 100 * src + 10 * dst + 1000 * k)
+    sends, recvs, keep = [], [], []
+    for p in range(world):
+        if p == rank:
+            continue
+        for k in range(2):
+            out = np.ascontiguousarray(block(rank, p, k)); keep.append(out)
+            sends.append(_native.GpdP2P(peer=p, ptr=out.ctypes.data, count=out.size))
+            buf = np.full(block(p, rank, k).size, -1, dtype=np.float32); keep.append(buf)
+            recvs.append((p, k, buf))
+    S = (_native.GpdP2P * len(sends))(*sends)
+    Rv = (_native.GpdP2P * len(recvs))(*[_native.GpdP2P(peer=p, ptr=b.ctypes.data, count=b.size) for p, k, b in recvs])
+    for _ in range(2):
+        _native.check(L.gpd_p2p_group(comm, S, len(sends), Rv, len(recvs), None), "gpd_p2p_group")
+        for p, k, b in recvs:
+            assert np.array_equal(b, block(p, rank, k)), (rank, p, k, b)
+            b[:] = -1
+    assert L.gpd_p2p_group(comm, None, 1, Rv, len(recvs), None) == _native.GPD_EINVAL
+    assert L.gpd_p2p_group(comm, S, 0, Rv, 0, None) == 0                     # nothing to do
     # argument errors come back as codes, not crashes
     assert L.gpd_allgather_obs(comm, None, full.ctypes.data_as(ctypes.c_void_p), 12, None) == _native.GPD_EINVAL
     assert L.gpd_comm_count(None, ctypes.byref(n)) == _native.GPD_EINVAL
@@ -319,7 +342,7 @@ def _comm_worker(rank, world, stub, idfile):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_comm_glue_with_several_ranks_over_a_stub_rccl(tmp_path, world):
-    """The C-ABI's multi-rank entries (`gpd_comm_unique_id / _init / _count`, `gpd_allgather_obs`, `gpd_comm_destroy`) with
+    """The C-ABI's multi-rank entries (`gpd_comm_unique_id / _init / _count`, `gpd_allgather_obs`, `gpd_p2p_group`, `gpd_comm_destroy`) with
     rank > 0 and world_size > 1 -- which no single-GPU box can run against RCCL itself (it refuses two ranks on one device):
     `GPD_RCCL_LIB` points libgpd.so's dlopen at tests/stubs/rccl_stub.c, a stand-in that moves HOST buffers between processes
     through shared memory.  What it pins: the id hand-over, init on every rank, ONE communicator serving several calls and
@@ -395,3 +418,156 @@ def test_swarm_entries_reject_bad_arguments_before_touching_a_device():
     assert step_rc(num_envs=31) == _native.GPD_EINVAL and step_rc(drones_per_env=2) == _native.GPD_EINVAL
     assert step_rc(physics_flags=64) == _native.GPD_EINVAL
     assert L.gpd_swarm_pack(None, ctypes.byref(sw), None, None, None) == _native.GPD_EINVAL
+
+
+# ---- halo exchange of a shared world: the plan on CPU tensors, the torch transport over gloo ------------------
+class _FakeRank:
+    """what HaloPlan reads of a SwarmAviary: the partition numbers and the packed position array (here: CPU tensors)"""
+    def __init__(self, N, W, r, xyz_dealt):
+        import torch
+        from gym_pybullet_drones_amd.envs.SwarmAviary import swarm_first_drone, swarm_partition
+        self.WORLD_SIZE, self.RANK = W, r
+        self.per, self.slab, counts = swarm_partition(N, W)
+        self.NUM_DRONES = counts[r]
+        self.first = swarm_first_drone(N, W, r)
+        self.pos4 = torch.full((W * self.slab, 4), float("nan"))
+        self.device = self.pos4.device
+        self.set_own(xyz_dealt)
+
+    def set_own(self, xyz_dealt):
+        import torch
+        own = torch.as_tensor(xyz_dealt[self.first:self.first + self.NUM_DRONES], dtype=torch.float32)
+        self.pos4[self.RANK * self.slab:self.RANK * self.slab + self.NUM_DRONES, :3] = own
+        self.pos4[self.RANK * self.slab:self.RANK * self.slab + self.NUM_DRONES, 3] = 0
+        meta = self.slab - self.per
+        self.pos4[(self.RANK + 1) * self.slab - meta:(self.RANK + 1) * self.slab, 1:] = 7.0 + self.RANK       # (x stays NaN: no drone)
+
+
+def _plan_all(plans, ranks):
+    import torch
+    bounds = torch.stack([P.phase1(e) for P, e in zip(plans, ranks)])
+    counts = torch.stack([P.phase2(e, bounds) for P, e in zip(plans, ranks)])
+    for P, e in zip(plans, ranks):
+        P.phase3(e, counts)
+    for P, e in zip(plans, ranks):
+        P.gather(e)
+    for d, P in enumerate(plans):
+        for s in range(len(plans)):
+            if s != d:
+                out, inn = [b for p, b in plans[s].sends if p == d], [b for p, b in P.recvs if p == s]
+                assert len(out) == len(inn)
+                for a, b in zip(out, inn):
+                    b.copy_(a)
+
+
+@pytest.mark.parametrize("W", [2, 3, 8])
+def test_halo_plan_covers_every_pair_the_model_couples(W):
+    """`HaloPlan` on CPU tensors: a 200 m x 150 m world dealt to W ranks in stripes.  After the exchange every rank holds, for
+    each of its drones, EVERY drone of another rank within the model's 10 m lateral cut-off (envs/BaseAviary.py:801) -- now, and
+    after every drone has moved up to margin / 2 in any direction; stripes make the far ranks send nothing but their meta rows;
+    the bytes are a fraction of the all-gather's; a drone that outruns the margin is reported on every rank by the next plan."""
+    import torch
+    from gym_pybullet_drones_amd.envs.SwarmAviary import HaloPlan, swarm_spatial_order
+    rng = np.random.default_rng(W)
+    N, margin = 4000, 2.0
+    xyz = np.concatenate([rng.uniform(0, 200, size=(N, 1)), rng.uniform(0, 150, size=(N, 1)), rng.uniform(1, 12, size=(N, 1))], axis=1)
+    order = swarm_spatial_order(xyz, 10.5)
+    dealt = xyz[order]
+    ranks = [_FakeRank(N, W, r, dealt) for r in range(W)]
+    plans = [HaloPlan(margin) for _ in ranks]
+    _plan_all(plans, ranks)
+    owner = np.concatenate([np.full(e.NUM_DRONES, e.RANK) for e in ranks])
+
+    def held_by(e):
+        p = e.pos4[:, :3].numpy()
+        return p[np.isfinite(p).all(axis=1)]
+
+    def check(now):
+        for e in ranks:
+            mine = now[owner == e.RANK]
+            have = held_by(e)
+            others = now[owner != e.RANK]
+            d = np.hypot(others[:, None, 0] - mine[None, :, 0], others[:, None, 1] - mine[None, :, 1]).min(axis=1)
+            need = others[d < 10.0]
+            # every needed drone's CURRENT position is among the rows the rank holds (the same rows travel every sub-step)
+            assert len(need) > 0
+            key = {tuple(np.float32(v)) for v in have}
+            assert all(tuple(np.float32(v)) in key for v in need), e.RANK
+
+    check(dealt)
+    # the same plan, every drone displaced by up to margin / 2 (in y; any amount in x and z): re-send current positions, still covered
+    moved = dealt + np.concatenate([rng.uniform(-30, 30, size=(N, 1)), rng.uniform(-0.49 * margin, 0.49 * margin, size=(N, 1)),
+                                    rng.uniform(-1, 1, size=(N, 1))], axis=1)
+    for e in ranks:
+        e.set_own(moved)
+    for P, e in zip(plans, ranks):
+        P.gather(e)
+    for d, P in enumerate(plans):
+        for s in range(W):
+            if s != d:
+                for a, b in zip([b for p, b in plans[s].sends if p == d], [b for p, b in P.recvs if p == s]):
+                    b.copy_(a)
+    check(moved)
+    # stripes: far ranks exchange nothing but meta rows; every rank got everybody's meta rows; the halo is a fraction of the all-gather
+    for e, P in zip(ranks, plans):
+        for s in range(W):
+            if abs(s - e.RANK) >= 2 and W > 3:
+                assert P.recv_cnt[s] == 0 or abs(s - e.RANK) == 2, (e.RANK, s, P.recv_cnt)
+            if s != e.RANK:
+                meta = e.pos4.view(W, e.slab, 4)[s, e.per:]
+                assert torch.isnan(meta[:, 0]).all() and (meta[:, 1:] == 7.0 + s).all()
+        if W > 2:
+            assert P.bytes_sent < 0.7 * P.bytes_allgather, (P.bytes_sent, P.bytes_allgather)
+    # a drone that outran the margin: the next plan says so, on every rank
+    far = moved.copy()
+    far[order.tolist().index(int(order[5])), 1] += 3 * margin
+    for e in ranks:
+        e.set_own(far)
+    bounds = torch.stack([P.phase1(e) for P, e in zip(plans, ranks)])
+    assert float(bounds[:, 2].sum()) >= 1
+    for P, e in zip(plans, ranks):
+        with pytest.raises(RuntimeError, match="halo exchange"):
+            P.phase2(e, bounds)
+
+
+def _halo_gloo_worker(rank, world, port, N):
+    import torch
+    import torch.distributed as dist
+    from gym_pybullet_drones_amd.envs.SwarmAviary import TorchHaloExchange, swarm_spatial_order
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(5)
+        xyz = np.concatenate([rng.uniform(0, 100, size=(N, 1)), rng.uniform(0, 90, size=(N, 1)), rng.uniform(1, 5, size=(N, 1))], axis=1)
+        dealt = xyz[swarm_spatial_order(xyz, 10.5)]
+        e = _FakeRank(N, world, rank, dealt)
+        e._since_bin, e.rebin_every = 1, 1
+        ex = TorchHaloExchange(margin=1.0)
+        ex.exchange(e, replan=True)
+        for step in range(3):                    # the same plan, new positions every sub-step
+            e.set_own(dealt + 0.1 * (step + 1))
+            ex.exchange(e, replan=False)
+        assert ex.plans_made == 1 and ex.bytes_per_substep > 0
+        now = dealt + 0.3
+        first = [_FakeRank(N, world, r, now) for r in range(world)]
+        mine = now[first[rank].first:first[rank].first + e.NUM_DRONES]
+        have = {tuple(np.float32(v)) for v in e.pos4[:, :3].numpy() if np.isfinite(v).all()}
+        for r in range(world):
+            if r == rank:
+                continue
+            theirs = now[first[r].first:first[r].first + first[r].NUM_DRONES]
+            d = np.hypot(theirs[:, None, 0] - mine[None, :, 0], theirs[:, None, 1] - mine[None, :, 1]).min(axis=1)
+            assert all(tuple(np.float32(v)) in have for v in theirs[d < 10.0]), (rank, r)
+            meta = e.pos4.view(world, e.slab, 4)[r, e.per:]
+            assert (meta[:, 1:] == 7.0 + r).all()
+        ex.check(e)                              # (collective; nobody outran the margin)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange_over_torch_distributed_gloo(world):
+    """`TorchHaloExchange` between real processes (gloo, CPU tensors): the two tiny all-gathers of the plan and the batched
+    point-to-point blocks; every rank ends up with the current positions of the drones it needs and everybody's meta rows."""
+    import torch.multiprocessing as mp
+    mp.spawn(_halo_gloo_worker, args=(world, 29600 + os.getpid() % 300 + world, 1500), nprocs=world, join=True)

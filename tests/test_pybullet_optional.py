@@ -1,0 +1,64 @@
+"""Pins the two models behind `Physics.PYB` that have no counterpart in the reference's explicit integrator -- the ground plane
+(GPD_PHYS_GROUND) and Bullet's default multibody damping (GPD_PHYS_DAMP), both restated from the Bullet sources and labelled
+"parity unpinned" in include/gpd.h -- against the REAL thing the first time a box has it: `pybullet` plus the reference package
+(`pip install pybullet gym-pybullet-drones`).  This image has neither (no network): the tests skip.  Nothing here reads
+/root/reference; the reference must be importable as an installed package."""
+import numpy as np
+import pytest
+
+pybullet = pytest.importorskip("pybullet")
+ref_envs = pytest.importorskip("gym_pybullet_drones.envs.HoverAviary")
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(act_name, **kw):
+    from gym_pybullet_drones.utils.enums import ActionType, Physics
+    return ref_envs.HoverAviary(gui=False, physics=Physics.PYB, act=ActionType[act_name], **kw)
+
+
+def test_one_second_hover_of_physics_pyb_follows_bullet(gpu_device):
+    """HoverAviary() defaults (Physics.PYB, 30 Hz control), ONE_D_RPM, a constant slightly-above-hover action for 1 s: the drone
+    leaves the ground (ground plane: rests at z = 0.0125 + 0.1 start), climbs against Bullet's damping.  Bullet integrates with
+    its own (Featherstone, semi-implicit) scheme: agreement is to its step error, not to rounding -- 2 mm / 2 mm/s over 1 s."""
+    from gym_pybullet_drones_amd.envs import HoverAviary
+    from gym_pybullet_drones_amd.utils.enums import ActionType, Physics
+    ref = _ref("ONE_D_RPM")
+    mine = HoverAviary(physics=Physics.PYB, act=ActionType.ONE_D_RPM, device=gpu_device)
+    o_ref, _ = ref.reset(seed=0)
+    o_mine, _ = mine.reset(seed=0)
+    np.testing.assert_allclose(o_mine[:, :12], o_ref[:, :12], atol=1e-6)
+    a = np.full((1, 1), 0.3, dtype=np.float32)
+    worst = np.zeros(12)
+    for k in range(30):
+        o_ref, r_ref, te_ref, tr_ref, _ = ref.step(a)
+        o_mine, r_mine, te_mine, tr_mine, _ = mine.step(a)
+        worst = np.maximum(worst, np.abs(o_mine[0, :12] - o_ref[0, :12]))
+        assert (te_ref, tr_ref) == (te_mine, tr_mine), k
+    print("max |Physics.PYB here - Bullet| over 1 s, obs12:", worst)
+    assert worst[:3].max() < 2e-3 and worst[6:9].max() < 2e-3 and worst[3:6].max() < 1e-3 and abs(r_mine - r_ref) < 1e-2
+    ref.close()
+
+
+def test_idle_rotors_rest_on_the_plane_like_bullet(gpu_device):
+    """rotors at the lower end of ONE_D_RPM (95 % of hover): the drone sinks from its 0.1 m start onto the plane and stays --
+    contact height (COLLISION_H / 2 - COLLISION_Z_OFFSET) and zero velocity as Bullet's solver leaves them."""
+    from gym_pybullet_drones_amd.envs import HoverAviary
+    from gym_pybullet_drones_amd.utils.enums import ActionType, Physics
+    ref = _ref("ONE_D_RPM")
+    mine = HoverAviary(physics=Physics.PYB, act=ActionType.ONE_D_RPM, device=gpu_device)
+    ref.reset(seed=0)
+    mine.reset(seed=0)
+    a = np.full((1, 1), -1.0, dtype=np.float32)
+    for _ in range(60):
+        o_ref, *_ = ref.step(a)
+        o_mine, *_ = mine.step(a)
+    print("rest pose: Bullet", o_ref[0, :3], "here", o_mine[0, :3])
+    assert abs(o_mine[0, 2] - o_ref[0, 2]) < 1e-3 and np.abs(o_mine[0, 6:9]).max() < 1e-3 and np.abs(o_ref[0, 6:9]).max() < 1e-2
+    ref.close()
+
+
+def test_bench_times_the_real_reference_when_it_is_there():
+    import bench
+    r = bench.pybullet_baseline(budget_s=5.0, steps=242)
+    assert r["available"] and r["kind"] == "reference" and r["value"] > 0 and "HoverAviary()" in r["sample"]
