@@ -766,6 +766,62 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
     }
 
 
+def swarm_pairs(env):
+    """Pairs the wake lists of the current binning hold = what every replay launch evaluates (valid entries of the batches the
+    four waves of every group recorded; include/gpd.h, GpdSwarm.pair_list / pair_nb).  None without lists."""
+    if getattr(env, "_pair_list", None) is None:
+        return None
+    torch.cuda.synchronize()
+    nb = (env._pair_nb.to(torch.int32) & 0xffff).sum(dim=2)                    # [groups, 4] batches per wave
+    ok = env._list_ok.to(torch.bool)
+    cap64 = env._pair_list.shape[2]
+    idx = torch.arange(cap64, device=env.device).view(1, 1, -1)
+    live = (idx < (nb * 64).unsqueeze(2)) & ok.view(-1, 1, 1)
+    pairs = int(((env._pair_list != -1) & live).sum().item())
+    slots = int((nb * 64)[ok].sum().item())
+    return {"pairs": pairs, "list_slots": slots, "groups_with_a_list": int(ok.sum().item()), "groups": int(ok.numel()),
+            "list_bytes_read_per_substep": slots * 2}
+
+
+def swarm_roofline(out, env, m, clock_ghz):
+    """The roofline that binds a one-world line.  The HBM figure stays (as `hbm`), but a sub-step moves ~200 B per drone and takes
+    tens of microseconds: what it spends is pair evaluations and the dependent trips to memory around them.  Bound named here:
+    VALU issue -- wave-instructions of all kernels of a sub-step (rocprofv3 --pmc SQ_INSTS_VALU, profiles/swarm_counters.json)
+    x 4 cycles on 1024 SIMDs, against the measured sub-step; beside it the pairs per sub-step (the lists the timed region
+    replayed), the lane-instructions per pair, and where the rest of the time goes (per-kernel durations of the same trace)."""
+    roof = out["roofline"]
+    hbm = {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "achievable", "frac_of_achievable", "bytes_per_launch",
+                                "bytes_per_drone_per_env_step", "floor_us") if k in roof}
+    pairs = swarm_pairs(env)
+    us = m["us_per_step"] / max(env.PYB_STEPS_PER_CTRL, 1)                 # per physics sub-step
+    rec = None
+    f = os.path.join(REPO, "profiles", "swarm_counters.json")
+    if os.path.exists(f):
+        rec = json.load(open(f)).get(out["config"]["workload"])
+    peak = NUM_SIMDS * PEAK_CLOCK_GHZ / 4.0                                # G wave-instructions per second (a wave64 VALU op holds its SIMD 4 cycles)
+    new = {"bound": "valu_issue", "achieved": None, "peak": peak, "unit": "G wave-instructions/s", "frac": None, "traffic": roof.get("traffic"),
+           "kernel": roof["kernel"], "us_per_substep": us, "pairs": pairs, "hbm": hbm, "clock": roof.get("clock"),
+           "env_steps_per_launch": roof.get("env_steps_per_launch"), "launch_us_hip_events": roof.get("launch_us_hip_events")}
+    if pairs:
+        new["pairs_per_substep"] = pairs["pairs"]
+        new["pairs_per_drone"] = pairs["pairs"] / env.TOTAL_DRONES
+        new["pair_evaluations_per_s"] = pairs["pairs"] / (us * 1e-6)
+    if rec:
+        valu = rec["valu_wave_instructions_per_substep"]
+        new["achieved"] = valu / (us * 1e-6) / 1e9
+        new["frac"] = new["achieved"] / peak
+        new["valu_floor_us"] = valu * 4.0 / (NUM_SIMDS * PEAK_CLOCK_GHZ * 1e3)
+        if clock_ghz:
+            new["frac_at_measured_clock"] = valu * 4.0 / (NUM_SIMDS * clock_ghz * 1e3) / us
+        new["counters"] = rec
+        if pairs and rec.get("replay_valu_wave_instructions"):
+            new["valu_lane_instructions_per_pair"] = rec["replay_valu_wave_instructions"] * 64.0 / pairs["pairs"]
+        new["source"] = "profiles/swarm_counters.json (rocprofv3 --pmc SQ_INSTS_*, scratch/profile_r04.py)"
+    else:
+        new["note"] = "no profiles/swarm_counters.json entry for this workload: instruction counts unknown, frac not computed"
+    out["roofline"] = new
+
+
 def attach_counters(roof, key, m, core, clock_ghz):
     """Offline-measured per-kernel figures (separate rocprofv3 passes, profiles/*.json) next to the live numbers:
     HBM traffic from the FETCH_SIZE / WRITE_SIZE counters, scaled to this launch's step count, and the instruction
@@ -1192,6 +1248,11 @@ def run_workload(args, job):
         issue = attach_counters(out["roofline"], f"{args.workload}:{key_launch}", m, core, clock_ghz)
         if issue is not None:
             out["roofline_valu_issue"] = issue
+        if w.get("swarm"):
+            try:
+                swarm_roofline(out, envs[0], m, clock_ghz)
+            except Exception as e:      # noqa: BLE001 -- the line survives without the extra block
+                out["roofline"]["swarm_roofline_error"] = f"{type(e).__name__}: {e}"[:200]
         if clock_ghz:
             out["shader_clock_ghz_probe"] = clock_ghz
         if second is not None:

@@ -68,12 +68,19 @@ constexpr int kBlock = GPD_BLOCK;   // 256 = 4 wavefronts; one workgroup per CU 
 // than the step / rollout kernels (-amdgpu-sched-strategy: max-ilp fills the packed-fp32 hazards of the physics; the default
 // strategy is 10 % faster on the MFMA / activation mix of the policy, A/B in round 2).  The last-error string is shared.
 std::string& gpd_detail_last_error();
-// The DSLPID variants of the policy kernel are instantiated in the MAIN unit (max-ilp scheduler): compiled with the default
-// scheduler, the VEL variant returns `truncated` = 1 and a task reward for every aviary whatever the configuration says -- the
-// physics and the actions stay right, no parameter of the truncation test changes it, spilling SGPRs to memory instead of VGPR
-// lanes does not either, and the same source is correct under max-ilp (tests/test_gpu_policy.py, bitwise against gpd_step).
-// A scheduler-dependent miscompile or an undefined behaviour we could not find; until it is understood the variants that
-// inline the controller stay where their tests pass.
+// The DSLPID variants of the policy kernel are instantiated in the MAIN unit (max-ilp scheduler).  Compiled in the policy unit
+// (default scheduler) at commit 7333ea5, the VEL variant returned `truncated` = 1 and a task reward for every aviary whatever the
+// configuration said.  ROOT CAUSE (found in the assembly; reproduced again in round 4, scratch/exp_r04/
+// README.md): a register-allocation defect of hipcc (ROCm 7.2.0, AMD clang 22.0.0git roc-7.2.0), not undefined behaviour in this source -- the entry
+// block loads GpdStepCfg.task .. init_per_env with `s_load_dwordx8 s[48:55], s[0:1], 0x19c`, the next block loads sixteen
+// GpdParams words with `s_load_dwordx16 s[36:51], s[0:1], 0x18` OVER the first four while they are live, and only then is "the
+// configuration" saved with `v_writelane_b32 v164, s48..s55, 29..36`: the step loop reloads prop_y[1..3] and gnd_eff_coeff as
+// task / xy_bound / z_bound / tilt_bound.  It depends on how the allocator splits that one live range, i.e. on everything
+// around it: today's source compiles clean in BOTH units under BOTH schedulers.  Fences: tests/isa_spill_check.py (backward SGPR
+// liveness over every kernel of both units: a kernel-argument tuple that is spilled whole after part of it was overwritten),
+// tests/test_kernel_isa.py (also builds the policy unit WITH these variants -- GPD_PID_POLICY_IN_POLICY_TU -- under both
+// schedulers and checks them), the bitwise cross-kernel tests with every argument word scrambled (tests/test_gpu_policy.py), and
+// tests/test_gpu_policy.py::test_vel_policy_kernel_is_right_under_both_schedulers (the variant library, built on the GPU box).
 struct GpdPolicyLaunch {
     const GpdParams* params; const GpdState* state; const GpdStepCfg* cfg; const void* span; const GpdPolicy* policy;
     const float* obs12_in; const float* target_pos; const float* init_pose; float* actions_out; float* obs12; float* reward;
@@ -3080,7 +3087,9 @@ int step_impl(const char* who, const GpdParams* params, const GpdState* state, c
 // ==================================================================================================
 // C ABI
 // ==================================================================================================
-#ifndef GPD_POLICY_TU
+// (GPD_PID_POLICY_IN_POLICY_TU: experiment / regression switch -- instantiate the DSLPID policy kernels in the policy unit, under
+// ITS scheduler, instead of the main unit; tests/test_kernel_isa.py and scratch/exp_r04/vel_probe.py)
+#if defined(GPD_POLICY_TU) == defined(GPD_PID_POLICY_IN_POLICY_TU)
 void gpd_detail_launch_policy_pid(const GpdPolicyLaunch& a) {
     const Span& T = *static_cast<const Span*>(a.span);
     const dim3 grid(a.grid);

@@ -60,8 +60,8 @@ def kernels(text):
         i += 1
 
 
-def check(body):
-    """[(line index within the kernel body, text, dead registers)] for every scalar load with a dead destination dword."""
+def parse(body):
+    """(instructions [(line index in body, mnemonic, operands, text)], successors per instruction, (defs, uses) per instruction)"""
     ins, labels = [], {}
     for n, raw in enumerate(body):
         l = raw.split(";")[0].strip()
@@ -89,6 +89,13 @@ def check(body):
         else:
             succ.append((k + 1,) if k + 1 < n_ins else ())
     du = [def_use(mn, ops) for _, mn, ops, _ in ins]
+    return ins, succ, du
+
+
+def check(body):
+    """[(line index within the kernel body, text, dead registers)] for every scalar load with a dead destination dword."""
+    ins, succ, du = parse(body)
+    n_ins = len(ins)
     live_in = [set() for _ in range(n_ins)]
     changed = True
     while changed:                                   # backward liveness, iterated to the fixed point (instruction granularity)
@@ -133,10 +140,11 @@ def spill_runs(body):
 
 def torn_spills(body):
     """The miscompile proper: a scalar load A keeps some destination dwords alive and loses others to a later definition,
-    and afterwards ONE spill run saves both kinds together as if A's tuple were intact (textual order approximates the path)."""
+    and afterwards ONE spill run saves both kinds together as if A's tuple were intact (reachability over the kernel's control-flow graph)."""
     dead_of = {n: (l, set(dead)) for n, l, dead in check(body)}
     out = []
     runs = spill_runs(body)
+    ins, succ, du = parse(body)
     for n, (l, dead) in dead_of.items():
         mn, rest = l.split(None, 1)
         dst = sregs(split_ops(rest)[0])
@@ -149,17 +157,27 @@ def torn_spills(body):
             regs = set(run["regs"])
             if regs != dst:          # the signature: A's whole destination tuple, and nothing else, saved as one value
                 continue
-            # A's surviving dwords must still be A's at the spill: no textual redefinition in between
-            redefined = set()
-            for k in range(n + 1, run["start"]):
-                t = body[k].split(";")[0].strip()
-                if not t or t.startswith(".") or t.endswith(":"):
-                    continue
-                p = t.split(None, 1)
-                d, _ = def_use(p[0], split_ops(p[1] if len(p) > 1 else ""))
-                redefined |= d
-            if (regs & alive) - redefined:
-                out.append((n, l, sorted(dead), run))
+            # A's surviving dwords must still be A's at the spill: the load's value of at least one of them REACHES the first
+            # instruction of the run along the control-flow graph without a redefinition (a latch block laid out in front of its
+            # loop is reached through the loop body, which sits textually behind it: textual order is not the path)
+            k_load = next(k for k, (nn, *_r) in enumerate(ins) if nn == n)
+            k_run = next(k for k, (nn, *_r) in enumerate(ins) if nn >= run["start"])
+            for r in sorted(regs & alive):
+                seen, todo, hit = set(), list(succ[k_load]), False
+                while todo:
+                    k = todo.pop()
+                    if k in seen:
+                        continue
+                    seen.add(k)
+                    if k == k_run:
+                        hit = True
+                        break
+                    if r in du[k][0]:
+                        continue
+                    todo.extend(succ[k])
+                if hit:
+                    out.append((n, l, sorted(dead), run))
+                    break
     return out
 
 

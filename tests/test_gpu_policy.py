@@ -284,3 +284,36 @@ def test_sampling_argument_errors(gpu_device):
     penv = _env("pid", 30, False, 64, gpu_device)
     with pytest.raises(_native.GpdError, match="RPM"):
         penv.rollout_policy(MlpPolicy.random(12, 3, device=gpu_device), 4, noise=torch.zeros((4, 64, 1, 3), device=gpu_device), action_std=[1, 1, 1])
+
+
+def test_vel_policy_kernel_is_right_under_both_schedulers(gpu_device, tmp_path):
+    """VERDICT r03 #6.  The VEL policy kernel once came out of hipcc with four configuration words replaced by drone parameters
+    (a register-allocation defect) when it was compiled in the policy unit under the default scheduler.
+    This test BUILDS that configuration on the GPU box -- both units with -DGPD_PID_POLICY_IN_POLICY_TU, the policy unit under
+    the default scheduler -- and runs the DSLPID cases of the bitwise cross-kernel test (scrambled arguments included) against it
+    in a fresh process (`GPD_LIB`); the shipped library (those kernels in the max-ilp unit) runs them in this one."""
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    from gym_pybullet_drones_amd import _native
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    objs, procs = [], []
+    for unit, extra in _native.UNITS:
+        obj = str(tmp_path / unit.replace(".hip", ".o"))
+        cmd = [hipcc] + _native.COMMON_FLAGS + extra + ["-DGPD_PID_POLICY_IN_POLICY_TU", "-I", _native.INCLUDE, "-c", os.path.join(_native.CSRC, unit), "-o", obj]
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        objs.append(obj)
+    for pr in procs:
+        out, _ = pr.communicate()
+        assert pr.returncode == 0, out[-3000:]
+    lib = str(tmp_path / "libgpd_pid_in_policy_unit.so")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib], check=True, capture_output=True)
+    # the DSLPID policy kernels are now defined by the policy unit's object (default scheduler), not the main one
+    assert "-amdgpu-sched-strategy=max-ilp" in " ".join(_native.UNITS[0][1]) and "max-ilp" not in " ".join(_native.UNITS[1][1])
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REPO, "tests", "test_gpu_policy.py"), "-q", "-x", "-k",
+                          "bitwise_stepping and (vel or pid)"], cwd=REPO, env=dict(os.environ, GPD_LIB=lib), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and " passed" in res.stdout, res.stdout[-3000:] + res.stderr[-2000:]
+    print(res.stdout.strip().splitlines()[-1])

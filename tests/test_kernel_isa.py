@@ -165,6 +165,25 @@ def test_no_kernel_saves_a_half_overwritten_argument_tuple(gpd_asm, policy_asm):
     assert n >= 130, n
 
 
+@pytest.mark.parametrize("sched", ["default", "max-ilp"])
+def test_dslpid_policy_kernels_in_the_policy_unit_under_both_schedulers(sched):
+    """The configuration the miscompile was found in: the DSLPID policy kernels instantiated in the
+    POLICY unit (`-DGPD_PID_POLICY_IN_POLICY_TU`), compiled under the default scheduler -- and, for the A/B, under max-ilp.
+    Whatever the allocator does with today's source, no kernel of that unit may save a half-overwritten argument tuple; the VEL
+    shape that broke at commit 7333ea5 (<PID, 4, VEL, 1, tanh>) must be among the kernels checked.  (Its run-time twin:
+    tests/test_gpu_policy.py::test_vel_policy_kernel_is_right_under_both_schedulers.)"""
+    import isa_spill_check as chk
+    extra = ["-DGPD_PID_POLICY_IN_POLICY_TU"] + (["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if sched == "max-ilp" else [])
+    asm = "\n".join(_asm("gpd_policy.hip", extra))
+    names = []
+    for name, body in chk.kernels(asm):
+        names.append(name)
+        found = chk.torn_spills(body)
+        assert not found, (sched, name, [(l, dead, run["lanes"]) for _, l, dead, run in found])
+    assert any("gpd_rollout_policy_kernelILb1ELi4ELi2ELi1ELb0E" in n for n in names), names[:5]
+    assert sum("gpd_rollout_policy_kernelILb1" in n for n in names) == 12          # 3 action types x {12-float, full row} x {tanh, relu}
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_swarm_force_kernel_tests_pairs_packed_and_evaluates_them_compacted(gpd_asm, mode):
     """dwg_force_kernel<MODE> (MODE 0: no wake lists, 1: the launch after a binning builds them, 2: the
