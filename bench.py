@@ -1005,6 +1005,12 @@ def hbm_leg(args, job, out):
     a = argparse.Namespace(**vars(args))
     a.workload, a.no_cpu_baseline, a.no_second_leg, a.split, a.allgather = "hover4m_240hz", True, True, 1, False
     a.min_time = min(args.min_time, 0.1)
+    # 64 steps per launch whatever the headline's --steps: the block is about the rate HBM serves this kernel at, and at 4M drones a
+    # 20-step launch (16 rounds of resident workgroups, each starting and ending together) reads 0.63-0.71 depending on the box
+    # where the 64-step one reads 0.72-0.75 (profiles/r04_hbm_leg_steps_per_launch.txt)
+    a.steps, a.warmup = max(64, args.steps // 64 * 64), 64
+    if a.steps > 256:
+        a.steps = 256
     try:
         r = run_workload(a, job)
     except Exception as e:          # noqa: BLE001 -- reported; the headline survives
