@@ -814,6 +814,7 @@ def swarm_roofline(out, env, m, clock_ghz):
         if clock_ghz:
             new["frac_at_measured_clock"] = valu * 4.0 / (NUM_SIMDS * clock_ghz * 1e3) / us
         new["counters"] = rec
+        new["traffic"] = rec.get("hbm_bytes_per_substep")       # FETCH_SIZE x 2 + WRITE_SIZE of every kernel of a sub-step (separate --pmc passes)
         if pairs and rec.get("replay_valu_wave_instructions"):
             new["valu_lane_instructions_per_pair"] = rec["replay_valu_wave_instructions"] * 64.0 / pairs["pairs"]
         new["source"] = "profiles/swarm_counters.json (rocprofv3 --pmc SQ_INSTS_*, scratch/profile_r04.py)"

@@ -19,7 +19,7 @@ for f in glob.glob(f"{SRC}/*_kernel_stats*.csv") + glob.glob(f"{SRC}/pmc_*.csv")
 shutil.copy(f"{SRC}/summary.json", "profiles/r04_summary.json")
 for tag, line in d.get("bench_lines", {}).items():          # the JSON lines the traced commands printed
     if line:
-        json.dump(line, open(f"profiles/r04_bench_{tag.replace('trace_', '')}.json", "w"))
+        json.dump(line, open(f"profiles/r04_bench_{tag.replace('trace_', '')}_under_rocprofv3.json", "w"))
 
 
 def grid_row(tag, frag, grid):
