@@ -402,11 +402,15 @@ def parity_check(w, env, actions, K, POOL, max_steps=256):
                 arr *= 1.0 + 2.0 ** -24 * erng.choice([-1.0, 1.0], size=arr.shape)
             orp.rpy = np.ascontiguousarray(bm.euler_from_quaternion_b(orp.quat))
         nudge()                                       # (the first step's input is already a rounded one)
+    # (every replayed step's rows go to the host, and once more as float64: a launch is cut so that its rows stay under 2 GB --
+    # 10 steps at 4M drones -- and the whole replay under 6 GB)
+    per_launch = max(1, int(2.0e9 // (N * 48)))
+    max_steps = min(max_steps, max(per_launch, int(6.0e9 // (N * 48))))
     groups, left = [], max_steps
     for n in groups_of(K, POOL):
         if left <= 0:
             break
-        groups.append(min(n, left))
+        groups.append(min(n, left, per_launch))
         left -= groups[-1]
     names = ("pos", "quat", "vel", "rates")
     sl = {"pos": slice(0, 3), "quat": slice(3, 7), "vel": slice(7, 10), "rates": slice(10, 13)}
@@ -1012,6 +1016,9 @@ def hbm_leg(args, job, out):
     a.steps, a.warmup = max(64, args.steps // 64 * 64), 64
     if a.steps > 256:
         a.steps = 256
+    # (the parity replay copies every replayed step's rows to the host, twice as float64: 8 steps of 4M drones are 1.6 + 3.2 GB,
+    # 64 would be 13 + 26 GB)
+    a.parity_max_steps = 8
     try:
         r = run_workload(a, job)
     except Exception as e:          # noqa: BLE001 -- reported; the headline survives
@@ -1179,6 +1186,13 @@ def run_workload(args, job):
             e.reset()
     m = measure(args.mode, args, envs, actions, gather if len(envs) == 1 else None, device, world, POOL)
 
+    halo_check = None
+    if w.get("swarm") and world > 1 and getattr(envs[0].exchange, "halo", False):
+        try:        # (collective) did every drone of every rank stay within the halo's margin since the last plan?
+            envs[0].exchange.check(envs[0])
+            halo_check = "ok"
+        except RuntimeError as e:
+            halo_check = str(e)[:300]
     parity = None
     all_pos = None
     if not args.no_parity and w.get("swarm") and envs[0].flags & 4 and world > 1:
@@ -1190,7 +1204,7 @@ def run_workload(args, job):
             parity = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0 and not args.no_parity and args.mode == "rollout" and not w.get("policy") and not w.get("swarm"):
         try:
-            parity = parity_check(w, envs[0], actions[0], args.steps, POOL)
+            parity = parity_check(w, envs[0], actions[0], args.steps, POOL, max_steps=getattr(args, "parity_max_steps", 256))
         except Exception as e:          # noqa: BLE001 -- the checker must never take the measurement down with it
             parity = {"error": f"{type(e).__name__}: {e}"[:300]}
 
@@ -1239,7 +1253,7 @@ def run_workload(args, job):
                                      "exchange_bytes_sent_per_rank_per_substep": None if world == 1 else
                                      (envs[0].exchange.bytes_per_substep if getattr(envs[0].exchange, "halo", False) else envs[0].slab * 16),
                                      "exchange_bytes_received_allgather": None if world == 1 else (world - 1) * envs[0].slab * 16,
-                                     "halo_plans_made": getattr(envs[0].exchange, "plans_made", None)}}
+                                     "halo_plans_made": getattr(envs[0].exchange, "plans_made", None), "halo_margin_check": halo_check}}
                           if w.get("swarm") else {})},
             "roofline": m["roofline"],
             "per_gpu": {"unit": "drone-steps/s", "values": m["per_gpu"], "min": min(m["per_gpu"]), "max": max(m["per_gpu"]),
