@@ -776,7 +776,7 @@ def swarm_pairs(env):
     if getattr(env, "_pair_list", None) is None:
         return None
     torch.cuda.synchronize()
-    nb = (env._pair_nb.to(torch.int32) & 0xffff).sum(dim=2)                    # [groups, 4] batches per wave
+    nb = env._pair_nb[..., 0].to(torch.int32) & 0xffff                         # [groups, 4] batches per wave
     ok = env._list_ok.to(torch.bool)
     cap64 = env._pair_list.shape[2]
     idx = torch.arange(cap64, device=env.device).view(1, 1, -1)
@@ -784,7 +784,7 @@ def swarm_pairs(env):
     pairs = int(((env._pair_list != -1) & live).sum().item())
     slots = int((nb * 64)[ok].sum().item())
     return {"pairs": pairs, "list_slots": slots, "groups_with_a_list": int(ok.sum().item()), "groups": int(ok.numel()),
-            "list_bytes_read_per_substep": slots * 2}
+            "list_bytes_read_per_substep": slots * 4}
 
 
 def swarm_roofline(out, env, m, clock_ghz):

@@ -2279,16 +2279,20 @@ struct DwWorld {
 // Wake lists (GpdSwarm): what survives phase A changes little from one sub-step to the next -- drones move centimetres, the
 // model's reach is metres.  The force launch right after a binning (MODE 1, "build") runs phase A with a margin -- a pair is
 // kept if it COULD pass the exact tests once both drones have moved up to `delta` in any direction -- and writes every batch it
-// evaluates to a per-wave list in HBM (the queue entries: 6 bits lane, 10 bits candidate slot of the tile; tiles are
-// reproducible: same stale `start` / `order`, same runs).  The launches until the next binning (MODE 2, "replay") skip phases A
-// and Q: load the tile (current positions), read the batches back, evaluate -- the same exact tests and integer sums.  Valid
-// while no drone is further than delta from where it was binned (dmax, the quantity the search radius follows; delta is what
-// keeps R = 1: just under half the skin cell - 10 m) and the group's list did not overflow; otherwise the launch sweeps as if
-// there were no lists.  MODE 0: no lists (gpd_downwash_global, or none allocated).
-constexpr int kDwMaxTiles = 16;                            // per row segment sequence of a group; more: no list for the group
+// evaluates to a per-wave list in HBM.  An entry is 32 bits: 6 bits lane (the drone of the group the pair belongs to) and 26 bits
+// the candidate's ABSOLUTE index in the array its current position is read from (the sorted slot in a single-rank world, the row
+// of pos4 in a shared one).  The launches until the next binning (MODE 2, "replay") therefore need neither the cell table nor
+// the runs nor a staged tile: they read their batches back, GATHER the candidates' current positions straight from memory
+// (a group's ~600 candidates are 10 KB that its four waves share: L2 hits after the first touch), and evaluate -- the same exact
+// tests and integer sums.  (Round 3's entries were 16 bits, lane + slot of the LDS tile, and a replay launch re-staged the
+// tiles like a sweep: of its 14 us, 3 went to dependent set-up loads and 3 to staging before the first pair was evaluated,
+// profiles/r03_force_timeline.txt.)  Valid while no drone is further than delta from where it was binned (dmax, the quantity
+// the search radius follows; delta is what keeps R = 1: just under half the skin cell - 10 m) and the group's list did not
+// overflow; otherwise the launch sweeps as if there were no lists.  MODE 0: no lists (gpd_downwash_global, or none allocated).
+constexpr int kDwMaxTiles = 16;                            // (entries of DwLists.nb per wave; [0]: the wave's batches)
 struct DwLists {
-    unsigned short* list;  // [groups][4 waves][cap * 64] queue entries, batch-major; 0xffff: no pair in this lane of the batch
-    unsigned short* nb;    // [groups][4 waves][kDwMaxTiles] batches per tile
+    uint32_t* list;        // [groups][4 waves][cap * 64] entries, batch-major; 0xffffffff: no pair in this lane of the batch
+    unsigned short* nb;    // [groups][4 waves][kDwMaxTiles]: [0] = batches the wave recorded
     int* ok;               // [groups] 1: the group's list is complete for the current binning
     int cap;               // batches per wave
     float delta;           // the displacement the lists allow for
@@ -2298,12 +2302,9 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
                                                            const int* __restrict__ start, const int* __restrict__ order,
                                                            const float4* __restrict__ sorted, float* __restrict__ dw_out,
                                                            int* __restrict__ cursor) {
-    // one LDS block: the tile's x / y / z planes, then the four waves' queues.  A group that REPLAYS its list queues nothing, and
-    // the queues' 18 KiB hold a second tile (planes at kDwTileB, same spacing): two tiles staged behind one barrier -- the 3 % of
-    // the groups with more than 1023 candidates were what a replay launch waited for (profiles/r03_force_timeline.txt)
-    constexpr int kDwTileB = 3 * kDwTile;                  // floats: where the second tile's x plane starts
-    static_assert((kBlock / 64) * kDwQueue * 2 >= 3 * kDwTile * 4, "the queues hold a second tile");
+    // one LDS block: the tile's x / y / z planes, then the four waves' queues; (build) the candidates' source indices beside them
     __shared__ __attribute__((aligned(16))) float lds_tile[3 * kDwTile + (kBlock / 64) * kDwQueue / 2];
+    __shared__ int tsrc[MODE == 1 ? kDwTile : 1];
     float* const tx = lds_tile;
     float* const ty = lds_tile + kDwTile;
     float* const tz = lds_tile + 2 * kDwTile;
@@ -2368,17 +2369,23 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
     // groups of a rank of eight hold none of its drones, and were reading 64 rows per lane before they found out)
     if (Wd.meta && few) read_maxima();
     // (replay) whether the group's list is complete, this wave's batches on the first tile
-    unsigned short* const my_list = MODE ? Ls.list + (static_cast<size_t>(blockIdx.x) * (kBlock / 64) + wave) * Ls.cap * 64 : nullptr;
+    uint32_t* const my_list = MODE ? Ls.list + (static_cast<size_t>(blockIdx.x) * (kBlock / 64) + wave) * Ls.cap * 64 : nullptr;
     unsigned short* const my_nb = MODE ? Ls.nb + (static_cast<size_t>(blockIdx.x) * (kBlock / 64) + wave) * kDwMaxTiles : nullptr;
     int list_ok = 0, nb0 = 0;
     float delta = Ls.delta;                                // the lists' margin: what gpd_swarm_bin chose for this binning
     if (MODE && Wd.drift) delta = Wd.drift[2];
+    // (replay) the wave's first four batches are requested HERE, with everything else the set-up needs: their addresses depend on
+    // nothing but the workgroup, the wave and the lane (cap >= 4 is checked by the host; a wave with fewer batches reads stale
+    // entries of its own list and never uses them)
+    uint32_t e0 = 0xffffffffu, e1 = 0xffffffffu, e2 = 0xffffffffu, e3 = 0xffffffffu;
     if (MODE == 2) {
         list_ok = Ls.ok[blockIdx.x];
         nb0 = my_nb[0];
+        e0 = my_list[lane]; e1 = my_list[64 + lane]; e2 = my_list[128 + lane]; e3 = my_list[192 + lane];
     }
     // (the loads above are all in flight; this is where they are waited for, together)
     asm volatile("" : "+v"(row_l), "+v"(key_l), "+v"(me_l.x), "+v"(me_l.y), "+v"(me_l.z), "+v"(d2), "+v"(list_ok), "+v"(nb0), "+v"(delta));
+    if (MODE == 2) asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
     list_ok = __builtin_amdgcn_readfirstlane(list_ok); nb0 = __builtin_amdgcn_readfirstlane(nb0);
     if (base >= sorted_n) return;
     const bool have = s < sorted_n;
@@ -2427,7 +2434,7 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
 #if defined(GPD_EXP_TS) && defined(GPD_EXP_TSF)
     if (MODE == 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tf1 = wall_clock64(); }
 #endif
-    int lb = 0, tcount = 0;                                // batches recorded / replayed so far; tiles so far
+    int lb = 0;                                            // (build) batches recorded so far
     // (build) the list is complete so far -- and only a build on the binning's own positions counts (a caller that builds later
     // gets no lists rather than lists whose margin was measured from somewhere else)
     bool rec_ok = R == 1 && d2 == 0.0f;
@@ -2436,6 +2443,62 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
     const bool sweep_all = R > kDwMaxR;                    // the group's candidates: every sorted drone, one run
     const int nrows = sweep_all ? 0 : min(2 * R + 1, ny);
     my_sums[lane] = 0ull;                                  // sum of contributions in units of 2^-30 N: order-independent
+    // one pair: drone `dl` of the group under the candidate at (cx, cy, cz) -- the exact tests and the model (:798-808), added to
+    // the drone's sum (called by ALL lanes -- ds_bpermute reads nothing from a lane that is masked off -- with `valid` false
+    // where there is no pair)
+    auto pair_model = [&](int dl, bool valid, float cx, float cy, float cz) {
+        const float px = __shfl(me.x, dl), py = __shfl(me.y, dl), pz = __shfl(me.z, dl);
+        const float dz = cz - pz;
+        const float ddx = cx - px, ddy = cy - py;
+        const float dxy2 = fmaf(ddy, ddy, ddx * ddx);
+        if (valid && dz > 0.0f && dxy2 < 100.0f) {     // dz > 0 and dxy < 10 m  (:800-801)
+            const float ratio = kr * fast_rcp(dz);
+            const float alpha = P.dw_coeff[0] * (ratio * ratio);
+            const float beta = fmaf(P.dw_coeff[1], dz, P.dw_coeff[2]);
+            const float ib = fast_rcp(beta);
+            const float arg = 0.5f * (dxy2 * (ib * ib));
+            if (arg < 40.0f) {                         // exp(-40) = 4e-18: below the 2^-31 N the sum resolves
+                const float sc = (alpha * fast_exp(-arg)) * 1073741824.0f;
+                // (< 4 N, i.e. unless two drones are centimetres apart: one conversion instead of the 14-instruction
+                // float -> int64 sequence; the same integer either way)
+                unsigned long long v;
+                if (__builtin_amdgcn_ballot_w64(!(sc >= 0.0f && sc < 4.0e9f)) != 0) {
+                    asm volatile("; a contribution of 4 N or more" ::: "memory");      // (keeps this a branch, not a select)
+                    v = static_cast<unsigned long long>(__float2ll_rn(sc));
+                } else {
+                    v = static_cast<unsigned long long>(__float2uint_rn(sc));
+                }
+                atomicAdd(&my_sums[dl], v);
+            }
+        }
+    };
+    if (MODE == 2 && replay) {
+        // REPLAY: the wave's recorded batches, four at a time, in a three-deep software pipeline -- the entries of batches b+8..
+        // are requested while the candidates of b+4.. are gathered and b.. is evaluated (loads only in this loop: the waits the
+        // compiler derives are exact counts).  An empty lane (0xffffffff) gathers index 0 and evaluates nothing.
+        const int nbw = nb0;
+        const uint32_t* const lp = my_list + lane;
+        auto cand = [&](uint32_t e) {
+            // (clamped: the first four entries are read before the wave knows how many batches it has -- whatever a list holds,
+            // the gather stays inside the array)
+            const uint32_t idx = min(e == 0xffffffffu ? 0u : (e & 0x03ffffffu), static_cast<uint32_t>(Wd.n_slots - 1));
+            return Wd.pos4 ? Wd.pos4[idx] : sorted[idx];
+        };
+        auto entry = [&](int b) { return b < nbw ? lp[static_cast<size_t>(b) * 64] : 0xffffffffu; };
+        uint32_t f0 = entry(4), f1 = entry(5), f2 = entry(6), f3 = entry(7);
+        float4 p0 = cand(e0), p1 = cand(e1), p2 = cand(e2), p3 = cand(e3);
+        if (nbw < 4) { if (nbw < 1) e0 = 0xffffffffu; if (nbw < 2) e1 = 0xffffffffu; if (nbw < 3) e2 = 0xffffffffu; e3 = 0xffffffffu; }
+        for (int b = 0; b < nbw; b += 4) {
+            const uint32_t g0 = entry(b + 8), g1 = entry(b + 9), g2 = entry(b + 10), g3 = entry(b + 11);
+            const float4 q0 = cand(f0), q1 = cand(f1), q2 = cand(f2), q3 = cand(f3);
+            pair_model(static_cast<int>(e0 >> 26), e0 != 0xffffffffu, p0.x, p0.y, p0.z);
+            pair_model(static_cast<int>(e1 >> 26), e1 != 0xffffffffu, p1.x, p1.y, p1.z);
+            pair_model(static_cast<int>(e2 >> 26), e2 != 0xffffffffu, p2.x, p2.y, p2.z);
+            pair_model(static_cast<int>(e3 >> 26), e3 != 0xffffffffu, p3.x, p3.y, p3.z);
+            e0 = f0; e1 = f1; e2 = f2; e3 = f3; p0 = q0; p1 = q1; p2 = q2; p3 = q3;
+            f0 = g0; f1 = g1; f2 = g2; f3 = g3;
+        }
+    } else
     for (int cs = c_first; cs <= c_last;) {                // row segments of the group's cells (nearly always one)
         const int cy = cs / nx;
         const int ce = sweep_all ? c_last : min(c_last, cy * nx + nx - 1);
@@ -2496,60 +2559,21 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
         const int total = fast ? prer[6] : pre[nruns];
         const fp2 mx = splat(me.x), my = splat(me.y), mz = splat(mez);
         int pending = 0;                                   // pairs in this wave's queue (wave-uniform)
-        // one queued pair: the exact tests and the model (:798-808), added to the drone's sum
-        // (called by ALL lanes -- ds_bpermute reads nothing from a lane that is masked off -- with `valid` false where there is no pair)
-        auto evaluate = [&](unsigned e, bool valid, int org = 0) {         // org: 0, or kDwTileB for a pair of the second tile
+        // one queued pair of the tile in LDS (queue entry: 6 bits lane, 10 bits candidate slot of the tile)
+        auto evaluate = [&](unsigned e, bool valid) {
+            const int dl = static_cast<int>(e >> 10), ci = static_cast<int>(e & 1023u);
             if (MODE == 1) {                               // build: the batch goes to the list as it is evaluated
-                if (rec_ok && lb < Ls.cap) my_list[static_cast<size_t>(lb) * 64 + lane] = static_cast<unsigned short>(valid ? e : 0xffffu);
+                if (rec_ok && lb < Ls.cap)
+                    my_list[static_cast<size_t>(lb) * 64 + lane] = valid ? ((static_cast<uint32_t>(dl) << 26) | static_cast<uint32_t>(tsrc[ci])) : 0xffffffffu;
                 else rec_ok = false;
                 ++lb;
             }
-            const int dl = static_cast<int>(e >> 10), ci = static_cast<int>(e & 1023u);
-            const float px = __shfl(me.x, dl), py = __shfl(me.y, dl), pz = __shfl(me.z, dl);
-            const float dz = tz[org + ci] - pz;
-            const float ddx = tx[org + ci] - px, ddy = ty[org + ci] - py;
-            const float dxy2 = fmaf(ddy, ddy, ddx * ddx);
-            if (valid && dz > 0.0f && dxy2 < 100.0f) {     // dz > 0 and dxy < 10 m  (:800-801)
-                const float ratio = kr * fast_rcp(dz);
-                const float alpha = P.dw_coeff[0] * (ratio * ratio);
-                const float beta = fmaf(P.dw_coeff[1], dz, P.dw_coeff[2]);
-                const float ib = fast_rcp(beta);
-                const float arg = 0.5f * (dxy2 * (ib * ib));
-                if (arg < 40.0f) {                         // exp(-40) = 4e-18: below the 2^-31 N the sum resolves
-                    const float sc = (alpha * fast_exp(-arg)) * 1073741824.0f;
-                    // (< 4 N, i.e. unless two drones are centimetres apart: one conversion instead of the 14-instruction
-                    // float -> int64 sequence; the same integer either way)
-                    unsigned long long v;
-                    if (__builtin_amdgcn_ballot_w64(!(sc >= 0.0f && sc < 4.0e9f)) != 0) {
-                        asm volatile("; a contribution of 4 N or more" ::: "memory");      // (keeps this a branch, not a select)
-                        v = static_cast<unsigned long long>(__float2ll_rn(sc));
-                    } else {
-                        v = static_cast<unsigned long long>(__float2uint_rn(sc));
-                    }
-                    atomicAdd(&my_sums[dl], v);
-                }
-            }
+            pair_model(dl, valid, tx[ci], ty[ci], tz[ci]);
         };
         // (a tile holds kDwTile - 1 candidates: the entry "lane 63, slot 1023" never occurs and 0xffff can mark an empty lane)
         for (int v0 = 0; v0 < total;) {
             const int cnt = min(kDwTile - 1, total - v0);
             const int chunks = (cnt + kDwChunk - 1) / kDwChunk;
-            const int cnt2 = replay ? min(kDwTile - 1, total - v0 - cnt) : 0;   // (replay) the tile after this one comes along
-            // (replay) the batches this wave evaluated on this tile at the build: the first four are requested BEFORE the tile is
-            // staged -- their addresses depend on nothing the staging produces, and the wave would otherwise wait a full memory
-            // round trip for 128 bytes behind the barrier (SQ_WAIT_ANY 68 % of the wave's cycles, profiles/r03_swarm_counters.txt)
-            int nbt = 0, nbt1 = 0;                         // batches on this tile; on the two tiles together
-            const unsigned short* lp = nullptr;
-            unsigned e0 = 0xffffu, e1 = 0xffffu, e2 = 0xffffu, e3 = 0xffffu;
-            if (replay) {
-                nbt = tcount == 0 ? nb0 : tcount < kDwMaxTiles ? my_nb[tcount] : 0;
-                nbt1 = nbt + ((cnt2 > 0 && tcount + 1 < kDwMaxTiles) ? my_nb[tcount + 1] : 0);
-                lp = my_list + static_cast<size_t>(lb) * 64 + lane;
-                if (0 < nbt1) e0 = lp[0];
-                if (1 < nbt1) e1 = lp[64];
-                if (2 < nbt1) e2 = lp[128];
-                if (3 < nbt1) e3 = lp[192];
-            }
             auto source = [&](int v) {                     // position in the concatenated list -> run q, element src
                 int src;
                 if (fast) {
@@ -2565,38 +2589,21 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
             __syncthreads();
             for (int j = threadIdx.x; j < chunks * kDwChunk; j += kBlock) {
                 float4 o = make_float4(0.0f, 0.0f, -3.0e38f, 0.0f);        // (padding of the last chunk: below everything)
-                if (j < cnt) o = pos_at(source(v0 + j));
+                if (j < cnt) {
+                    // (build) where a replay launch will find this candidate's current position: its row of pos4 in a shared
+                    // world, its sorted slot in a single-rank one
+                    const int sl = source(v0 + j);
+                    const int src = Wd.pos4 ? order[sl] : sl;
+                    o = Wd.pos4 ? Wd.pos4[src] : sorted[src];
+                    if (MODE == 1) tsrc[j] = src;
+                }
                 tx[j] = o.x; ty[j] = o.y; tz[j] = o.z;
-            }
-            for (int j = threadIdx.x; j < cnt2; j += kBlock) {
-                const float4 o = pos_at(source(v0 + cnt + j));
-                tx[kDwTileB + j] = o.x; ty[kDwTileB + j] = o.y; tz[kDwTileB + j] = o.z;
             }
             __syncthreads();
 #if defined(GPD_EXP_TS) && defined(GPD_EXP_TSF)
             if (MODE == 2 && tf2 == 0) tf2 = wall_clock64();
 #endif
-            v0 += cnt + cnt2;
-            if (replay) {
-                // ... and the next four are requested before the current four are evaluated
-                auto org_of = [&](int b) { return b < nbt ? 0 : kDwTileB; };
-                for (int b = 0; b < nbt1; b += 4) {
-                    const unsigned short* const np = lp + static_cast<size_t>(b + 4) * 64;
-                    const unsigned f0 = b + 4 < nbt1 ? np[0] : 0xffffu;
-                    const unsigned f1 = b + 5 < nbt1 ? np[64] : 0xffffu;
-                    const unsigned f2 = b + 6 < nbt1 ? np[128] : 0xffffu;
-                    const unsigned f3 = b + 7 < nbt1 ? np[192] : 0xffffu;
-                    evaluate(e0, e0 != 0xffffu, org_of(b));
-                    if (b + 1 < nbt1) evaluate(e1, e1 != 0xffffu, org_of(b + 1));
-                    if (b + 2 < nbt1) evaluate(e2, e2 != 0xffffu, org_of(b + 2));
-                    if (b + 3 < nbt1) evaluate(e3, e3 != 0xffffu, org_of(b + 3));
-                    e0 = f0; e1 = f1; e2 = f2; e3 = f3;
-                }
-                lb += nbt1;
-                tcount += cnt2 > 0 ? 2 : 1;
-                continue;
-            }
-            const int tile_b0 = lb;
+            v0 += cnt;
             for (int ch = wave; ch < chunks; ch += kBlock / 64) {       // this wave's share of the candidates
                 const int j0 = ch * kDwChunk;
                 uint32_t mask = 0;                                     // candidate j0 + j of the chunk -> bit 31 - j
@@ -2647,15 +2654,11 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
                 for (int b = 0; b < nb; ++b) { const int k = b + lane * nb; evaluate(k < pending ? my_queue[k] : 0u, k < pending); }
             }
             pending = 0;
-            if (MODE == 1) {
-                if (tcount < kDwMaxTiles) { if (lane == 0) my_nb[tcount] = static_cast<unsigned short>(lb - tile_b0); }
-                else rec_ok = false;
-            }
-            ++tcount;
         }
         cs = ce + 1;
     }
     if (MODE == 1) {                                       // the group's list counts only if all four waves completed theirs
+        if (lane == 0) my_nb[0] = static_cast<unsigned short>(rec_ok ? lb : 0);      // the wave's batches (< cap <= 65535)
         int* const okf = reinterpret_cast<int*>(pre);
         __syncthreads();
         if (lane == 0) okf[wave] = rec_ok ? 1 : 0;
@@ -3472,8 +3475,9 @@ int gpd_swarm_forces(const GpdParams* params, const GpdSwarm* w, int32_t build_l
     if (int rc = swarm_args("gpd_swarm_forces", w, true)) return rc;
     if (!w->dw_force) return fail(GPD_EINVAL, "gpd_swarm_forces: NULL dw_force");
     const bool lists = w->pair_list != nullptr;
-    if (lists && (!w->pair_nb || !w->list_ok || w->list_cap < 1 || !(w->list_delta >= 0.0f)))
-        return fail(GPD_EINVAL, "gpd_swarm_forces: pair_list needs pair_nb, list_ok, list_cap >= 1 and list_delta >= 0");
+    if (lists && (!w->pair_nb || !w->list_ok || w->list_cap < 4 || w->list_cap > 65535 || !(w->list_delta >= 0.0f)))
+        return fail(GPD_EINVAL, "gpd_swarm_forces: pair_list needs pair_nb, list_ok, 4 <= list_cap <= 65535 and list_delta >= 0");
+    if (lists && w->n_rows > (1 << 26)) return fail(GPD_ERANGE, "gpd_swarm_forces: wake lists address 2^26 rows at most");
     const DwGrid G{1.0f / w->cell, w->x0, w->y0, w->nx, w->ny, w->z0, w->nz > 1 ? 1.0f / w->zbin : 0.0f, w->nz};
     const float4* const p4 = reinterpret_cast<const float4*>(w->pos4);
     const DwWorld Wd{w->pos_sorted ? nullptr : p4, w->slot_key, p4, w->rank * w->slab, w->own_count, w->slab, w->world_size, w->meta_rows, w->cell,

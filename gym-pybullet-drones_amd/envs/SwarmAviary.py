@@ -444,8 +444,11 @@ class SwarmAviary:
         # hovering swarm lists 34 pairs per drone instead of 47 at cell = 10.5 m; a swarm that outruns the guess sweeps (exactly)
         # until the next binning.  False: always the full margin.
         self.adaptive_lists = bool(adaptive_lists)
+        if self.wake_lists and not 4 <= int(list_cap) <= 65535:
+            raise ValueError("list_cap must be in 4..65535 (a replay launch requests a wave's first four batches before it knows how many there are)")
         u16 = dict(dtype=torch.int16, device=dev)
-        self._pair_list = torch.zeros((groups, 4, int(list_cap) * 64), **u16) if self.wake_lists else None
+        # (32-bit entries: 6 bits drone of the group + 26 bits the candidate's slot / row -- include/gpd.h)
+        self._pair_list = torch.zeros((groups, 4, int(list_cap) * 64), dtype=torch.int32, device=dev) if self.wake_lists else None
         self._pair_nb = torch.zeros((groups, 4, 16), **u16) if self.wake_lists else None
         self._list_ok = torch.zeros(groups, **i32) if self.wake_lists else None
         self._drift = torch.zeros(4, dtype=torch.float32, device=dev)          # the swarm's common lateral drift since the binning

@@ -464,10 +464,12 @@ typedef struct GpdSwarm {
      * pair_list; the launches until the next binning read them back instead of sweeping all candidates -- as long as no drone is
      * further than list_delta from where it was binned (otherwise they sweep as if there were no lists: still exact).
      * list_delta: just under (cell - 10 m) / 2, e.g. 0.49 (cell - 10). */
-    uint16_t* pair_list;   /* [ceil(n_rows / 64)][4][list_cap * 64] */
-    uint16_t* pair_nb;     /* [ceil(n_rows / 64)][4][16] */
+    uint32_t* pair_list;   /* [ceil(n_rows / 64)][4][list_cap * 64]: (ABI 8) 32-bit entries -- 6 bits drone of the group, 26 bits the
+                              candidate's index in the array its position is read from (sorted slot / row of pos4): a replay launch
+                              gathers the candidates' current positions directly, no cell table, no staged tile */
+    uint16_t* pair_nb;     /* [ceil(n_rows / 64)][4][16]: [0] = batches the wavefront recorded */
     int32_t* list_ok;      /* [ceil(n_rows / 64)] */
-    int32_t list_cap;      /* batches of 64 pairs per wavefront (a group of 64 drones has four); a group that needs more sweeps */
+    int32_t list_cap;      /* batches of 64 pairs per wavefront (a group of 64 drones has four), 4 .. 65535; a group that needs more sweeps */
     float list_delta;
     /* "Displacement" above is measured relative to the swarm's COMMON lateral drift since the binning (a translation all drones
      * share changes no pair: a swarm in transit keeps R = 1 and its wake lists).  gpd_swarm_forces computes the drift -- the mean

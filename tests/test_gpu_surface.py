@@ -613,7 +613,7 @@ def test_wake_lists_replay_the_pairs_of_the_last_binning_exactly(gpu_device, var
     xyz, rpy = _layered_scene(rng, N)
     kw = dict(initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.PYB_GND_DRAG_DW, device=gpu_device, cell=10.5)
     ref = SwarmAviary(N, rebin_every=1, **kw)
-    env = SwarmAviary(N, rebin_every=12, list_cap=1 if variant == "overflowing lists" else 48, adaptive_lists=adaptive, **kw)
+    env = SwarmAviary(N, rebin_every=12, list_cap=4 if variant == "overflowing lists" else 48, adaptive_lists=adaptive, **kw)
     assert env.wake_lists and not ref.wake_lists and 0.2 < env.list_delta < 0.25
     for e in (ref, env):
         e.reset()
