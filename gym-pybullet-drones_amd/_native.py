@@ -67,10 +67,16 @@ class GpdSwarm(ctypes.Structure):
                 ("drift", ctypes.c_void_p), ("total_drones", ctypes.c_int32), ("list_adapt", ctypes.c_int32)]
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/gpd.hip + csrc/gpd_policy.hip -> csrc/libgpd.so for gfx950.  Returns the library path."""
+DEBUG_LIB_PATH = os.path.join(CSRC, "libgpd_debug.so")
+
+
+def build(force: bool = False, verbose: bool = False, debug: bool = False) -> str:
+    """Compile csrc/gpd.hip + csrc/gpd_policy.hip -> csrc/libgpd.so for gfx950.  Returns the library path.
+    `debug=True`: the debug-bounds build (-DGPD_DEBUG_BOUNDS, include/gpd.h `gpd_debug_status`) -> csrc/libgpd_debug.so; use it by
+    setting GPD_LIB to that path before the package is imported."""
     srcs = [os.path.join(CSRC, u) for u, _ in UNITS]
     hdr = os.path.join(INCLUDE, "gpd.h")
+    LIB_PATH = DEBUG_LIB_PATH if debug else globals()["LIB_PATH"]
     if not force and os.path.exists(LIB_PATH):
         newest = max([os.path.getmtime(f) for f in srcs] + [os.path.getmtime(hdr)])
         if os.path.getmtime(LIB_PATH) >= newest:
@@ -78,8 +84,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs, procs = [], []
     for (unit, extra), src in zip(UNITS, srcs):          # the two units compile side by side
-        obj = os.path.join(CSRC, unit.replace(".hip", ".o"))
-        cmd = [hipcc] + COMMON_FLAGS + extra + ["-I", INCLUDE, "-c", src, "-o", obj]
+        obj = os.path.join(CSRC, unit.replace(".hip", ".dbg.o" if debug else ".o"))
+        cmd = [hipcc] + COMMON_FLAGS + extra + (["-DGPD_DEBUG_BOUNDS"] if debug else []) + ["-I", INCLUDE, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -141,6 +147,7 @@ _SIGNATURES = {
     "gpd_comm_destroy": (ctypes.c_int, [_P]),
     "gpd_allgather_obs": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, _P]),
     "gpd_p2p_group": (ctypes.c_int, [_P, ctypes.POINTER(GpdP2P), ctypes.c_int32, ctypes.POINTER(GpdP2P), ctypes.c_int32, _P]),
+    "gpd_debug_status": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint32), ctypes.c_int32, _P]),
     "gpd_clock_probe": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _P]),
 }
 COMM_ID_BYTES = 128

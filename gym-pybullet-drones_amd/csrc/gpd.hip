@@ -93,6 +93,31 @@ std::string& gpd_detail_last_error() {
     return e;
 }
 #endif
+// ------------------------------------------------------------------------------------------------
+// Debug-bounds build (-DGPD_DEBUG_BOUNDS; `_native.build(debug=True)` -> libgpd_debug.so, used through GPD_LIB): the kernels
+// check every index they READ FROM MEMORY before they address with it -- ring positions, sort keys, slot -> row entries, wake-list
+// entries and counts -- record the first violation in a device word (code, workgroup, offending value, number of violations) and
+// clamp the index so that the launch stays inside its buffers; `gpd_debug_status` reads the record.  The reference has nothing of
+// the kind (no sanitizer, no race or bounds checks; its numpy indexing raises IndexError instead).  A
+// release build compiles the checks away and `gpd_debug_status` returns GPD_ENOTSUP.  Checks live in the main unit's kernels.
+// ------------------------------------------------------------------------------------------------
+#if defined(GPD_DEBUG_BOUNDS) && !defined(GPD_POLICY_TU)
+__device__ unsigned int gpd_dbg_word[4];
+#define GPD_DBG(cond, code, val)                                                                  \
+    do {                                                                                          \
+        if (!(cond)) {                                                                            \
+            if (atomicCAS(&gpd_dbg_word[0], 0u, static_cast<unsigned int>(code)) == 0u) {         \
+                gpd_dbg_word[1] = blockIdx.x;                                                     \
+                gpd_dbg_word[2] = static_cast<unsigned int>(val);                                 \
+            }                                                                                     \
+            atomicAdd(&gpd_dbg_word[3], 1u);                                                      \
+        }                                                                                         \
+    } while (0)
+#define GPD_DBG_CLAMP(v, lo, hi) ((v) < (lo) ? (lo) : ((v) > (hi) ? (hi) : (v)))
+#else
+#define GPD_DBG(cond, code, val) do { } while (0)
+#define GPD_DBG_CLAMP(v, lo, hi) (v)
+#endif
 namespace {
 #define g_last_error gpd_detail_last_error()
 
@@ -815,6 +840,7 @@ __device__ __forceinline__ void load_carry(const GpdState& S, const GpdStepCfg& 
     k.vx = ld_row(S.kin, ld, 7, off4); k.vy = ld_row(S.kin, ld, 8, off4); k.vz = ld_row(S.kin, ld, 9, off4);
     k.wx = ld_row(S.kin, ld, 10, off4); k.wy = ld_row(S.kin, ld, 11, off4); k.wz = ld_row(S.kin, ld, 12, off4);
     c.counter = S.step_counter[L.env];                       // every drone of an aviary reads its aviary's counter
+    GPD_DBG(c.counter >= 0, GPD_DBG_STEP_COUNTER, c.counter);
     // target (task NONE: the host passes a readable dummy, the values are not used)
     const float* tp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(target_pos) +
                                                      (C.target_per_env ? L.n * 12u : static_cast<uint32_t>(L.d) * 12u));
@@ -913,7 +939,8 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     const float4 act = load_action<AW>(action, L.n);
     // action history: the slot this aviary's action goes to (read with the other loads, from a readable dummy when there is
     // no ring: the load section stays branch-free)
-    const int ring_q = (S.act_ring ? S.ring_pos : S.step_counter)[L.env];
+    int ring_q = (S.act_ring ? S.ring_pos : S.step_counter)[L.env];
+    if (S.act_ring) { GPD_DBG(ring_q >= 0 && ring_q < S.hist_len, GPD_DBG_RING_POS, ring_q); ring_q = GPD_DBG_CLAMP(ring_q, 0, S.hist_len - 1); }
     // a single step reads its reset pose only if it resets (in env_step); the slots `ip` are filled from a cached row
     const float* ipose = reinterpret_cast<const float*>(reinterpret_cast<const char*>(init_pose) +
                                                         (C.init_per_env ? L.n * 28u : static_cast<uint32_t>(L.d) * 28u));
@@ -1395,7 +1422,10 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
                                                         (C.init_per_env ? L.n * 28u : static_cast<uint32_t>(L.d) * 28u));
     load_carry<PID, EXT>(S, C, flags, L, target_pos, C.auto_reset ? ipose : S.kin, c, tgx, tgy, tgz, ip);
     int ring_q = 0;                                                  // RING: the slot this aviary's next action goes to
-    if constexpr (RING) ring_q = S.ring_pos[L.env];
+    if constexpr (RING) {
+        ring_q = S.ring_pos[L.env];
+        GPD_DBG(ring_q >= 0 && ring_q < S.hist_len, GPD_DBG_RING_POS, ring_q); ring_q = GPD_DBG_CLAMP(ring_q, 0, S.hist_len - 1);
+    }
     asm volatile("" :: "v"(c.k.px), "v"(c.k.py), "v"(c.k.pz), "v"(c.k.qx), "v"(c.k.qy), "v"(c.k.qz), "v"(c.k.qw), "v"(c.k.vx),
                        "v"(c.k.vy), "v"(c.k.vz), "v"(c.k.wx), "v"(c.k.wy), "v"(c.k.wz), "v"(tgx), "v"(tgy), "v"(tgz),
                        "v"(c.counter), "v"(ip[0]), "v"(ip[1]), "v"(ip[2]), "v"(ip[3]), "v"(ip[4]), "v"(ip[5]), "v"(ip[6])
@@ -2352,7 +2382,9 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
     auto pos_at = [&](int slot) { return Wd.pos4 ? Wd.pos4[order[slot]] : sorted[slot]; };
     const int sorted_n = start[keys];                      // drones with a finite position (the others: force 0, set by the sort)
     int row_l = order[sc];
+    GPD_DBG(row_l >= 0 && row_l < Wd.n_slots, GPD_DBG_SLOT_ROW, row_l); row_l = GPD_DBG_CLAMP(row_l, 0, Wd.n_slots - 1);
     int key_l = key_at(sc);
+    GPD_DBG(s >= start[keys] || (key_l >= 0 && key_l < keys), GPD_DBG_SORT_KEY, key_l);
     float4 me_l = Wd.pos4 ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : sorted[sc];
     // dmax^2: the largest of the step kernel's per-workgroup maxima (one meta row each, every rank's)
     // (rank by rank: an index k -> (rank, row) split would be two divisions by a run-time meta_rows per element)
@@ -2476,11 +2508,13 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
         // REPLAY: the wave's recorded batches, four at a time, in a three-deep software pipeline -- the entries of batches b+8..
         // are requested while the candidates of b+4.. are gathered and b.. is evaluated (loads only in this loop: the waits the
         // compiler derives are exact counts).  An empty lane (0xffffffff) gathers index 0 and evaluates nothing.
-        const int nbw = nb0;
+        GPD_DBG(nb0 >= 0 && nb0 <= Ls.cap, GPD_DBG_LIST_COUNT, nb0);
+        const int nbw = GPD_DBG_CLAMP(nb0, 0, Ls.cap);
         const uint32_t* const lp = my_list + lane;
         auto cand = [&](uint32_t e) {
             // (clamped: the first four entries are read before the wave knows how many batches it has -- whatever a list holds,
             // the gather stays inside the array)
+            GPD_DBG(e == 0xffffffffu || (e & 0x03ffffffu) < static_cast<uint32_t>(Wd.n_slots), GPD_DBG_LIST_ENTRY, e & 0x03ffffffu);
             const uint32_t idx = min(e == 0xffffffffu ? 0u : (e & 0x03ffffffu), static_cast<uint32_t>(Wd.n_slots - 1));
             return Wd.pos4 ? Wd.pos4[idx] : sorted[idx];
         };
@@ -3622,6 +3656,24 @@ extern "C" int gpd_debug_ts(unsigned long long* ts, unsigned int* cnt) {
     return 0;
 }
 #endif
+int gpd_debug_status(uint32_t out[4], int32_t reset, void* stream) {
+#ifdef GPD_DEBUG_BOUNDS
+    if (!out) return fail(GPD_EINVAL, "gpd_debug_status: NULL out");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(gpd_dbg_word), 4 * sizeof(uint32_t));
+    if (e == hipSuccess && reset) {
+        const uint32_t zero[4] = {0u, 0u, 0u, 0u};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(gpd_dbg_word), zero, sizeof(zero));
+    }
+    if (e != hipSuccess) return hip_fail(e, "gpd_debug_status");
+    return 0;
+#else
+    (void)out; (void)reset; (void)stream;
+    return fail(GPD_ENOTSUP, "gpd_debug_status: this is a release build (no -DGPD_DEBUG_BOUNDS)");
+#endif
+}
+
 int gpd_clock_probe(double* shader_ghz, double* ns_per_fma, void* stream) {
     if (!shader_ghz) return fail(GPD_EINVAL, "gpd_clock_probe: NULL shader_ghz");
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -586,6 +586,25 @@ typedef struct GpdP2P {
 int gpd_p2p_group(void* comm, const GpdP2P* sends, int32_t n_sends, const GpdP2P* recvs, int32_t n_recvs, void* stream);
 
 /*
+ * (ABI 8) Debug-bounds build.  A library compiled with -DGPD_DEBUG_BOUNDS (`python -c "from gym_pybullet_drones_amd import _native;
+ * _native.build(debug=True)"` -> csrc/libgpd_debug.so; select it with GPD_LIB) checks every index its kernels READ FROM MEMORY before
+ * they address with it, records the first violation and clamps the index, so that a corrupted ring position or wake list shows up
+ * as a code instead of as an out-of-bounds access.  The reference has no counterpart (no sanitizer, no bounds
+ * or race checks beyond numpy's own IndexError).  gpd_debug_status waits for `stream` and returns the record:
+ *     out[0] code of the first violation (0: none), out[1] its workgroup, out[2] the offending value, out[3] violations so far;
+ * reset != 0 clears the record.  A release build returns GPD_ENOTSUP (its kernels carry no checks).
+ */
+enum {
+    GPD_DBG_RING_POS = 1,      /* GpdState.ring_pos outside [0, hist_len)          (gpd_step, gpd_rollout_history) */
+    GPD_DBG_STEP_COUNTER = 2,  /* GpdState.step_counter negative */
+    GPD_DBG_SLOT_ROW = 3,      /* GpdSwarm.order: sorted slot -> row outside [0, n_rows)   (gpd_swarm_forces) */
+    GPD_DBG_SORT_KEY = 4,      /* GpdSwarm.slot_key outside the grid's keys */
+    GPD_DBG_LIST_COUNT = 5,    /* GpdSwarm.pair_nb: more batches than list_cap */
+    GPD_DBG_LIST_ENTRY = 6     /* GpdSwarm.pair_list: a candidate index outside [0, n_rows) */
+};
+int gpd_debug_status(uint32_t out[4], int32_t reset, void* stream);
+
+/*
  * Diagnostics for the measurement harness (bench.py's issue roofline): runs a dependent v_fma_f32 chain at one wave per
  * SIMD and reports the shader clock it ran at [GHz] (shader-clock cycles / constant-rate wall-clock time) and, optionally,
  * the time per dependent FMA [ns].  Synchronous (it waits for `stream`).

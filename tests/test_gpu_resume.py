@@ -150,3 +150,85 @@ def test_nan_guard_flags_exactly_the_poisoned_aviaries(gpu_device, mode):
     plain = VectorHoverAviary(8, device=gpu_device)
     with pytest.raises(ValueError):
         plain.bad_envs()
+
+
+_DEBUG_PROBE = r'''
+import ctypes, sys
+import numpy as np, torch
+from gym_pybullet_drones_amd import _native
+from gym_pybullet_drones_amd.envs import SwarmAviary, VectorHoverAviary
+from gym_pybullet_drones_amd.utils.enums import ActionType, Physics
+L = _native.lib()
+dev = torch.device("cuda:0")
+def status(reset=0):
+    out = (ctypes.c_uint32 * 4)()
+    rc = L.gpd_debug_status(out, reset, None)
+    assert rc == 0, (rc, L.gpd_last_error())
+    return list(out)
+env = VectorHoverAviary(300, ctrl_freq=30, act=ActionType.RPM, full_obs="lazy", device=dev)
+a = torch.zeros((20, 300, 1, 4), device=dev)
+env.reset()
+for k in range(20):
+    env.step(a[k])
+env.rollout(a)
+# (five layers 1 m apart on a 4 m lattice with jitter: no two drones at the same height within reach of each other -- the
+# reference's model is singular there, alpha ~ 1 / dz^2)
+rng = np.random.default_rng(0)
+sites = np.array([(x, y) for x in np.arange(-24, 25, 4.0) for y in np.arange(-24, 25, 4.0)])
+N = len(sites) * 5
+xyz = np.concatenate([np.tile(sites, (5, 1)) + rng.uniform(-0.3, 0.3, size=(N, 2)), np.repeat(np.arange(1.0, 6.0), len(sites))[:, None]], axis=1)
+sw = SwarmAviary(N, initial_xyzs=xyz, physics=Physics.PYB_DW, device=dev, rebin_every=4)
+sw.reset()
+rpm = torch.full((N, 4), float(sw.HOVER_RPM), device=dev)
+for k in range(10):
+    sw.step(rpm)
+torch.cuda.synchronize()
+print("CLEAN", status())
+# a ring position beyond the ring: caught, clamped, the run goes on
+env.core.ring_pos[7] = 1000
+env.step(a[0])
+torch.cuda.synchronize()
+print("RING", status(reset=1))
+env.core.ring_pos[7] = 0
+env.rollout(a)
+print("AFTER_RESET", status())
+# a wake-list entry that points beyond the world, and a batch count beyond the capacity
+while sw._since_bin >= sw.rebin_every - 1:          # (the next sub-step must REPLAY the lists, not rebuild them)
+    sw.step(rpm)
+assert int(sw._list_ok.sum()) > 0
+sw._pair_list[:, 1, :64] = (5 << 26) | 0x3ffffff
+sw._pair_nb[:, 2, 0] = 30000
+sw.step(rpm)
+torch.cuda.synchronize()
+st = status(reset=1)
+print("LIST", st)
+'''
+
+
+def test_debug_bounds_build_reports_a_corrupted_index_instead_of_following_it(gpu_device, tmp_path):
+    """SURVEY.md section 5 lists no sanitizer or bounds checks upstream (numpy raises IndexError for the reference); a release build
+    of this library follows whatever index memory holds.  The debug-bounds build (`_native.build(debug=True)`,
+    `-DGPD_DEBUG_BOUNDS`, selected with GPD_LIB) checks every index its kernels read from memory: a clean run of the step, rollout
+    and one-world kernels reports nothing; a ring position beyond the ring and wake-list entries / counts beyond the world are
+    reported with their code, workgroup and value and CLAMPED -- the process survives and goes on; the release build answers
+    `gpd_debug_status` with GPD_ENOTSUP."""
+    import ctypes
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    from gym_pybullet_drones_amd import _native
+    out = (ctypes.c_uint32 * 4)()
+    assert _native.lib().gpd_debug_status(out, 0, None) == _native.GPD_ENOTSUP          # this process runs the release build
+    if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) and not os.path.exists(_native.DEBUG_LIB_PATH):
+        pytest.skip("no hipcc and no prebuilt debug library")
+    lib = _native.build(debug=True)                      # (travels with the snapshot when it was built before; rebuilt when stale)
+    res = subprocess.run([sys.executable, "-c", _DEBUG_PROBE], cwd=REPO, env=dict(os.environ, GPD_LIB=lib), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = {l.split(" ", 1)[0]: eval(l.split(" ", 1)[1]) for l in res.stdout.splitlines() if l.split(" ", 1)[0] in ("CLEAN", "RING", "AFTER_RESET", "LIST")}
+    assert lines["CLEAN"] == [0, 0, 0, 0], lines
+    code, wg, val, count = lines["RING"]
+    assert code == 1 and val == 1000 and count >= 1 and wg == 0, lines          # GPD_DBG_RING_POS, aviary 7 sits in workgroup 0
+    assert lines["AFTER_RESET"] == [0, 0, 0, 0], lines
+    code, wg, val, count = lines["LIST"]
+    assert code in (5, 6) and count >= 2 and (val == 30000 if code == 5 else val == 0x3ffffff), lines
