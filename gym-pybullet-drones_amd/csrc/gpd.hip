@@ -2437,19 +2437,13 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
     // search radius in cells
     int R = 1;
     if (Wd.meta) {
-        if (!few) read_maxima();
-        if (few) {
+        // (many meta rows -- a world of 10^6 drones, or one shared by many ranks: gpd_swarm_step's own reduction left every
+        // rank's maximum in the w of the rank's FIRST meta row, dwg_reduce_meta_kernel; one value per rank is read here.  Every
+        // workgroup reading all 4 097 rows of a 1M-drone world was 1 GB of L2 traffic per force launch and a third of a replay
+        // launch's vector instructions)
+        if (!few) for (int r = lane; r < Wd.world; r += 64) d2 = fmaxf(d2, Wd.meta[static_cast<size_t>(r + 1) * Wd.slab - Wd.meta_rows].w);
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, off));
-        } else {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, off));
-            float* const red = reinterpret_cast<float*>(pre);      // (free until the first segment)
-            if (lane == 0) red[wave] = d2;
-            __syncthreads();
-            d2 = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-            __syncthreads();
-        }
+        for (int off = 32; off > 0; off >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, off));
         if (d2 > 0.0f) {                                   // (rounded up: a wider search is still exact, a narrower one is not)
             const float reach = 10.0f + 2.0002f * sqrtf(d2) + 2.0e-6f;
             const float cells = ceilf(reach / Wd.cell * 1.000001f);
@@ -2893,6 +2887,25 @@ __global__ __launch_bounds__(kBlock) void gpd_swarm_step_kernel(const GpdParams 
     }
     if (!L.active) return;
     store_carry<false>(S, L, c);
+}
+
+// The rank's largest squared displacement (the maximum of its workgroups' maxima, one per meta row) -> the w of its FIRST meta
+// row.  Launched behind gpd_swarm_step_kernel when the world has too many meta rows for every force workgroup to read them all
+// (world_size x meta_rows > 1024); the kernel boundary is the synchronisation (an in-kernel "last workgroup reduces" would need an
+// agent-scope release per workgroup: microseconds each on this part, profiles/r04_doorbell_step_server.txt).
+__global__ __launch_bounds__(kBlock) void dwg_reduce_meta_kernel(float* __restrict__ meta_own, int rows) {
+    __shared__ float red[kBlock / 64];
+    float m = 0.0f;
+    for (int k = threadIdx.x; k < rows; k += kBlock) m = fmaxf(m, meta_own[4 * k + 3]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 1; k < kBlock / 64; ++k) m = fmaxf(m, red[k]);
+        meta_own[3] = m;
+    }
 }
 
 // after a reset / an outside change of the state: the rank's slab of pos4 from state.kin -- its drones, the rows without one
@@ -3459,6 +3472,9 @@ int gpd_swarm_step(const GpdParams* params, const GpdState* state, const GpdStep
         case GPD_ACT_DIRECT_RPM: hipLaunchKernelGGL(gpd_swarm_step_kernel<GPD_ACT_DIRECT_RPM>, grid, dim3(kBlock), 0, st, *params, *state, *cfg, action, obs12, O); break;
         default: hipLaunchKernelGGL(gpd_swarm_step_kernel<GPD_ACT_RPM>, grid, dim3(kBlock), 0, st, *params, *state, *cfg, action, obs12, O); break;
     }
+    // (too many meta rows for every force workgroup to read: leave the rank's maximum in its first meta row)
+    if (static_cast<int64_t>(swarm->world_size) * swarm->meta_rows > 1024)
+        hipLaunchKernelGGL(dwg_reduce_meta_kernel, dim3(1), dim3(kBlock), 0, st, O.meta_own, static_cast<int>(grid.x));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gpd_swarm_step launch");
     return 0;

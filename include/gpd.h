@@ -487,7 +487,9 @@ typedef struct GpdSwarm {
 /* One physics sub-step of the rank's own_count drones (state / cfg as for gpd_step: drones_per_env = 1, num_envs = own_count,
  * substeps = 1, task NONE, no auto-reset; act_type RPM, RAW_RPM or DIRECT_RPM; state.dw_force = swarm.dw_force with
  * GPD_PHYS_DW), plus: pos4 rows of the rank, the rank's dmax^2, and -- vec_out != NULL -- the [own_count][20] state vectors
- * of gpd_state_vectors.  Replaces the body of BaseAviary.step's sub-step loop for one world (envs/BaseAviary.py:346-372). */
+ * of gpd_state_vectors.  Replaces the body of BaseAviary.step's sub-step loop for one world (envs/BaseAviary.py:346-372).
+ * When world_size * meta_rows > 1024 the call also leaves the rank's largest dmax^2 in the w of the rank's FIRST meta row (a second,
+ * one-workgroup launch): gpd_swarm_forces then reads one value per rank instead of every meta row. */
 /* sizeof(GpdSwarm), for a binding to verify its mirror (gpd_struct_sizes covers the three structs of ABI 1). */
 int gpd_sizeof_swarm(void);
 
