@@ -1049,6 +1049,7 @@ def run_suite(args, job, out):
     fires, rank 0 prints the headline line it already holds (the suite entry says what happened) and every rank leaves -- a
     hang in a collective of a workload that has never met this node must not cost the headline."""
     import threading
+    from gym_pybullet_drones_amd import dist as gdist
     results = {}
     if job.rank == 0:
         out["suite"] = results
@@ -1078,7 +1079,7 @@ def run_suite(args, job, out):
                 r = run_workload(a, job)
             except Exception as e:          # noqa: BLE001 -- reported; the headline survives
                 r = {"error": f"{type(e).__name__}: {e}"[:300]}
-            ok = __import__("gym_pybullet_drones_amd.dist", fromlist=["x"]).all_ranks_ok(r is None or "error" not in r, device=job.device)
+            ok = gdist.all_ranks_ok(r is None or "error" not in r, device=job.device)
             if job.rank == 0:
                 if "error" in r or not ok:
                     results[name] = {"error": r.get("error", "failed on another rank")}

@@ -574,6 +574,40 @@ def test_worlds_with_many_meta_rows_take_the_ranks_own_displacement_maximum(gpu_
     assert saw_wide and float(twin.dw_force[:N].abs().max()) > 1e-3
 
 
+def test_a_diverged_drone_does_not_turn_the_sub_steps_into_sweeps(gpu_device):
+    """the reference's downwash model diverges as dz -> 0+, so a drone CAN be flung to +-inf.  Its displacement since the
+    binning is then infinite; taken as the workgroup's maximum it pushed the search radius beyond every bound and turned every
+    group of every rank into an O(N^2) sweep until the next binning.  A non-finite position fails every pair test -- it needs no
+    search radius: the tracked maximum ignores it, the other drones keep replaying their lists, and their forces are those of
+    the same world without that drone."""
+    from gym_pybullet_drones_amd.envs import SwarmAviary
+    from gym_pybullet_drones_amd.utils.enums import Physics
+    rng = np.random.default_rng(5)
+    N = 1200
+    xyz, rpy = _layered_scene(rng, N)
+    kw = dict(initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.PYB_DW, device=gpu_device, pyb_like=False, rebin_every=8)
+    env, ref = SwarmAviary(N, **kw), SwarmAviary(N, **kw)
+    rpm = torch.full((N, 4), float(env.HOVER_RPM), device=gpu_device)
+    for e in (env, ref):
+        e.reset()
+        e.step(rpm)
+    lost = 17
+    for e, where in ((env, float("inf")), (ref, 1.0e6)):       # flung to infinity / merely very far away (finite: a legitimate sweep)
+        kin = e.core.kin[:, :N].clone()
+        kin[0, lost] = where
+        e.core.set_state(kin=kin)
+        e.invalidate()
+    for k in range(6):
+        env.step(rpm)
+        ref.step(rpm)
+        torch.cuda.synchronize()
+        keep = torch.arange(N, device=gpu_device) != lost
+        assert torch.equal(env.dw_force[:N][keep], ref.dw_force[:N][keep]), k       # nobody is within 10 m of either
+        meta = env.pos4[env.per:env.slab, 3]
+        assert bool(torch.isfinite(meta).all()) and float(meta.max()) < 1.0, (k, float(meta.max()))      # the radius stays 1
+    assert float(env.dw_force[lost]) == 0.0 and not bool(torch.isfinite(env.core.kin[0, lost]))
+
+
 def test_stale_cell_order_stays_exact_when_drones_outrun_the_skin(gpu_device):
     """Between two binnings the force kernel searches the STALE cell order with a radius that follows the largest displacement
     since the binning (R = ceil((10 m + 2 dmax) / cell); beyond R = 3 a group sweeps every drone).  Drones given lateral
