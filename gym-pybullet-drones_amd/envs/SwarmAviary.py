@@ -613,6 +613,27 @@ class SwarmAviary:
         """(n, 20) `_getDroneStateVector` rows (envs/BaseAviary.py:559-561)."""
         return self.core.state_vectors()
 
+    # ---- checkpoint / resume (SURVEY.md section 5: absent upstream) ----------------------------------------------------------
+    def get_state(self) -> dict:
+        """Snapshot of this rank's drones: the core's complete state (`SimCore.get_state`) + the embedded controllers' members +
+        the step counter.  The sort, the wake lists and the halo plan are NOT part of it: forces are exact functions of the
+        positions (order-independent integer sums), so `set_state` simply makes the next step re-pack, re-bin and recompute
+        them -- the trajectory that follows is bit for bit the one that followed the snapshot (every rank of a shared world
+        restores its own snapshot)."""
+        out = dict(self.core.get_state(), step_counter_py=self.step_counter)
+        if self.ctrl is not None:
+            out["ctrl"] = self.ctrl._state.clone()
+        return out
+
+    def set_state(self, state: dict):
+        state = dict(state)
+        self.step_counter = int(state.pop("step_counter_py", self.step_counter))
+        ctrl = state.pop("ctrl", None)
+        if ctrl is not None and self.ctrl is not None:
+            self.ctrl._state.copy_(ctrl)
+        self.core.set_state(**state)
+        self.invalidate()
+
     def downwash_oneshot(self) -> torch.Tensor:
         """The forces through the C-ABI's one-call entry `gpd_downwash_global` (count + scan/scatter + force on the state block,
         no persistent sort): single-rank worlds only; the cross-check of the persistent path."""

@@ -85,6 +85,51 @@ def test_restore_continues_a_policy_rollout_bitwise(gpu_device):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("act_name", ["raw_rpm", "PID"])
+def test_one_world_resumes_bitwise_whatever_the_sort_and_the_lists_held(gpu_device, act_name):
+    """ONE aviary of 1 500 drones with the downwash over the whole swarm: save -> 23 control steps -> restore -> the same 23 steps.
+    The sort, the wake lists and their margins are not in the snapshot (and differ: the restored run re-bins at once, the
+    original was mid-interval); the forces are exact whatever they hold, so state vectors and forces repeat bit for bit -- on the
+    world that was saved and on a fresh one."""
+    from gym_pybullet_drones_amd.envs import SwarmAviary
+    from gym_pybullet_drones_amd.utils.enums import ActionType, Physics
+    rng = np.random.default_rng(77)
+    sites = np.array([(x, y) for x in np.arange(-28, 29, 4.0) for y in np.arange(-18, 19, 4.0)])
+    N = 1500
+    idx = rng.permutation(len(sites) * 12)[:N]
+    xyz = np.concatenate([sites[idx % len(sites)] + rng.uniform(-0.3, 0.3, size=(N, 2)), (1.0 + idx // len(sites))[:, None]], axis=1)
+    act = "raw_rpm" if act_name == "raw_rpm" else ActionType.PID
+    mk = lambda: SwarmAviary(N, initial_xyzs=xyz, physics=Physics.PYB_GND_DRAG_DW, pyb_freq=240, ctrl_freq=120, act=act, rebin_every=7,  # noqa: E731
+                             device=gpu_device)
+    env = mk()
+    if act_name == "raw_rpm":
+        acts = torch.as_tensor((env.HOVER_RPM * (1 + 0.04 * rng.uniform(-1, 1, size=(60, N, 4)))).astype(np.float32), device=gpu_device)
+    else:
+        acts = torch.as_tensor((xyz[None] + rng.uniform(-0.2, 0.2, size=(60, N, 3))).astype(np.float32), device=gpu_device)
+    env.reset()
+    for k in range(10):
+        env.step(acts[k])
+    snap = env.get_state()
+
+    def run(e):
+        out = []
+        for k in range(10, 33):
+            v, *_ = e.step(acts[k])
+            out.append((v.clone(), e.dw_force[:N].clone()))
+        return out
+
+    first = run(env)
+    for k in range(33, 45):
+        env.step(acts[k])
+    fresh = mk()
+    fresh.reset()
+    for e in (env, fresh):
+        e.set_state(snap)
+        for k, (a, b) in enumerate(zip(first, run(e))):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (k, e is fresh)
+    assert env.step_counter == fresh.step_counter == 2 * 33 and float(first[-1][1].abs().max()) > 1e-3
+
+
 @pytest.mark.parametrize("mode", ["step", "rollout", "rollout_pid", "multi"])
 def test_nan_guard_flags_exactly_the_poisoned_aviaries(gpu_device, mode):
     """A NaN (or an infinity) that enters through an action poisons the drone's state for good, and no truncation bound ever trips
