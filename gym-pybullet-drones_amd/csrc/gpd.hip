@@ -2487,8 +2487,10 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
                 const float sc = (alpha * fast_exp(-arg)) * 1073741824.0f;
                 // (< 4 N, i.e. unless two drones are centimetres apart: one conversion instead of the 14-instruction
                 // float -> int64 sequence; the same integer either way)
+                // (marked unlikely: without it the 14-instruction conversion is laid out as the fall-through and the usual case
+                // pays two taken branches per batch to get around it)
                 unsigned long long v;
-                if (__builtin_amdgcn_ballot_w64(!(sc >= 0.0f && sc < 4.0e9f)) != 0) {
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(sc >= 0.0f && sc < 4.0e9f)) != 0, 0)) {
                     asm volatile("; a contribution of 4 N or more" ::: "memory");      // (keeps this a branch, not a select)
                     v = static_cast<unsigned long long>(__float2ll_rn(sc));
                 } else {
@@ -2512,7 +2514,8 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
             const uint32_t idx = min(e == 0xffffffffu ? 0u : (e & 0x03ffffffu), static_cast<uint32_t>(Wd.n_slots - 1));
             return Wd.pos4 ? Wd.pos4[idx] : sorted[idx];
         };
-        auto entry = [&](int b) { return b < nbw ? lp[static_cast<size_t>(b) * 64] : 0xffffffffu; };
+        // (no branch around the load: beyond the wave's batches the last one is read again and discarded)
+        auto entry = [&](int b) { const uint32_t e = lp[static_cast<size_t>(min(b, max(nbw - 1, 0))) * 64]; return b < nbw ? e : 0xffffffffu; };
         uint32_t f0 = entry(4), f1 = entry(5), f2 = entry(6), f3 = entry(7);
         float4 p0 = cand(e0), p1 = cand(e1), p2 = cand(e2), p3 = cand(e3);
         if (nbw < 4) { if (nbw < 1) e0 = 0xffffffffu; if (nbw < 2) e1 = 0xffffffffu; if (nbw < 3) e2 = 0xffffffffu; e3 = 0xffffffffu; }
