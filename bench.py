@@ -1002,6 +1002,30 @@ def main(argv=None):
         torch.distributed.destroy_process_group()
 
 
+class Watchdog:
+    """Bounds an EXTRA leg of the job (the HBM-saturating leg, the multi-GPU suite): when `seconds` pass before `done()`, rank 0
+    prints the headline line it already holds -- `note(out)` has written what happened into it -- and every rank leaves the
+    process.  A rank that raised before a collective leaves the others waiting in it; that must not cost the headline."""
+
+    def __init__(self, seconds, job, out, note):
+        import threading
+        self._done = threading.Event()
+
+        def watch():
+            if self._done.wait(seconds):
+                return
+            if job.rank == 0:
+                note(out)
+                print(json.dumps(out))
+                sys.stdout.flush()
+            os._exit(0)
+
+        threading.Thread(target=watch, daemon=True).start()
+
+    def done(self):
+        self._done.set()
+
+
 def hbm_leg(args, job, out):
     """The headline's working set (99 MB per 20-step launch, re-used by every launch) fits the 256 MiB Infinity Cache, and the
     FETCH_SIZE / WRITE_SIZE counters count L2 -> fabric requests whether HBM or the cache serves them: "of the HBM roofline"
@@ -1019,10 +1043,14 @@ def hbm_leg(args, job, out):
     # (the parity replay copies every replayed step's rows to the host, twice as float64: 8 steps of 4M drones are 1.6 + 3.2 GB,
     # 64 would be 13 + 26 GB)
     a.parity_max_steps = 8
+    limit = min(120.0, args.suite_timeout)
+    dog = Watchdog(limit, job, out, lambda o: o.__setitem__("hbm_saturating", {"error": f"not finished after {limit:.0f} s: line printed without it"}))
     try:
         r = run_workload(a, job)
     except Exception as e:          # noqa: BLE001 -- reported; the headline survives
         r = {"error": f"{type(e).__name__}: {e}"[:300]}
+    finally:
+        dog.done()
     if job.rank == 0:
         if "error" in r:
             out["hbm_saturating"] = r
@@ -1048,23 +1076,12 @@ def run_suite(args, job, out):
     """The other multi-GPU lines in the same job, compact, under out["suite"].  A watchdog bounds the whole suite: when it
     fires, rank 0 prints the headline line it already holds (the suite entry says what happened) and every rank leaves -- a
     hang in a collective of a workload that has never met this node must not cost the headline."""
-    import threading
     from gym_pybullet_drones_amd import dist as gdist
     results = {}
     if job.rank == 0:
         out["suite"] = results
-    done = threading.Event()
-
-    def watchdog():
-        if done.wait(args.suite_timeout):
-            return
-        if job.rank == 0:
-            results["error"] = f"suite not finished after {args.suite_timeout:.0f} s: line printed without the rest"
-            print(json.dumps(out))
-            sys.stdout.flush()
-        os._exit(0)
-
-    threading.Thread(target=watchdog, daemon=True).start()
+    dog = Watchdog(args.suite_timeout, job, out,
+                   lambda o: results.__setitem__("error", f"suite not finished after {args.suite_timeout:.0f} s: line printed without the rest"))
     try:
         for name in SUITE:
             a = argparse.Namespace(**vars(args))
@@ -1097,7 +1114,7 @@ def run_suite(args, job, out):
             if not ok:
                 break
     finally:
-        done.set()
+        dog.done()
 
 
 def run_workload(args, job):

@@ -120,3 +120,21 @@ def test_suite_names_are_workloads_and_cover_baseline_configs_4_and_5():
     assert "hover65536x8_allgather" in bench.SUITE and "multihover2x16384x8" in bench.SUITE and "swarm1m_ext_240hz" in bench.SUITE
     a = bench.parse_args([])
     assert a.gpus == 1 and not a.scale_suite and not a.no_suite and a.suite_timeout > 0
+
+
+def test_watchdog_prints_the_line_it_holds_and_leaves():
+    """An extra leg that never returns (a rank waiting in a collective another rank left): rank 0 prints the headline with a
+    note, every rank exits 0; a leg that finishes in time prints nothing."""
+    import subprocess
+    code = ("import sys, time, types; sys.path.insert(0, %r); import bench\n"
+            "out = {'metric': 'm', 'value': 1.0}\n"
+            "job = types.SimpleNamespace(rank=int(sys.argv[1]))\n"
+            "quick = bench.Watchdog(0.2, job, out, lambda o: o.__setitem__('quick', 'fired')); quick.done(); time.sleep(0.4)\n"
+            "bench.Watchdog(0.3, job, out, lambda o: o.__setitem__('extra', {'error': 'late'}))\n"
+            "time.sleep(60)\n" % REPO)
+    for rank, lines in ((0, 1), (1, 0)):
+        res = subprocess.run([sys.executable, "-c", code, str(rank)], capture_output=True, text=True, timeout=120)
+        got = [l for l in res.stdout.splitlines() if l.startswith("{")]
+        assert res.returncode == 0 and len(got) == lines, (res.stdout, res.stderr)
+        if lines:
+            assert json.loads(got[0]) == {"metric": "m", "value": 1.0, "extra": {"error": "late"}}
