@@ -110,6 +110,13 @@ def counters(tag, kern):
 
 
 summary = {"traces": {}, "by_grid": {}, "pmc": {}, "bench_lines": {}, "graph_leg": {}, "swarm": {}}
+# a partial run (e.g. `swarm` after a change of the one-world kernels only) starts from the committed summary: the sections it does
+# not measure stay what they were
+_prev = os.path.join(R, "profiles", "r04_summary.json")
+if WHAT != {"traces", "pmc", "swarm"} and os.path.exists(_prev):
+    _old = json.load(open(_prev))
+    for _k in summary:
+        summary[_k] = _old.get(_k, summary[_k])
 if os.path.exists(os.path.join(OUT, "summary.json")):
     try:
         summary.update(json.load(open(os.path.join(OUT, "summary.json"))))
