@@ -138,3 +138,19 @@ def test_watchdog_prints_the_line_it_holds_and_leaves():
         assert res.returncode == 0 and len(got) == lines, (res.stdout, res.stderr)
         if lines:
             assert json.loads(got[0]) == {"metric": "m", "value": 1.0, "extra": {"error": "late"}}
+
+
+def test_committed_counter_profiles_hold_the_keys_the_bench_line_reads():
+    """`roofline.traffic` and `roofline_valu_issue` of the live line come from these files (a partial profile run once left them
+    empty and the line silently lost both blocks)."""
+    t = json.load(open(os.path.join(REPO, "profiles", "hbm_traffic.json")))
+    c = json.load(open(os.path.join(REPO, "profiles", "kernel_counters.json")))
+    s = json.load(open(os.path.join(REPO, "profiles", "swarm_counters.json")))
+    for key in ("hover65536_240hz:rollout64", "hover65536_240hz:graph", "hover4m_240hz:rollout64"):
+        assert t[key]["traffic_bytes"] > 0 and t[key]["algorithmic_bytes"] > 0, key
+        # traffic within a few per cent of the algorithmic bytes: no wasted re-reads
+        assert 0.9 < t[key]["traffic_bytes"] / t[key]["algorithmic_bytes"] < 1.15, key
+    for key in ("hover65536_240hz:rollout64", "hover65536_240hz:graph"):
+        assert c[key]["slots_per_wave_env_step"] > c[key]["valu_per_wave_env_step"] > 0, key
+    for wl in ("swarm65536_ext_240hz", "swarm1m_ext_240hz"):
+        assert s[wl]["valu_wave_instructions_per_substep"] > 0 and s[wl]["replay_waves"] > 0, wl
