@@ -473,6 +473,10 @@ def parity_check(w, env, actions, K, POOL, max_steps=256):
     for g in names:
         res[g] = float(np.abs(kin32[m][:, sl[g]] - k64[m][:, sl[g]]).max() / scale[g])
         worst = max(worst, res[g])
+    # (SURVEY.md section 8(d) also asks for the element-wise figure: the share of the final state's floats with
+    # |x32 - x64| <= 1e-5 + 1e-4 |x64|)
+    if m.any():
+        res["allclose_pass_rate"] = float(np.isclose(kin32[m], k64[m], rtol=1e-4, atol=1e-5).mean())
     res["obs_every_step"] = {g: obs_err[g] / scale[g] for g in osl}
     res["obs_first_step"] = {g: first_err.get(g, 0.0) / scale[g] for g in osl}
     if D > 1 and core.physics_flags & 4:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""SURVEY.md §8(d) parity metric on the GPU box -> gpurun_out/parity_report.json (copied to profiles/r01_parity_report.json).
+"""SURVEY.md §8(d) parity metric on the GPU box -> gpurun_out/parity_report.json (copied to profiles/rNN_parity_report.json: r01 with the first library, r04 with the final one).
 
 65 536 HoverAviaries (cf2x, DYN, RPM actions), the HIP path (float32, `gpd_rollout` in launches of 64 steps and `gpd_step`)
 against the C restatement of the oracle (float64, all host threads), identical fp32-rounded initial states and actions:
