@@ -368,6 +368,27 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path):
     assert "ABI 8" in run.stdout and "-> -1:" in run.stdout
 
 
+def test_every_entry_answers_null_pointers_with_a_code_not_a_crash():
+    """Every function of include/gpd.h called with NULL for every pointer (and 1, -1, INT_MAX for every integer): a negative
+    code and a message that names the entry -- the reference's convention is `print` + `exit()`, the
+    boundary's is an error code; no GPU needed, nothing is launched."""
+    from gym_pybullet_drones_amd import _native
+    L = _native.lib()
+    plain = {"gpd_abi_version", "gpd_last_error", "gpd_struct_sizes", "gpd_sizeof_swarm", "gpd_comm_destroy"}     # (no failure mode / NULL is fine)
+    ints = (ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t)
+    tried = 0
+    for ival in (1, -1, 2 ** 31 - 1):
+        for name in sorted(set(_native.exported_symbols()) - plain):
+            f = getattr(L, name)
+            args = [(0 if (t is ctypes.c_size_t and ival < 0) else ival) if t in ints else 1.0 if t is ctypes.c_float else None for t in f.argtypes]
+            rc = f(*args)
+            msg = L.gpd_last_error().decode()
+            assert rc < 0 and msg.startswith(name), (name, ival, rc, msg)
+            tried += 1
+    assert tried >= 3 * 20
+    assert L.gpd_comm_destroy(None) == 0          # (destroying nothing is not an error)
+
+
 def test_swarm_entries_reject_bad_arguments_before_touching_a_device():
     """The `GpdSwarm` entries validate their arguments before the first HIP call: codes and messages, no crash, no GPU needed."""
     from gym_pybullet_drones_amd import _native
