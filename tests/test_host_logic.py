@@ -592,3 +592,16 @@ def test_halo_exchange_over_torch_distributed_gloo(world):
     point-to-point blocks; every rank ends up with the current positions of the drones it needs and everybody's meta rows."""
     import torch.multiprocessing as mp
     mp.spawn(_halo_gloo_worker, args=(world, 29600 + os.getpid() % 300 + world, 1500), nprocs=world, join=True)
+
+
+def test_documents_name_every_entry_and_the_current_abi():
+    """DESIGN.md's boundary table and INTEGRATION.md's mapping name every function include/gpd.h declares, and quote the ABI
+    version the header defines (a stale entry list was a round-3 finding)."""
+    hdr = open(os.path.join(REPO, "include", "gpd.h")).read()
+    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(gpd_\w+)\s*\(", hdr, flags=re.M))
+    abi = re.search(r"#define GPD_ABI_VERSION (\d+)", hdr).group(1)
+    for doc in ("DESIGN.md", "INTEGRATION.md"):
+        text = open(os.path.join(REPO, doc)).read()
+        assert not [n for n in sorted(declared) if n not in text], doc
+    assert f"C-ABI (v{abi})" in open(os.path.join(REPO, "DESIGN.md")).read()
+    assert f"gpd_abi_version() == {abi}" in open(os.path.join(REPO, "INTEGRATION.md")).read()
