@@ -20,7 +20,7 @@ import torch
 
 from . import _native
 from .params import DroneParams, PIDGains, euler_to_quat, trunc_counter
-from .utils.enums import ACT_RAW_RPM, ActionType, DroneModel, PHYS_DRAG, Physics
+from .utils.enums import DroneModel, PHYS_DRAG, Physics
 
 TASK_NONE, TASK_HOVER, TASK_MULTIHOVER = 0, 1, 2
 _ACT_DIM = {0: 4, 1: 3, 2: 4, 3: 1, 4: 1, 5: 4, 6: 4}
