@@ -202,6 +202,16 @@ class BaseAviary(Env):
         self._k_terminated = bool(packed[0, 24] != 0)
         self._k_truncated = bool(packed[0, 25] != 0)
 
+    def _parseURDFParameters(self):
+        """The tuple the reference's URDF parser returns, in its order (envs/BaseAviary.py:985-1017): M, L,
+        THRUST2WEIGHT_RATIO, J, J_INV, KF, KM, COLLISION_H, COLLISION_R, COLLISION_Z_OFFSET, MAX_SPEED_KMH, GND_EFF_COEFF,
+        PROP_RADIUS, DRAG_COEFF, DW_COEFF_1, DW_COEFF_2, DW_COEFF_3 -- from the shipped copy of the same `assets/<model>.urdf`
+        (`params.DroneParams`), for callers and subclasses that unpack it themselves."""
+        P = DroneParams(self.DRONE_MODEL)
+        return tuple(getattr(P, n) for n in ("M", "L", "THRUST2WEIGHT_RATIO", "J", "J_INV", "KF", "KM", "COLLISION_H", "COLLISION_R",
+                                             "COLLISION_Z_OFFSET", "MAX_SPEED_KMH", "GND_EFF_COEFF", "PROP_RADIUS", "DRAG_COEFF",
+                                             "DW_COEFF_1", "DW_COEFF_2", "DW_COEFF_3"))
+
     def _getDroneStateVector(self, nth_drone):
         """(20,) state vector: pos3 | quat4 | rpy3 | vel3 | ang_v3 | last_clipped_action4."""
         state = np.hstack([self.pos[nth_drone, :], self.quat[nth_drone, :], self.rpy[nth_drone, :],

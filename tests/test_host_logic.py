@@ -605,3 +605,17 @@ def test_documents_name_every_entry_and_the_current_abi():
         assert not [n for n in sorted(declared) if n not in text], doc
     assert f"C-ABI (v{abi})" in open(os.path.join(REPO, "DESIGN.md")).read()
     assert f"gpd_abi_version() == {abi}" in open(os.path.join(REPO, "INTEGRATION.md")).read()
+
+
+def test_parse_urdf_parameters_keeps_the_reference_tuple():
+    """`_parseURDFParameters` (envs/BaseAviary.py:985-1017): 17 values in the reference's order; needs no device."""
+    import types
+    from gym_pybullet_drones_amd.envs.BaseAviary import BaseAviary
+    from gym_pybullet_drones_amd.utils.enums import DroneModel
+    t = BaseAviary._parseURDFParameters(types.SimpleNamespace(DRONE_MODEL=DroneModel.CF2X))
+    assert len(t) == 17
+    M, L, T2W, J, J_INV, KF, KM, CH, CR, CZ, VMAX, GND, PROP, DRAG, DW1, DW2, DW3 = t
+    assert (M, L, T2W, KF, KM) == (0.027, 0.0397, 2.25, 3.16e-10, 7.94e-12)                  # SURVEY.md appendix D
+    assert np.allclose(np.diag(J), [1.4e-5, 1.4e-5, 2.17e-5]) and np.allclose(J @ J_INV, np.eye(3))
+    assert (CH, CR, VMAX, GND, PROP) == (0.025, 0.06, 30.0, 11.36859, 2.31348e-2) and CZ == 0.0
+    assert np.allclose(DRAG, [9.1785e-7, 9.1785e-7, 10.311e-7]) and (DW1, DW2, DW3) == (2267.18, 0.16, -0.11)
