@@ -46,6 +46,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 
 #include "gpd.h"
 
@@ -2842,32 +2843,59 @@ __global__ __launch_bounds__(kBlock) void gpd_swarm_step_kernel(const GpdParams 
     const uint32_t flags = C.physics_flags;
     Carry c;
     float tgx, tgy, tgz, ip[7];
+#if defined(GPD_EXP_TS) && defined(GPD_EXP_TSS)
+    // (experiment build, scratch/exp_r04/step_timeline.py: where a launch of this kernel spends its time)
+    const unsigned long long tss0 = wall_clock64();
+    unsigned long long tss1 = 0, tss2 = 0;
+#endif
     const float4 act = load_action<4>(action, L.n);
     const SwarmIn I = swarm_head(O, L.active, L.n);        // (one trip to memory with the state's loads instead of one behind the step)
     load_carry<false, true>(S, C, flags, L, S.kin, S.kin, c, tgx, tgy, tgz, ip);     // (no task, no reset: readable dummies)
     c.roll = c.pitch = c.yaw = 0.0f;
+#if defined(GPD_EXP_TS) && defined(GPD_EXP_TSS)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tss1 = wall_clock64();
+#endif
     StepOut out;
     env_step<false, true, false, 4, ACT, true>(P, C, flags, 1, L, act, tgx, tgy, tgz, false, S.kin, ip[0], ip[1], ip[2], ip[3], ip[4],
                                                ip[5], ip[6], nullptr, nullptr, c, out);
     swarm_tail(O, I, L.active, L.n, c.k.px, c.k.py, c.k.pz);
+#if defined(GPD_EXP_TS) && defined(GPD_EXP_TSS)
+    asm volatile("" :: "v"(c.k.px), "v"(c.k.qw), "v"(c.k.wz), "v"(out.o[11]) : "memory"); tss2 = wall_clock64();
+#endif
     // observation rows (48 B) and state vectors (80 B, BaseAviary._getDroneStateVector, envs/BaseAviary.py:541-561): a lane's row
     // is a strided piece of cache lines, a wave's 64 rows are one contiguous block -- transposed through LDS and stored as
     // 1 KiB bursts (the wave's own LDS instructions execute in order: no barrier between its writes and its reads)
     __shared__ __attribute__((aligned(16))) float4 sh_rows[kBlock * 5];
     const int wave0 = threadIdx.x & ~63, lane = threadIdx.x & 63;
     const uint32_t n0 = n_raw - static_cast<uint32_t>(lane);               // first drone of this wave
-    const uint32_t rows = n0 < N ? (N - n0 < 64u ? N - n0 : 64u) : 0u;
+    const uint32_t rows = __builtin_amdgcn_readfirstlane(n0 < N ? (N - n0 < 64u ? N - n0 : 64u) : 0u);
     const Kin& k = c.k;
-    auto burst = [&](float* dst_rows, int F4) {            // F4 float4 per row; the wave's rows start at dst_rows
+    auto burst = [&](float* dst_rows, auto f4c) {          // F4 float4 per row; the wave's rows start at dst_rows
+        constexpr int F4 = decltype(f4c)::value;
         float4* patch = sh_rows + wave0 * 5;
         __builtin_amdgcn_wave_barrier();
+        if (rows == 64u) {
+            // every row of the wave exists (all waves but the grid's last): F4 LDS reads in one run, then F4 stores -- with a
+            // test around every store each read is waited for before its store and the next read starts behind it, F4 LDS
+            // round trips in a row (profiles/r04_swarm_step_timeline.txt: the stores are issued 0.14 us sooner this way; the
+            // memory pipeline paces the rest, 0.08 us of a 3.8 us workgroup is what it is worth)
+            float4 v[F4];
 #pragma unroll
-        for (int j = 0; j < F4; ++j) {
-            const int idx = j * 64 + lane;
-            const float4 v = patch[idx];
-            if (static_cast<uint32_t>(idx) < rows * F4) {
-                f4v wv = {v.x, v.y, v.z, v.w};
-                __builtin_nontemporal_store(wv, reinterpret_cast<f4v*>(dst_rows) + idx);
+            for (int j = 0; j < F4; ++j) v[j] = patch[j * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < F4; ++j) {
+                f4v wv = {v[j].x, v[j].y, v[j].z, v[j].w};
+                __builtin_nontemporal_store(wv, reinterpret_cast<f4v*>(dst_rows) + (j * 64 + lane));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < F4; ++j) {
+                const int idx = j * 64 + lane;
+                const float4 v = patch[idx];
+                if (static_cast<uint32_t>(idx) < rows * F4) {
+                    f4v wv = {v.x, v.y, v.z, v.w};
+                    __builtin_nontemporal_store(wv, reinterpret_cast<f4v*>(dst_rows) + idx);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -2877,7 +2905,7 @@ __global__ __launch_bounds__(kBlock) void gpd_swarm_step_kernel(const GpdParams 
         mine[0] = make_float4(out.o[0], out.o[1], out.o[2], out.o[3]);
         mine[1] = make_float4(out.o[4], out.o[5], out.o[6], out.o[7]);
         mine[2] = make_float4(out.o[8], out.o[9], out.o[10], out.o[11]);
-        burst(obs12 + static_cast<size_t>(n0) * 12, 3);
+        burst(obs12 + static_cast<size_t>(n0) * 12, std::integral_constant<int, 3>{});
     }
     if (O.vec_out) {
         float4* mine = sh_rows + wave0 * 5 + lane * 5;
@@ -2886,8 +2914,20 @@ __global__ __launch_bounds__(kBlock) void gpd_swarm_step_kernel(const GpdParams 
         mine[2] = make_float4(out.o[4], out.o[5], k.vx, k.vy);
         mine[3] = make_float4(k.vz, out.o[9], out.o[10], out.o[11]);
         mine[4] = make_float4(c.l0, c.l1, c.l2, c.l3);
-        burst(O.vec_out + static_cast<size_t>(n0) * 20, 5);
+        burst(O.vec_out + static_cast<size_t>(n0) * 20, std::integral_constant<int, 5>{});
     }
+#if defined(GPD_EXP_TS) && defined(GPD_EXP_TSS)
+    if (L.active) store_carry<false>(S, L, c);
+    const unsigned long long tss3 = wall_clock64();            // every store issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tss4 = wall_clock64();            // ... and acknowledged
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        const unsigned int slot = gpd_ts_cnt[blockIdx.x]++ & 7u;
+        unsigned long long* o = gpd_ts + (static_cast<size_t>(slot) * 4096 + blockIdx.x) * 4;
+        o[0] = tss0; o[1] = tss1; o[2] = tss2; o[3] = (tss3 & 0xffffffffull) | (tss4 << 32);
+    }
+    return;
+#endif
     if (!L.active) return;
     store_carry<false>(S, L, c);
 }
