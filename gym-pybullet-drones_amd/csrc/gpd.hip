@@ -2270,6 +2270,30 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_add(int v) {   // v + (v of the lane the DPP control selects; 0 where there is none / the row is masked)
     return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
 }
+// Reduction over the 64 lanes of a wave, the result in every lane, without a trip through the LDS crossbar per level (six
+// dependent ds_bpermute round trips, ~0.25 us on a path that has nothing else to issue): four DPP steps inside the rows of 16
+// lanes -- quad permutes for xor 1 / xor 2; after them the four lanes of a quad hold one value, so the row_half_mirror / row_mirror
+// permutes read the same VALUE lane ^ 4 / lane ^ 8 would -- then the four rows' values as scalars (v_readlane), combined
+// (r0 . r1) . (r2 . r3) in every lane: bit for bit the ascending xor butterfly (1, 2, 4, .. 32) of a commutative `op`.  All 64 lanes
+// must be executing.
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <class Op>
+__device__ __forceinline__ float wave_allreduce(float v, Op op) {
+    v = op(v, dpp_perm<0xB1>(v));                          // quad_perm [1, 0, 3, 2]
+    v = op(v, dpp_perm<0x4E>(v));                          // quad_perm [2, 3, 0, 1]
+    v = op(v, dpp_perm<0x141>(v));                         // row_half_mirror
+    v = op(v, dpp_perm<0x140>(v));                         // row_mirror
+    const int b = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+    return op(op(r0, r1), op(r2, r3));
+}
+__device__ __forceinline__ float wave_max(float v) { return wave_allreduce(v, [](float a, float b) { return fmaxf(a, b); }); }
+__device__ __forceinline__ float wave_sum(float v) { return wave_allreduce(v, [](float a, float b) { return a + b; }); }
+
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
     v = dpp_add<0x111, 0xf>(v);      // row_shr:1
     v = dpp_add<0x112, 0xf>(v);      // row_shr:2
@@ -2443,8 +2467,7 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
         // workgroup reading all 4 097 rows of a 1M-drone world was 1 GB of L2 traffic per force launch and a third of a replay
         // launch's vector instructions)
         if (!few) for (int r = lane; r < Wd.world; r += 64) d2 = fmaxf(d2, Wd.meta[static_cast<size_t>(r + 1) * Wd.slab - Wd.meta_rows].w);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, off));
+        d2 = wave_max(d2);
         if (d2 > 0.0f) {                                   // (rounded up: a wider search is still exact, a narrower one is not)
             const float reach = 10.0f + 2.0002f * sqrtf(d2) + 2.0e-6f;
             const float cells = ceilf(reach / Wd.cell * 1.000001f);
@@ -2813,12 +2836,7 @@ __device__ __forceinline__ void swarm_tail(const SwarmOut& O, const SwarmIn& I, 
         d2 = fin ? d2 : 0.0f;
         sx = fin ? dx : 0.0f; sy = fin ? dy : 0.0f;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        d2 = fmaxf(d2, __shfl_xor(d2, off));
-        sx += __shfl_xor(sx, off);
-        sy += __shfl_xor(sy, off);
-    }
+    d2 = wave_max(d2); sx = wave_sum(sx); sy = wave_sum(sy);
     if ((threadIdx.x & 63) == 0) { wg_red[threadIdx.x >> 6][0] = d2; wg_red[threadIdx.x >> 6][1] = sx; wg_red[threadIdx.x >> 6][2] = sy; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -2940,8 +2958,7 @@ __global__ __launch_bounds__(kBlock) void dwg_reduce_meta_kernel(float* __restri
     __shared__ float red[kBlock / 64];
     float m = 0.0f;
     for (int k = threadIdx.x; k < rows; k += kBlock) m = fmaxf(m, meta_own[4 * k + 3]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    m = wave_max(m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
