@@ -2531,6 +2531,16 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
         GPD_DBG(nb0 >= 0 && nb0 <= Ls.cap, GPD_DBG_LIST_COUNT, nb0);
         const int nbw = GPD_DBG_CLAMP(nb0, 0, Ls.cap);
         const uint32_t* const lp = my_list + lane;
+        // A launch ends with its slowest workgroup, and that is the one with the most pairs (profiles/r04_swarm_force_timeline.txt:
+        // 9.1 us against a median of 6.6; all workgroups are resident at once, nothing fills in behind it).  A wave with many batches
+        // asks the SIMD's arbiter for priority over the three it shares the SIMD with: they have slack, it has none.
+        // (thresholds 12 / 16 / 20 and 11 / 13 / 16 measure the same, profiles/r04_ab_swarm_replay_priority.txt; a scene where every
+        // wave is above them gives every wave the same priority: nothing gained, nothing lost)
+        if (nbw >= 12) {
+            if (nbw >= 20) __builtin_amdgcn_s_setprio(3);
+            else if (nbw >= 16) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(1);
+        }
         auto cand = [&](uint32_t e) {
             // (clamped: the first four entries are read before the wave knows how many batches it has -- whatever a list holds,
             // the gather stays inside the array)
