@@ -226,3 +226,22 @@ def test_two_drone_aviaries_exchange_through_dpp(gpd_asm):
     distance / out-of-bounds terms (3) arrive by `quad_perm:[1,0,3,2]` moves -- in each of the three copies of the step."""
     body, _ = _kernel(gpd_asm, "gpd_rollout1_kernelILb0ELb1ELi4ELi0ELb0ELb1ELb1E")
     assert sum("quad_perm:[1,0,3,2]" in l for l in body) == 18
+
+
+def test_one_world_step_kernel_reduces_without_the_lds_crossbar_and_bursts_in_two_runs(gpd_asm):
+    """gpd_swarm_step_kernel (profiles/r04_swarm_step_timeline.txt): the tail's three wave reductions are DPP
+    steps + v_readlane (`wave_allreduce`: no ds_bpermute left in the kernel), and the row bursts of a full wave are LDS reads in a
+    run followed by their stores -- somewhere in the kernel five ds_read_b128 stand next to each other (the state vectors' fast
+    path), which the per-store test of the ragged path never produces; one sub-step's physics fits 96 VGPRs, no scratch."""
+    body, meta = _kernel(gpd_asm, "gpd_swarm_step_kernelILi5E")
+    assert re.search(r"ScratchSize: 0\b", meta) and int(re.search(r"; NumVgprs: (\d+)", meta).group(1)) <= 96
+    ops = [op for op, _ in _ops(body)]
+    c = Counter(ops)
+    assert c["ds_bpermute_b32"] == 0 and c["v_readlane_b32"] >= 12
+    assert sum(1 for op, s in _ops(body) if "_dpp" in op and ("row_mirror" in s or "row_half_mirror" in s)) >= 6
+    lds = [op for op in ops if op.startswith(("ds_read_b128", "global_store", "ds_write"))]
+    runs, best = 0, 0
+    for op in lds:
+        runs = runs + 1 if op == "ds_read_b128" else 0
+        best = max(best, runs)
+    assert best >= 5, best
