@@ -248,12 +248,33 @@ def cpu_baseline(w, budget_s=12.0, phys=None):
             c_oracle.lib().orc_set_threads(1)
     except Exception as e:   # the C restatement is optional test infrastructure
         out.setdefault("c_port", {"error": str(e)[:200]})
+    out["reference_python"] = reference_python_figure(w, out["value"])
     out["pybullet"] = pybullet_baseline()
     if out["pybullet"].get("available"):        # the stated baseline itself was timed: it leads, the ports stay beside it
         port = {k: out[k] for k in ("value", "unit", "cores", "kind", "sample")}
         out.update({k: out["pybullet"][k] for k in ("value", "unit", "cores", "kind", "sample")})
         out["port"] = port
     return out
+
+
+def reference_python_figure(w, port_value):
+    """The reference's OWN Python (its unmodified HoverAviary, Physics.DYN, imported over oracle/pybullet_shim.py) as timed in the
+    build container by scratch/time_reference_dyn.py -- /root/reference does not exist on the GPU box, so the figure travels as
+    profiles/r05_reference_python_dyn_cpu.json (host CPU stated there) and is QUOTED here, next to the port timed on this box."""
+    path = os.path.join(REPO, "profiles", "r05_reference_python_dyn_cpu.json")
+    try:
+        rec = json.load(open(path))
+    except Exception as e:      # noqa: BLE001
+        return {"available": False, "why": f"{type(e).__name__}: {e}"[:160]}
+    same_shape = w["ctrl"] == 240 and "at_240hz_control" in rec
+    value = rec["at_240hz_control"]["value"] if same_shape else rec["value"]
+    return {"available": True, "kind": "reference", "value": value, "unit": rec["unit"], "cores": rec["cores"],
+            "schedule": "240 Hz control, ActionType.RPM (this workload's per-drone work)" if same_shape else
+                        "HoverAviary() defaults: 30 Hz control / 240 Hz physics, ONE_D_RPM (BASELINE config 1 with Physics.DYN)",
+            "default_schedule_value": rec["value"], "host_cpu": rec.get("host_cpu"), "measured_in": "the build container, not this box",
+            "port_over_reference": port_value / value if value else None, "file": "profiles/r05_reference_python_dyn_cpu.json",
+            "sample": f"{rec['steps']} env.step() of the reference's unmodified HoverAviary(physics=Physics.DYN) over oracle/pybullet_shim.py, "
+                      f"best of {len(rec['runs'])} runs, 1 core of {rec.get('host_cpu')}"}
 
 
 def swarm_cpu_baseline(w, env, budget_s=10.0):

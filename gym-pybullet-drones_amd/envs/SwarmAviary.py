@@ -144,6 +144,13 @@ class HaloPlan:
         self.ready = False
         self.y_plan = None
 
+    def forget(self):
+        """Drop the plan AND the positions it was made from: the next exchange plans from scratch and checks nothing.  Called
+        whenever positions change discontinuously (reset(), set_state(), invalidate() -- everything that re-packs): a teleport
+        is not a margin violation, and the interval that ends with it has no pairs left to miss."""
+        self.ready = False
+        self.y_plan = None
+
     def _own(self, env):
         r0 = env.RANK * env.slab
         return env.pos4[r0:r0 + env.NUM_DRONES]
@@ -166,7 +173,7 @@ class HaloPlan:
         """`bounds`: [W, 3] of phase1, every rank's row -> float counts [W] (rows of mine rank d needs; 0 for myself)"""
         if bool((bounds[:, 2] > 0).any().item()):
             who = torch.nonzero(bounds[:, 2] > 0).flatten().tolist()
-            self.ready = False
+            self.forget()           # (reported once: the next call plans afresh from the current positions)
             raise RuntimeError(f"halo exchange: drones of rank(s) {who} moved more than margin / 2 = {0.5 * self.margin:g} m in y since the last "
                                f"plan -- the halo may have missed pairs; results since the last binning are not guaranteed.  Use a larger "
                                f"halo_margin, a smaller rebin_every, or exchange='allgather'.")
@@ -478,6 +485,8 @@ class SwarmAviary:
             rc = c.lib.gpd_swarm_pack(ctypes.byref(c._state), ctypes.byref(self._sw), _ptr(c.obs12), _ptr(vectors), c._stream())
         _native.check(rc, "gpd_swarm_pack")
         self._since_bin = self.rebin_every           # (forces a binning)
+        if getattr(self.exchange, "halo", False):    # ... and a new halo plan that holds nothing against the jump
+            self.exchange.plan.forget()
 
     def _refs(self):
         """ctypes references of the four structs and the address of the observation block: built once (an eager sub-step is three
@@ -715,6 +724,8 @@ class LocalSwarmGroup:
 
     def reset(self):
         out = []
+        for P in self.plans or ():
+            P.forget()                  # the jump back to the initial poses is not a margin violation
         for e in self.ranks:
             e.core.reset()
             if e.ctrl is not None:

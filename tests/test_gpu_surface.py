@@ -519,6 +519,47 @@ def test_halo_exchange_is_bitwise_the_all_gather_world(gpu_device, W, rebin):
             halo.step(rpm)
 
 
+def test_halo_world_runs_a_second_episode_after_reset(gpu_device):
+    """`reset()` is a teleport, not a margin violation.  A 3-rank halo world in which every drone drifts
+    sideways (y) by more than margin / 2 over an episode -- slowly enough that every plan's own interval holds -- is reset to its
+    initial poses and flown again: the second episode is bit for bit the first (and the single-rank world's), no RuntimeError;
+    the same through set_state() + invalidate() on a real SwarmAviary rank is covered by the resume tests."""
+    from gym_pybullet_drones_amd.envs import LocalSwarmGroup, SwarmAviary
+    from gym_pybullet_drones_amd.utils.enums import Physics
+    rng = np.random.default_rng(77)
+    N, margin = 1500, 1.0
+    xyz, rpy = _tall_scene(rng, N)
+    kw = dict(initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.PYB_GND_DRAG_DW, pyb_freq=240, ctrl_freq=240, device=gpu_device)
+    one = SwarmAviary(N, rebin_every=4, **kw)
+    halo = LocalSwarmGroup(N, 3, rebin_every=4, exchange="halo", halo_margin=margin, **kw)
+    rpm = torch.full((N, 4), float(one.HOVER_RPM), device=gpu_device)
+
+    def push(envs):        # 6 m/s in y for everybody: 0.1 m per 4-sub-step plan interval (< margin / 2), 0.75 m over 30 steps (> margin / 2)
+        for e in envs:
+            kin = e.core.kin[:, :e.NUM_DRONES].clone()
+            kin[8] = 6.0
+            e.core.set_state(kin=kin)
+            e.invalidate()
+
+    episodes = []
+    for ep in range(2):
+        v1, _ = one.reset()
+        vh = halo.reset()
+        assert torch.equal(v1, vh), ep
+        push([one] + halo.ranks)
+        y0 = v1[:, 1].clone()
+        rows = []
+        for k in range(30):
+            v1, *_ = one.step(rpm)
+            vh = halo.step(rpm)
+            assert torch.equal(v1, vh), (ep, k)
+            rows.append(vh.clone())
+        assert float((v1[:, 1] - y0).abs().min()) > 0.5 * margin      # every drone is further from its reset pose than margin / 2
+        episodes.append(torch.stack(rows))
+    assert torch.equal(episodes[0], episodes[1])
+    assert halo.plans_made >= 2 * 7
+
+
 @pytest.mark.parametrize("W", [1, 8])
 def test_worlds_with_many_meta_rows_take_the_ranks_own_displacement_maximum(gpu_device, W):
     """A world with more than 1024 meta rows (one per 256 drones and rank: here 300 000 drones, 1 172 rows; shared by 8 ranks, 8 x 147):

@@ -549,6 +549,19 @@ def test_halo_plan_covers_every_pair_the_model_couples(W):
     for P, e in zip(plans, ranks):
         with pytest.raises(RuntimeError, match="halo exchange"):
             P.phase2(e, bounds)
+    # ... ONCE: the violation is reported, the plan and the positions it was made from are dropped, and the next exchange plans
+    # afresh from where the drones are (`y_plan` used to survive the raise, so every later call raised too)
+    assert all(P.y_plan is None and not P.ready for P in plans)
+    _plan_all(plans, ranks)
+    check(far)
+    # a legitimate teleport (reset() to the initial poses, set_state(), invalidate(): everything that re-packs calls forget()):
+    # every drone jumps by much more than margin / 2 -- not a violation, the new plan covers the new positions
+    for P, e in zip(plans, ranks):
+        P.forget()
+        e.set_own(dealt)
+    _plan_all(plans, ranks)
+    check(dealt)
+    assert all(P.ready for P in plans)
 
 
 def _halo_gloo_worker(rank, world, port, N):
