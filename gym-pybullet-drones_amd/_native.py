@@ -22,7 +22,10 @@ ABI_VERSION = 8
 #   of a rollout step); the policy kernel (MFMA + activations) is 10 % faster with the default scheduler (round-2 A/B).
 COMMON_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC"]
 HIPCC_FLAGS = COMMON_FLAGS + ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-shared"]        # gpd.hip (kept under this name for the ISA tests)
-UNITS = (("gpd.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]), ("gpd_policy.hip", []))
+#   -mllvm -amdgpu-kernarg-preload-count=14: the first 14 argument dwords of a kernel arrive in SGPRs with the wave (gfx942+ command
+#   processor) instead of through a scalar load -- gpd_step_kernel's argument list starts with what its load section needs
+KERNARG_PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=14"]
+UNITS = (("gpd.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] + KERNARG_PRELOAD), ("gpd_policy.hip", []))
 
 
 class GpdError(RuntimeError):

@@ -835,11 +835,22 @@ __device__ __forceinline__ void load_carry(const GpdState& S, const GpdStepCfg& 
     const int64_t ld = S.ld;
     const uint32_t off4 = L.n * 4u;
     Kin& k = c.k;
+#ifdef GPD_EXP_KIN4
+    {   // experiment: rows 0-3 | 4-7 | 8-11 interleaved as three float4 planes, row 12 as it is (the same 13 x ld floats)
+        const uint32_t off16 = L.n * 16u;
+        const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.kin) + off16);
+        const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.kin + 4 * ld) + off16);
+        const float4 d = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.kin + 8 * ld) + off16);
+        k.px = a.x; k.py = a.y; k.pz = a.z; k.qx = a.w; k.qy = b.x; k.qz = b.y; k.qw = b.z; k.vx = b.w;
+        k.vy = d.x; k.vz = d.y; k.wx = d.z; k.wy = d.w; k.wz = ld_row(S.kin, ld, 12, off4);
+    }
+#else
     k.px = ld_row(S.kin, ld, 0, off4); k.py = ld_row(S.kin, ld, 1, off4); k.pz = ld_row(S.kin, ld, 2, off4);
     k.qx = ld_row(S.kin, ld, 3, off4); k.qy = ld_row(S.kin, ld, 4, off4); k.qz = ld_row(S.kin, ld, 5, off4);
     k.qw = ld_row(S.kin, ld, 6, off4);
     k.vx = ld_row(S.kin, ld, 7, off4); k.vy = ld_row(S.kin, ld, 8, off4); k.vz = ld_row(S.kin, ld, 9, off4);
     k.wx = ld_row(S.kin, ld, 10, off4); k.wy = ld_row(S.kin, ld, 11, off4); k.wz = ld_row(S.kin, ld, 12, off4);
+#endif
     c.counter = S.step_counter[L.env];                       // every drone of an aviary reads its aviary's counter
     GPD_DBG(c.counter >= 0, GPD_DBG_STEP_COUNTER, c.counter);
     // target (task NONE: the host passes a readable dummy, the values are not used)
@@ -884,11 +895,24 @@ __device__ __forceinline__ void store_carry(const GpdState& S, const Lane& L, co
         // recovers, where the reference's drone is gone for good.  tests/test_gpu_resume.py pins both behaviours.)
         S.bad[L.n] = fabsf(sum) <= 3.4028234e38f ? 0 : 1;
     }
+#ifdef GPD_EXP_KIN4
+    {
+        const uint32_t off16 = L.n * 16u;
+        const f4v a = {k.px, k.py, k.pz, k.qx}, b = {k.qy, k.qz, k.qw, k.vx}, d = {k.vy, k.vz, k.wx, k.wy};
+        f4v* pa = reinterpret_cast<f4v*>(reinterpret_cast<char*>(S.kin) + off16);
+        f4v* pb = reinterpret_cast<f4v*>(reinterpret_cast<char*>(S.kin + 4 * ld) + off16);
+        f4v* pd = reinterpret_cast<f4v*>(reinterpret_cast<char*>(S.kin + 8 * ld) + off16);
+        if (NT) { __builtin_nontemporal_store(a, pa); __builtin_nontemporal_store(b, pb); __builtin_nontemporal_store(d, pd); }
+        else { *pa = a; *pb = b; *pd = d; }
+        st_row<NT>(S.kin, ld, 12, off4, k.wz);
+    }
+#else
     st_row<NT>(S.kin, ld, 0, off4, k.px); st_row<NT>(S.kin, ld, 1, off4, k.py); st_row<NT>(S.kin, ld, 2, off4, k.pz);
     st_row<NT>(S.kin, ld, 3, off4, k.qx); st_row<NT>(S.kin, ld, 4, off4, k.qy); st_row<NT>(S.kin, ld, 5, off4, k.qz);
     st_row<NT>(S.kin, ld, 6, off4, k.qw);
     st_row<NT>(S.kin, ld, 7, off4, k.vx); st_row<NT>(S.kin, ld, 8, off4, k.vy); st_row<NT>(S.kin, ld, 9, off4, k.vz);
     st_row<NT>(S.kin, ld, 10, off4, k.wx); st_row<NT>(S.kin, ld, 11, off4, k.wy); st_row<NT>(S.kin, ld, 12, off4, k.wz);
+#endif
     if (S.last_rpm) {
         st_row<NT>(S.last_rpm, ld, 0, off4, c.l0); st_row<NT>(S.last_rpm, ld, 1, off4, c.l1);
         st_row<NT>(S.last_rpm, ld, 2, off4, c.l2); st_row<NT>(S.last_rpm, ld, 3, off4, c.l3);
@@ -907,12 +931,24 @@ __device__ __forceinline__ void store_carry(const GpdState& S, const Lane& L, co
 // N = 65 536 a launch lasts ~5 us).
 // ------------------------------------------------------------------------------------------------
 // ACT / S1: the action type and "one sub-step per step" as compile-time constants (no action-type ladder, no sub-step loop)
+//
+// The argument list STARTS with the fourteen dwords the load section needs (kernarg preload, `-mllvm -amdgpu-kernarg-preload-count=14`
+// in _native.py: the command processor puts them into SGPRs before the wave starts, so the state / action / counter / target loads are
+// issued without first waiting for a scalar load of the argument block -- one memory round trip off the launch's critical path; the
+// by-value structs follow and are fetched while the vector loads are in flight).  Hot: copies of S.kin, S.step_counter, S.ld, the slot
+// source (S.ring_pos, or the step counters when there is no ring), C.num_envs, C.lanes_per_wave, C.target_per_env.
 template <bool PID, bool EXT, bool MULTI, int AW, int ACT, bool S1>
 __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
-    const GpdParams P, const GpdState S, const GpdStepCfg C, const float* __restrict__ action,
-    const float* __restrict__ target_pos, const float* __restrict__ init_pose, float* __restrict__ obs12,
+    float* __restrict__ hot_kin, const float* __restrict__ action, int32_t* __restrict__ hot_counter,
+    const float* __restrict__ target_pos, const int32_t* __restrict__ hot_slot, const uint32_t hot_ld, const int32_t hot_num_envs,
+    const int32_t hot_lanes_per_wave, const int32_t hot_target_per_env,
+    const GpdParams P, const GpdState S_, const GpdStepCfg C_, const float* __restrict__ init_pose, float* __restrict__ obs12,
     float* __restrict__ reward, uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
     float* __restrict__ term_obs12) {
+    GpdState S = S_;
+    S.kin = hot_kin; S.step_counter = hot_counter; S.ld = hot_ld;
+    GpdStepCfg C = C_;
+    C.num_envs = hot_num_envs; C.lanes_per_wave = hot_lanes_per_wave; C.target_per_env = hot_target_per_env;
     const int D = MULTI ? C.drones_per_env : 1;
     const int tid = threadIdx.x;
     const uint32_t N = static_cast<uint32_t>(C.num_envs) * static_cast<uint32_t>(D);
@@ -940,7 +976,7 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     const float4 act = load_action<AW>(action, L.n);
     // action history: the slot this aviary's action goes to (read with the other loads, from a readable dummy when there is
     // no ring: the load section stays branch-free)
-    int ring_q = (S.act_ring ? S.ring_pos : S.step_counter)[L.env];
+    int ring_q = hot_slot[L.env];
     if (S.act_ring) { GPD_DBG(ring_q >= 0 && ring_q < S.hist_len, GPD_DBG_RING_POS, ring_q); ring_q = GPD_DBG_CLAMP(ring_q, 0, S.hist_len - 1); }
     // a single step reads its reset pose only if it resets (in env_step); the slots `ip` are filled from a cached row
     const float* ipose = reinterpret_cast<const float*>(reinterpret_cast<const char*>(init_pose) +
@@ -3084,16 +3120,19 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
     if (T.num_steps == 1) {      // gpd_step, or a rollout of one step: the low-latency single-step kernel
         const int lanes = multi ? (kBlock / C.drones_per_env) * C.drones_per_env : (kBlock / 64) * C.lanes_per_wave;
         const dim3 grid(static_cast<unsigned>((N + lanes - 1) / lanes));
+#define GPD_STEP_HOT S.kin, action, S.step_counter, target_pos, static_cast<const int32_t*>(S.act_ring ? S.ring_pos : S.step_counter), \
+                     static_cast<uint32_t>(S.ld), C.num_envs, C.lanes_per_wave, C.target_per_env
         if (multi) {
-            hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, true, AW, ACT, false>), grid, dim3(kBlock), 0, st, P, S, C, action,
-                               target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+            hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, true, AW, ACT, false>), grid, dim3(kBlock), 0, st, GPD_STEP_HOT, P, S, C,
+                               init_pose, obs12, reward, terminated, truncated, term_obs12);
         } else if (C.substeps == 1) {
-            hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, false, AW, ACT, true>), grid, dim3(kBlock), 0, st, P, S, C, action,
-                               target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+            hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, false, AW, ACT, true>), grid, dim3(kBlock), 0, st, GPD_STEP_HOT, P, S, C,
+                               init_pose, obs12, reward, terminated, truncated, term_obs12);
         } else {
-            hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, false, AW, ACT, false>), grid, dim3(kBlock), 0, st, P, S, C, action,
-                               target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+            hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, false, AW, ACT, false>), grid, dim3(kBlock), 0, st, GPD_STEP_HOT, P, S, C,
+                               init_pose, obs12, reward, terminated, truncated, term_obs12);
         }
+#undef GPD_STEP_HOT
     } else {
         const int lanes = multi ? (kBlock / C.drones_per_env) * C.drones_per_env : kBlock;
         const dim3 grid(static_cast<unsigned>((N + lanes - 1) / lanes));
@@ -3597,7 +3636,8 @@ int gpd_swarm_forces(const GpdParams* params, const GpdSwarm* w, int32_t build_l
     const bool lists = w->pair_list != nullptr;
     if (lists && (!w->pair_nb || !w->list_ok || w->list_cap < 4 || w->list_cap > 65535 || !(w->list_delta >= 0.0f)))
         return fail(GPD_EINVAL, "gpd_swarm_forces: pair_list needs pair_nb, list_ok, 4 <= list_cap <= 65535 and list_delta >= 0");
-    if (lists && w->n_rows > (1 << 26)) return fail(GPD_ERANGE, "gpd_swarm_forces: wake lists address 2^26 rows at most");
+    // (an entry is lane << 26 | index and 0xffffffff marks an empty lane: index 2^26 - 1 of lane 63 must not exist)
+    if (lists && w->n_rows >= (1 << 26)) return fail(GPD_ERANGE, "gpd_swarm_forces: wake lists address fewer than 2^26 rows");
     const DwGrid G{1.0f / w->cell, w->x0, w->y0, w->nx, w->ny, w->z0, w->nz > 1 ? 1.0f / w->zbin : 0.0f, w->nz};
     const float4* const p4 = reinterpret_cast<const float4*>(w->pos4);
     const DwWorld Wd{w->pos_sorted ? nullptr : p4, w->slot_key, p4, w->rank * w->slab, w->own_count, w->slab, w->world_size, w->meta_rows, w->cell,

@@ -198,6 +198,11 @@ class SimCore:
             rc = self.lib.gpd_reset(ctypes.byref(self._state), _ptr(self.init_pose), self.init_per_env, _ptr(mask),
                                     self.E, self.D, int(reset_pid), _ptr(self.obs12), self._stream())
         _native.check(rc, "gpd_reset")
+        if os.environ.get("GPD_EXP_KIN4") and mask is None:       # EXPERIMENT (scratch/exp_r05/ab_step.sh): a -DGPD_EXP_KIN4 library
+            k = self.kin.clone()
+            flat = self.kin.view(-1)
+            for j in range(3):
+                flat[4 * j * self.ld:4 * (j + 1) * self.ld] = k[4 * j:4 * j + 4].t().reshape(-1)
         return self.obs12
 
     def step(self, action: torch.Tensor):
@@ -288,6 +293,8 @@ class SimCore:
             self.reward.copy_(rew[K - 1])
             self.terminated.copy_(term[K - 1])
             self.truncated.copy_(trunc[K - 1])
+            if tobs is not None and self.auto_reset:      # term_obs12 = what K single steps would have left
+                self._latest_terminal(tobs, term, trunc, K)
         return obs, rew, term, trunc
 
     def rollout_policy(self, policy, num_steps: int, want_actions: bool = True, noise: torch.Tensor = None, action_std=None,
@@ -335,8 +342,8 @@ class SimCore:
                                              _ptr(acts), _ptr(obs), self.N * 12, _ptr(rew), _ptr(term), _ptr(trunc), self.E,
                                              _ptr(noise), std, _ptr(mean_out), _ptr(tobs), self._stream())
         _native.check(rc, "gpd_rollout_policy")
-        if tobs is not None:
-            self._latest_terminal(tobs, term, trunc, K)
+        if tobs is not None and self.auto_reset:       # (the kernel writes terminal rows only when it resets: K single steps of an
+            self._latest_terminal(tobs, term, trunc, K)   # aviary without auto-reset leave term_obs12 untouched, and so does this)
         self.obs12.copy_(obs[K - 1])
         self.reward.copy_(rew[K - 1])
         self.terminated.copy_(term[K - 1])

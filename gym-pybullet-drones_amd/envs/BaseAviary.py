@@ -11,11 +11,12 @@ handful of resulting floats back to numpy attributes with the reference's names 
 
 Deviations from the reference, on purpose:
   * `physics`: only the explicit integrator exists.  `Physics.DYN` is the reference's `Physics.DYN`.  `Physics.PYB*` (the
-    default!) runs the same integrator PLUS two models the reference's DYN does not have, standing in for Bullet: a ground
-    plane at z = 0 (`GPD_PHYS_GROUND`) and Bullet's default multibody damping 0.04 (`GPD_PHYS_DAMP`; restated from the Bullet
-    sources, parity unpinned -- include/gpd.h); `PYB_GND/DRAG/DW/GND_DRAG_DW` also enable those force models *inside* the
-    explicit integrator.  `utils.enums.set_pyb_like(False)` or `GPD_PYB_LIKE=0` removes the plane and the damping:
-    `Physics.PYB` is then exactly `Physics.DYN`.  A one-time `UserWarning` says all this when a PYB member is used.
+    default!) runs the same integrator PLUS a ground plane at z = 0 (`GPD_PHYS_GROUND`, a model the reference's DYN does not have,
+    standing in for Bullet's contact solver: the advertised observation space, z >= 0, needs it) -- above the plane a `PYB` run is
+    bit for bit the reference's DYN; `PYB_GND/DRAG/DW/GND_DRAG_DW` also enable those force models *inside* the explicit integrator.
+    Bullet's default multibody damping 0.04 (`GPD_PHYS_DAMP`; restated from the Bullet sources, parity unpinned -- include/gpd.h)
+    is OPT-IN: `utils.enums.set_pyb_like("damped")` or `GPD_PYB_LIKE=damped`.  `set_pyb_like(False)` / `GPD_PYB_LIKE=0` removes
+    the plane too: `Physics.PYB` is then exactly `Physics.DYN`.  A one-time `UserWarning` says all this when a PYB member is used.
   * arithmetic is float32 on the device (the reference is float64 numpy); attributes are float64
     numpy copies of the float32 results.
   * GUI, video recording, cameras, obstacles are not available (`gui=True`/`record=True` raise).

@@ -50,21 +50,27 @@ class Physics(Enum):
 
     @property
     def damping(self) -> bool:
-        """Whether Bullet's default damping acts (`GPD_PHYS_DAMP`): every `PYB*` run of the reference integrates the drone as a
-        Bullet multibody with linear and angular damping 0.04 (`p.loadURDF`, `BaseAviary.py:488-494`; the reference never calls
-        `changeDynamics`), `DYN` has none (`:831-877`)."""
+        """Whether Bullet's default damping CAN act (`GPD_PHYS_DAMP`, with `pyb_like="damped"`): every `PYB*` run of the reference
+        integrates the drone as a Bullet multibody with linear and angular damping 0.04 (`p.loadURDF`, `BaseAviary.py:488-494`; the
+        reference never calls `changeDynamics`), `DYN` has none (`:831-877`)."""
         return self != Physics.DYN
 
-    def mask(self, pyb_like: bool = None) -> int:
-        """The `GPD_PHYS_*` mask a kernel launch gets for this member: the add-on force models, plus -- for `PYB*`, unless
-        `pyb_like` is False -- the two stand-ins for what Bullet itself adds to such a run (ground plane, default damping).
-        `pyb_like=None` reads the process default (`set_pyb_like`, env `GPD_PYB_LIKE=0`): with False a `PYB_*` member means
-        exactly "the reference's explicit `Physics.DYN` integrator + the selected add-on models"."""
-        if pyb_like is None:
-            pyb_like = _pyb_like
+    def mask(self, pyb_like=None) -> int:
+        """The `GPD_PHYS_*` mask a kernel launch gets for this member: the add-on force models, plus -- for `PYB*` -- the stand-ins
+        for what Bullet itself adds to such a run:
+            pyb_like=False / "off"     nothing: exactly "the reference's explicit `Physics.DYN` integrator + the selected add-on models"
+            pyb_like=True / "ground"   the ground plane (`GPD_PHYS_GROUND`; the advertised observation space, z >= 0, needs it)
+            pyb_like="damped"          the ground plane AND Bullet's default multibody damping 0.04 (`GPD_PHYS_DAMP`)
+        `pyb_like=None` reads the process default (`set_pyb_like`, env `GPD_PYB_LIKE` = 0 | 1 | damped): "ground".  The damping is
+        OPT-IN since round 5: it is restated from the Bullet sources and pinned against nothing (tests/test_pybullet_optional.py
+        pins it the first time a box has PyBullet); above the plane a default `Physics.PYB*` run is therefore bit for bit the
+        reference's explicit integrator with the selected add-on models."""
+        mode = _pyb_mode(_pyb_like if pyb_like is None else pyb_like)
         m = self.flags
-        if pyb_like:
-            m |= (PHYS_GROUND if self.ground else 0) | (PHYS_DAMP if self.damping else 0)
+        if mode != "off" and self.ground:
+            m |= PHYS_GROUND
+        if mode == "damped" and self.damping:
+            m |= PHYS_DAMP
         return m
 
 
@@ -116,15 +122,21 @@ def warn_if_pyb(physics) -> None:
         return
     _warned_pyb = True
     import warnings
+    mode = _pyb_mode(_pyb_like)
+    extra = {"off": ".  Trajectories follow the reference's Physics.DYN (pyb_like is off: no ground plane, no damping).",
+             "ground": ".  On top of it this package adds a ground plane at z = 0 (GPD_PHYS_GROUND; a model the reference's Physics.DYN does "
+                       "NOT have, standing in for Bullet's contact solver): above the plane trajectories follow the reference's Physics.DYN "
+                       "exactly.  Bullet's default multibody damping of 0.04 (GPD_PHYS_DAMP; restated from the Bullet sources, parity "
+                       "unpinned) is opt-in: set_pyb_like('damped') / GPD_PYB_LIKE=damped / pyb_like='damped'.  set_pyb_like(False) / "
+                       "GPD_PYB_LIKE=0 / pyb_like=False remove the plane too.",
+             "damped": ".  On top of it this package adds two models the reference's Physics.DYN does NOT have, standing in for what Bullet "
+                       "does in Physics.PYB*: a ground plane at z = 0 (GPD_PHYS_GROUND) and Bullet's default multibody damping of 0.04 "
+                       "(GPD_PHYS_DAMP; restated from the Bullet sources, parity unpinned).  set_pyb_like(False) / GPD_PYB_LIKE=0 / "
+                       "pyb_like=False turn both off: trajectories then follow the reference's Physics.DYN exactly."}[mode]
     warnings.warn(f"Physics.{physics.name} was requested, but PyBullet's integrator does not exist in this package: the "
                   f"explicit Physics.DYN integrator (envs/BaseAviary.py:815-877 of the reference) is used instead"
                   + (", with the " + "/".join(n for b, n in ((1, "ground-effect"), (2, "drag"), (4, "downwash")) if physics.flags & b)
-                     + " model(s) evaluated inside it" if physics.flags else "")
-                  + (".  On top of it this package adds two models the reference's Physics.DYN does NOT have, standing in for what Bullet "
-                     "does in Physics.PYB*: a ground plane at z = 0 (GPD_PHYS_GROUND) and Bullet's default multibody damping of 0.04 "
-                     "(GPD_PHYS_DAMP; restated from the Bullet sources, parity unpinned).  set_pyb_like(False) / GPD_PYB_LIKE=0 / "
-                     "pyb_like=False turn both off: trajectories then follow the reference's Physics.DYN exactly."
-                     if _pyb_like else ".  Trajectories follow the reference's Physics.DYN (pyb_like is off: no ground plane, no damping)."),
+                     + " model(s) evaluated inside it" if physics.flags else "") + extra,
                   UserWarning, stacklevel=3)
 
 
@@ -132,16 +144,34 @@ def warn_if_pyb(physics) -> None:
 PHYS_GND, PHYS_DRAG, PHYS_DW, PHYS_GROUND, PHYS_DAMP = 1, 2, 4, 8, 16
 
 import os as _os
-_pyb_like = _os.environ.get("GPD_PYB_LIKE", "1") not in ("0", "false", "False", "")
 
 
-def set_pyb_like(on: bool) -> None:
-    """Process-wide default of `Physics.mask()`: whether `Physics.PYB*` adds the ground plane and Bullet's default damping
-    (both extensions with no counterpart in the reference's explicit integrator, include/gpd.h) to the explicit integrator.
-    The drop-in classes keep the reference's constructor signatures, so this switch (or `GPD_PYB_LIKE=0`) is their opt-out;
-    the batched classes also take `pyb_like=` per instance."""
+def _pyb_mode(v) -> str:
+    """False / 0 / "off" -> "off";  True / 1 / "ground" -> "ground";  "damped" (or 2) -> "damped" """
+    if isinstance(v, str):
+        t = v.strip().lower()
+        if t in ("0", "false", "off", "no", ""):
+            return "off"
+        if t in ("damped", "damp", "2", "bullet"):
+            return "damped"
+        return "ground"
+    if v is None:
+        return "ground"
+    if isinstance(v, bool):
+        return "ground" if v else "off"
+    return {0: "off", 1: "ground"}.get(int(v), "damped")
+
+
+_pyb_like = _pyb_mode(_os.environ.get("GPD_PYB_LIKE", "1"))
+
+
+def set_pyb_like(on) -> None:
+    """Process-wide default of `Physics.mask()`: what `Physics.PYB*` adds to the explicit integrator -- False: nothing; True (the
+    default): the ground plane; "damped": the plane and Bullet's default damping (both extensions with no counterpart in the
+    reference's explicit integrator, include/gpd.h).  The drop-in classes keep the reference's constructor signatures, so this
+    switch (or `GPD_PYB_LIKE=0|1|damped`) is their knob; the batched classes also take `pyb_like=` per instance."""
     global _pyb_like
-    _pyb_like = bool(on)
+    _pyb_like = _pyb_mode(on)
 #: raw-RPM action clipped to [0, MAX_RPM] (CtrlAviary, `CtrlAviary.py:140`); kernel-only code
 ACT_RAW_RPM = 5
 #: RPMs taken as they are (output of a user subclass's own `_preprocessAction`); kernel-only code

@@ -73,8 +73,10 @@ enum {
  * changes them) and acts on the base as the forces  -M v d (1 + |v|)  and  -J w d (1 + |w|)  (Bullet 3.2.x,
  * src/BulletDynamics/Featherstone/btMultiBody.cpp, computeAccelerationsArticulatedBodyAlgorithmMultiDof, "adding damping
  * terms (only)", DAMPING_K1 = DAMPING_K2 = the coefficient; third-party source, not under the reference checkout: parity
- * unpinned).  Evaluated on the velocities at the start of the sub-step, like drag.  The Python classes enable it together with
- * GPD_PHYS_GROUND for Physics.PYB* (`pyb_like=False` opts out of both: the reference's explicit integrator + the add-on models). */
+ * unpinned).  Evaluated on the velocities at the start of the sub-step, like drag.  OPT-IN on the Python side (round 5): Physics.PYB*
+ * enables GPD_PHYS_GROUND by default and GPD_PHYS_DAMP only with `pyb_like="damped"` / GPD_PYB_LIKE=damped, until
+ * tests/test_pybullet_optional.py has pinned it on a box with PyBullet (`pyb_like=False` opts out of the plane too: the reference's
+ * explicit integrator + the add-on models). */
 enum { GPD_PHYS_GND = 1, GPD_PHYS_DRAG = 2, GPD_PHYS_DW = 4, GPD_PHYS_GROUND = 8, GPD_PHYS_DAMP = 16 };
 #define GPD_BULLET_DAMPING 0.04f
 

@@ -74,6 +74,36 @@ def test_config3_stacks_of_8_all_force_terms(gpu_device):
     np.testing.assert_allclose(core.reward.cpu().numpy(), orc.reward, rtol=1e-3, atol=1e-3)
 
 
+def test_config3_conditioned_stacks_meet_the_plain_tolerance_over_256_steps(gpu_device):
+    """BASELINE config 3 (ii) at full size -- 8192 aviaries x 8 stacked drones, GND|DRAG|DW -- over the bench's 256-step horizon against
+    the PLAIN 1e-4 tolerance (VERDICT r04 "next" #5), on a scene the downwash model is well-conditioned on for that long: the drones
+    0.3 m apart in height on a staircase of 0.2 m per drone (|dxy| = 3.2 |beta|, beta = DW2 * 0.3 + DW3 = -0.062 m: every drone sits
+    on the far shoulder of its upper neighbour's wake, exp(-5.2) of its peak), tilts of +-0.01 rad, per-rotor RPM noise of +-0.1 %
+    (the bench's +-5 % tumbles a drone past 0.4 rad within the second and sends it through its neighbours' wakes: that horizon is
+    held against the float64 envelope instead, next test).  No task: a stack of eight 0.3 m apart is 2.2 m tall, above the
+    MultiHover ceiling.  Two float64 runs of this scene, one nudged by half an fp32 ulp per step, stay within 2.4e-5 of each other
+    in their worst aviary (median 3.8e-6): what is left for the fp32 path is its own rounding."""
+    E, D, S = 8192, 8, 1
+    rng = np.random.default_rng(8)
+    xyz = rng.uniform(-0.02, 0.02, size=(E, D, 3)) + np.arange(D)[None, :, None] * np.array([0.2, 0.0, 0.3]) + np.array([0, 0, 0.1])
+    rpy = rng.uniform(-0.01, 0.01, size=(E, D, 3))
+    orc = CAviary(urdf("cf2x"), "cf2x", E, D, initial_xyzs=xyz, initial_rpys=rpy, physics_flags=7, pyb_freq=240,
+                  ctrl_freq=240, act="rpm", task="none")
+    core = _core("cf2x", E, D, 7, S, "rpm", "none", xyz, rpy, gpu_device)
+    _sync_c(core, orc)
+    _all_threads()
+    acts = (0.02 * rng.uniform(-1, 1, size=(256, E, D, 4))).astype(np.float32)
+    errs = _run(core, orc, acts, gpu_device, {1, 64, 128, 256})
+    for t, e in sorted(errs.items()):
+        print(f"t={t:5d} " + " ".join(f"{g}={v:.2e}" for g, v in e.items()))
+        assert max(e.values()) < 1e-4, (t, e)
+    # the downwash term is active on this scene: the second drone from the top feels its neighbour (a few percent of its weight)
+    N = E * D
+    z = core.kin[2, :N].view(E, D).cpu().numpy()
+    free = 0.1 + 0.3 * np.arange(D)
+    assert np.abs(z - free).max() > 1e-3
+
+
 @pytest.mark.parametrize("workload", ["stack8x8192_ext_240hz", "stack8x8192_ext_pid_240hz"])
 def test_stack8_downwash_stays_inside_the_float64_envelope(gpu_device, workload):
     """The bench's OWN stack8 workload -- its scene, its random +-5 % RPM (or DSLPID waypoint) blocks, same-step auto-reset, its
@@ -96,7 +126,11 @@ def test_stack8_downwash_stays_inside_the_float64_envelope(gpu_device, workload)
         print("t=%3d %-5s median fp32 %.2e envelope %.2e | p95 fp32 %.2e envelope %.2e | max fp32 %.2e envelope %.2e | %d aviaries" % tuple(r))
     print({k: res[k] for k in ("max", "flag_mismatch_frac", "ok", "ok_by", "episodes_ended_in_window")}, "ratio", e["ratio"], e["worst"])
     assert res["checked_steps"] == 256 and len(e["rows"]) >= 4 * 16
-    assert e["ratio"] <= 4.0 and e["ok"] and res["ok"], e["worst"]
+    assert e["ratio"] <= 4.0 and e["ok"] and res["ok_envelope"], e["worst"]
+    # `ok` is the plain tolerance's verdict and nothing else; the line also says how many aviaries are inside it on their
+    # own, and how close the worst one's drones came to each other in height
+    assert res["ok"] == (res["max"] < 1e-4) and res["frac_aviaries_within_tolerance"] >= 0.97, res["frac_aviaries_within_tolerance"]
+    print("aviaries inside 1e-4:", res["frac_aviaries_within_tolerance"], res.get("worst_aviary"))
     # the first steps are plain rounding on both sides ...
     first = [r for r in e["rows"] if r[0] == 1]
     assert all(r[4] < 2e-6 for r in first), first

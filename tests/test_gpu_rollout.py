@@ -86,6 +86,9 @@ def test_rollout_is_bitwise_k_steps(gpu_device, act, flags, D, S, model, E, K, k
     for k in range(K):
         m = done[k].repeat_interleave(D)
         assert torch.equal(tob[k][m], tobs_s[k][m])
+    # ... and the persistent term_obs12 afterwards is what the K single steps left (the plain rollout did not update it)
+    if a.auto_reset:
+        assert torch.equal(a.term_obs12, b.term_obs12)
 
 
 def _scramble_arguments(rng, *cores):

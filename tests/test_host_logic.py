@@ -68,10 +68,22 @@ def test_enums_are_value_compatible():
     assert [m.value for m in ObservationType] == ["kin", "rgb"]
     assert [a.dim for a in ActionType] == [4, 3, 4, 1, 1]
     assert Physics.PYB_GND_DRAG_DW.flags == 7 and Physics.DYN.flags == 0
-    # PYB* = the add-on models + the two stand-ins for what Bullet adds to such a run (ground plane 8, default damping 16);
+    # PYB* = the add-on models + the ground plane (8); Bullet's default damping (16; restated, unpinned) is opt-in since round 5;
     # pyb_like=False: exactly the reference's explicit integrator + the add-on models
-    assert Physics.PYB.mask(True) == 24 and Physics.PYB_GND_DRAG_DW.mask(True) == 31 and Physics.DYN.mask(True) == 0
+    assert Physics.PYB.mask(True) == 8 and Physics.PYB_GND_DRAG_DW.mask(True) == 15 and Physics.DYN.mask(True) == 0
+    assert Physics.PYB.mask("damped") == 24 and Physics.PYB_GND_DRAG_DW.mask("damped") == 31 and Physics.DYN.mask("damped") == 0
     assert Physics.PYB.mask(False) == 0 and Physics.PYB_DW.mask(False) == 4
+    from gym_pybullet_drones_amd.utils import enums
+    assert enums._pyb_mode("0") == "off" and enums._pyb_mode("1") == "ground" and enums._pyb_mode("damped") == "damped"
+    assert Physics.PYB.mask() == {"off": 0, "ground": 8, "damped": 24}[enums._pyb_like]      # (the process default: GPD_PYB_LIKE)
+    keep = enums._pyb_like
+    try:
+        enums.set_pyb_like("damped")
+        assert Physics.PYB.mask() == 24
+        enums.set_pyb_like(False)
+        assert Physics.PYB_GND.mask() == 1
+    finally:
+        enums.set_pyb_like(keep)
 
 
 def test_trunc_counter_is_the_float64_threshold():
