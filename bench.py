@@ -1130,7 +1130,7 @@ def hbm_leg(args, job, out):
         roof = r["roofline"]
         prof = rocprof_record("hover4m_240hz:rollout64")
         out["hbm_saturating"] = {
-            "workload": "hover4m_240hz", "drones_per_gpu": 4194304, "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+            "workload": "hover4m_240hz", "drones_per_gpu": r["config"]["envs_per_gpu"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
             "timed_steps": r["timed_steps"], "timed_region_ms": r["timed_region_ms"], "kernel": roof["kernel"],
             "env_steps_per_launch": roof["env_steps_per_launch"], "launch_us_hip_events": roof["launch_us_hip_events"],
             "bytes_per_launch": roof["bytes_per_launch"], "achieved": roof["achieved"], "peak": roof["peak"], "unit_bw": "GB/s",
@@ -1209,6 +1209,8 @@ def run_suite(args, job, out):
                 r = run_workload(a, job)
             except Exception as e:          # noqa: BLE001 -- reported; the headline survives
                 r = {"error": f"{type(e).__name__}: {e}"[:300]}
+            if os.environ.get("GPD_BENCH_INJECT_HANG") == "suite":       # (test hook: a collective that never returns -- the watchdog's case)
+                time.sleep(3600)
             ok = gdist.all_ranks_ok(r is None or "error" not in r, device=job.device)
             if job.rank == 0:
                 if "error" in r or not ok:
@@ -1230,11 +1232,26 @@ def run_suite(args, job, out):
         dog.done()
 
 
+def rehearsal_scale(w):
+    """GPD_BENCH_E_DIV=k (a REHEARSAL hook, e.g. eight ranks sharing one device in tests/test_gpu_multirank.py): every workload runs
+    with 1/k of its aviaries (or, one world: of its drones).  The line then says so (`config.rehearsal_divisor`) and its `value`
+    is not a measurement of the named configuration."""
+    k = int(os.environ.get("GPD_BENCH_E_DIV", "1") or 1)
+    if k <= 1:
+        return w, 1
+    w = dict(w)
+    if w.get("swarm"):
+        w["D"] = max(4096, w["D"] // k)
+    else:
+        w["E"] = max(256, w["E"] // k)
+    return w, k
+
+
 def run_workload(args, job):
     """Measure ONE workload on every rank of the job; rank 0 gets the JSON object, the others None."""
     from gym_pybullet_drones_amd import dist as gdist
     backend, rank, world, device = job.backend, job.rank, job.world, job.device
-    w = WORKLOADS[args.workload]
+    w, rehearsal_div = rehearsal_scale(WORKLOADS[args.workload])
     want_gather = bool(args.allgather or w.get("allgather"))
     POOL = 64      # env steps per rollout launch / per captured hipGraph
     if w.get("swarm") and args.mode == "rollout":
@@ -1364,6 +1381,7 @@ def run_workload(args, job):
             "repeats": m["repeats"], "timed_steps": m["timed_steps"], "timed_region_ms": m["ev_s"] * 1e3,
             "wall_ms_per_step": m["wall_s"] * 1e3 / m["timed_steps"], "value_wall": m["value_wall"],
             "config": {"workload": args.workload, "envs_per_gpu": w["E"], "drones_per_env": D,
+                       **({"rehearsal_divisor": rehearsal_div, "rehearsal_note": "GPD_BENCH_E_DIV: NOT the named configuration's size"} if rehearsal_div > 1 else {}),
                        "total_drones": n_total, "physics": "DYN" + "".join(n for b, n in ((1, "+GND"), (2, "+DRAG"), (4, "+DW"), (8, "+GROUND_PLANE"), (16, "+BULLET_DAMPING")) if core.physics_flags & b),
                        "physics_flags": core.physics_flags,
                        "pyb_freq": 240, "ctrl_freq": w["ctrl"], "substeps_per_step": S, "action": w["act"],

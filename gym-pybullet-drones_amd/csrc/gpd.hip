@@ -828,7 +828,7 @@ __device__ __forceinline__ float4 load_action(const float* __restrict__ action, 
 // target, (rollout: reset pose).  Branch-free on purpose: every load is issued back to back and ONE wait
 // covers them all (a load inside a branch makes the compiler wait for it -- a full memory round trip --
 // before the next one is even issued).  Lanes without a drone read drone 0's rows.
-template <bool PID, bool EXT>
+template <bool PID, bool EXT, bool IP = true>     // IP: also fetch the reset pose (rollouts; a single step reads it only when it resets)
 __device__ __forceinline__ void load_carry(const GpdState& S, const GpdStepCfg& C, const uint32_t flags, const Lane& L,
                                            const float* __restrict__ target_pos, const float* __restrict__ ipl,
                                            Carry& c, float& tgx, float& tgy, float& tgz, float ip[7]) {
@@ -838,9 +838,9 @@ __device__ __forceinline__ void load_carry(const GpdState& S, const GpdStepCfg& 
 #ifdef GPD_EXP_KIN4
     {   // experiment: rows 0-3 | 4-7 | 8-11 interleaved as three float4 planes, row 12 as it is (the same 13 x ld floats)
         const uint32_t off16 = L.n * 16u;
-        const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.kin) + off16);
-        const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.kin + 4 * ld) + off16);
-        const float4 d = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.kin + 8 * ld) + off16);
+        const f4v a = *reinterpret_cast<const f4v*>(reinterpret_cast<const char*>(S.kin) + off16);
+        const f4v b = *reinterpret_cast<const f4v*>(reinterpret_cast<const char*>(S.kin + 4 * ld) + off16);
+        const f4v d = *reinterpret_cast<const f4v*>(reinterpret_cast<const char*>(S.kin + 8 * ld) + off16);
         k.px = a.x; k.py = a.y; k.pz = a.z; k.qx = a.w; k.qy = b.x; k.qz = b.y; k.qw = b.z; k.vx = b.w;
         k.vy = d.x; k.vz = d.y; k.wx = d.z; k.wy = d.w; k.wz = ld_row(S.kin, ld, 12, off4);
     }
@@ -876,7 +876,7 @@ __device__ __forceinline__ void load_carry(const GpdState& S, const GpdStepCfg& 
         const float v = ld_row(ext_dw ? S.dw_force : S.kin, ld, 0, off4);      // (unused case: a cached kin row)
         c.dw_in = ext_dw ? v : 0.0f;
     }
-    ip[0] = ipl[0]; ip[1] = ipl[1]; ip[2] = ipl[2]; ip[3] = ipl[3]; ip[4] = ipl[4]; ip[5] = ipl[5]; ip[6] = ipl[6];
+    if (IP) { ip[0] = ipl[0]; ip[1] = ipl[1]; ip[2] = ipl[2]; ip[3] = ipl[3]; ip[4] = ipl[4]; ip[5] = ipl[5]; ip[6] = ipl[6]; }
 }
 
 template <bool PID, bool NT = false>
@@ -898,7 +898,12 @@ __device__ __forceinline__ void store_carry(const GpdState& S, const Lane& L, co
 #ifdef GPD_EXP_KIN4
     {
         const uint32_t off16 = L.n * 16u;
-        const f4v a = {k.px, k.py, k.pz, k.qx}, b = {k.qy, k.qz, k.qw, k.vx}, d = {k.vy, k.vz, k.wx, k.wy};
+        // (opaque copies: without them the twelve field reads are combined into vector loads of the Carry struct, which then stays
+        // an alloca -- promoted to LDS, indexed by a flat thread id computed from the DISPATCH PACKET, a read of host memory per wave:
+        // 4.0 -> 14.6 us per step at 65 536 drones, gpurun_out/ab_step_r05.log)
+        float e0 = k.px, e1 = k.py, e2 = k.pz, e3 = k.qx, e4 = k.qy, e5 = k.qz, e6 = k.qw, e7 = k.vx, e8 = k.vy, e9 = k.vz, e10 = k.wx, e11 = k.wy;
+        asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5), "+v"(e6), "+v"(e7), "+v"(e8), "+v"(e9), "+v"(e10), "+v"(e11));
+        const f4v a = {e0, e1, e2, e3}, b = {e4, e5, e6, e7}, d = {e8, e9, e10, e11};
         f4v* pa = reinterpret_cast<f4v*>(reinterpret_cast<char*>(S.kin) + off16);
         f4v* pb = reinterpret_cast<f4v*>(reinterpret_cast<char*>(S.kin + 4 * ld) + off16);
         f4v* pd = reinterpret_cast<f4v*>(reinterpret_cast<char*>(S.kin + 8 * ld) + off16);
@@ -972,16 +977,16 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
 
     const uint32_t flags = EXT ? C.physics_flags : 0u;
     Carry c;
-    float tgx, tgy, tgz, ip[7];
+    float tgx, tgy, tgz;
     const float4 act = load_action<AW>(action, L.n);
     // action history: the slot this aviary's action goes to (read with the other loads, from a readable dummy when there is
     // no ring: the load section stays branch-free)
     int ring_q = hot_slot[L.env];
     if (S.act_ring) { GPD_DBG(ring_q >= 0 && ring_q < S.hist_len, GPD_DBG_RING_POS, ring_q); ring_q = GPD_DBG_CLAMP(ring_q, 0, S.hist_len - 1); }
-    // a single step reads its reset pose only if it resets (in env_step); the slots `ip` are filled from a cached row
+    // a single step reads its reset pose only if it resets (in env_step)
     const float* ipose = reinterpret_cast<const float*>(reinterpret_cast<const char*>(init_pose) +
                                                         (C.init_per_env ? L.n * 28u : static_cast<uint32_t>(L.d) * 28u));
-    load_carry<PID, EXT>(S, C, flags, L, target_pos, S.kin, c, tgx, tgy, tgz, ip);
+    load_carry<PID, EXT, false>(S, C, flags, L, target_pos, nullptr, c, tgx, tgy, tgz, nullptr);
     // An aviary that spans several waves of the workgroup (D not a power of two <= 64): its lane 0 publishes ring_pos + 1 at
     // the end of this kernel, and with no task and no downwash nothing else synchronises the waves -- every wave must have
     // READ ring_pos before any of them gets there (the barrier also waits for the loads above: vmcnt(0))
@@ -990,8 +995,8 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     if (PID) quat_to_rpy(c.k.qx, c.k.qy, c.k.qz, c.k.qw, c.roll, c.pitch, c.yaw);
 
     StepOut out;
-    env_step<PID, EXT, MULTI, AW, ACT, S1>(P, C, flags, D, L, act, tgx, tgy, tgz, false, ipose, ip[0], ip[1], ip[2], ip[3], ip[4],
-                                           ip[5], ip[6], sh_pos, sh_red, c, out);
+    env_step<PID, EXT, MULTI, AW, ACT, S1>(P, C, flags, D, L, act, tgx, tgy, tgz, false, ipose, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
+                                           0.0f, 0.0f, sh_pos, sh_red, c, out);
     // Observation rows.  A lane's row is 48 bytes, so a wave's direct stores are 48-byte-strided pieces of cache
     // lines; in the bandwidth-bound regime (large batches) the wave transposes its 64 rows through LDS and
     // stores three fully coalesced 1 KiB bursts instead (the rows of a wave are contiguous in memory); narrower waves
@@ -1055,8 +1060,12 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
                     out.to[8], out.to[9], out.to[10], out.to[11]);
     // the state block: kept in the 256 MB Infinity Cache between steps while it fits (4.2M drones = 218 MB), streamed
     // through non-temporally beyond (measured: 4M 125 vs 130 us cached, 16.7M 499 vs 513..558 us streamed)
+#ifdef GPD_EXP_NTSTATE
+    store_carry<PID, true>(S, L, c);
+#else
     if (N > (1u << 22)) store_carry<PID, true>(S, L, c);
     else store_carry<PID, false>(S, L, c);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -26,11 +26,11 @@ def _bench(args, world, port, timeout=900):
     return json.loads(lines[0])
 
 
-def _bench_self(args, timeout=1200):
-    """`python bench.py --gpus 2 ...` the way the driver types it -- NO torch.distributed.run around it."""
+def _bench_self(args, timeout=1200, gpus=2, **extra_env):
+    """`python bench.py --gpus N ...` the way the driver types it -- NO torch.distributed.run around it."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(GPD_DIST_BACKEND="gloo", GPD_BENCH_SINGLE_DEVICE="1")
-    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"] + args, cwd=REPO, env=env, capture_output=True,
+    env.update(GPD_DIST_BACKEND="gloo", GPD_BENCH_SINGLE_DEVICE="1", **extra_env)
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(gpus)] + args, cwd=REPO, env=env, capture_output=True,
                          text=True, timeout=timeout)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
@@ -62,6 +62,37 @@ def test_bench_gpus_2_default_run_carries_the_suite_and_the_hbm_leg(gpu_device):
     assert mh["config"]["total_drones"] == 2 * 2 * 16384 and mh["value"] > 1e8
     sw = su["swarm1m_ext_240hz"]
     assert sw["scaling"] == "strong" and sw["config"]["swarm"]["ranks"] == 2 and sw["config"]["total_drones"] == 1048576
+
+
+def test_bench_gpus_8_rehearsal_of_the_driver_command(gpu_device):
+    """The command the driver's SCALE run types at N = 8 -- `python bench.py --gpus 8 --steps K --warmup W`, no launcher around it --
+    rehearsed end to end on ONE device: eight self-launched ranks (gloo rendezvous, every rank on device 0, 1/8 of every workload's
+    aviaries: `GPD_BENCH_E_DIV=8`).  What is shown is plumbing, not performance (VERDICT r04 "next" #4; no 8-GPU node is available to
+    this build: no hardware scaling curve exists): eight per-GPU values, eight ranks in the process group, the HBM leg, and the suite
+    with BASELINE config 4 (with AND without the all-gather), config 5 and the shared one-world workload split over eight ranks."""
+    j = _bench_self(["--steps", "20", "--warmup", "5", "--min-time", "0.02", "--hbm-leg-time", "0.05", "--no-cpu-baseline", "--suite-timeout", "900"],
+                    timeout=2400, gpus=8, GPD_BENCH_E_DIV="8")
+    assert j["n_gpus"] == 8 and len(j["per_gpu"]["values"]) == 8 and j["config"]["ranks_in_process_group"] == 8
+    assert j["config"]["rehearsal_divisor"] == 8 and j["config"]["total_drones"] == 8 * 8192 and "self-launch" in j["config"]["launcher"]
+    assert j["scaling"] == "weak" and j["value"] <= sum(j["per_gpu"]["values"]) * 1.0001 and "error" not in j["hbm_saturating"]
+    su = j["suite"]
+    assert "error" not in su and not [n for n, r in su.items() if "error" in r], su
+    ag = su["hover65536x8_allgather"]
+    assert ag["n_gpus"] == 8 and ag["config"]["obs_allgather"] is True and ag["without_allgather"]["value"] > 0 and len(ag["per_gpu"]["values"]) == 8
+    assert su["multihover2x16384x8"]["n_gpus"] == 8 and su["multihover2x16384x8"]["config"]["total_drones"] == 8 * 2 * 2048
+    sw = su["swarm1m_ext_240hz"]
+    assert sw["scaling"] == "strong" and sw["config"]["swarm"]["ranks"] == 8 and sw["config"]["swarm"]["exchange"] == "halo"
+    assert sw["config"]["swarm"]["halo_margin_check"] == "ok"
+
+
+def test_bench_watchdog_prints_the_headline_when_the_suite_hangs(gpu_device):
+    """A collective of a workload that has never met the node hangs: injected (`GPD_BENCH_INJECT_HANG=suite`: every rank sleeps inside
+    the suite).  The watchdog prints the headline line it holds, with the suite's entry saying what happened, and every rank leaves:
+    return code 0, ONE JSON line."""
+    j = _bench_self(["--steps", "20", "--warmup", "5", "--min-time", "0.02", "--no-cpu-baseline", "--no-hbm-leg", "--suite-timeout", "25"],
+                    timeout=900, gpus=4, GPD_BENCH_E_DIV="8", GPD_BENCH_INJECT_HANG="suite")
+    assert j["n_gpus"] == 4 and j["value"] > 0 and len(j["per_gpu"]["values"]) == 4
+    assert "not finished after 25 s" in j["suite"]["error"]
 
 
 def test_bench_two_ranks_with_obs_allgather(gpu_device):
@@ -184,3 +215,45 @@ def test_two_processes_share_one_swarm_world_bitwise(gpu_device, tmp_path, halo)
         assert (int(d["sent"]) > 0) == halo
         seen[d["ids"]] = True
     assert seen.all() and np.abs(f1).max() > 1e-3
+
+
+def test_native_p2p_group_one_rank_self_send_and_inside_a_graph(gpu_device):
+    """`gpd_p2p_group` (the halo exchange's transport: ncclSend / ncclRecv of RCCL inside one group) on the REAL library with the
+    one-rank communicator a single GPU allows: the rank sends two blocks of different sizes to itself and receives them into two
+    other buffers -- eagerly, and captured in a hipGraph behind the kernel that produces the blocks (what a captured sub-step of a
+    shared world replays).  The multi-rank form of the same call runs against the stub in tests/test_host_logic.py; RCCL with more
+    than one rank has never run (no multi-GPU node was available to this build)."""
+    import ctypes
+    from gym_pybullet_drones_amd import _native
+    from gym_pybullet_drones_amd import dist as gdist
+    nc = gdist.NativeComm.shared(device=gpu_device)
+    assert nc.world == 1 and nc.ranks_seen == 1
+    a = torch.arange(1000, dtype=torch.float32, device=gpu_device)
+    b = torch.arange(37, dtype=torch.float32, device=gpu_device) * -2.0
+    ra, rb = torch.zeros_like(a), torch.zeros_like(b)
+    mk = lambda ops: (_native.GpdP2P * len(ops))(*[_native.GpdP2P(peer=0, ptr=t.data_ptr(), count=t.numel()) for t in ops])  # noqa: E731
+    S, R = mk([a, b]), mk([ra, rb])
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream(gpu_device).cuda_stream)  # noqa: E731
+    with torch.cuda.device(gpu_device):
+        _native.check(nc.lib.gpd_p2p_group(nc.comm, S, 2, R, 2, st()), "gpd_p2p_group")
+    torch.cuda.synchronize()
+    assert torch.equal(ra, a) and torch.equal(rb, b)
+    # captured: producer kernel + the grouped exchange, replayed with new contents
+    stream = torch.cuda.Stream(gpu_device)
+    stream.wait_stream(torch.cuda.current_stream(gpu_device))
+    with torch.cuda.stream(stream):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            a.mul_(3.0)
+            b.add_(1.0)
+            with torch.cuda.device(gpu_device):
+                _native.check(nc.lib.gpd_p2p_group(nc.comm, S, 2, R, 2, ctypes.c_void_p(stream.cuda_stream)), "gpd_p2p_group (captured)")
+    torch.cuda.current_stream(gpu_device).wait_stream(stream)
+    ra.zero_(); rb.zero_()
+    a0, b0 = a.clone(), b.clone()
+    g.replay()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(a, a0 * 9.0) and torch.equal(ra, a) and torch.equal(rb, b0 + 2.0)
+    # argument errors come back as codes
+    assert nc.lib.gpd_p2p_group(nc.comm, None, 1, R, 2, st()) == _native.GPD_EINVAL

@@ -217,16 +217,14 @@ def test_default_physics_in_free_flight_is_the_reference_dyn_bit_for_bit(gpu_dev
     o2, _ = dyn.reset(seed=0)
     o3, _ = damped.reset(seed=0)
     differs = False
-    for k in range(90):                          # 3 s at 30 Hz: climbing and drifting, never near the plane
-        a = (0.4 + 0.6 * rng.uniform(-1, 1, size=(1, 4))).astype(np.float32)
+    for k in range(60):                          # 2 s at 30 Hz: climbing (+2.5 % RPM) and drifting a little, never near the plane
+        a = (0.5 + 0.03 * rng.uniform(-1, 1, size=(1, 4))).astype(np.float32)
         o1, r1, te1, tr1, _ = pyb.step(a)
         o2, r2, te2, tr2, _ = dyn.step(a)
         o3, *_ = damped.step(a)
         assert np.array_equal(o1, o2) and r1 == r2 and (te1, tr1) == (te2, tr2), k
         differs = differs or not np.array_equal(o1, o3)
-        if tr1:
-            break
-    assert pyb.pos[0, 2] > 0.2 and differs
+    assert pyb.pos[0, 2] > 0.5 and differs
     # the batched classes take the same switch per instance
     v = VectorHoverAviary(4, physics=Physics.PYB, pyb_like="damped", device=gpu_device)
     assert v.core.physics_flags == 24 and VectorHoverAviary(4, physics=Physics.PYB, device=gpu_device).core.physics_flags == 8
