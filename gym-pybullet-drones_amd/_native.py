@@ -14,18 +14,23 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(CSRC, "libgpd.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
-# Two translation units (csrc/gpd.hip, csrc/gpd_policy.hip = the same source with GPD_POLICY_TU defined), one library:
-#   -mllvm -amdgpu-sched-strategy=max-ilp for the step / rollout kernels: it interleaves independent dependency chains, which
-#   fills the one-wait-state hazard behind every packed-fp32 result with useful work instead of s_nops (13 of 287 issue slots
-#   of a rollout step); the policy kernel (MFMA + activations) is 10 % faster with the default scheduler (round-2 A/B).
-COMMON_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC"]
-HIPCC_FLAGS = COMMON_FLAGS + ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-shared"]        # gpd.hip (kept under this name for the ISA tests)
+# Four translation units over csrc/gpd_common.inc (the shared physics), one library:
+#   step_rollout.hip  gpd_step / gpd_rollout*            -mllvm -amdgpu-sched-strategy=max-ilp: interleaves independent dependency chains, which
+#                     fills the one-wait-state hazard behind every packed-fp32 result with useful work instead of s_nops (13 of 287 issue
+#                     slots of a rollout step)
+#   policy.hip        gpd_rollout_policy                 the default scheduler: 10 % faster on its MFMA + activation mix (round-2 A/B)
+#   swarm.hip         the one-world kernels              max-ilp, as in rounds 2-4
+#   abi.hip           small kernels, RCCL, library-level entries
 #   -mllvm -amdgpu-kernarg-preload-count=14: the first 14 argument dwords of a kernel arrive in SGPRs with the wave (gfx942+ command
 #   processor) instead of through a scalar load -- gpd_step_kernel's argument list starts with what its load section needs
+COMMON_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC"]
+MAX_ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 KERNARG_PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=14"]
-UNITS = (("gpd.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] + KERNARG_PRELOAD), ("gpd_policy.hip", []))
+HIPCC_FLAGS = COMMON_FLAGS + MAX_ILP + ["-shared"]        # (kept under this name for the ISA tests)
+UNITS = (("step_rollout.hip", MAX_ILP + KERNARG_PRELOAD), ("policy.hip", []), ("swarm.hip", MAX_ILP + KERNARG_PRELOAD), ("abi.hip", MAX_ILP))
+HEADERS = ("gpd_common.inc", "policy_kernel.inc")
 
 
 class GpdError(RuntimeError):
@@ -74,19 +79,19 @@ DEBUG_LIB_PATH = os.path.join(CSRC, "libgpd_debug.so")
 
 
 def build(force: bool = False, verbose: bool = False, debug: bool = False) -> str:
-    """Compile csrc/gpd.hip + csrc/gpd_policy.hip -> csrc/libgpd.so for gfx950.  Returns the library path.
+    """Compile the four units of csrc/ -> csrc/libgpd.so for gfx950 (side by side).  Returns the library path.
     `debug=True`: the debug-bounds build (-DGPD_DEBUG_BOUNDS, include/gpd.h `gpd_debug_status`) -> csrc/libgpd_debug.so; use it by
     setting GPD_LIB to that path before the package is imported."""
     srcs = [os.path.join(CSRC, u) for u, _ in UNITS]
     hdr = os.path.join(INCLUDE, "gpd.h")
     LIB_PATH = DEBUG_LIB_PATH if debug else globals()["LIB_PATH"]
     if not force and os.path.exists(LIB_PATH):
-        newest = max([os.path.getmtime(f) for f in srcs] + [os.path.getmtime(hdr)])
+        newest = max([os.path.getmtime(f) for f in srcs] + [os.path.getmtime(hdr)] + [os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS])
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs, procs = [], []
-    for (unit, extra), src in zip(UNITS, srcs):          # the two units compile side by side
+    for (unit, extra), src in zip(UNITS, srcs):          # the units compile side by side
         obj = os.path.join(CSRC, unit.replace(".hip", ".dbg.o" if debug else ".o"))
         cmd = [hipcc] + COMMON_FLAGS + extra + (["-DGPD_DEBUG_BOUNDS"] if debug else []) + ["-I", INCLUDE, "-c", src, "-o", obj]
         if verbose:

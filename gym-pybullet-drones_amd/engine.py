@@ -4,8 +4,10 @@ tensors) and launches the HIP kernels of `csrc/libgpd.so` through the C-ABI (`in
 PyTorch is used for device memory and streams only; every arithmetic step of the simulator runs
 in the hand-written kernels.  Layout (N = num_envs * drones_per_env, drone n = env*D + d):
 
-    kin       float32 [13][ld]   pos xyz | quat xyzw | vel xyz | body rates xyz   (ld = N rounded
-                                 up to 64 so every row starts on a 256-byte boundary)
+    kin_store float32 [13*ld]    the kinematic block in four planes (include/gpd.h, GpdState.kin; ld = N rounded up to 64):
+                                 kin_P [ld][4] pos xyz + body rate x | kin_Q [ld][4] quat xyzw | kin_V [ld][4] vel xyz + body rate y |
+                                 kin_W [ld] body rate z -- views of the one buffer; `kin` is the logical [13][ld] matrix
+                                 (pos xyz | quat xyzw | vel xyz | body rates xyz), assembled on request (a copy)
     last_rpm  float32 [4][ld]    last applied RPMs (optional)
     pid       float32 [9][ld]    DSLPID integrators / last rpy (PID action types only)
     counter   int32   [E]        physics steps since the env's last reset
@@ -63,6 +65,14 @@ def lanes_per_wave(num_drones: int, drones_per_env: int) -> int:
     return 64
 
 
+def kin_rows_from_planes(store, ld: int):
+    """The four planes of `GpdState.kin` (a flat array of 13 * ld floats: torch tensor or numpy array) -> the logical [13, ld] matrix
+    pos xyz | quat xyzw | vel xyz | body rates xyz (a copy)."""
+    P, Q, V, W = store[:4 * ld].reshape(ld, 4), store[4 * ld:8 * ld].reshape(ld, 4), store[8 * ld:12 * ld].reshape(ld, 4), store[12 * ld:13 * ld]
+    rows = [P[:, 0], P[:, 1], P[:, 2], Q[:, 0], Q[:, 1], Q[:, 2], Q[:, 3], V[:, 0], V[:, 1], V[:, 2], P[:, 3], V[:, 3], W]
+    return torch.stack(rows) if torch.is_tensor(store) else np.stack(rows)
+
+
 class SimCore:
     """E aviaries x D drones advanced by one fused kernel launch per `step()`."""
 
@@ -106,7 +116,10 @@ class SimCore:
         self._params = self.P.to_struct(pid_model=DroneModel.CF2X, gains=gains)   # BaseRLAviary.py:75-76
 
         dev, f32 = self.device, torch.float32
-        self.kin = torch.zeros((13, self.ld), dtype=f32, device=dev)
+        self.kin_store = torch.zeros((13 * self.ld,), dtype=f32, device=dev)
+        ld = self.ld
+        self.kin_P, self.kin_Q = self.kin_store[:4 * ld].view(ld, 4), self.kin_store[4 * ld:8 * ld].view(ld, 4)
+        self.kin_V, self.kin_W = self.kin_store[8 * ld:12 * ld].view(ld, 4), self.kin_store[12 * ld:]
         need_rpm = track_rpm or bool(self.physics_flags & PHYS_DRAG)
         self.last_rpm = torch.zeros((4, self.ld), dtype=f32, device=dev) if need_rpm else None
         # (force_pid: the controller state exists although the kernel is fed RPMs -- a host-side caller runs gpd_pid on it)
@@ -140,7 +153,7 @@ class SimCore:
         # nan_guard: one byte per drone, rewritten by every call that stores the state: 1 = a NaN / infinity sits in the drone's
         # kinematic state (GpdState.bad; the reference has no such check)
         self.bad = torch.zeros((self.N,), dtype=torch.bool, device=dev) if nan_guard else None
-        self._state = _native.GpdState(kin=self.kin.data_ptr(),
+        self._state = _native.GpdState(kin=self.kin_store.data_ptr(),
                                        last_rpm=self.last_rpm.data_ptr() if self.last_rpm is not None else None,
                                        pid=self.pid.data_ptr() if self.pid is not None else None,
                                        step_counter=self.step_counter.data_ptr(), ld=self.ld,
@@ -198,12 +211,31 @@ class SimCore:
             rc = self.lib.gpd_reset(ctypes.byref(self._state), _ptr(self.init_pose), self.init_per_env, _ptr(mask),
                                     self.E, self.D, int(reset_pid), _ptr(self.obs12), self._stream())
         _native.check(rc, "gpd_reset")
-        if os.environ.get("GPD_EXP_KIN4") and mask is None:       # EXPERIMENT (scratch/exp_r05/ab_step.sh): a -DGPD_EXP_KIN4 library
-            k = self.kin.clone()
-            flat = self.kin.view(-1)
-            for j in range(3):
-                flat[4 * j * self.ld:4 * (j + 1) * self.ld] = k[4 * j:4 * j + 4].t().reshape(-1)
         return self.obs12
+
+    # ---- the kinematic block as the logical [13][ld] matrix (rows: pos xyz | quat xyzw | vel xyz | body rates xyz) -------------
+    @property
+    def kin(self) -> torch.Tensor:
+        """A COPY of the kinematic state as the [13, ld] matrix of rounds 1-4 (the device keeps it in four planes, `kin_P` /
+        `kin_Q` / `kin_V` / `kin_W`: write through those views, or through `set_state(kin=...)`)."""
+        return kin_rows_from_planes(self.kin_store, self.ld)
+
+    def positions(self, n: int = None) -> torch.Tensor:
+        """[n, 3] VIEW of the positions"""
+        return self.kin_P[:self.N if n is None else n, :3]
+
+    def quaternions(self, n: int = None) -> torch.Tensor:
+        """[n, 4] VIEW of the quaternions (x, y, z, w)"""
+        return self.kin_Q[:self.N if n is None else n]
+
+    def velocities(self, n: int = None) -> torch.Tensor:
+        """[n, 3] VIEW of the linear velocities"""
+        return self.kin_V[:self.N if n is None else n, :3]
+
+    def body_rates(self, n: int = None) -> torch.Tensor:
+        """[n, 3] COPY of the body rates (the reference's rpy_rates)"""
+        n = self.N if n is None else n
+        return torch.stack([self.kin_P[:n, 3], self.kin_V[:n, 3], self.kin_W[:n]], dim=1)
 
     def step(self, action: torch.Tensor):
         """One env step for every aviary.  `action`: float32 device tensor with E*D*A elements.
@@ -500,7 +532,7 @@ class SimCore:
         for name in self._STATE_FIELDS:
             t = getattr(self, name, None)
             if t is not None:
-                out[name] = (t[:, :n] if name in ("kin", "last_rpm", "pid") else t).clone()
+                out[name] = (t[:, :n] if name in ("kin", "last_rpm", "pid") else t).clone()      # (`kin`: the logical rows)
         return out
 
     def set_state(self, kin=None, last_rpm=None, pid=None, step_counter=None, **rest):
@@ -519,6 +551,13 @@ class SimCore:
             src = torch.as_tensor(v, device=self.device)
             if tuple(src.shape) != tuple(dst.shape):
                 raise ValueError(f"set_state: {name} has shape {tuple(src.shape)}, expected {tuple(dst.shape)}")
+            if name == "kin":                # logical rows -> the four planes
+                src = src.to(torch.float32)
+                self.kin_P[:n, :3] = src[0:3].t(); self.kin_P[:n, 3] = src[10]
+                self.kin_Q[:n] = src[3:7].t()
+                self.kin_V[:n, :3] = src[7:10].t(); self.kin_V[:n, 3] = src[11]
+                self.kin_W[:n] = src[12]
+                continue
             dst.copy_(src.to(dst.dtype))
 
     def bytes_per_step(self) -> int:

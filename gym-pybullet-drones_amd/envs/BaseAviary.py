@@ -189,7 +189,7 @@ class BaseAviary(Env):
         """Refresh the numpy kinematic cache from the device (one small device-to-host copy)."""
         n = self.NUM_DRONES
         core = self._core
-        packed = torch.cat([core.state_vectors(), core.kin[10:13, :n].t(),
+        packed = torch.cat([core.state_vectors(), core.body_rates(n),
                             core.reward.expand(n, 1), core.terminated.to(torch.float32).expand(n, 1),
                             core.truncated.to(torch.float32).expand(n, 1)], dim=1).cpu().numpy().astype(np.float64)
         self.pos = packed[:, 0:3].copy()

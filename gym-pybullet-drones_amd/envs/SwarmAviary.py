@@ -523,7 +523,7 @@ class SwarmAviary:
         `torch.distributed` (diagnostics / checks: a rank of a halo-exchanging world holds only its own and its neighbours'
         border drones)."""
         own = torch.full((self.per, 3), float("nan"), dtype=torch.float32, device=self.device)
-        own[:self.NUM_DRONES] = self.core.kin[0:3, :self.NUM_DRONES].t()
+        own[:self.NUM_DRONES] = self.core.positions(self.NUM_DRONES)
         if self.WORLD_SIZE == 1:
             return own[:self.NUM_DRONES].clone()
         import torch.distributed as dist
@@ -590,8 +590,8 @@ class SwarmAviary:
         a = torch.as_tensor(action, dtype=torch.float32, device=self.device)
         if self.ctrl is None:
             return a.reshape(n, 4)
-        k = self.core.kin[:, :n]
-        rpm, _, _ = self.ctrl.computeControl(self.CTRL_TIMESTEP, k[0:3].t(), k[3:7].t(), k[7:10].t(), None, a.reshape(n, 3))
+        c = self.core
+        rpm, _, _ = self.ctrl.computeControl(self.CTRL_TIMESTEP, c.positions(n), c.quaternions(n), c.velocities(n), None, a.reshape(n, 3))
         return rpm
 
     def step(self, action):
@@ -654,7 +654,7 @@ class SwarmAviary:
         count, start, order = torch.zeros(2 * (keys + 1), **i32), torch.zeros(keys + 1, **i32), torch.zeros(n, **i32)
         srt, out = torch.zeros((n, 4), dtype=torch.float32, device=self.device), torch.zeros(n, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            rc = c.lib.gpd_downwash_global(ctypes.byref(c._params), _ptr(c.kin), c.ld, n, self.cell, self.x0, self.y0, self.nx, self.ny,
+            rc = c.lib.gpd_downwash_global(ctypes.byref(c._params), _ptr(c.kin_store), c.ld, n, self.cell, self.x0, self.y0, self.nx, self.ny,
                                            self.z0, self.zbin, self.nz, None, _ptr(count), _ptr(start), _ptr(order), _ptr(srt), _ptr(out),
                                            None, None, None, c._stream())
         _native.check(rc, "gpd_downwash_global")

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GPD_ABI_VERSION 8
+#define GPD_ABI_VERSION 9
 
 /* DroneModel (utils/enums.py:3-8) */
 enum { GPD_MODEL_CF2X = 0, GPD_MODEL_CF2P = 1, GPD_MODEL_RACE = 2 };
@@ -138,7 +138,13 @@ typedef struct GpdParams {
  * DSLPIDControl members (control/DSLPIDControl.py:65-78).
  */
 typedef struct GpdState {
-    float* kin;            /* [13][ld]: pos xyz | quat xyzw | vel xyz | rpy_rates (body rates) xyz */
+    float* kin;            /* 13 x ld floats in FOUR PLANES (ABI 9; ABI <= 8: thirteen rows of ld floats):
+                                P  float4[ld] at kin          (pos x, pos y, pos z, body rate x)
+                                Q  float4[ld] at kin + 4 ld   (quat x, y, z, w)
+                                V  float4[ld] at kin + 8 ld   (vel x, vel y, vel z, body rate y)
+                                W  float [ld] at kin + 12 ld  body rate z
+                              (body rates = the reference's rpy_rates, envs/BaseAviary.py:474).  A lane moves its drone with three
+                              16-byte accesses and one 4-byte access per direction instead of thirteen 4-byte ones */
     float* last_rpm;       /* [4][ld] last applied RPMs (last_clipped_action); NULL = not tracked
                               (required with GPD_PHYS_DRAG) */
     float* pid;            /* [9][ld]: integral_pos_e | last_rpy | integral_rpy_e; NULL unless a
@@ -374,7 +380,7 @@ int gpd_full_obs(const GpdState* state, int32_t num_steps, int32_t n_drones, int
  * in 64-bit fixed point (2^-30 N), so the result does not depend on the order the sort leaves the neighbours in; a pair
  * whose exponent 0.5 (dxy / (DW2*dz + DW3))^2 reaches 40 is dropped (it is below e^-40 = 4.3e-18 of its own amplitude).
  *
- *   kin, ld       the state block of gpd_step (rows 0..2 = positions are read)
+ *   kin, ld       the state block of gpd_step (plane P = positions is read: float4 n at kin + 4 n)
  *   cell, x0, y0, nx, ny   grid: cell size [m] (>= 10), lower-left corner, cells per side (nx, ny >= 3)
  *   z0, zbin, nz  every cell is split into nz height bins of zbin metres starting at z0 (bin 0 also holds everything below z0,
  *                 bin nz-1 everything above; nz = 1: no bins, z0/zbin ignored); nx*ny*nz <= 65536.  The sort key is

@@ -14,8 +14,10 @@ import subprocess
 import sys
 
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-LIBS = {"v0": ("scratch/exp/libgpd_v0.so", {}), "v1": ("gym-pybullet-drones_amd/csrc/libgpd.so", {}),
-        "v2": ("scratch/exp/libgpd_v2.so", {"GPD_EXP_KIN4": "1"})}
+LIBS = {"v1": ("gym-pybullet-drones_amd/csrc/libgpd.so", {}),
+        "v2": ("scratch/exp/libgpd_v2.so", {"GPD_EXP_KIN4": "1"}),
+        "v3": ("scratch/exp/libgpd_v3.so", {"GPD_EXP_KIN4": "1"}),       # v2 + the state stored non-temporally at every size
+        "v4": ("scratch/exp/libgpd_v4.so", {})}                         # v1 + the state stored non-temporally at every size
 WORK = [("hover65536_240hz", ["--min-time", "0.5"]), ("hover65536_pid_240hz", ["--min-time", "0.3"]), ("hover65536_30hz", ["--min-time", "0.3"]),
         ("hover4096_240hz", ["--min-time", "0.3"]), ("hover4m_240hz", ["--min-time", "0.3"])]
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3

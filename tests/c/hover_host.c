@@ -10,7 +10,7 @@
  * input  (binary, native endianness): int32 E, D, A, K, init_rows, target_rows, has_last_rpm, has_pid | GpdParams | GpdStepCfg |
  *         init_pose [init_rows][7] f32 | target_pos [target_rows][3] f32 | actions [K][E*D][A] f32   (rows: D or E*D, as the
  *         configuration's init_per_env / target_per_env say)
- * output: kin [13][N] f32 | obs12 [N][12] f32 | reward [E] f32 | terminated [E] u8 | truncated [E] u8 | step_counter [E] i32
+ * output: kin [13 * N] f32 (GpdState.kin's four planes, ld = N) | obs12 [N][12] f32 | reward [E] f32 | terminated [E] u8 | truncated [E] u8 | step_counter [E] i32
  *         -- first after the K gpd_step calls, then the same block after the single gpd_rollout call from the same start
  */
 #include <stdio.h>

@@ -45,7 +45,9 @@ def _blocks(buf, E, D):
                             ("truncated", np.uint8, E), ("step_counter", np.int32, E)):
             b[name] = np.frombuffer(buf, dtype=dt, count=n, offset=off)
             off += n * np.dtype(dt).itemsize
-        b["kin"], b["obs12"] = b["kin"].reshape(13, N), b["obs12"].reshape(N, 12)
+        # (the host's state block has ld = N; GpdState.kin is four planes since ABI 9: back to the logical [13][N] rows)
+        from gym_pybullet_drones_amd.engine import kin_rows_from_planes
+        b["kin"], b["obs12"] = kin_rows_from_planes(b["kin"], N), b["obs12"].reshape(N, 12)
         out.append(b)
     assert off == len(buf)
     return out

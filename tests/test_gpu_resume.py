@@ -180,7 +180,7 @@ def test_nan_guard_flags_exactly_the_poisoned_aviaries(gpu_device, mode):
         env.rollout(good)
         assert not env.bad_envs().any() and torch.isfinite(env.core.pid[:, :E]).all()
         # ... and a non-finite value that does sit in the kinematic state is found
-        env.core.kin[8, int(poisoned[5])] = float("inf")
+        env.core.kin_V[int(poisoned[5]), 1] = float("inf")          # (vel y; the kinematic block lives in four planes, ABI 9)
         env.rollout(good)
         assert np.flatnonzero(env.bad_envs().cpu().numpy()).tolist() == [int(poisoned[5])]
     else:

@@ -377,7 +377,7 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path):
     assert res.returncode == 0, res.stderr
     run = subprocess.run([exe], capture_output=True, text=True)
     assert run.returncode == 0, run.stdout + run.stderr
-    assert "ABI 8" in run.stdout and "-> -1:" in run.stdout
+    assert "ABI 9" in run.stdout and "-> -1:" in run.stdout
 
 
 def test_every_entry_answers_null_pointers_with_a_code_not_a_crash():

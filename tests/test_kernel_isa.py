@@ -47,6 +47,20 @@ def policy_asm():
     return _asm(*_native.UNITS[1])
 
 
+@pytest.fixture(scope="module")
+def swarm_asm():
+    from gym_pybullet_drones_amd import _native
+    assert _native.UNITS[2][0] == "swarm.hip"
+    return _asm(*_native.UNITS[2])
+
+
+@pytest.fixture(scope="module")
+def abi_asm():
+    from gym_pybullet_drones_amd import _native
+    assert _native.UNITS[3][0] == "abi.hip"
+    return _asm(*_native.UNITS[3])
+
+
 def _kernel(lines, name):
     start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*" + name + r"\w*:", l))
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
@@ -150,14 +164,14 @@ def test_spill_checker_recognises_the_miscompile_it_was_written_for():
     assert chk.torn_spills(body) == []
 
 
-def test_no_kernel_saves_a_half_overwritten_argument_tuple(gpd_asm, policy_asm):
-    """Every kernel of both units, every instantiation: no scalar-load destination tuple is spilled after part of it was
+def test_no_kernel_saves_a_half_overwritten_argument_tuple(gpd_asm, policy_asm, swarm_asm, abi_asm):
+    """Every kernel of the four units, every instantiation: no scalar-load destination tuple is spilled after part of it was
     overwritten (backward SGPR liveness over the kernel's control-flow graph, tests/isa_spill_check.py).  All of these kernels
     run with their 106 SGPRs full and spill kernel arguments to VGPR lanes, so the register allocator's handling of exactly
     this is load-bearing for every GpdParams / GpdStepCfg field they read."""
     import isa_spill_check as chk
     n = 0
-    for asm in (gpd_asm, policy_asm):
+    for asm in (gpd_asm, policy_asm, swarm_asm, abi_asm):
         for name, body in chk.kernels("\n".join(asm)):
             n += 1
             found = chk.torn_spills(body)
@@ -174,7 +188,7 @@ def test_dslpid_policy_kernels_in_the_policy_unit_under_both_schedulers(sched):
     tests/test_gpu_policy.py::test_vel_policy_kernel_is_right_under_both_schedulers.)"""
     import isa_spill_check as chk
     extra = ["-DGPD_PID_POLICY_IN_POLICY_TU"] + (["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if sched == "max-ilp" else [])
-    asm = "\n".join(_asm("gpd_policy.hip", extra))
+    asm = "\n".join(_asm("policy.hip", extra))
     names = []
     for name, body in chk.kernels(asm):
         names.append(name)
@@ -185,13 +199,13 @@ def test_dslpid_policy_kernels_in_the_policy_unit_under_both_schedulers(sched):
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
-def test_swarm_force_kernel_tests_pairs_packed_and_evaluates_them_compacted(gpd_asm, mode):
+def test_swarm_force_kernel_tests_pairs_packed_and_evaluates_them_compacted(swarm_asm, mode):
     """dwg_force_kernel<MODE> (MODE 0: no wake lists, 1: the launch after a binning builds them, 2: the
     launches in between replay them): phase A is packed and branch-free (v_pk_* + v_and + v_alignbit, no compare in the sweep;
     the build's margins add scalar min / abs, still no branch), the compaction is a DPP prefix sum into an LDS queue of 16-bit
     pairs, the evaluation gathers its drone by ds_bpermute and adds 64-bit integers with LDS atomics; the build writes its
     batches as 16-bit stores, the replay reads them back; no scratch, at most 128 VGPRs (four workgroups per CU)."""
-    body, meta = _kernel(gpd_asm, f"dwg_force_kernelILi{mode}E")
+    body, meta = _kernel(swarm_asm, f"dwg_force_kernelILi{mode}E")
     assert re.search(r"ScratchSize: 0\b", meta)
     assert int(re.search(r"; NumVgprs: (\d+)", meta).group(1)) <= 128
     ops = Counter(op for op, _ in _ops(body))
@@ -213,9 +227,9 @@ def test_swarm_force_kernel_tests_pairs_packed_and_evaluates_them_compacted(gpd_
     assert not [op for op in sweep if op.startswith(("v_cmp", "s_cbranch", "v_rcp", "v_exp"))], sweep
 
 
-def test_history_rows_are_streamed_out_in_16_byte_pieces(gpd_asm):
+def test_history_rows_are_streamed_out_in_16_byte_pieces(abi_asm):
     """gpd_hist_rows_kernel: whole rows per workgroup, written as ONE contiguous block with non-temporal 16-byte stores."""
-    body, meta = _kernel(gpd_asm, "gpd_hist_rows_kernel")
+    body, meta = _kernel(abi_asm, "gpd_hist_rows_kernel")
     assert re.search(r"ScratchSize: 0\b", meta)
     stores = [s for op, s in _ops(body) if op.startswith("global_store")]
     assert any(s.startswith("global_store_dwordx4") and s.endswith(" nt") for s in stores) and all(s.endswith(" nt") for s in stores), stores
@@ -228,12 +242,12 @@ def test_two_drone_aviaries_exchange_through_dpp(gpd_asm):
     assert sum("quad_perm:[1,0,3,2]" in l for l in body) == 18
 
 
-def test_one_world_step_kernel_reduces_without_the_lds_crossbar_and_bursts_in_two_runs(gpd_asm):
+def test_one_world_step_kernel_reduces_without_the_lds_crossbar_and_bursts_in_two_runs(swarm_asm):
     """gpd_swarm_step_kernel (profiles/r04_swarm_step_timeline.txt): the tail's three wave reductions are DPP
     steps + v_readlane (`wave_allreduce`: no ds_bpermute left in the kernel), and the row bursts of a full wave are LDS reads in a
     run followed by their stores -- somewhere in the kernel five ds_read_b128 stand next to each other (the state vectors' fast
     path), which the per-store test of the ragged path never produces; one sub-step's physics fits 96 VGPRs, no scratch."""
-    body, meta = _kernel(gpd_asm, "gpd_swarm_step_kernelILi5E")
+    body, meta = _kernel(swarm_asm, "gpd_swarm_step_kernelILi5E")
     assert re.search(r"ScratchSize: 0\b", meta) and int(re.search(r"; NumVgprs: (\d+)", meta).group(1)) <= 96
     ops = [op for op, _ in _ops(body)]
     c = Counter(ops)
