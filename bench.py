@@ -970,7 +970,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-suite", action="store_true")
     ap.add_argument("--suite-timeout", type=float, default=300.0,
                     help="seconds the suite may take before the headline line is printed without it")
-    ap.add_argument("--hbm-leg-time", type=float, default=2.0, help="seconds of timed region of the `hbm_saturating` leg (>= 2 by default)")
+    ap.add_argument("--hbm-leg-time", type=float, default=2.2, help="seconds of timed region of the `hbm_saturating` leg (its whole launches: >= 2 s)")
     ap.add_argument("--segment-events", type=int, default=0,
                     help="record this many extra events inside the timed region and report first-100-ms vs steady-state rates under `segments`")
     ap.add_argument("--no-hbm-leg", action="store_true",
@@ -1101,7 +1101,7 @@ def hbm_leg(args, job, out):
     a.workload, a.no_cpu_baseline, a.no_second_leg, a.split, a.allgather = "hover4m_240hz", True, True, 1, False
     # >= 2 s of timed region, seen in 48 pieces (0.1 s = 32 launches cannot tell a boost clock from a steady one);
     # --hbm-leg-time shortens it for tests
-    a.min_time = float(getattr(args, "hbm_leg_time", 2.0))
+    a.min_time = float(getattr(args, "hbm_leg_time", 2.2))
     a.segment_events = 48
     # 64 steps per launch whatever the headline's --steps: the block is about the rate HBM serves this kernel at, and at 4M drones a
     # 20-step launch (16 rounds of resident workgroups, each starting and ending together) reads 0.63-0.71 depending on the box

@@ -72,7 +72,7 @@ class GpdSwarm(ctypes.Structure):
                 ("slot_key", ctypes.c_void_p), ("dw_force", ctypes.c_void_p), ("slot_of", ctypes.c_void_p),
                 ("pos_sorted", ctypes.c_void_p), ("pair_list", ctypes.c_void_p), ("pair_nb", ctypes.c_void_p),
                 ("list_ok", ctypes.c_void_p), ("list_cap", ctypes.c_int32), ("list_delta", ctypes.c_float),
-                ("drift", ctypes.c_void_p), ("total_drones", ctypes.c_int32), ("list_adapt", ctypes.c_int32)]
+                ("drift", ctypes.c_void_p), ("group_perm", ctypes.c_void_p), ("total_drones", ctypes.c_int32), ("list_adapt", ctypes.c_int32)]
 
 
 DEBUG_LIB_PATH = os.path.join(CSRC, "libgpd_debug.so")
@@ -167,6 +167,10 @@ def lib() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    try:        # PyTorch's HIP runtime first: libgpd.so then binds to the copy torch mapped (one runtime per process; loaded the other way
+        import torch  # noqa: F401 -- round a kernel launch fails with "no ROCm-capable device is detected", gpurun_out/smoke3.log, round 5)
+    except ImportError:
+        pass
     path = os.environ.get("GPD_LIB", LIB_PATH)     # GPD_LIB: A/B-test another build of the same ABI
     if not os.path.exists(path):
         raise GpdError(f"{path} not found: the HIP extension has not been built "

@@ -321,12 +321,75 @@ struct DwLists {
     int* ok;               // [groups] 1: the group's list is complete for the current binning
     int cap;               // batches per wave
     float delta;           // the displacement the lists allow for
+    const int* perm;       // [2][groups] + [1]: which GROUP workgroup b works on -- perm[cur * groups + b], cur = perm[2 * groups] -- or NULL
+                           // (identity).  Lists, batch counts and `ok` are indexed by the WORKGROUP (b), so a build and the replays of its
+                           // lists must see the same permutation: dwg_balance_kernel changes it at a binning only.
+    int groups;
 };
+
+// Pair-balanced placement of the groups (round 5).  A replay launch holds all its workgroups at once -- four per CU, one wave of each on
+// every SIMD -- and runs as long as its most loaded CU: the groups' pair counts differ by a factor of two (a dense patch of the scene),
+// and workgroup b lands on CU b mod 256 (profiles/r05_workgroup_placement.txt: 768 of 768, launch after launch), i.e. four groups a
+// quarter of the world apart share a CU by accident of their index.  At every binning ONE workgroup sorts the groups by the batches their
+// lists held (what the previous build recorded: a group's pairs change little from one binning to the next) and deals them to the
+// workgroup slots boustrophedon over rounds of 256 -- heaviest to CUs 0..255, the next 256 to CUs 255..0, ... -- so that every CU's
+// four groups add up to the same work; beyond the first 1024 (worlds whose groups run in several rounds) heaviest first.  Sums are
+// integers: WHICH workgroup evaluates a group changes no bit of any force.  A group whose list overflowed (it sweeps) counts as the
+// heaviest, one without a drone of this rank (it leaves at once) as empty.
+constexpr int kDwCus = 256, kDwRound = 4 * kDwCus, kDwNoList = 0xffff;
+__global__ __launch_bounds__(1024) void dwg_balance_kernel(int groups, int* __restrict__ perm, const unsigned short* __restrict__ nb) {
+    __shared__ int hist[1024], offs[1024];
+    const int t = threadIdx.x;
+    const int cur = perm[2 * groups] & 1;
+    const int* const old = perm + static_cast<size_t>(cur) * groups;
+    int* const nw = perm + static_cast<size_t>(1 - cur) * groups;
+    auto bin_of = [&](int b) {                             // 0: heaviest ... 1023: empty
+        int w = 0;
+#pragma unroll
+        for (int k = 0; k < kBlock / 64; ++k) {
+            const int n = nb[(static_cast<size_t>(b) * (kBlock / 64) + k) * kDwMaxTiles];
+            w += n == kDwNoList ? 1023 : n;
+        }
+        return 1023 - min(w, 1023);
+    };
+    hist[t] = 0;
+    __syncthreads();
+    for (int b = t; b < groups; b += 1024) atomicAdd(&hist[bin_of(b)], 1);
+    __syncthreads();
+    const int mine = hist[t];
+    offs[t] = mine;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                   // inclusive scan of the 1024 bins
+        const int v = t >= d ? offs[t - d] : 0;
+        __syncthreads();
+        offs[t] += v;
+        __syncthreads();
+    }
+    const int excl = offs[t] - mine;
+    __syncthreads();
+    offs[t] = excl;                                        // first rank of the bin; counted up as its groups arrive (any order within a
+    __syncthreads();                                       // bin: equal weights)
+    const int first = min(groups, kDwRound) / kDwCus * kDwCus;       // the whole rounds of 256 inside the resident set
+    for (int b = t; b < groups; b += 1024) {
+        const int k = atomicAdd(&offs[bin_of(b)], 1);      // rank of this group, heaviest first
+        int slot = k;
+        if (k < first) { const int r = k / kDwCus, c = k - r * kDwCus; slot = r * kDwCus + ((r & 1) ? kDwCus - 1 - c : c); }
+        nw[slot] = old[b];
+    }
+    __syncthreads();
+    if (t == 0) perm[2 * groups] = 1 - cur;
+}
+// (the argument list STARTS with the fourteen dwords a replay's first loads need -- the workgroup's list, its batch counts, the
+// permutation, the sorted positions: kernarg preload, as for gpd_step_kernel; the structs follow)
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, const DwGrid G, const DwWorld Wd, const DwLists Ls,
-                                                           const int* __restrict__ start, const int* __restrict__ order,
-                                                           const float4* __restrict__ sorted, float* __restrict__ dw_out,
+__global__ __launch_bounds__(kBlock) void dwg_force_kernel(uint32_t* __restrict__ hot_list, unsigned short* __restrict__ hot_nb, int* __restrict__ hot_ok,
+                                                           const int* __restrict__ hot_perm, const int* __restrict__ order,
+                                                           const float4* __restrict__ sorted, const int hot_cap, const int hot_groups,
+                                                           const GpdParams P, const DwGrid G, const DwWorld Wd, const DwLists Ls_,
+                                                           const int* __restrict__ start, float* __restrict__ dw_out,
                                                            int* __restrict__ cursor) {
+    DwLists Ls = Ls_;
+    Ls.list = hot_list; Ls.nb = hot_nb; Ls.ok = hot_ok; Ls.perm = hot_perm; Ls.cap = hot_cap; Ls.groups = hot_groups;
     // one LDS block: the tile's x / y / z planes, then the four waves' queues; (build) the candidates' source indices beside them
     __shared__ __attribute__((aligned(16))) float lds_tile[3 * kDwTile + (kBlock / 64) * kDwQueue / 2];
     __shared__ int tsrc[MODE == 1 ? kDwTile : 1];
@@ -366,7 +429,14 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
     // workgroup's early exits used to sit between the loads (drones sorted -> slot's row -> positions, keys, maxima, list
     // header: four dependent trips to memory, 3.2 of a replay launch's 15 us, profiles/r03_force_timeline.txt); slot indices
     // are clamped so that a workgroup which is about to leave reads valid memory.
-    const int base = 64 * blockIdx.x;
+    // which group of 64 sorted slots this workgroup works on (the lists below are the WORKGROUP's: they follow the permutation)
+    int grp = blockIdx.x;
+    if (MODE && Ls.perm && static_cast<int>(blockIdx.x) < Ls.groups) {
+        const int cur = Ls.perm[2 * Ls.groups], p0 = Ls.perm[blockIdx.x], p1 = Ls.perm[Ls.groups + blockIdx.x];      // (three independent scalar loads)
+        grp = (cur & 1) ? p1 : p0;
+        GPD_DBG(grp >= 0 && grp < Ls.groups, GPD_DBG_LIST_ENTRY, grp); grp = GPD_DBG_CLAMP(grp, 0, Ls.groups - 1);
+    }
+    const int base = 64 * grp;
     const int s = base + lane;
     const int sc = min(s, Wd.n_slots - 1);
     auto key_at = [&](int slot) { return Wd.slot_key ? Wd.slot_key[slot] : __float_as_int(sorted[slot].w); };
@@ -410,11 +480,14 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
     asm volatile("" : "+v"(row_l), "+v"(key_l), "+v"(me_l.x), "+v"(me_l.y), "+v"(me_l.z), "+v"(d2), "+v"(list_ok), "+v"(nb0), "+v"(delta));
     if (MODE == 2) asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
     list_ok = __builtin_amdgcn_readfirstlane(list_ok); nb0 = __builtin_amdgcn_readfirstlane(nb0);
-    if (base >= sorted_n) return;
+    if (base >= sorted_n) { if (MODE == 1 && lane == 0) my_nb[0] = 0; return; }          // (no pairs: dwg_balance_kernel reads the counts)
     const bool have = s < sorted_n;
     const int my_row = have ? row_l : -1;
     const bool own = have && my_row >= Wd.own_lo && my_row < Wd.own_lo + Wd.own_cnt;
-    if (__builtin_amdgcn_ballot_w64(own) == 0) return;     // (the four waves hold the same 64 slots: the whole workgroup leaves)
+    if (__builtin_amdgcn_ballot_w64(own) == 0) {           // (the four waves hold the same 64 slots: the whole workgroup leaves)
+        if (MODE == 1 && lane == 0) my_nb[0] = 0;
+        return;
+    }
     unsigned short* const my_queue = queue[wave];
     unsigned long long* const my_sums = sums[wave];
     const float kr = 0.25f * P.prop_radius;
@@ -683,7 +756,8 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(const GpdParams P, co
         cs = ce + 1;
     }
     if (MODE == 1) {                                       // the group's list counts only if all four waves completed theirs
-        if (lane == 0) my_nb[0] = static_cast<unsigned short>(rec_ok ? lb : 0);      // the wave's batches (< cap <= 65535)
+        // the wave's batches (<= cap < 65535), or "no list": this group sweeps until the next binning (dwg_balance_kernel: the heaviest)
+        if (lane == 0) my_nb[0] = static_cast<unsigned short>(rec_ok ? lb : kDwNoList);
         int* const okf = reinterpret_cast<int*>(pre);
         __syncthreads();
         if (lane == 0) okf[wave] = rec_ok ? 1 : 0;
@@ -757,10 +831,20 @@ __device__ __forceinline__ void swarm_tail(const SwarmOut& O, const SwarmIn& I, 
         row[1] = tx; row[2] = ty; row[3] = m;
     }
 }
+// (the argument list starts with what the load section needs: kernarg preload, as for gpd_step_kernel)
 template <int ACT>
-__global__ __launch_bounds__(kBlock) void gpd_swarm_step_kernel(const GpdParams P, const GpdState S, const GpdStepCfg C,
-                                                                const float* __restrict__ action, float* __restrict__ obs12,
-                                                                const SwarmOut O) {
+__global__ __launch_bounds__(kBlock) void gpd_swarm_step_kernel(float* __restrict__ hot_kin, const float* __restrict__ action,
+                                                                float* __restrict__ hot_last_rpm, float* __restrict__ hot_dw_force,
+                                                                const float4* __restrict__ hot_bin_pos_own, const int* __restrict__ hot_slot_of_own,
+                                                                const uint32_t hot_ld, const int32_t hot_n,
+                                                                const GpdParams P, const GpdState S_, const GpdStepCfg C_,
+                                                                float* __restrict__ obs12, const SwarmOut O_) {
+    GpdState S = S_;
+    S.kin = hot_kin; S.last_rpm = hot_last_rpm; S.dw_force = hot_dw_force; S.ld = hot_ld;
+    GpdStepCfg C = C_;
+    C.num_envs = hot_n;
+    SwarmOut O = O_;
+    O.bin_pos_own = hot_bin_pos_own; O.slot_of_own = hot_slot_of_own;
     const uint32_t N = static_cast<uint32_t>(C.num_envs);
     const uint32_t n_raw = blockIdx.x * kBlock + threadIdx.x;
     Lane L;
@@ -917,8 +1001,9 @@ int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, i
                            cell_start, order, reinterpret_cast<float4*>(sorted_xyzc), dw_out, B);
     }
     const DwWorld Wd{nullptr, nullptr, nullptr, 0, n, 0, 0, 0, cell, nullptr, 0.0f, n};
-    hipLaunchKernelGGL(dwg_force_kernel<0>, dim3(static_cast<unsigned>((n + 63) / 64)), dim3(kBlock), 0, st, *params, G, Wd, DwLists{},
-                       cell_start, order, reinterpret_cast<const float4*>(sorted_xyzc), dw_out, cell_count);
+    hipLaunchKernelGGL(dwg_force_kernel<0>, dim3(static_cast<unsigned>((n + 63) / 64)), dim3(kBlock), 0, st, static_cast<uint32_t*>(nullptr),
+                       static_cast<unsigned short*>(nullptr), static_cast<int*>(nullptr), static_cast<const int*>(nullptr), order,
+                       reinterpret_cast<const float4*>(sorted_xyzc), 0, 0, *params, G, Wd, DwLists{}, cell_start, dw_out, cell_count);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gpd_downwash_global launch");
     return 0;
@@ -967,10 +1052,11 @@ int gpd_swarm_step(const GpdParams* params, const GpdState* state, const GpdStep
                      reinterpret_cast<float4*>(swarm->pos_sorted), swarm->drift, vec_out};
     const dim3 grid(static_cast<unsigned>((cfg->num_envs + kBlock - 1) / kBlock));
     hipStream_t st = static_cast<hipStream_t>(stream);
+#define GPD_SWARM_HOT state->kin, action, state->last_rpm, state->dw_force, O.bin_pos_own, O.slot_of_own, static_cast<uint32_t>(state->ld), cfg->num_envs
     switch (cfg->act_type) {
-        case GPD_ACT_RAW_RPM: hipLaunchKernelGGL(gpd_swarm_step_kernel<GPD_ACT_RAW_RPM>, grid, dim3(kBlock), 0, st, *params, *state, *cfg, action, obs12, O); break;
-        case GPD_ACT_DIRECT_RPM: hipLaunchKernelGGL(gpd_swarm_step_kernel<GPD_ACT_DIRECT_RPM>, grid, dim3(kBlock), 0, st, *params, *state, *cfg, action, obs12, O); break;
-        default: hipLaunchKernelGGL(gpd_swarm_step_kernel<GPD_ACT_RPM>, grid, dim3(kBlock), 0, st, *params, *state, *cfg, action, obs12, O); break;
+        case GPD_ACT_RAW_RPM: hipLaunchKernelGGL(gpd_swarm_step_kernel<GPD_ACT_RAW_RPM>, grid, dim3(kBlock), 0, st, GPD_SWARM_HOT, *params, *state, *cfg, obs12, O); break;
+        case GPD_ACT_DIRECT_RPM: hipLaunchKernelGGL(gpd_swarm_step_kernel<GPD_ACT_DIRECT_RPM>, grid, dim3(kBlock), 0, st, GPD_SWARM_HOT, *params, *state, *cfg, obs12, O); break;
+        default: hipLaunchKernelGGL(gpd_swarm_step_kernel<GPD_ACT_RPM>, grid, dim3(kBlock), 0, st, GPD_SWARM_HOT, *params, *state, *cfg, obs12, O); break;
     }
     // (too many meta rows for every force workgroup to read: leave the rank's maximum in its first meta row)
     if (static_cast<int64_t>(swarm->world_size) * swarm->meta_rows > 1024)
@@ -1015,6 +1101,9 @@ int gpd_swarm_bin(const GpdSwarm* w, void* stream) {
         hipLaunchKernelGGL(dwg_scatter_kernel<false>, grid, dim3(kBlock), 0, st, src, n, G, w->visit, w->cell_count, cursors,
                            w->cell_start, w->order, srt, w->dw_force, B);
     }
+    // (the lists of the binning that ends here say how much work every group was: deal the groups to the workgroup slots for the next one)
+    if (w->group_perm && w->pair_list && w->pair_nb)
+        hipLaunchKernelGGL(dwg_balance_kernel, dim3(1), dim3(1024), 0, st, (n + 63) / 64, w->group_perm, w->pair_nb);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gpd_swarm_bin launch");
     return 0;
@@ -1033,13 +1122,16 @@ int gpd_swarm_forces(const GpdParams* params, const GpdSwarm* w, int32_t build_l
     const float4* const p4 = reinterpret_cast<const float4*>(w->pos4);
     const DwWorld Wd{w->pos_sorted ? nullptr : p4, w->slot_key, p4, w->rank * w->slab, w->own_count, w->slab, w->world_size, w->meta_rows, w->cell,
                      w->drift, 1.0f / static_cast<float>(w->total_drones), w->n_rows};
-    const DwLists Ls{w->pair_list, w->pair_nb, w->list_ok, w->list_cap, w->list_delta};
+    if (lists && w->list_cap >= kDwNoList) return fail(GPD_ERANGE, "gpd_swarm_forces: list_cap must stay below 65535 (the batch count 0xffff marks a group without a list)");
+    const DwLists Ls{w->pair_list, w->pair_nb, w->list_ok, w->list_cap, w->list_delta, lists ? w->group_perm : nullptr, (w->n_rows + 63) / 64};
     const dim3 grid(static_cast<unsigned>((w->n_rows + 63) / 64) + 1u);        // (+ the workgroup that computes the drift)
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float4* const srt = reinterpret_cast<const float4*>(w->pos_sorted);
-    if (!lists) hipLaunchKernelGGL(dwg_force_kernel<0>, grid, dim3(kBlock), 0, st, *params, G, Wd, Ls, w->cell_start, w->order, srt, w->dw_force, w->cell_count);
-    else if (build_lists) hipLaunchKernelGGL(dwg_force_kernel<1>, grid, dim3(kBlock), 0, st, *params, G, Wd, Ls, w->cell_start, w->order, srt, w->dw_force, w->cell_count);
-    else hipLaunchKernelGGL(dwg_force_kernel<2>, grid, dim3(kBlock), 0, st, *params, G, Wd, Ls, w->cell_start, w->order, srt, w->dw_force, w->cell_count);
+#define GPD_FORCE_ARGS Ls.list, Ls.nb, Ls.ok, Ls.perm, w->order, srt, Ls.cap, Ls.groups, *params, G, Wd, Ls, w->cell_start, w->dw_force, w->cell_count
+    if (!lists) hipLaunchKernelGGL(dwg_force_kernel<0>, grid, dim3(kBlock), 0, st, GPD_FORCE_ARGS);
+    else if (build_lists) hipLaunchKernelGGL(dwg_force_kernel<1>, grid, dim3(kBlock), 0, st, GPD_FORCE_ARGS);
+    else hipLaunchKernelGGL(dwg_force_kernel<2>, grid, dim3(kBlock), 0, st, GPD_FORCE_ARGS);
+#undef GPD_FORCE_ARGS
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gpd_swarm_forces launch");
     return 0;

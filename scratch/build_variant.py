@@ -5,8 +5,10 @@
 
 --define       -D macros for every unit
 --flags-UNIT   replace the extra flags of one unit (UNIT = step_rollout | policy | swarm | abi), e.g. --flags-policy -mllvm -amdgpu-sched-strategy=max-ilp
---patch        apply a patch (`patch -p1`, paths relative to the repo) to a COPY of csrc/ and include/ first -- e.g. the timeline
-               instrumentation of rounds 3 / 4, which lives outside the product sources: scratch/exp_r05/timeline_instrumentation.patch"""
+--patch        apply a patch (`patch -p1`, paths relative to the repo) to a COPY of csrc/ and include/ first: experiment scaffolding lives
+               outside the product sources (the per-workgroup timeline instrumentation of rounds 3 / 4 -- `GPD_EXP_TS*`, read by
+               scratch/exp_r04/force_timeline.py / step_timeline.py -- left them in round 5; `git show fd66d7c:gym-pybullet-drones_amd/csrc/gpd.hip`
+               has its last form)"""
 import os
 import shutil
 import subprocess
