@@ -340,6 +340,7 @@ constexpr int kDwCus = 256, kDwRound = 4 * kDwCus, kDwNoList = 0xffff;
 __global__ __launch_bounds__(1024) void dwg_balance_kernel(int groups, int* __restrict__ perm, const unsigned short* __restrict__ nb) {
     __shared__ int hist[1024], offs[1024];
     const int t = threadIdx.x;
+    if (perm[2 * groups] & 2) return;                      // (bit 1: the caller has frozen the permutation it wrote itself -- experiments, tests)
     const int cur = perm[2 * groups] & 1;
     const int* const old = perm + static_cast<size_t>(cur) * groups;
     int* const nw = perm + static_cast<size_t>(1 - cur) * groups;

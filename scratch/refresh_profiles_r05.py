@@ -77,3 +77,101 @@ if "ab" in what:
         if f.startswith("ab_step_r05"):
             shutil.copy(os.path.join(G, f), os.path.join(P, "r05_" + f))
             print("profiles/r05_" + f)
+
+if "counters" in what and os.path.exists(os.path.join(G, "prof_r05", "summary.json")):
+    # gpurun_out/prof_r05/summary.json (scratch/profile_r05.py) -> profiles/r05_trace_* / r05_pmc_* + the three tables bench.py reads:
+    # the keys measured this round are REPLACED (measured_in_round: 5), the others stay what round 4 measured (their kernels changed in
+    # ABI 9 only in the once-per-launch load / store of the state: the per-step figures of the rollout keys are unaffected)
+    import glob
+    sys.path.insert(0, R)
+    SRC = os.path.join(G, "prof_r05")
+    d = json.load(open(os.path.join(SRC, "summary.json")))
+    for f in glob.glob(os.path.join(P, "r05_pmc_*")) + glob.glob(os.path.join(P, "r05_trace_*")):
+        os.remove(f)
+    for f in glob.glob(os.path.join(SRC, "*_kernel_stats*.csv")) + glob.glob(os.path.join(SRC, "pmc_*.csv")):
+        shutil.copy(f, os.path.join(P, "r05_" + os.path.basename(f)))
+    shutil.copy(os.path.join(SRC, "summary.json"), os.path.join(P, "r05_summary.json"))
+    for tag, line in d.get("bench_lines", {}).items():
+        if line:
+            json.dump(line, open(os.path.join(P, f"r05_bench_{tag.replace('trace_', '')}_under_rocprofv3.json"), "w"))
+    from bench import WORKLOADS
+
+    def grid_row(tag, frag, grid):
+        for r in d["by_grid"].get(tag, []):
+            if frag in r["Name"] and int(r["Grid_Size_X"]) == grid:
+                return r
+        return None
+
+    def alg_bytes(key, spl):
+        w = WORKLOADS[key.split(":")[0]]
+        N, E = w["E"] * w["D"], w["E"]
+        A = {"rpm": 4, "pid": 3, "raw_rpm": 4}[w["act"]]
+        pid, drag = w["act"] == "pid", bool(w["phys"] & 2)
+        if "rollout" in key:
+            state = 2 * 13 * 4 + (2 * 9 * 4 if pid else 0) + (2 * 16 if drag else 0)
+            return (state + spl * A * 4 + spl * 48) * N + (8 + spl * 6) * E
+        per = (13 + A) * 4 + 25 * 4 + (72 if pid else 0) + (32 if drag else 0)
+        return per * N + 14 * E
+
+    traffic = json.load(open(os.path.join(P, "hbm_traffic.json")))
+    counters = json.load(open(os.path.join(P, "kernel_counters.json")))
+    trace_of = {"hover65536_240hz": "trace_default", "stack8x8192_ext_240hz": "trace_stack8"}
+    for key, rec in d.get("pmc", {}).items():
+        g = lambda c: rec.get(c, {}).get("mean_per_dispatch")  # noqa: E731
+        wl, spl = key.split(":")[0], rec["env_steps_per_launch"]
+        if g("FETCH_SIZE") is None or g("WRITE_SIZE") is None:
+            print("no traffic counters for", key)
+            continue
+        t = {"env_steps_per_launch": spl, "algorithmic_bytes": alg_bytes(key, spl), "measured_in_round": 5, "FETCH_SIZE_KB": g("FETCH_SIZE"),
+             "WRITE_SIZE_KB": g("WRITE_SIZE"), "traffic_bytes": 2 * g("FETCH_SIZE") * 1024 + g("WRITE_SIZE") * 1024}
+        w = WORKLOADS[wl]
+        row = grid_row(trace_of.get(wl, ""), rec["kernel"], -(-w["E"] * w["D"] // 256) * 256) if trace_of.get(wl) else None
+        if row and ("rollout" in key and spl == 64 or "graph" in key):
+            t["rocprof_kernel_avg_ns"] = float(row["AverageNs"])
+        if rec.get("kernel_avg_ns_in_pmc_pass"):
+            t["kernel_avg_ns_in_pmc_pass"] = rec["kernel_avg_ns_in_pmc_pass"]
+        traffic[key] = t
+        if g("SQ_INSTS_VALU") is not None and g("SQ_WAVES"):
+            per = lambda c: (g(c) or 0.0) / g("SQ_WAVES") / spl  # noqa: E731
+            slots = sum(per(c) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM"))
+            counters[key] = {"slots_per_wave_env_step": slots, "valu_per_wave_env_step": per("SQ_INSTS_VALU"),
+                             "salu_per_wave_env_step": per("SQ_INSTS_SALU"), "branch_per_wave_env_step": per("SQ_INSTS_BRANCH"),
+                             "lds_per_wave_env_step": per("SQ_INSTS_LDS"), "vmem_per_wave_env_step": per("SQ_INSTS_VMEM_RD") + per("SQ_INSTS_VMEM_WR"),
+                             "wave_quad_cycles_per_env_step": per("SQ_WAVE_CYCLES"), "active_quad_cycles_per_env_step": per("SQ_ACTIVE_INST_ANY"),
+                             "parked_quad_cycles_per_env_step": per("SQ_WAIT_ANY"), "issue_stall_quad_cycles_per_env_step": per("SQ_WAIT_INST_ANY"),
+                             "waves": g("SQ_WAVES"), "measured_in_round": 5}
+            print(key, {k: round(v, 1) for k, v in counters[key].items() if isinstance(v, float)})
+    traffic["round"], counters["round"] = "4, keys marked measured_in_round 5 re-measured in round 5", "4, keys marked measured_in_round 5 re-measured in round 5"
+    json.dump(traffic, open(os.path.join(P, "hbm_traffic.json"), "w"), indent=1)
+    json.dump(counters, open(os.path.join(P, "kernel_counters.json"), "w"), indent=1)
+    # the one-world kernels
+    if d.get("swarm"):
+        swarm = {"_comment": "Wave-instructions per physics sub-step of the one-world path (rocprofv3 --pmc SQ_INSTS_*, eager launches, scratch/profile_r05.py, "
+                 "the FINAL round-5 library: pair-balanced groups, kernarg preload): per dispatch means of every kernel, and per sub-step = step + replay x "
+                 "(1 - 1/rebin) + (build + count + scatter + balance) / rebin with the workload's rebin_every = 16. bench.py prices the VALU instructions x 4 "
+                 "cycles on 1024 SIMDs against the measured sub-step (roofline.bound = valu_issue).", "round": 5}
+        for wl, rec in d["swarm"].items():
+            def get(kfrag, c):
+                for kn, cs in rec.items():
+                    if kfrag in kn and c in cs:
+                        return cs[c]["mean_per_dispatch"]
+                return 0.0
+            rebin = 16.0
+            per_kernel = {kn: {c: v["mean_per_dispatch"] for c, v in cs.items()} for kn, cs in rec.items()}
+            if not per_kernel:
+                continue
+
+            def per_substep(c):
+                return (get("gpd_swarm_step_kernel", c) + get("dwg_force_kernel<2>", c) * (1 - 1 / rebin) +
+                        (get("dwg_force_kernel<1>", c) + get("dwg_count_kernel", c) + get("dwg_scatter_kernel", c) + get("dwg_balance_kernel", c)) / rebin)
+            swarm[wl] = {"valu_wave_instructions_per_substep": per_substep("SQ_INSTS_VALU"), "salu_wave_instructions_per_substep": per_substep("SQ_INSTS_SALU"),
+                         "lds_wave_instructions_per_substep": per_substep("SQ_INSTS_LDS"),
+                         "vmem_wave_instructions_per_substep": per_substep("SQ_INSTS_VMEM_RD") + per_substep("SQ_INSTS_VMEM_WR"),
+                         "replay_valu_wave_instructions": get("dwg_force_kernel<2>", "SQ_INSTS_VALU"), "replay_waves": get("dwg_force_kernel<2>", "SQ_WAVES"),
+                         "replay_wave_quad_cycles": get("dwg_force_kernel<2>", "SQ_WAVE_CYCLES"), "replay_parked_quad_cycles": get("dwg_force_kernel<2>", "SQ_WAIT_ANY"),
+                         "replay_active_quad_cycles": get("dwg_force_kernel<2>", "SQ_ACTIVE_INST_ANY"),
+                         "hbm_bytes_per_substep": 1024 * (2 * per_substep("FETCH_SIZE") + per_substep("WRITE_SIZE")), "rebin_every": rebin,
+                         "per_kernel_per_dispatch": per_kernel,
+                         "kernel_avg_ns": {r["Name"].split("::")[-1][:40]: float(r["AverageNs"]) for r in d["traces"].get("trace_" + wl, [])}}
+            print(wl, {k: (round(v, 1) if isinstance(v, float) else v) for k, v in swarm[wl].items() if not isinstance(v, dict)})
+        json.dump(swarm, open(os.path.join(P, "swarm_counters.json"), "w"), indent=1)
