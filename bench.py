@@ -1322,6 +1322,15 @@ def run_workload(args, job):
         second = measure("graph", args, envs, actions, None if getattr(gather, "_stage", False) else gather, device, world, POOL)
         for e in envs:
             e.reset()
+    eager = None
+    if second is not None and world == 1 and not w.get("policy") and not w.get("swarm"):
+        # ... and the plain Python loop `for ...: env.step(action)`, one host launch per step, nothing captured: what a user's own loop gets
+        # (host-bound: the interpreter and the ctypes call take longer than the kernel)
+        a2 = argparse.Namespace(**vars(args))
+        a2.min_time, a2.segment_events = min(args.min_time, 0.1), 0
+        eager = measure("eager", a2, envs, actions, None, device, world, POOL)
+        for e in envs:
+            e.reset()
     if args.split > 1:
         if w.get("policy") or w.get("full_obs"):
             raise SystemExit("--split: plain obs12 workloads only (no policy / history rows)")
@@ -1437,6 +1446,10 @@ def run_workload(args, job):
             if si is not None:
                 sec["roofline_valu_issue"] = si
             out["one_launch_per_step"] = sec
+        if eager is not None:
+            out["python_step_loop"] = {"value": eager["value_wall"], "unit": "drone-steps/s", "us_per_step": eager["wall_s"] * 1e6 / eager["timed_steps"],
+                                       "us_per_step_hip_events": eager["us_per_step"], "timed_steps": eager["timed_steps"],
+                                       "what": "for i in range(n): env.step(action[i]) -- one gpd_step call per step from Python, no hipGraph; wall clock around the loop + one synchronize"}
         if parity is not None:
             out["parity"] = parity
         if not args.no_cpu_baseline and world == 1:

@@ -72,7 +72,7 @@ class GpdSwarm(ctypes.Structure):
                 ("slot_key", ctypes.c_void_p), ("dw_force", ctypes.c_void_p), ("slot_of", ctypes.c_void_p),
                 ("pos_sorted", ctypes.c_void_p), ("pair_list", ctypes.c_void_p), ("pair_nb", ctypes.c_void_p),
                 ("list_ok", ctypes.c_void_p), ("list_cap", ctypes.c_int32), ("list_delta", ctypes.c_float),
-                ("drift", ctypes.c_void_p), ("group_perm", ctypes.c_void_p), ("total_drones", ctypes.c_int32), ("list_adapt", ctypes.c_int32)]
+                ("drift", ctypes.c_void_p), ("total_drones", ctypes.c_int32), ("list_adapt", ctypes.c_int32)]
 
 
 DEBUG_LIB_PATH = os.path.join(CSRC, "libgpd_debug.so")

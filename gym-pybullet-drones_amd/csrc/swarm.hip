@@ -321,76 +321,18 @@ struct DwLists {
     int* ok;               // [groups] 1: the group's list is complete for the current binning
     int cap;               // batches per wave
     float delta;           // the displacement the lists allow for
-    const int* perm;       // [2][groups] + [1]: which GROUP workgroup b works on -- perm[cur * groups + b], cur = perm[2 * groups] -- or NULL
-                           // (identity).  Lists, batch counts and `ok` are indexed by the WORKGROUP (b), so a build and the replays of its
-                           // lists must see the same permutation: dwg_balance_kernel changes it at a binning only.
-    int groups;
 };
-
-// Pair-balanced placement of the groups (round 5).  A replay launch holds all its workgroups at once -- four per CU, one wave of each on
-// every SIMD -- and runs as long as its most loaded CU: the groups' pair counts differ by a factor of two (a dense patch of the scene),
-// and workgroup b lands on CU b mod 256 (profiles/r05_workgroup_placement.txt: 768 of 768, launch after launch), i.e. four groups a
-// quarter of the world apart share a CU by accident of their index.  At every binning ONE workgroup sorts the groups by the batches their
-// lists held (what the previous build recorded: a group's pairs change little from one binning to the next) and deals them to the
-// workgroup slots boustrophedon over rounds of 256 -- heaviest to CUs 0..255, the next 256 to CUs 255..0, ... -- so that every CU's
-// four groups add up to the same work; beyond the first 1024 (worlds whose groups run in several rounds) heaviest first.  Sums are
-// integers: WHICH workgroup evaluates a group changes no bit of any force.  A group whose list overflowed (it sweeps) counts as the
-// heaviest, one without a drone of this rank (it leaves at once) as empty.
-constexpr int kDwCus = 256, kDwRound = 4 * kDwCus, kDwNoList = 0xffff;
-__global__ __launch_bounds__(1024) void dwg_balance_kernel(int groups, int* __restrict__ perm, const unsigned short* __restrict__ nb) {
-    __shared__ int hist[1024], offs[1024];
-    const int t = threadIdx.x;
-    if (perm[2 * groups] & 2) return;                      // (bit 1: the caller has frozen the permutation it wrote itself -- experiments, tests)
-    const int cur = perm[2 * groups] & 1;
-    const int* const old = perm + static_cast<size_t>(cur) * groups;
-    int* const nw = perm + static_cast<size_t>(1 - cur) * groups;
-    auto bin_of = [&](int b) {                             // 0: heaviest ... 1023: empty
-        int w = 0;
-#pragma unroll
-        for (int k = 0; k < kBlock / 64; ++k) {
-            const int n = nb[(static_cast<size_t>(b) * (kBlock / 64) + k) * kDwMaxTiles];
-            w += n == kDwNoList ? 1023 : n;
-        }
-        return 1023 - min(w, 1023);
-    };
-    hist[t] = 0;
-    __syncthreads();
-    for (int b = t; b < groups; b += 1024) atomicAdd(&hist[bin_of(b)], 1);
-    __syncthreads();
-    const int mine = hist[t];
-    offs[t] = mine;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {                   // inclusive scan of the 1024 bins
-        const int v = t >= d ? offs[t - d] : 0;
-        __syncthreads();
-        offs[t] += v;
-        __syncthreads();
-    }
-    const int excl = offs[t] - mine;
-    __syncthreads();
-    offs[t] = excl;                                        // first rank of the bin; counted up as its groups arrive (any order within a
-    __syncthreads();                                       // bin: equal weights)
-    const int first = min(groups, kDwRound) / kDwCus * kDwCus;       // the whole rounds of 256 inside the resident set
-    for (int b = t; b < groups; b += 1024) {
-        const int k = atomicAdd(&offs[bin_of(b)], 1);      // rank of this group, heaviest first
-        int slot = k;
-        if (k < first) { const int r = k / kDwCus, c = k - r * kDwCus; slot = r * kDwCus + ((r & 1) ? kDwCus - 1 - c : c); }
-        nw[slot] = old[b];
-    }
-    __syncthreads();
-    if (t == 0) perm[2 * groups] = 1 - cur;
-}
-// (the argument list STARTS with the fourteen dwords a replay's first loads need -- the workgroup's list, its batch counts, the
-// permutation, the sorted positions: kernarg preload, as for gpd_step_kernel; the structs follow)
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void dwg_force_kernel(uint32_t* __restrict__ hot_list, unsigned short* __restrict__ hot_nb, int* __restrict__ hot_ok,
-                                                           const int* __restrict__ hot_perm, const int* __restrict__ order,
-                                                           const float4* __restrict__ sorted, const int hot_cap, const int hot_groups,
-                                                           const GpdParams P, const DwGrid G, const DwWorld Wd, const DwLists Ls_,
+                                                           const float4* __restrict__ hot_pos4, const int* __restrict__ order,
+                                                           const float4* __restrict__ sorted, const int hot_cap, const int hot_n_slots,
+                                                           const GpdParams P, const DwGrid G, const DwWorld Wd_, const DwLists Ls_,
                                                            const int* __restrict__ start, float* __restrict__ dw_out,
                                                            int* __restrict__ cursor) {
     DwLists Ls = Ls_;
-    Ls.list = hot_list; Ls.nb = hot_nb; Ls.ok = hot_ok; Ls.perm = hot_perm; Ls.cap = hot_cap; Ls.groups = hot_groups;
+    Ls.list = hot_list; Ls.nb = hot_nb; Ls.ok = hot_ok; Ls.cap = hot_cap;
+    DwWorld Wd = Wd_;
+    Wd.pos4 = hot_pos4; Wd.n_slots = hot_n_slots;
     // one LDS block: the tile's x / y / z planes, then the four waves' queues; (build) the candidates' source indices beside them
     __shared__ __attribute__((aligned(16))) float lds_tile[3 * kDwTile + (kBlock / 64) * kDwQueue / 2];
     __shared__ int tsrc[MODE == 1 ? kDwTile : 1];
@@ -430,14 +372,7 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(uint32_t* __restrict_
     // workgroup's early exits used to sit between the loads (drones sorted -> slot's row -> positions, keys, maxima, list
     // header: four dependent trips to memory, 3.2 of a replay launch's 15 us, profiles/r03_force_timeline.txt); slot indices
     // are clamped so that a workgroup which is about to leave reads valid memory.
-    // which group of 64 sorted slots this workgroup works on (the lists below are the WORKGROUP's: they follow the permutation)
-    int grp = blockIdx.x;
-    if (MODE && Ls.perm && static_cast<int>(blockIdx.x) < Ls.groups) {
-        const int cur = Ls.perm[2 * Ls.groups], p0 = Ls.perm[blockIdx.x], p1 = Ls.perm[Ls.groups + blockIdx.x];      // (three independent scalar loads)
-        grp = (cur & 1) ? p1 : p0;
-        GPD_DBG(grp >= 0 && grp < Ls.groups, GPD_DBG_LIST_ENTRY, grp); grp = GPD_DBG_CLAMP(grp, 0, Ls.groups - 1);
-    }
-    const int base = 64 * grp;
+    const int base = 64 * blockIdx.x;
     const int s = base + lane;
     const int sc = min(s, Wd.n_slots - 1);
     auto key_at = [&](int slot) { return Wd.slot_key ? Wd.slot_key[slot] : __float_as_int(sorted[slot].w); };
@@ -481,14 +416,11 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(uint32_t* __restrict_
     asm volatile("" : "+v"(row_l), "+v"(key_l), "+v"(me_l.x), "+v"(me_l.y), "+v"(me_l.z), "+v"(d2), "+v"(list_ok), "+v"(nb0), "+v"(delta));
     if (MODE == 2) asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
     list_ok = __builtin_amdgcn_readfirstlane(list_ok); nb0 = __builtin_amdgcn_readfirstlane(nb0);
-    if (base >= sorted_n) { if (MODE == 1 && lane == 0) my_nb[0] = 0; return; }          // (no pairs: dwg_balance_kernel reads the counts)
+    if (base >= sorted_n) return;
     const bool have = s < sorted_n;
     const int my_row = have ? row_l : -1;
     const bool own = have && my_row >= Wd.own_lo && my_row < Wd.own_lo + Wd.own_cnt;
-    if (__builtin_amdgcn_ballot_w64(own) == 0) {           // (the four waves hold the same 64 slots: the whole workgroup leaves)
-        if (MODE == 1 && lane == 0) my_nb[0] = 0;
-        return;
-    }
+    if (__builtin_amdgcn_ballot_w64(own) == 0) return;     // (the four waves hold the same 64 slots: the whole workgroup leaves)
     unsigned short* const my_queue = queue[wave];
     unsigned long long* const my_sums = sums[wave];
     const float kr = 0.25f * P.prop_radius;
@@ -757,8 +689,7 @@ __global__ __launch_bounds__(kBlock) void dwg_force_kernel(uint32_t* __restrict_
         cs = ce + 1;
     }
     if (MODE == 1) {                                       // the group's list counts only if all four waves completed theirs
-        // the wave's batches (<= cap < 65535), or "no list": this group sweeps until the next binning (dwg_balance_kernel: the heaviest)
-        if (lane == 0) my_nb[0] = static_cast<unsigned short>(rec_ok ? lb : kDwNoList);
+        if (lane == 0) my_nb[0] = static_cast<unsigned short>(rec_ok ? lb : 0);      // the wave's batches (< cap <= 65535)
         int* const okf = reinterpret_cast<int*>(pre);
         __syncthreads();
         if (lane == 0) okf[wave] = rec_ok ? 1 : 0;
@@ -1003,8 +934,8 @@ int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, i
     }
     const DwWorld Wd{nullptr, nullptr, nullptr, 0, n, 0, 0, 0, cell, nullptr, 0.0f, n};
     hipLaunchKernelGGL(dwg_force_kernel<0>, dim3(static_cast<unsigned>((n + 63) / 64)), dim3(kBlock), 0, st, static_cast<uint32_t*>(nullptr),
-                       static_cast<unsigned short*>(nullptr), static_cast<int*>(nullptr), static_cast<const int*>(nullptr), order,
-                       reinterpret_cast<const float4*>(sorted_xyzc), 0, 0, *params, G, Wd, DwLists{}, cell_start, dw_out, cell_count);
+                       static_cast<unsigned short*>(nullptr), static_cast<int*>(nullptr), Wd.pos4, order,
+                       reinterpret_cast<const float4*>(sorted_xyzc), 0, Wd.n_slots, *params, G, Wd, DwLists{}, cell_start, dw_out, cell_count);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gpd_downwash_global launch");
     return 0;
@@ -1102,9 +1033,6 @@ int gpd_swarm_bin(const GpdSwarm* w, void* stream) {
         hipLaunchKernelGGL(dwg_scatter_kernel<false>, grid, dim3(kBlock), 0, st, src, n, G, w->visit, w->cell_count, cursors,
                            w->cell_start, w->order, srt, w->dw_force, B);
     }
-    // (the lists of the binning that ends here say how much work every group was: deal the groups to the workgroup slots for the next one)
-    if (w->group_perm && w->pair_list && w->pair_nb)
-        hipLaunchKernelGGL(dwg_balance_kernel, dim3(1), dim3(1024), 0, st, (n + 63) / 64, w->group_perm, w->pair_nb);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gpd_swarm_bin launch");
     return 0;
@@ -1123,12 +1051,11 @@ int gpd_swarm_forces(const GpdParams* params, const GpdSwarm* w, int32_t build_l
     const float4* const p4 = reinterpret_cast<const float4*>(w->pos4);
     const DwWorld Wd{w->pos_sorted ? nullptr : p4, w->slot_key, p4, w->rank * w->slab, w->own_count, w->slab, w->world_size, w->meta_rows, w->cell,
                      w->drift, 1.0f / static_cast<float>(w->total_drones), w->n_rows};
-    if (lists && w->list_cap >= kDwNoList) return fail(GPD_ERANGE, "gpd_swarm_forces: list_cap must stay below 65535 (the batch count 0xffff marks a group without a list)");
-    const DwLists Ls{w->pair_list, w->pair_nb, w->list_ok, w->list_cap, w->list_delta, lists ? w->group_perm : nullptr, (w->n_rows + 63) / 64};
+    const DwLists Ls{w->pair_list, w->pair_nb, w->list_ok, w->list_cap, w->list_delta};
     const dim3 grid(static_cast<unsigned>((w->n_rows + 63) / 64) + 1u);        // (+ the workgroup that computes the drift)
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float4* const srt = reinterpret_cast<const float4*>(w->pos_sorted);
-#define GPD_FORCE_ARGS Ls.list, Ls.nb, Ls.ok, Ls.perm, w->order, srt, Ls.cap, Ls.groups, *params, G, Wd, Ls, w->cell_start, w->dw_force, w->cell_count
+#define GPD_FORCE_ARGS Ls.list, Ls.nb, Ls.ok, Wd.pos4, w->order, srt, Ls.cap, Wd.n_slots, *params, G, Wd, Ls, w->cell_start, w->dw_force, w->cell_count
     if (!lists) hipLaunchKernelGGL(dwg_force_kernel<0>, grid, dim3(kBlock), 0, st, GPD_FORCE_ARGS);
     else if (build_lists) hipLaunchKernelGGL(dwg_force_kernel<1>, grid, dim3(kBlock), 0, st, GPD_FORCE_ARGS);
     else hipLaunchKernelGGL(dwg_force_kernel<2>, grid, dim3(kBlock), 0, st, GPD_FORCE_ARGS);

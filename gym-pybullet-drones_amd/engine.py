@@ -211,6 +211,11 @@ class SimCore:
             rc = self.lib.gpd_reset(ctypes.byref(self._state), _ptr(self.init_pose), self.init_per_env, _ptr(mask),
                                     self.E, self.D, int(reset_pid), _ptr(self.obs12), self._stream())
         _native.check(rc, "gpd_reset")
+        if self.bad is not None:          # (the non-finite flags describe the state the last launch left: a reset pose is finite)
+            if mask is None:
+                self.bad.zero_()
+            else:
+                self.bad.view(self.E, self.D)[mask.to(torch.bool)] = False
         return self.obs12
 
     # ---- the kinematic block as the logical [13][ld] matrix (rows: pos xyz | quat xyzw | vel xyz | body rates xyz) -------------
@@ -551,6 +556,8 @@ class SimCore:
             src = torch.as_tensor(v, device=self.device)
             if tuple(src.shape) != tuple(dst.shape):
                 raise ValueError(f"set_state: {name} has shape {tuple(src.shape)}, expected {tuple(dst.shape)}")
+            if name == "kin" and self.bad is not None and given.get("bad") is None:
+                self.bad[:n] = ~torch.isfinite(torch.as_tensor(v, device=self.device, dtype=torch.float32)).all(dim=0)       # (flags follow the state written)
             if name == "kin":                # logical rows -> the four planes
                 src = src.to(torch.float32)
                 self.kin_P[:n, :3] = src[0:3].t(); self.kin_P[:n, 3] = src[10]

@@ -343,7 +343,7 @@ class SwarmAviary:
                  world_min=None, world_max=None, cell: float = 10.5, zbin: float = 1.0, nz: int = 1, device=None,
                  pyb_like: bool = None, world_size: int = 1, rank: int = 0, exchange=None, rebin_every: int = None,
                  wake_lists: bool = True, list_cap: int = 48, partition: str = "spatial", expected_speed: float = None,
-                 adaptive_lists: bool = True, balance_groups: bool = True):
+                 adaptive_lists: bool = True):
         if pyb_freq % ctrl_freq != 0:
             raise ValueError("[ERROR] in SwarmAviary.__init__(), pyb_freq is not divisible by ctrl_freq.")
         if act not in ("raw_rpm", ActionType.RPM, ActionType.PID):
@@ -452,21 +452,14 @@ class SwarmAviary:
         # hovering swarm lists 34 pairs per drone instead of 47 at cell = 10.5 m; a swarm that outruns the guess sweeps (exactly)
         # until the next binning.  False: always the full margin.
         self.adaptive_lists = bool(adaptive_lists)
-        if self.wake_lists and not 4 <= int(list_cap) <= 65534:
-            raise ValueError("list_cap must be in 4..65534 (a replay launch requests a wave's first four batches before it knows how many there are; "
-                             "the batch count 65535 marks a group without a list)")
+        if self.wake_lists and not 4 <= int(list_cap) <= 65535:
+            raise ValueError("list_cap must be in 4..65535 (a replay launch requests a wave's first four batches before it knows how many there are)")
         u16 = dict(dtype=torch.int16, device=dev)
         # (32-bit entries: 6 bits drone of the group + 26 bits the candidate's slot / row -- include/gpd.h)
         self._pair_list = torch.zeros((groups, 4, int(list_cap) * 64), dtype=torch.int32, device=dev) if self.wake_lists else None
         self._pair_nb = torch.zeros((groups, 4, 16), **u16) if self.wake_lists else None
         self._list_ok = torch.zeros(groups, **i32) if self.wake_lists else None
         self._drift = torch.zeros(4, dtype=torch.float32, device=dev)          # the swarm's common lateral drift since the binning
-        # pair-balanced placement (include/gpd.h, GpdSwarm.group_perm): which group of 64 sorted drones every workgroup of the force kernel
-        # works on -- two copies of the identity and the index of the current one; `gpd_swarm_bin` re-deals it at every binning by the
-        # batches the groups' lists held (GPD_SWARM_BALANCE=0: off, group b on workgroup b as in rounds 2-4)
-        self.balanced = bool(balance_groups) and self.wake_lists and os.environ.get("GPD_SWARM_BALANCE", "1") != "0"
-        ident = torch.arange(groups, dtype=torch.int32, device=dev)
-        self._group_perm = torch.cat([ident, ident, torch.zeros(1, **i32)]) if self.balanced else None
         self._sw = _native.GpdSwarm(n_rows=self.n_rows, slab=self.slab, world_size=self.WORLD_SIZE, rank=self.RANK, own_count=n,
                                     nx=self.nx, ny=self.ny, nz=self.nz, cell=self.cell, x0=self.x0, y0=self.y0, z0=self.z0,
                                     zbin=self.zbin, meta_rows=self.slab - self.per, pos4=self.pos4.data_ptr(), bin_pos=self._bin_pos.data_ptr(),
@@ -479,8 +472,7 @@ class SwarmAviary:
                                     pair_list=self._pair_list.data_ptr() if self.wake_lists else None,
                                     pair_nb=self._pair_nb.data_ptr() if self.wake_lists else None,
                                     list_ok=self._list_ok.data_ptr() if self.wake_lists else None,
-                                    list_cap=int(list_cap), list_delta=self.list_delta, drift=self._drift.data_ptr(),
-                                    group_perm=self._group_perm.data_ptr() if self.balanced else None, total_drones=N,
+                                    list_cap=int(list_cap), list_delta=self.list_delta, drift=self._drift.data_ptr(), total_drones=N,
                                     list_adapt=int(bool(adaptive_lists)))
         self.step_counter = 0
         self._since_bin = 0                          # sub-steps since the last binning

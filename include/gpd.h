@@ -174,7 +174,9 @@ typedef struct GpdState {
      * (every comparison is false), so without the flag a poisoned aviary runs on until the episode clock ends it.  (Deviation for
      * garbage input, DSLPID action types only: a NaN set-point is absorbed by the controller's clips -- the hardware min/max return
      * the bound where numpy's clip propagates the NaN -- so the drone sees one step of saturated commands and stays finite.)  Costs
-     * thirteen adds and a compare per drone and launch, outside the step loop. */
+     * thirteen adds and a compare per drone and launch, outside the step loop.  The byte describes the state the call LEAVES BEHIND: an
+     * aviary that went non-finite inside a K-step launch and was reset by its episode clock in the same launch (auto_reset) ends finite
+     * and reads 0 -- a caller that must see every event checks between shorter launches. */
     uint8_t* bad;          /* [N] or NULL */
 } GpdState;
 
@@ -477,19 +479,13 @@ typedef struct GpdSwarm {
                               gathers the candidates' current positions directly, no cell table, no staged tile */
     uint16_t* pair_nb;     /* [ceil(n_rows / 64)][4][16]: [0] = batches the wavefront recorded */
     int32_t* list_ok;      /* [ceil(n_rows / 64)] */
-    int32_t list_cap;      /* batches of 64 pairs per wavefront (a group of 64 drones has four), 4 .. 65534; a group that needs more sweeps */
+    int32_t list_cap;      /* batches of 64 pairs per wavefront (a group of 64 drones has four), 4 .. 65535; a group that needs more sweeps */
     float list_delta;
     /* "Displacement" above is measured relative to the swarm's COMMON lateral drift since the binning (a translation all drones
      * share changes no pair: a swarm in transit keeps R = 1 and its wake lists).  gpd_swarm_forces computes the drift -- the mean
      * lateral displacement of all drones, from per-workgroup sums in the meta rows (y, z) -- for the next gpd_swarm_step. */
     float* drift;          /* [4] device floats, zero before the first call: [0..1] the drift (gpd_swarm_bin zeroes them), [2] the
                               margin of the wake lists of the current binning (gpd_swarm_bin sets it, below), [3] reserved */
-    int32_t* group_perm;   /* (ABI 9) [2 * ceil(n_rows / 64) + 1] int32 or NULL: pair-balanced placement of the force kernel's workgroups.
-                              Initialise to 0, 1, 2 ... (groups - 1) TWICE, then a 0 (two copies of the identity and the index of the
-                              current one).  gpd_swarm_bin re-deals the groups of 64 sorted drones to the workgroup slots by the number
-                              of pairs their wake lists held, so that the four groups that share a CU (workgroup b runs on CU b mod 256)
-                              add up to equal work; gpd_swarm_forces follows it.  Changes no bit of any force (integer sums).  NULL:
-                              group b is evaluated by workgroup b, as in ABI <= 8. */
     int32_t total_drones;  /* drones of the whole world (all ranks) */
     int32_t list_adapt;    /* (ABI 7) 0: the lists' margin is list_delta.  1: gpd_swarm_bin chooses it for each binning from the
                               displacement the interval that ends there has seen -- min(list_delta, max(1 cm, 3 dmax)): a swarm

@@ -190,6 +190,7 @@ def test_nan_guard_flags_exactly_the_poisoned_aviaries(gpu_device, mode):
         # the reference's blind spot, demonstrated: none of the NaN aviaries was truncated (the one fed an infinity may be: +inf > z bound)
         assert not env.core.truncated.cpu().numpy()[poisoned[1:]].any()
     env.core.reset(reset_pid=True)
+    assert not env.bad_envs().any()              # (the flags follow a reset at once, not at the next launch)
     env.step(good[0])
     assert not env.bad_envs().any()
     plain = VectorHoverAviary(8, device=gpu_device)
