@@ -12,7 +12,7 @@ import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
-what = set(sys.argv[1:]) or {"hbm", "ab"}
+what = set(sys.argv[1:]) or {"hbm", "ab", "counters", "bench"}
 
 if "hbm" in what and os.path.exists(os.path.join(G, "hbm_r05", "summary.json")):
     s = json.load(open(os.path.join(G, "hbm_r05", "summary.json")))
@@ -175,3 +175,12 @@ if "counters" in what and os.path.exists(os.path.join(G, "prof_r05", "summary.js
                          "kernel_avg_ns": {r["Name"].split("::")[-1][:40]: float(r["AverageNs"]) for r in d["traces"].get("trace_" + wl, [])}}
             print(wl, {k: (round(v, 1) if isinstance(v, float) else v) for k, v in swarm[wl].items() if not isinstance(v, dict)})
         json.dump(swarm, open(os.path.join(P, "swarm_counters.json"), "w"), indent=1)
+
+if "bench" in what and os.path.isdir(os.path.join(G, "bench_r05")):
+    for f in sorted(os.listdir(os.path.join(G, "bench_r05"))):
+        if f.endswith(".json"):
+            txt = open(os.path.join(G, "bench_r05", f)).read().strip().splitlines()
+            line = next((l for l in reversed(txt) if l.startswith("{")), None)
+            if line:
+                open(os.path.join(P, "r05_bench_" + f), "w").write(line + "\n")
+                print("profiles/r05_bench_" + f)
