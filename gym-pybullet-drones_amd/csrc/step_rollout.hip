@@ -24,10 +24,13 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     const GpdParams P, const GpdState S_, const GpdStepCfg C_, const float* __restrict__ init_pose, float* __restrict__ obs12,
     float* __restrict__ reward, uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
     float* __restrict__ term_obs12) {
-    GpdState S = S_;
-    S.kin = hot_kin; S.step_counter = hot_counter; S.ld = hot_ld;
-    GpdStepCfg C = C_;
-    C.num_envs = hot_num_envs; C.lanes_per_wave = hot_lanes_per_wave; C.target_per_env = hot_target_per_env;
+    // (built member by member: a copy of the argument struct with three members overwritten stays an 80-byte alloca in the EXT variants --
+    // the `flag ? S.last_rpm : S.kin` selects become loads from a selected ADDRESS inside it -- i.e. scratch memory, and a launch that
+    // needs scratch costs 1.6 us more: hover65536_ext 5.07 -> 6.65 us per step, gpurun_out/bench_r05.log of the first round-5 build)
+    const GpdState S{hot_kin, S_.last_rpm, S_.pid, hot_counter, static_cast<int64_t>(hot_ld), S_.dw_force, S_.act_ring, S_.ring_pos, S_.hist_len, 0, S_.bad};
+    const GpdStepCfg C{hot_num_envs, C_.drones_per_env, C_.act_type, C_.substeps, C_.physics_flags, C_.pyb_dt, C_.ctrl_dt, C_.inv_ctrl_dt,
+                       hot_lanes_per_wave, C_.task, C_.xy_bound, C_.z_bound, C_.tilt_bound, C_.term_dist, C_.trunc_counter, hot_target_per_env,
+                       C_.init_per_env, C_.auto_reset};
     const int D = MULTI ? C.drones_per_env : 1;
     const int tid = threadIdx.x;
     const uint32_t N = static_cast<uint32_t>(C.num_envs) * static_cast<uint32_t>(D);

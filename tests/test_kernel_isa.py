@@ -179,6 +179,24 @@ def test_no_kernel_saves_a_half_overwritten_argument_tuple(gpd_asm, policy_asm, 
     assert n >= 130, n
 
 
+def test_no_kernel_needs_scratch_memory_or_reads_the_dispatch_packet(gpd_asm, policy_asm, swarm_asm, abi_asm):
+    """Two ways a kernel of this library got 1.6 - 10 us slower in round 5 without changing a bit of its results, both invisible to
+    every numerical test (profiles/r05_ab_step_kernel_round1.log, r05_bench_*): (1) a struct the kernel builds for itself stays an
+    alloca (a select between two of its members became a load from a selected address) -> scratch memory, and a launch that needs
+    scratch pays for its set-up; (2) twelve field reads combined into vector loads of a struct -> the alloca is promoted to LDS and
+    indexed by a flat thread id computed from the DISPATCH PACKET, which lives in host memory: one PCIe read per wave.  No kernel of
+    the four units may use either."""
+    n = 0
+    for unit, asm in (("step_rollout", gpd_asm), ("policy", policy_asm), ("swarm", swarm_asm), ("abi", abi_asm)):
+        text = "\n".join(asm)
+        scratch = re.findall(r"; ScratchSize: (\d+)", text)
+        n += len(scratch)
+        assert scratch and all(v == "0" for v in scratch), (unit, [v for v in scratch if v != "0"])
+        assert ".amdhsa_user_sgpr_dispatch_ptr 1" not in text, unit
+        assert not re.search(r"^\s*scratch_(load|store)", text, flags=re.M), unit
+    assert n >= 150, n
+
+
 @pytest.mark.parametrize("sched", ["default", "max-ilp"])
 def test_dslpid_policy_kernels_in_the_policy_unit_under_both_schedulers(sched):
     """The configuration the miscompile was found in: the DSLPID policy kernels instantiated in the
