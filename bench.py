@@ -884,7 +884,7 @@ def swarm_roofline(out, env, m, clock_ghz):
         new["traffic"] = rec.get("hbm_bytes_per_substep")       # FETCH_SIZE x 2 + WRITE_SIZE of every kernel of a sub-step (separate --pmc passes)
         if pairs and rec.get("replay_valu_wave_instructions"):
             new["valu_lane_instructions_per_pair"] = rec["replay_valu_wave_instructions"] * 64.0 / pairs["pairs"]
-        new["source"] = "profiles/swarm_counters.json (rocprofv3 --pmc SQ_INSTS_*, scratch/profile_r04.py)"
+        new["source"] = "profiles/swarm_counters.json (rocprofv3 --pmc SQ_INSTS_*, scratch/profile_r05.py)"
     else:
         new["note"] = "no profiles/swarm_counters.json entry for this workload: instruction counts unknown, frac not computed"
     out["roofline"] = new
