@@ -25,7 +25,7 @@
  *   - all arithmetic is fp32, no -ffast-math; FP contraction is off and every fused multiply-add is explicit in the
  *     source, so a drone's trajectory is bit-identical in every kernel variant (gpd_step vs gpd_rollout, aviary
  *     size, batch size, lane); reciprocals/square roots are the 1-ulp hardware instructions and
- *     atan2/asin/sin/cos are <= 2-ulp polynomials (csrc/gpd.hip).
+ *     atan2/asin/sin/cos are <= 2-ulp polynomials (csrc/gpd_common.inc).
  */
 #ifndef GPD_H
 #define GPD_H
