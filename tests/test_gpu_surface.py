@@ -821,3 +821,27 @@ def test_wake_lists_replay_the_pairs_of_the_last_binning_exactly(gpu_device, var
         assert ok == 1.0                            # every group replays
     elif variant == "overflowing lists":
         assert ok < 0.5                             # most groups evaluate more than one batch per wave: they sweep
+
+
+def test_kinematic_planes_are_writable_views_and_kin_is_their_logical_matrix(gpu_device):
+    """ABI 9 on the Python side: `SimCore.kin_P / kin_Q / kin_V / kin_W` are views of the one state buffer the kernels read and write,
+    `positions() / quaternions() / velocities()` views of those, `kin` the logical [13][ld] matrix (a copy), `set_state(kin=...)` its
+    inverse.  A velocity written through a view is what the next step integrates."""
+    from gym_pybullet_drones_amd.envs import VectorHoverAviary
+    from gym_pybullet_drones_amd.utils.enums import ActionType, Physics
+    env = VectorHoverAviary(64, physics=Physics.DYN, act=ActionType.RPM, ctrl_freq=240, auto_reset=False, device=gpu_device)
+    c = env.core
+    env.reset()
+    k = c.kin
+    assert k.shape == (13, c.ld) and torch.equal(k[0:3, :64].t(), c.positions()) and torch.equal(k[3:7, :64].t(), c.quaternions())
+    assert torch.equal(k[7:10, :64].t(), c.velocities()) and torch.equal(k[10:13, :64].t(), c.body_rates())
+    assert c.kin_P.data_ptr() == c.kin_store.data_ptr() and c.kin_W.data_ptr() == c.kin_store.data_ptr() + 12 * c.ld * 4
+    np.testing.assert_allclose(c.positions().cpu().numpy(), np.broadcast_to(c.INIT_XYZS, (64, 1, 3)).reshape(64, 3), atol=1e-7)
+    z0 = c.positions()[:, 2].clone()
+    c.velocities()[:, 2] = 1.2                                     # written through the view ...
+    env.step(torch.zeros((64, 1, 4), device=gpu_device))           # ... hover RPMs: z advances by v dt
+    np.testing.assert_allclose((c.positions()[:, 2] - z0).cpu().numpy(), 1.2 / 240, rtol=1e-4)
+    snap = c.kin[:, :64].clone()
+    snap[8] = -0.5
+    c.set_state(kin=snap)
+    assert torch.equal(c.kin[:, :64], snap) and float(c.kin_V[3, 1]) == -0.5

@@ -644,3 +644,19 @@ def test_parse_urdf_parameters_keeps_the_reference_tuple():
     assert np.allclose(np.diag(J), [1.4e-5, 1.4e-5, 2.17e-5]) and np.allclose(J @ J_INV, np.eye(3))
     assert (CH, CR, VMAX, GND, PROP) == (0.025, 0.06, 30.0, 11.36859, 2.31348e-2) and CZ == 0.0
     assert np.allclose(DRAG, [9.1785e-7, 9.1785e-7, 10.311e-7]) and (DW1, DW2, DW3) == (2267.18, 0.16, -0.11)
+
+
+def test_kin_planes_round_trip_on_the_host():
+    """ABI 9: `GpdState.kin` is four planes (P: pos xyz + body rate x | Q: quat xyzw | V: vel xyz + body rate y | W: body rate z);
+    `engine.kin_rows_from_planes` is the inverse the tests and the C host use to get the logical [13][ld] rows back."""
+    from gym_pybullet_drones_amd.engine import kin_rows_from_planes
+    ld = 8
+    rows = np.arange(13 * ld, dtype=np.float32).reshape(13, ld)
+    P = np.stack([rows[0], rows[1], rows[2], rows[10]], axis=1)
+    Q = np.stack([rows[3], rows[4], rows[5], rows[6]], axis=1)
+    V = np.stack([rows[7], rows[8], rows[9], rows[11]], axis=1)
+    store = np.concatenate([P.ravel(), Q.ravel(), V.ravel(), rows[12]])
+    assert store.size == 13 * ld
+    np.testing.assert_array_equal(kin_rows_from_planes(store, ld), rows)
+    import torch
+    np.testing.assert_array_equal(kin_rows_from_planes(torch.as_tensor(store), ld).numpy(), rows)
