@@ -1165,7 +1165,18 @@ def copy_probe(device, mib=1024, reps=20):
         ev1.record()
         torch.cuda.synchronize()
         sec = ev0.elapsed_time(ev1) * 1e-3
-        return {"gbs": 2 * n * 4 * reps / sec / 1e9, "mib": mib, "reps": reps, "what": "torch Tensor.copy_ device to device, read + write bytes"}
+        # ... and a write-only stream (the rollout kernel's traffic is 76 % stores: boxes of this pool that agree on the copy rate differ on it)
+        for _ in range(3):
+            b.fill_(1.0)
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(reps):
+            b.fill_(1.0)
+        ev1.record()
+        torch.cuda.synchronize()
+        sec_w = ev0.elapsed_time(ev1) * 1e-3
+        return {"gbs": 2 * n * 4 * reps / sec / 1e9, "fill_gbs": n * 4 * reps / sec_w / 1e9, "mib": mib, "reps": reps,
+                "what": "torch Tensor.copy_ device to device (read + write bytes); fill_gbs: Tensor.fill_ of the same buffer (write only)"}
     except Exception as e:          # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"[:160]}
 
