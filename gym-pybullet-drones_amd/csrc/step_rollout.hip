@@ -489,9 +489,10 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     float* __restrict__ reward, uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
     float* __restrict__ term_obs12) {
     const int tid = threadIdx.x;
-    // (workgroup -> drones is the identity: giving every XCD one contiguous block of drones instead of every eighth workgroup
-    // changed nothing, 0.816 vs 0.813-0.821 us per step, round-2 A/B)
-    const uint32_t bid = blockIdx.x;
+    // workgroup -> drones: the identity, or (T.xcd, large batches) every XCD one contiguous eighth of the drones instead of every eighth
+    // workgroup -- at 65 536 drones that changed nothing (0.816 vs 0.813-0.821 us per step, round-2 A/B)
+    uint32_t bid = blockIdx.x;
+    if (T.xcd) { const uint32_t per = gridDim.x >> 3; bid = (blockIdx.x & 7u) * per + (blockIdx.x >> 3); }
     const int D = MULTI ? C.drones_per_env : 1;
     const uint32_t dmask = static_cast<uint32_t>(D - 1);
     const uint32_t N = static_cast<uint32_t>(C.num_envs) * static_cast<uint32_t>(D);
@@ -633,6 +634,8 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
         const int lanes = multi ? (kBlock / C.drones_per_env) * C.drones_per_env : kBlock;
         const dim3 grid(static_cast<unsigned>((N + lanes - 1) / lanes));
         Span Tr = T;
+        static const char* const xcd_env = getenv("GPD_ROLLOUT_XCD");          // (diagnostics: 1 = contiguous eighths per XCD, 0 = never)
+        Tr.xcd = (grid.x % 8u == 0u && xcd_env != nullptr && xcd_env[0] == '1') ? 1 : 0;
         const bool shfl = multi && C.drones_per_env <= 64 && (C.drones_per_env & (C.drones_per_env - 1)) == 0;
         Tr.ring = ((!multi || shfl) && grid.x <= 2u * 256u) ? 4 : 2;   // <= 2 workgroups per CU: LDS is not what limits occupancy
         const size_t lds = static_cast<size_t>(Tr.ring) * kSlotBytes;
@@ -660,7 +663,11 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
             // shape (larger batches, sub-step loops, multi-drone aviaries) is 1-3 % faster with non-temporal ones
             // (A/B on one box, round 2: scratch/ab.sh, scratch/ab2.sh) -- and only for long rollouts: the ordinary stores leave
             // their lines to the end-of-kernel write-back, which a 20-step launch does not amortise (1.14 vs 1.00 us per step).
-            if (C.substeps == 1 && !PID && !EXT && ACT == GPD_ACT_RPM && N <= (1 << 17) && T.num_steps >= 48)
+            // (GPD_ROLLOUT_OBS_STORES=plain: the ordinary stores at every size -- diagnostics: the boxes of the pool differ on the
+            // non-temporal streaming rate, profiles/README.md)
+            static const char* const obs_stores = getenv("GPD_ROLLOUT_OBS_STORES");
+            const bool plain_obs = obs_stores != nullptr && obs_stores[0] == 'p';
+            if (C.substeps == 1 && !PID && !EXT && ACT == GPD_ACT_RPM && (plain_obs || (N <= (1 << 17) && T.num_steps >= 48)))
                 hipLaunchKernelGGL((gpd_rollout1_kernel<false, false, 4, GPD_ACT_RPM, true, false, false>), grid, dim3(kBlock), 0, st, P, S, C, Tr,
                                    action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
             else if (C.substeps == 1)
