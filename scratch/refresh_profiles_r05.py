@@ -52,11 +52,11 @@ if "hbm" in what and os.path.exists(os.path.join(G, "hbm_r05", "summary.json")):
             "rocprof_frac": bytes_launch / (tr["AverageNs"] * 1e-9) / 1e9 / 8000.0,
             "hip_events_us_in_the_traced_process": legs["b_traced"]["brief"]["launch_us_hip_events"],
             "hip_events_us_plain_before_after": [legs["a_plain"]["brief"]["launch_us_hip_events"], legs["d_plain"]["brief"]["launch_us_hip_events"]],
-            "note": "measured on ONE box of the pool (the reconciliation lease): there the tracer's durations, the traced process's HIP events and the plain runs "
-                    "agree within 2 % -- the tracer does not slow this kernel.  The line quoting this figure was measured on ANOTHER lease: this write-heavy "
-                    "kernel runs at 0.62-0.76 of 8 TB/s depending on the box (a device-to-device copy reads 5.0 TB/s on all of them, `copy_probe`), so "
-                    "`launch_us_hip_events` of a bench line and this figure differ by the box, not by the clock (round 4's 3 862 us trace vs 3 147 us "
-                    "bench line were two boxes)"}},
+            "note": "measured in ONE lease (the reconciliation): there the tracer's durations, the traced process's HIP events and the plain runs agree "
+                    "within 2 % -- the tracer does not slow this kernel.  The line quoting this figure ran with ANOTHER allocation of its buffers: this "
+                    "leg's rate follows their physical placement (0.62 / 0.68 / 0.72 / 0.75 of 8 TB/s in one process at identical virtual addresses, "
+                    "profiles/r05_hbm_placement_modes.txt), so `launch_us_hip_events` of a bench line and this figure may differ by the placement, not "
+                    "by the clock (round 4's 3 862 us trace vs 3 147 us bench line were two placements); `on_fresh_allocations` shows the spread"}},
     }
     fr = [out["legs"][k]["frac_hip_events"] for k in ("a_plain", "b_traced", "d_plain")] + [out["keys"]["hover4m_240hz:rollout64"]["rocprof_frac"]]
     out["one_fraction"] = {"value": sum(fr) / len(fr), "min": min(fr), "max": max(fr),
