@@ -482,12 +482,21 @@ struct RollOut {
 // RING (gpd_rollout_history): every step's raw action is also pushed into the action ring, like gpd_step does (slots q and
 // q + H of the double ring; two more stores per lane and step, which the explicit wait counts of the loop include because
 // they are unconditional -- a compile-time variant, not a run-time test).
+// (the argument list starts with the fourteen dwords the launch's first loads need -- kernarg preload, as for gpd_step_kernel: the state,
+// the first action rows, the counter, the target and the reset pose are requested without first waiting for the argument block)
 template <bool PID, bool EXT, int AW, int ACT, bool S1, bool MULTI, bool NT_OBS = true, bool RING = false>
 __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
-    const GpdParams P, const GpdState S, const GpdStepCfg C, const Span T, const float* __restrict__ action,
-    const float* __restrict__ target_pos, const float* __restrict__ init_pose, float* __restrict__ obs12,
+    float* __restrict__ hot_kin, const float* __restrict__ action, int32_t* __restrict__ hot_counter, const float* __restrict__ target_pos,
+    const float* __restrict__ init_pose, const uint32_t hot_ld, const int32_t hot_num_envs, const int32_t hot_num_steps, const uint32_t hot_bits,
+    const GpdParams P, const GpdState S_, const GpdStepCfg C_, const Span T_, float* __restrict__ obs12,
     float* __restrict__ reward, uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
     float* __restrict__ term_obs12) {
+    // (member by member, never a copy of the argument structs: see gpd_step_kernel)
+    const GpdState S{hot_kin, S_.last_rpm, S_.pid, hot_counter, static_cast<int64_t>(hot_ld), S_.dw_force, S_.act_ring, S_.ring_pos, S_.hist_len, 0, S_.bad};
+    const GpdStepCfg C{hot_num_envs, C_.drones_per_env, C_.act_type, C_.substeps, C_.physics_flags, C_.pyb_dt, C_.ctrl_dt, C_.inv_ctrl_dt,
+                       C_.lanes_per_wave, C_.task, C_.xy_bound, C_.z_bound, C_.tilt_bound, C_.term_dist, C_.trunc_counter,
+                       static_cast<int32_t>((hot_bits >> 2) & 1u), static_cast<int32_t>((hot_bits >> 1) & 1u), static_cast<int32_t>(hot_bits & 1u)};
+    const Span T{hot_num_steps, T_.action_stride, T_.obs_stride, T_.env_stride, T_.ring, static_cast<int32_t>((hot_bits >> 3) & 1u)};
     const int tid = threadIdx.x;
     // workgroup -> drones: the identity, or (T.xcd, large batches) every XCD one contiguous eighth of the drones instead of every eighth
     // workgroup -- at 65 536 drones that changed nothing (0.816 vs 0.813-0.821 us per step, round-2 A/B)
@@ -633,6 +642,9 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
     } else {
         const int lanes = multi ? (kBlock / C.drones_per_env) * C.drones_per_env : kBlock;
         const dim3 grid(static_cast<unsigned>((N + lanes - 1) / lanes));
+#define GPD_ROLL1_HOT S.kin, action, S.step_counter, target_pos, init_pose, static_cast<uint32_t>(S.ld), C.num_envs, Tr.num_steps, \
+                      (static_cast<uint32_t>(C.auto_reset != 0) | (static_cast<uint32_t>(C.init_per_env != 0) << 1) |      \
+                       (static_cast<uint32_t>(C.target_per_env != 0) << 2) | (static_cast<uint32_t>(Tr.xcd != 0) << 3))
         Span Tr = T;
         static const char* const xcd_env = getenv("GPD_ROLLOUT_XCD");          // (diagnostics: 1 = contiguous eighths per XCD, 0 = never)
         Tr.xcd = (grid.x % 8u == 0u && xcd_env != nullptr && xcd_env[0] == '1') ? 1 : 0;
@@ -642,18 +654,14 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
         static const bool store_wave_variant = getenv("GPD_ROLLOUT_STOREWAVE") != nullptr;   // A/B switch, diagnostics only
         if (S.act_ring && !store_wave_variant && term_obs12 == nullptr && (shfl || !multi)) {   // gpd_rollout_history (it checked the shape)
             if (shfl)
-                hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false, true, true, true>), grid, dim3(kBlock), 0, st, P, S, C, Tr,
-                                   action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+                hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false, true, true, true>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
             else if (C.substeps == 1)
-                hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, true, false, true, true>), grid, dim3(kBlock), 0, st, P, S, C, Tr,
-                                   action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+                hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, true, false, true, true>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
             else
-                hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false, false, true, true>), grid, dim3(kBlock), 0, st, P, S, C, Tr,
-                                   action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+                hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false, false, true, true>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
         } else
         if (shfl && !store_wave_variant && term_obs12 == nullptr) {   // aviaries of 2..64 (power of two) drones: no helper wave either
-            hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false, true>), grid, dim3(kBlock), 0, st, P, S, C, Tr, action,
-                               target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+            hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false, true>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
         } else if (multi) {
             hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, true, AW>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
                                action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
@@ -668,14 +676,11 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
             static const char* const obs_stores = getenv("GPD_ROLLOUT_OBS_STORES");
             const bool plain_obs = obs_stores != nullptr && obs_stores[0] == 'p';
             if (C.substeps == 1 && !PID && !EXT && ACT == GPD_ACT_RPM && (plain_obs || (N <= (1 << 17) && T.num_steps >= 48)))
-                hipLaunchKernelGGL((gpd_rollout1_kernel<false, false, 4, GPD_ACT_RPM, true, false, false>), grid, dim3(kBlock), 0, st, P, S, C, Tr,
-                                   action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+                hipLaunchKernelGGL((gpd_rollout1_kernel<false, false, 4, GPD_ACT_RPM, true, false, false>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
             else if (C.substeps == 1)
-                hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, true, false>), grid, dim3(kBlock), 0, st, P, S, C, Tr, action,
-                                   target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+                hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, true, false>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
             else
-                hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false, false>), grid, dim3(kBlock), 0, st, P, S, C, Tr, action,
-                                   target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+                hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false, false>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
         } else {
             hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, false, AW>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
                                action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""A/B of kernarg preload for gpd_rollout1_kernel: bench.py's rollout leg, previous library (scratch/exp/libgpd_prev.so) vs the product,
+interleaved rounds on one box.  usage (GPU box): python scratch/exp_r05/ab_rollout.py [rounds] -> gpurun_out/ab_rollout_r05.log"""
+import json
+import os
+import subprocess
+import sys
+
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+LIBS = {"prev": "scratch/exp/libgpd_prev.so", "preload": "gym-pybullet-drones_amd/csrc/libgpd.so"}
+WORK = [("hover65536_240hz", ["--steps", "20", "--warmup", "5"]), ("hover65536_240hz", ["--steps", "64", "--warmup", "64"]),
+        ("hover65536_pid_240hz", ["--steps", "20", "--warmup", "5"]), ("hover65536_30hz", ["--steps", "20", "--warmup", "5"]),
+        ("stack8x8192_ext_240hz", ["--steps", "20", "--warmup", "5"]), ("hover4096_240hz", ["--steps", "20", "--warmup", "5"])]
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+res = {}
+for rnd in range(rounds):
+    for wl, extra in WORK:
+        if rnd and wl != "hover65536_240hz":
+            continue
+        for v, lib in LIBS.items():
+            e = dict(os.environ, GPD_LIB=os.path.join(R, lib))
+            cmd = [sys.executable, os.path.join(R, "bench.py"), "--workload", wl, "--no-cpu-baseline", "--no-hbm-leg", "--no-parity", "--no-second-leg",
+                   "--min-time", "0.5"] + extra
+            p = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=300)
+            line = next((l for l in reversed(p.stdout.splitlines()) if l.startswith("{")), None)
+            if not line:
+                print(wl, v, "FAILED", p.stderr[-300:], flush=True)
+                continue
+            j = json.loads(line)
+            key = f"{wl} K={extra[1]}"
+            res.setdefault(key, {}).setdefault(v, []).append(j["roofline"]["launch_us_hip_events"])
+            print(f"round {rnd} {key:32s} {v:8s}: {j['roofline']['launch_us_hip_events']:.3f} us per launch, {j['ms_per_step'] * 1e3:.4f} us per step, frac {j['roofline']['frac']:.3f}", flush=True)
+print("\nus per launch (min .. max over rounds)")
+for k, d in res.items():
+    print(f"{k:34s} " + "   ".join(f"{v}: {min(x):.3f}..{max(x):.3f}" for v, x in d.items()))

@@ -53,7 +53,9 @@ def kernels(text):
     i = 0
     while i < len(lines):
         m = re.match(r"^(_Z\w+):", lines[i])
-        if m and i + 1 < len(lines) and "%bb.0" in lines[i + 1]:
+        # (a kernel's label is followed by its entry block: "%bb.0", or -- kernels whose leading arguments are preloaded into SGPRs,
+        # -amdgpu-kernarg-preload-count -- the numbered block of the backward-compatibility prologue that loads them and branches on)
+        if m and i + 1 < len(lines) and re.search(r"%bb\.\d+", lines[i + 1]):
             j = next(k for k in range(i, len(lines)) if lines[k].startswith(".Lfunc_end"))
             yield m.group(1), lines[i + 1:j]
             i = j
@@ -138,9 +140,12 @@ def spill_runs(body):
     return [r for r in runs if len(r["regs"]) > 1]
 
 
-def torn_spills(body):
+def torn_spills(body, unused_kernarg_offsets=()):
     """The miscompile proper: a scalar load A keeps some destination dwords alive and loses others to a later definition,
-    and afterwards ONE spill run saves both kinds together as if A's tuple were intact (reachability over the kernel's control-flow graph)."""
+    and afterwards ONE spill run saves both kinds together as if A's tuple were intact (reachability over the kernel's control-flow graph).
+    `unused_kernarg_offsets`: byte offsets of kernel-argument words NO device code reads (a host-only struct member): there is no
+    s_load_dwordx3, so three used words next to such a member are fetched as an x4 whose fourth register the allocator is free to
+    reuse at once -- the same shape, and harmless; a finding all of whose dead dwords sit at such offsets is not reported."""
     dead_of = {n: (l, set(dead)) for n, l, dead in check(body)}
     out = []
     runs = spill_runs(body)
@@ -150,6 +155,9 @@ def torn_spills(body):
         dst = sregs(split_ops(rest)[0])
         alive = dst - dead
         if not alive:
+            continue
+        m_imm = re.search(r",\s*(0x[0-9a-fA-F]+|\d+)\s*$", rest)
+        if unused_kernarg_offsets and m_imm and all(int(m_imm.group(1), 0) + 4 * (r - min(dst)) in unused_kernarg_offsets for r in dead):
             continue
         for run in runs:
             if run["start"] < n:

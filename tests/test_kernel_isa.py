@@ -174,9 +174,12 @@ def test_no_kernel_saves_a_half_overwritten_argument_tuple(gpd_asm, policy_asm, 
     for asm in (gpd_asm, policy_asm, swarm_asm, abi_asm):
         for name, body in chk.kernels("\n".join(asm)):
             n += 1
-            found = chk.torn_spills(body)
+            # GpdParams.pid_kf (word 36 of the struct) is read by the HOST only (the "no controller for this airframe" check): its three
+            # neighbours hover_resid / km_over_kf / pid_gravity are fetched as an x4 whose fourth register is reused at once.  The struct
+            # sits at byte 0 of the argument block, or at byte 56 behind the fourteen preloaded dwords of gpd_step_kernel / gpd_rollout1_kernel
+            found = chk.torn_spills(body, unused_kernarg_offsets={36 * 4, 56 + 36 * 4})
             assert not found, (name, [(l, dead, run["lanes"]) for _, l, dead, run in found])
-    assert n >= 130, n
+    assert n >= 180, n          # (every kernel of the four units, the preloaded-argument ones included)
 
 
 def test_no_kernel_needs_scratch_memory_or_reads_the_dispatch_packet(gpd_asm, policy_asm, swarm_asm, abi_asm):
