@@ -73,6 +73,18 @@ def kin_rows_from_planes(store, ld: int):
     return torch.stack(rows) if torch.is_tensor(store) else np.stack(rows)
 
 
+class KinRows(torch.Tensor):
+    """What `SimCore.kin` returns: a COPY of the state as the logical [13, ld] matrix.  Assigning into it (or into a slice of it) would
+    be lost without a trace -- up to ABI 8 `kin` WAS the device's state -- so item assignment raises; `clone()` gives a plain tensor."""
+
+    def __setitem__(self, key, value):
+        raise TypeError("SimCore.kin is a copy of the state (the device keeps it in four planes since ABI 9): write through the views "
+                        "kin_P / kin_Q / kin_V / kin_W (positions(), quaternions(), velocities()), or pass an edited clone to set_state(kin=...)")
+
+    def clone(self, *args, **kwargs):
+        return super().clone(*args, **kwargs).as_subclass(torch.Tensor)
+
+
 class SimCore:
     """E aviaries x D drones advanced by one fused kernel launch per `step()`."""
 
@@ -223,7 +235,7 @@ class SimCore:
     def kin(self) -> torch.Tensor:
         """A COPY of the kinematic state as the [13, ld] matrix of rounds 1-4 (the device keeps it in four planes, `kin_P` /
         `kin_Q` / `kin_V` / `kin_W`: write through those views, or through `set_state(kin=...)`)."""
-        return kin_rows_from_planes(self.kin_store, self.ld)
+        return kin_rows_from_planes(self.kin_store, self.ld).as_subclass(KinRows)
 
     def positions(self, n: int = None) -> torch.Tensor:
         """[n, 3] VIEW of the positions"""

@@ -841,6 +841,8 @@ def test_kinematic_planes_are_writable_views_and_kin_is_their_logical_matrix(gpu
     c.velocities()[:, 2] = 1.2                                     # written through the view ...
     env.step(torch.zeros((64, 1, 4), device=gpu_device))           # ... hover RPMs: z advances by v dt
     np.testing.assert_allclose((c.positions()[:, 2] - z0).cpu().numpy(), 1.2 / 240, rtol=1e-4)
+    with pytest.raises(TypeError, match="copy of the state"):      # (up to ABI 8 this assignment changed the device's state: now it says so)
+        c.kin[8, 3] = 1.0
     snap = c.kin[:, :64].clone()
     snap[8] = -0.5
     c.set_state(kin=snap)
