@@ -227,7 +227,7 @@ class SimCore:
             if mask is None:
                 self.bad.zero_()
             else:
-                self.bad.view(self.E, self.D)[mask.to(torch.bool)] = False
+                self.bad.view(self.E, self.D).masked_fill_(mask.to(torch.bool).unsqueeze(1), False)      # (no host sync)
         return self.obs12
 
     # ---- the kinematic block as the logical [13][ld] matrix (rows: pos xyz | quat xyzw | vel xyz | body rates xyz) -------------

@@ -27,7 +27,6 @@ Interface: `CtrlAviary`-like.  `step(action)` takes raw RPMs `(n_own, 4)` clippe
 GPU.
 """
 import ctypes
-import os
 
 import numpy as np
 import torch

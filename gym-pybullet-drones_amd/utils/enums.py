@@ -154,7 +154,9 @@ def _pyb_mode(v) -> str:
             return "off"
         if t in ("damped", "damp", "2", "bullet"):
             return "damped"
-        return "ground"
+        if t in ("1", "true", "on", "yes", "ground"):
+            return "ground"
+        raise ValueError(f"pyb_like / GPD_PYB_LIKE: {v!r} is none of 0 | off, 1 | ground, damped")
     if v is None:
         return "ground"
     if isinstance(v, bool):

@@ -75,6 +75,8 @@ def test_enums_are_value_compatible():
     assert Physics.PYB.mask(False) == 0 and Physics.PYB_DW.mask(False) == 4
     from gym_pybullet_drones_amd.utils import enums
     assert enums._pyb_mode("0") == "off" and enums._pyb_mode("1") == "ground" and enums._pyb_mode("damped") == "damped"
+    with pytest.raises(ValueError):
+        enums._pyb_mode("dampd")                 # a typo is not silently "ground"
     assert Physics.PYB.mask() == {"off": 0, "ground": 8, "damped": 24}[enums._pyb_like]      # (the process default: GPD_PYB_LIKE)
     keep = enums._pyb_like
     try:
