@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B of kernarg preload for gpd_rollout1_kernel: bench.py's rollout leg, previous library (scratch/exp/libgpd_prev.so) vs the product,
-interleaved rounds on one box.  usage (GPU box): python scratch/exp_r05/ab_rollout.py [rounds] -> gpurun_out/ab_rollout_r05.log"""
+interleaved rounds on one box.  usage (GPU box): python scratch/exp_r05/ab_rollout.py [rounds] -> gpurun_out/ab_rollout_r05.log
+(GPD_AB_LIBS="a=path,b=path" compares other variant libraries; GPD_AB_QUICK=1: the two headline shapes only)"""
 import json
 import os
 import subprocess
@@ -8,9 +9,13 @@ import sys
 
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 LIBS = {"prev": "scratch/exp/libgpd_prev.so", "preload": "gym-pybullet-drones_amd/csrc/libgpd.so"}
+if os.environ.get("GPD_AB_LIBS"):          # "label=path,label=path" (paths relative to the repo): any two (or more) variant libraries
+    LIBS = dict(kv.split("=", 1) for kv in os.environ["GPD_AB_LIBS"].split(","))
 WORK = [("hover65536_240hz", ["--steps", "20", "--warmup", "5"]), ("hover65536_240hz", ["--steps", "64", "--warmup", "64"]),
         ("hover65536_pid_240hz", ["--steps", "20", "--warmup", "5"]), ("hover65536_30hz", ["--steps", "20", "--warmup", "5"]),
         ("stack8x8192_ext_240hz", ["--steps", "20", "--warmup", "5"]), ("hover4096_240hz", ["--steps", "20", "--warmup", "5"])]
+if os.environ.get("GPD_AB_QUICK"):         # the two headline shapes only
+    WORK = WORK[:2]
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 res = {}
 for rnd in range(rounds):
