@@ -187,7 +187,7 @@ def cpu_baseline(w, budget_s=12.0, phys=None):
     """Time the loop-structured float64 oracle (the CPU 'port' of the reference's per-drone Python/numpy
     path; PyBullet itself is not installable here) on ONE host core, on a bounded sample of the workload."""
     from oracle.aviary_oracle import OracleAviary
-    urdf = os.path.join(REPO, "gym-pybullet-drones_amd", "assets", "cf2x.urdf")
+    urdf = os.path.join(REPO, "gym_pybullet_drones_amd", "assets", "cf2x.urdf")
     D = w["D"]
     phys = w["phys"] if phys is None else phys      # (the flags the device path really runs with: Physics.PYB* adds the ground plane)
     task = w["task"] if w["task"] != "hover" or D == 1 else "multihover"
@@ -317,7 +317,7 @@ def swarm_parity_check(env, all_pos=None):
         mine_ids = None
     if len(rows) != N or not np.isfinite(pos[rows]).all():
         return {"error": f"{N - len(rows)} drones without a finite position"}
-    urdf = os.path.join(REPO, "gym-pybullet-drones_amd", "assets", "cf2x.urdf")
+    urdf = os.path.join(REPO, "gym_pybullet_drones_amd", "assets", "cf2x.urdf")
     th = min(host_threads(), c_oracle.lib().orc_max_threads())
     first = int(np.searchsorted(rows, env.RANK * env.slab))         # this rank's rows start here; rows[] skips the meta rows before them
     # a BOUNDED check: every drone is a source, but beyond 131 072 receivers a seeded sample of this rank's drones (the full
@@ -385,7 +385,7 @@ def parity_check(w, env, actions, K, POOL, max_steps=256):
     from oracle.c_oracle import CAviary
     core = env.core
     E, D, N, A, S = core.E, core.D, core.N, core.A, core.S
-    urdf = os.path.join(REPO, "gym-pybullet-drones_amd", "assets", "cf2x.urdf")
+    urdf = os.path.join(REPO, "gym_pybullet_drones_amd", "assets", "cf2x.urdf")
     task = {0: "none", 1: "hover", 2: "multihover"}[core.task]
     torch.cuda.synchronize()
     st = core.get_state()

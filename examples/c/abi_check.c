@@ -1,10 +1,10 @@
 /*
  * The smallest C consumer of libgpd.so: include/gpd.h is plain C (C11, -pedantic clean), and a binding that mirrors its structs
- * verifies them against the library before its first call (what gym-pybullet-drones_amd/_native.py does through ctypes,
+ * verifies them against the library before its first call (what gym_pybullet_drones_amd/_native.py does through ctypes,
  * INTEGRATION.md section 2).  Needs no GPU: nothing is launched.
  *
- *   gcc -std=c11 -I include examples/c/abi_check.c -L gym-pybullet-drones_amd/csrc -lgpd \
- *       -Wl,-rpath,$PWD/gym-pybullet-drones_amd/csrc -o abi_check && ./abi_check
+ *   gcc -std=c11 -I include examples/c/abi_check.c -L gym_pybullet_drones_amd/csrc -lgpd \
+ *       -Wl,-rpath,$PWD/gym_pybullet_drones_amd/csrc -o abi_check && ./abi_check
  */
 #include <stdio.h>
 

@@ -12,7 +12,9 @@ from .params import GpdParams
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")        # the source tree's include/ ...
+if not os.path.exists(os.path.join(INCLUDE, "gpd.h")):            # ... or the copy setup.py puts inside an installed package
+    INCLUDE = os.path.join(_HERE, "include")
 LIB_PATH = os.path.join(CSRC, "libgpd.so")
 ABI_VERSION = 9
 

@@ -4,7 +4,9 @@
 return triple); `DSLPIDControlBatch` runs n independent controllers per call on torch tensors.
 Both call `gpd_pid` (include/gpd.h) — the same device function the fused step kernel uses for
 `ActionType.PID/VEL/ONE_D_PID`.  Controller state (integral_pos_e, last_rpy, integral_rpy_e)
-lives in a [9][ld] float32 device block.
+lives in a [9][ld] float32 block: in HBM for the batch class, in page-locked host memory the
+device addresses directly for the single-drone class, whose call is then one launch and one stream
+synchronisation (inputs written and outputs read by the host in place; no copies).
 """
 import ctypes
 
@@ -31,7 +33,8 @@ def _f32(x, n, k, device):
 class DSLPIDControlBatch(BaseControl):
     """n independent DSLPID controllers, one lane each."""
 
-    def __init__(self, num_controllers: int, drone_model: DroneModel = DroneModel.CF2X, g: float = 9.8, device=None):
+    def __init__(self, num_controllers: int, drone_model: DroneModel = DroneModel.CF2X, g: float = 9.8, device=None,
+                 host_visible: bool = False):
         if drone_model not in (DroneModel.CF2X, DroneModel.CF2P):
             raise ValueError("[ERROR] in DSLPIDControl.__init__(), DSLPIDControl requires DroneModel.CF2X or DroneModel.CF2P")
         self.lib = _native.lib()
@@ -48,7 +51,11 @@ class DSLPIDControlBatch(BaseControl):
         self.PWM2RPM_SCALE, self.PWM2RPM_CONST = gains.PWM2RPM_SCALE, gains.PWM2RPM_CONST
         self.MIN_PWM, self.MAX_PWM = gains.MIN_PWM, gains.MAX_PWM
         self.MIXER_MATRIX = MIXER[drone_model].copy()
-        self._state = torch.zeros((9, self.ld), dtype=torch.float32, device=self.device)
+        if host_visible:
+            with torch.cuda.device(self.device):
+                self._state = torch.zeros((9, self.ld), dtype=torch.float32).pin_memory()
+        else:
+            self._state = torch.zeros((9, self.ld), dtype=torch.float32, device=self.device)
         super().__init__(drone_model=drone_model, g=g)
         self._coefficients_changed()
 
@@ -98,20 +105,47 @@ class DSLPIDControlBatch(BaseControl):
 class DSLPIDControl(DSLPIDControlBatch):
     """PID control class for Crazyflies — single drone, numpy interface of the reference."""
 
-    def __init__(self, drone_model: DroneModel, g: float = 9.8, device=None):
-        super().__init__(1, drone_model=drone_model, g=g, device=device)
+    # one page-locked block for the call's operands, float offsets (the two 16-byte accesses of gpd_pid_kernel first)
+    _QUAT, _RPM, _POS, _VEL, _TPOS, _TRPY, _TVEL, _TRATES, _POS_E, _YAW_E, _IO_FLOATS = 0, 4, 8, 11, 14, 17, 20, 23, 26, 29, 32
 
-    integral_pos_e = property(lambda self: DSLPIDControlBatch.integral_pos_e.fget(self)[0])
-    last_rpy = property(lambda self: DSLPIDControlBatch.last_rpy.fget(self)[0])
-    integral_rpy_e = property(lambda self: DSLPIDControlBatch.integral_rpy_e.fget(self)[0])
+    def __init__(self, drone_model: DroneModel, g: float = 9.8, device=None):
+        super().__init__(1, drone_model=drone_model, g=g, device=device, host_visible=True)
+        with torch.cuda.device(self.device):
+            self._io_t = torch.zeros((self._IO_FLOATS,), dtype=torch.float32).pin_memory()
+        self._io = self._io_t.numpy()
+        base = self._io_t.data_ptr()
+        at = lambda off: ctypes.c_void_p(base + 4 * off)      # noqa: E731
+        self._pid_args = (_ptr(self._state), self.ld, at(self._POS), at(self._QUAT), at(self._VEL), at(self._TPOS), at(self._TRPY),
+                          at(self._TVEL), at(self._TRATES), at(self._RPM), at(self._POS_E), at(self._YAW_E))
+
+    def _member(self, row):
+        torch.cuda.current_stream(self.device).synchronize()
+        return self._state[row:row + 3, 0].numpy().astype(np.float64)
+
+    integral_pos_e = property(lambda self: self._member(0))
+    last_rpy = property(lambda self: self._member(3))
+    integral_rpy_e = property(lambda self: self._member(6))
 
     def computeControl(self, control_timestep, cur_pos, cur_quat, cur_vel, cur_ang_vel, target_pos,
                        target_rpy=np.zeros(3), target_vel=np.zeros(3), target_rpy_rates=np.zeros(3)):
         """-> (rpm (4,), pos_e (3,), yaw_e float), float64 numpy like the reference."""
-        rpm, pos_e, yaw_e = super().computeControl(control_timestep, cur_pos, cur_quat, cur_vel, cur_ang_vel,
-                                                   target_pos, target_rpy, target_vel, target_rpy_rates)
-        out = torch.cat([rpm.reshape(-1), pos_e.reshape(-1), yaw_e.reshape(-1)]).cpu().numpy().astype(np.float64)
-        return out[0:4], out[4:7], float(out[7])
+        self.control_counter += 1
+        io, a = self._io, self._pid_args
+        io[self._QUAT:self._QUAT + 4] = cur_quat
+        io[self._POS:self._POS + 3] = cur_pos
+        io[self._VEL:self._VEL + 3] = cur_vel
+        io[self._TPOS:self._TPOS + 3] = target_pos
+        io[self._TRPY:self._TRPY + 3] = target_rpy
+        io[self._TVEL:self._TVEL + 3] = target_vel
+        io[self._TRATES:self._TRATES + 3] = target_rpy_rates
+        stream = torch.cuda.current_stream(self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.gpd_pid(ctypes.byref(self._params), a[0], a[1], float(control_timestep), a[2], a[3], a[4], a[5], a[6], a[7], a[8],
+                                  a[9], a[10], a[11], 1, ctypes.c_void_p(stream.cuda_stream))
+        _native.check(rc, "gpd_pid")
+        stream.synchronize()
+        out = io.astype(np.float64)
+        return out[self._RPM:self._RPM + 4], out[self._POS_E:self._POS_E + 3], float(out[self._YAW_E])
 
     def _one23DInterface(self, thrust):
         """1, 2 or 4 desired thrusts -> 4 PWMs (reference `:263-287`)."""

@@ -365,6 +365,7 @@ int gpd_reset(const GpdState* state, const float* init_pose, int32_t init_per_en
               int32_t num_envs, int32_t drones_per_env, int32_t reset_pid, float* obs12, void* stream) {
     if (!state || !state->kin || !state->step_counter || !init_pose)
         return fail(GPD_EINVAL, "gpd_reset: NULL state/init_pose");
+    if (const char* why = state_layout_problem(state)) return fail(GPD_EINVAL, (std::string("gpd_reset: ") + why).c_str());
     if (num_envs <= 0 || drones_per_env <= 0) return fail(GPD_EINVAL, "gpd_reset: sizes must be positive");
     const int64_t N = static_cast<int64_t>(num_envs) * drones_per_env;
     if (state->ld < N) return fail(GPD_EINVAL, "gpd_reset: state.ld < num_envs*drones_per_env");
@@ -396,6 +397,7 @@ int gpd_pid(const GpdParams* params, float* pid, int64_t ld, float ctrl_dt, cons
 
 int gpd_state_vectors(const GpdState* state, const float* obs12, float* state20, int32_t n, void* stream) {
     if (!state || !state->kin || !obs12 || !state20) return fail(GPD_EINVAL, "gpd_state_vectors: NULL argument");
+    if (const char* why = state_layout_problem(state)) return fail(GPD_EINVAL, (std::string("gpd_state_vectors: ") + why).c_str());
     if (n <= 0 || state->ld < n) return fail(GPD_EINVAL, "gpd_state_vectors: need 0 < n <= state.ld");
     const int blocks = (n + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(gpd_state20_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), *state,

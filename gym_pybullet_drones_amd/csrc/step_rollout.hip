@@ -696,6 +696,7 @@ int step_impl(const char* who, const GpdParams* params, const GpdState* state, c
     auto bad = [&](int code, const char* msg) { return fail(code, (std::string(who) + ": " + msg).c_str()); };
     if (!params || !state || !cfg) return bad(GPD_EINVAL, "NULL params/state/cfg");
     if (!state->kin || !state->step_counter) return bad(GPD_EINVAL, "NULL state.kin/step_counter");
+    if (const char* why = state_layout_problem(state)) return bad(GPD_EINVAL, why);
     if (!action || !obs12 || !reward || !terminated || !truncated)
         return bad(GPD_EINVAL, "NULL action/obs12/reward/terminated/truncated");
     if (cfg->num_envs <= 0 || cfg->drones_per_env <= 0 || cfg->substeps <= 0)

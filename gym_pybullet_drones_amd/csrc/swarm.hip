@@ -902,6 +902,7 @@ int gpd_downwash_global(const GpdParams* params, const float* kin, int64_t ld, i
     if (!params || !kin || !cell_count || !cell_start || !order || !sorted_xyzc || !dw_out)
         return fail(GPD_EINVAL, "gpd_downwash_global: NULL argument");
     if (n <= 0 || ld < n) return fail(GPD_EINVAL, "gpd_downwash_global: need 0 < n <= ld");
+    if ((reinterpret_cast<uintptr_t>(kin) & 15u) != 0) return fail(GPD_EINVAL, "gpd_downwash_global: kin must be 16-byte aligned (plane P is read as float4)");
     if (visit_order == order) return fail(GPD_EINVAL, "gpd_downwash_global: visit_order must not alias order (ping-pong two buffers)");
     if (!(cell >= 10.0f)) return fail(GPD_EINVAL, "gpd_downwash_global: cell must be >= 10 m (the model's lateral cut-off)");
     if (nz < 1 || nz > kBlock || (nz > 1 && !(zbin > 0.0f))) return fail(GPD_EINVAL, "gpd_downwash_global: need 1 <= nz <= 256 and zbin > 0");
@@ -971,6 +972,7 @@ int gpd_swarm_step(const GpdParams* params, const GpdState* state, const GpdStep
     if (!params || !state || !cfg || !action || !obs12) return bad(GPD_EINVAL, "NULL params/state/cfg/action/obs12");
     if (int rc = swarm_args("gpd_swarm_step", swarm, false)) return rc;
     if (!state->kin || !state->step_counter) return bad(GPD_EINVAL, "NULL state.kin/step_counter");
+    if (const char* why = state_layout_problem(state)) return bad(GPD_EINVAL, why);
     if (cfg->drones_per_env != 1 || cfg->num_envs != swarm->own_count || cfg->num_envs <= 0) return bad(GPD_EINVAL, "need drones_per_env == 1 and num_envs == swarm.own_count > 0");
     if (cfg->substeps != 1 || cfg->task != GPD_TASK_NONE || cfg->auto_reset) return bad(GPD_ENOTSUP, "one physics sub-step per call, no task, no auto-reset");
     if (cfg->act_type != GPD_ACT_RPM && cfg->act_type != GPD_ACT_RAW_RPM && cfg->act_type != GPD_ACT_DIRECT_RPM)
@@ -1000,6 +1002,7 @@ int gpd_swarm_step(const GpdParams* params, const GpdState* state, const GpdStep
 
 int gpd_swarm_pack(const GpdState* state, const GpdSwarm* swarm, const float* obs12, float* vec_out, void* stream) {
     if (!state || !state->kin) return fail(GPD_EINVAL, "gpd_swarm_pack: NULL state / state.kin");
+    if (const char* why = state_layout_problem(state)) return fail(GPD_EINVAL, (std::string("gpd_swarm_pack: ") + why).c_str());
     if (int rc = swarm_args("gpd_swarm_pack", swarm, false)) return rc;
     if (state->ld < swarm->own_count) return fail(GPD_EINVAL, "gpd_swarm_pack: state.ld < own_count");
     if (vec_out && !obs12) return fail(GPD_EINVAL, "gpd_swarm_pack: vec_out needs obs12");

@@ -14,6 +14,7 @@ in the hand-written kernels.  Layout (N = num_envs * drones_per_env, drone n = e
     obs12     float32 [N][12]    pos | rpy | vel | ang_v — row-major, ready for a policy / all-gather
     reward    float32 [E], terminated/truncated bool (1 byte) [E]
 """
+import contextlib
 import ctypes
 import os
 
@@ -73,13 +74,26 @@ def kin_rows_from_planes(store, ld: int):
     return torch.stack(rows) if torch.is_tensor(store) else np.stack(rows)
 
 
+_KIN_COPY = ("SimCore.kin is a copy of the state (the device keeps it in four planes since ABI 9): write through the views "
+             "kin_P / kin_Q / kin_V / kin_W (positions(), quaternions(), velocities()), or pass an edited clone to set_state(kin=...)")
+
+
 class KinRows(torch.Tensor):
-    """What `SimCore.kin` returns: a COPY of the state as the logical [13, ld] matrix.  Assigning into it (or into a slice of it) would
-    be lost without a trace -- up to ABI 8 `kin` WAS the device's state -- so item assignment raises; `clone()` gives a plain tensor."""
+    """What `SimCore.kin` returns: a COPY of the state as the logical [13, ld] matrix.  Writing into it (or into a slice or row of it)
+    would be lost without a trace -- up to ABI 8 `kin` WAS the device's state -- so item assignment AND every in-place torch operation
+    on it or on a view of it (`kin[0:3].copy_(x)`, `kin[2].fill_(1.)`, `kin[:, i].zero_()` ...) raise (`kin += x` rebinds the name to a new tensor: torch turns the
+    TypeError of an augmented assignment into Python's out-of-place fallback); `clone()` gives a plain
+    tensor to edit.  Every access builds the full 13 x ld copy: loops read `positions()` / `velocities()` / `kin_P` ... instead."""
 
     def __setitem__(self, key, value):
-        raise TypeError("SimCore.kin is a copy of the state (the device keeps it in four planes since ABI 9): write through the views "
-                        "kin_P / kin_Q / kin_V / kin_W (positions(), quaternions(), velocities()), or pass an edited clone to set_state(kin=...)")
+        raise TypeError(_KIN_COPY)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        name = getattr(func, "__name__", "")
+        if name.endswith("_") and not name.endswith("__") and args and isinstance(args[0], KinRows):      # torch's in-place naming rule
+            raise TypeError(_KIN_COPY)
+        return super().__torch_function__(func, types, args, kwargs or {})
 
     def clone(self, *args, **kwargs):
         return super().clone(*args, **kwargs).as_subclass(torch.Tensor)
@@ -94,7 +108,13 @@ class SimCore:
                  episode_len_sec: float = 8.0, xy_bound: float = 1.5, z_bound: float = 2.0, tilt_bound: float = 0.4,
                  term_dist: float = 1e-4, auto_reset: bool = False, track_rpm: bool = True,
                  keep_terminal_obs: bool = False, device=None, gains: PIDGains = None, force_pid: bool = False,
-                 pyb_like: bool = None, nan_guard: bool = False):
+                 pyb_like: bool = None, nan_guard: bool = False, host_visible: bool = False):
+        """`host_visible`: keep the state and the per-step outputs in page-locked HOST memory that the device addresses directly
+        (one aviary of a few drones: the reference-shaped `HoverAviary()` & co).  A step is then ONE launch + one stream
+        synchronisation -- the kernel reads the action and the state over the link and writes state, observation row, reward and
+        flags where the host reads them, no copy engine, no second launch; `step()` / `reset()` return after the stream has
+        drained.  Same kernels, same bits (`test_host_visible_core_is_bitwise_the_device_core`).  Not for batches: every byte
+        crosses PCIe."""
         if pyb_freq % ctrl_freq != 0:
             raise ValueError("[ERROR] pyb_freq is not divisible by ctrl_freq.")
         self.lib = _native.lib()                      # raises if the HIP extension is missing
@@ -128,21 +148,33 @@ class SimCore:
         self._params = self.P.to_struct(pid_model=DroneModel.CF2X, gains=gains)   # BaseRLAviary.py:75-76
 
         dev, f32 = self.device, torch.float32
-        self.kin_store = torch.zeros((13 * self.ld,), dtype=f32, device=dev)
+        self.host_visible = bool(host_visible)
+
+        def buf(shape, dtype=f32):
+            """a zeroed buffer the kernels read and write: HBM, or (host_visible) page-locked host memory mapped into the device's
+            address space (hipHostMalloc through torch's pinned allocator: the host pointer IS the device pointer)"""
+            if self.host_visible:
+                with torch.cuda.device(dev):
+                    return torch.zeros(shape, dtype=dtype).pin_memory()
+            return torch.zeros(shape, dtype=dtype, device=dev)
+
+        self.kin_store = buf((13 * self.ld,))
         ld = self.ld
         self.kin_P, self.kin_Q = self.kin_store[:4 * ld].view(ld, 4), self.kin_store[4 * ld:8 * ld].view(ld, 4)
         self.kin_V, self.kin_W = self.kin_store[8 * ld:12 * ld].view(ld, 4), self.kin_store[12 * ld:]
         need_rpm = track_rpm or bool(self.physics_flags & PHYS_DRAG)
-        self.last_rpm = torch.zeros((4, self.ld), dtype=f32, device=dev) if need_rpm else None
+        self.last_rpm = buf((4, self.ld)) if need_rpm else None
         # (force_pid: the controller state exists although the kernel is fed RPMs -- a host-side caller runs gpd_pid on it)
-        self.pid = torch.zeros((9, self.ld), dtype=f32, device=dev) if (self.uses_pid or force_pid) else None
-        self.step_counter = torch.zeros((self.E,), dtype=torch.int32, device=dev)
-        self.obs12 = torch.zeros((self.N, 12), dtype=f32, device=dev)
-        self.reward = torch.zeros((self.E,), dtype=f32, device=dev)
+        self.pid = buf((9, self.ld)) if (self.uses_pid or force_pid) else None
+        self.step_counter = buf((self.E,), torch.int32)
+        self.obs12 = buf((self.N, 12))
+        self.reward = buf((self.E,))
         # torch.bool is one byte holding 0/1, exactly what the kernel stores: no conversion kernel needed
-        self.terminated = torch.zeros((self.E,), dtype=torch.bool, device=dev)
-        self.truncated = torch.zeros((self.E,), dtype=torch.bool, device=dev)
-        self.term_obs12 = torch.zeros((self.N, 12), dtype=f32, device=dev) if keep_terminal_obs else None
+        self.terminated = buf((self.E,), torch.bool)
+        self.truncated = buf((self.E,), torch.bool)
+        self.term_obs12 = buf((self.N, 12)) if keep_terminal_obs else None
+        # host_visible: the action row is written by the host where the kernel reads it (`step(core.action_host)`)
+        self.action_host = buf((self.N, self.A)) if self.host_visible else None
 
         # initial poses: (D,3) shared by all envs, or (E,D,3) per env
         if initial_xyzs is None:
@@ -164,7 +196,7 @@ class SimCore:
 
         # nan_guard: one byte per drone, rewritten by every call that stores the state: 1 = a NaN / infinity sits in the drone's
         # kinematic state (GpdState.bad; the reference has no such check)
-        self.bad = torch.zeros((self.N,), dtype=torch.bool, device=dev) if nan_guard else None
+        self.bad = buf((self.N,), torch.bool) if nan_guard else None
         self._state = _native.GpdState(kin=self.kin_store.data_ptr(),
                                        last_rpm=self.last_rpm.data_ptr() if self.last_rpm is not None else None,
                                        pid=self.pid.data_ptr() if self.pid is not None else None,
@@ -200,6 +232,7 @@ class SimCore:
         return ctypes.c_void_p(_raw_stream(self.device))
 
     _own_stream = None
+    _pinned = None
     _step_args = None       # the arguments of gpd_step that never change between two calls, as ctypes objects (built on first use)
 
     def use_stream(self, stream: "torch.cuda.Stream" = None):
@@ -223,12 +256,23 @@ class SimCore:
             rc = self.lib.gpd_reset(ctypes.byref(self._state), _ptr(self.init_pose), self.init_per_env, _ptr(mask),
                                     self.E, self.D, int(reset_pid), _ptr(self.obs12), self._stream())
         _native.check(rc, "gpd_reset")
+        if self.host_visible:
+            self.drain()
         if self.bad is not None:          # (the non-finite flags describe the state the last launch left: a reset pose is finite)
-            if mask is None:
-                self.bad.zero_()
-            else:
-                self.bad.view(self.E, self.D).masked_fill_(mask.to(torch.bool).unsqueeze(1), False)      # (no host sync)
+            # on the stream the kernels of this core run on: behind an in-flight step's flag store, before the next launch
+            with torch.cuda.stream(self._pinned) if self._pinned is not None else contextlib.nullcontext():
+                if mask is None:
+                    self.bad.zero_()
+                else:
+                    self.bad.view(self.E, self.D).masked_fill_(mask.to(device=self.bad.device, dtype=torch.bool).unsqueeze(1), False)   # (no host sync)
         return self.obs12
+
+    def drain(self):
+        """Wait until the stream this core launches on is empty (what makes host-visible buffers readable)."""
+        if self._pinned is not None:
+            self._pinned.synchronize()
+        else:
+            torch.cuda.current_stream(self.device).synchronize()
 
     # ---- the kinematic block as the logical [13][ld] matrix (rows: pos xyz | quat xyzw | vel xyz | body rates xyz) -------------
     @property
@@ -260,7 +304,7 @@ class SimCore:
         Returns views of the persistent output tensors (obs12 [N,12], reward [E], terminated [E],
         truncated [E]); they are overwritten by the next call.  Asynchronous on the current stream.
         """
-        if action.device != self.device or action.dtype != torch.float32 or not action.is_contiguous():
+        if action is not self.action_host and (action.device != self.device or action.dtype != torch.float32 or not action.is_contiguous()):
             action = action.to(device=self.device, dtype=torch.float32).contiguous()
         if action.numel() != self.N * self.A:
             raise ValueError(f"action has {action.numel()} elements, expected {self.N}x{self.A}")
@@ -282,6 +326,8 @@ class SimCore:
                                        self._stream())
         if rc:
             _native.check(rc, "gpd_step")
+        if self.host_visible:
+            self.drain()
         return self.obs12, self.reward, self.terminated, self.truncated
 
     def rollout(self, actions: torch.Tensor, num_steps: int = None, last_only: bool = False,

@@ -6,8 +6,11 @@ constants, `reset` `:220-255`, `step` `:259-383`, `render`/`close` `:387-421`, t
 `_calculateNextStep` `:1108-1150`) so subclasses written against the reference keep working.  What
 is different underneath: there is no PyBullet — the whole `step()` body (action mapping, PID,
 physics sub-steps, cache refresh, observation, reward, termination, truncation) is one launch of
-the fused gfx950 kernel (`engine.SimCore`, E=1 aviary x NUM_DRONES), and this class only copies the
-handful of resulting floats back to numpy attributes with the reference's names and shapes.
+the fused gfx950 kernel (`engine.SimCore`, E=1 aviary x NUM_DRONES), and this class only exposes the
+handful of resulting floats as numpy attributes with the reference's names and shapes.  The aviary's
+state lives in page-locked host memory the device addresses directly (`SimCore(host_visible=True)`):
+a `step()` is the action row written by the host, ONE launch, one stream synchronisation, and numpy
+reads of what the kernel wrote -- no copy engine, no second launch (`bench.py`: `dropin_single_env`).
 
 Deviations from the reference, on purpose:
   * `physics`: only the explicit integrator exists.  `Physics.DYN` is the reference's `Physics.DYN`.  `Physics.PYB*` (the
@@ -21,6 +24,7 @@ Deviations from the reference, on purpose:
     numpy copies of the float32 results.
   * GUI, video recording, cameras, obstacles are not available (`gui=True`/`record=True` raise).
 """
+import os
 import time
 
 import numpy as np
@@ -56,7 +60,7 @@ class BaseAviary(Env):
                  device=None):
         if gui or record or vision_attributes:
             raise NotImplementedError("GUI, video recording and camera observations are outside the MI355X hot path")
-        #### Constants (reference names) ###########################
+        # constants, under the reference's names
         self.G = 9.8
         self.RAD2DEG = 180 / np.pi
         self.DEG2RAD = np.pi / 180
@@ -85,7 +89,6 @@ class BaseAviary(Env):
                      "MAX_XY_TORQUE", "MAX_Z_TORQUE", "GND_EFF_H_CLIP"):
             setattr(self, name, getattr(P, name))
         self._drone_params = P
-        #### Initial poses ##########################################
         if initial_xyzs is None:
             self.INIT_XYZS = P.default_init_xyzs(self.NUM_DRONES)
         elif np.array(initial_xyzs).shape == (self.NUM_DRONES, 3):
@@ -98,10 +101,9 @@ class BaseAviary(Env):
             self.INIT_RPYS = np.array(initial_rpys, dtype=np.float64)
         else:
             raise ValueError("[ERROR] invalid initial_rpys in BaseAviary.__init__(), try initial_rpys.reshape(NUM_DRONES,3)")
-        #### Spaces ##################################################
         self.action_space = self._actionSpace()
         self.observation_space = self._observationSpace()
-        #### The engine: one aviary of NUM_DRONES drones on the GPU ##
+        # the engine: one aviary of NUM_DRONES drones; GPD_HOST_VISIBLE=0 keeps its state in HBM instead (A/B)
         fused = self._fusedActionCode()
         self._fused_action = fused is not None
         task_kw = self._taskConfig()
@@ -110,14 +112,20 @@ class BaseAviary(Env):
                                     act_code=fused if self._fused_action else ACT_DIRECT_RPM,
                                     task=self._TASK, initial_xyzs=self.INIT_XYZS, initial_rpys=self.INIT_RPYS,
                                     auto_reset=False, track_rpm=True, device=device,
+                                    host_visible=os.environ.get("GPD_HOST_VISIBLE", "1") != "0",
                                     # a subclass that overrides _preprocessAction and calls super()'s for a PID action type
                                     # still needs the embedded controllers' state (BaseRLAviary.py:75-76)
                                     force_pid=bool(getattr(getattr(self, "ACT_TYPE", None), "uses_pid", False)), **task_kw)
         self.DRONE_IDS = np.arange(1, self.NUM_DRONES + 1)
+        if self._core.host_visible:           # numpy windows onto the buffers the kernel writes (valid after SimCore.drain())
+            c, n = self._core, self.NUM_DRONES
+            self._host_views = {"obs": c.obs12.numpy(), "P": c.kin_P.numpy()[:n], "Q": c.kin_Q.numpy()[:n], "V": c.kin_V.numpy()[:n],
+                                "W": c.kin_W.numpy()[:n], "rpm": c.last_rpm.numpy()[:, :n], "reward": c.reward.numpy(),
+                                "terminated": c.terminated.numpy(), "truncated": c.truncated.numpy()}
+            self._action_row = c.action_host.numpy()
         self._housekeeping()
         self._updateAndStoreKinematicInformation()
 
-    ################################################################################
 
     def reset(self, seed: int = None, options: dict = None):
         """Resets the environment -> (obs, info)."""
@@ -126,19 +134,21 @@ class BaseAviary(Env):
         self._updateAndStoreKinematicInformation()
         return self._computeObs(), self._computeInfo()
 
-    ################################################################################
 
     def step(self, action):
         """Advances the environment by one control step -> (obs, reward, terminated, truncated, info)."""
         action = np.asarray(action)
         if self._fused_action:
             self._recordAction(action)
-            dev_action = torch.as_tensor(np.ascontiguousarray(action, dtype=np.float32).reshape(self.NUM_DRONES, -1),
-                                         device=self._core.device)
+            row = action
         else:
-            rpm = np.reshape(self._preprocessAction(action), (self.NUM_DRONES, 4))
-            dev_action = torch.as_tensor(np.ascontiguousarray(rpm, dtype=np.float32), device=self._core.device)
-        self._core.step(dev_action)
+            row = self._preprocessAction(action)        # the subclass's own mapping: RPMs, fed to the kernel as they are
+        core = self._core
+        if core.host_visible:
+            self._action_row[...] = np.reshape(row, self._action_row.shape)       # (casts to float32 where the kernel reads it)
+            core.step(core.action_host)
+        else:
+            core.step(torch.as_tensor(np.ascontiguousarray(row, dtype=np.float32).reshape(self.NUM_DRONES, -1), device=core.device))
         self._updateAndStoreKinematicInformation()
         obs = self._computeObs()
         reward = self._computeReward()
@@ -148,24 +158,20 @@ class BaseAviary(Env):
         self.step_counter = self.step_counter + (1 * self.PYB_STEPS_PER_CTRL)
         return obs, reward, terminated, truncated, info
 
-    ################################################################################
 
     def render(self, mode='human', close=False):
-        """Prints a textual output of the environment."""
-        if self.first_render_call:
-            print("[WARNING] BaseAviary.render() is implemented as text-only")
-            self.first_render_call = False
-        elapsed = max(time.time() - self.RESET_TIME, 1e-9)
-        print("\n[INFO] BaseAviary.render() ——— it {:04d}".format(self.step_counter),
-              "——— wall-clock time {:.1f}s,".format(elapsed),
-              "simulation time {:.1f}s@{:d}Hz ({:.2f}x)".format(self.step_counter * self.PYB_TIMESTEP, self.PYB_FREQ,
-                                                                (self.step_counter * self.PYB_TIMESTEP) / elapsed))
+        """Text only (there is no GUI): one table row per drone -- position, velocity, attitude in degrees, world body rates --
+        under a header with the step count and simulated vs wall-clock time.  Prints it and returns the string."""
+        wall = max(time.time() - self.RESET_TIME, 1e-9)
+        sim = self.step_counter * self.PYB_TIMESTEP
+        lines = [f"step {self.step_counter}  sim {sim:.2f} s @ {self.PYB_FREQ} Hz  wall {wall:.2f} s  ({sim / wall:.1f}x real time)",
+                 "drone        x        y        z       vx       vy       vz     roll    pitch      yaw       wx       wy       wz"]
         for i in range(self.NUM_DRONES):
-            print("[INFO] BaseAviary.render() ——— drone {:d}".format(i),
-                  "——— x {:+06.2f}, y {:+06.2f}, z {:+06.2f}".format(*self.pos[i]),
-                  "——— velocity {:+06.2f}, {:+06.2f}, {:+06.2f}".format(*self.vel[i]),
-                  "——— roll {:+06.2f}, pitch {:+06.2f}, yaw {:+06.2f}".format(*(self.rpy[i] * self.RAD2DEG)),
-                  "——— angular velocity {:+06.4f}, {:+06.4f}, {:+06.4f} ——— ".format(*self.ang_v[i]))
+            cells = (*self.pos[i], *self.vel[i], *np.degrees(self.rpy[i]), *self.ang_v[i])
+            lines.append(f"{i:5d} " + " ".join(f"{c:8.3f}" for c in cells))
+        text = "\n".join(lines)
+        print(text)
+        return text
 
     def close(self):
         """Terminates the environment (nothing to disconnect from)."""
@@ -176,19 +182,29 @@ class BaseAviary(Env):
     def getDroneIds(self):
         return self.DRONE_IDS
 
-    ################################################################################
 
     def _housekeeping(self):
         """Zero the counters and put every drone back at its initial pose (on the device)."""
         self.RESET_TIME = time.time()
         self.step_counter = 0
-        self.first_render_call = True
         self._core.reset()
 
     def _updateAndStoreKinematicInformation(self):
-        """Refresh the numpy kinematic cache from the device (one small device-to-host copy)."""
+        """Refresh the numpy kinematic cache (float64 copies of the float32 results) from what the latest launch wrote.  With the
+        state in host-visible memory these are plain numpy reads; otherwise one packed device-to-host copy."""
         n = self.NUM_DRONES
         core = self._core
+        if core.host_visible:
+            v = self._host_views
+            obs = v["obs"].astype(np.float64)                      # pos | rpy | vel | ang_v, as the kernel's observation row has them
+            self.pos, self.rpy, self.vel, self.ang_v = obs[:, 0:3], obs[:, 3:6], obs[:, 6:9], obs[:, 9:12]
+            self.quat = v["Q"].astype(np.float64)
+            self.rpy_rates = np.stack([v["P"][:, 3], v["V"][:, 3], v["W"]], axis=1).astype(np.float64)
+            self.last_clipped_action = v["rpm"].T.astype(np.float64)
+            self._k_reward = float(v["reward"][0])
+            self._k_terminated = bool(v["terminated"][0])
+            self._k_truncated = bool(v["truncated"][0])
+            return
         packed = torch.cat([core.state_vectors(), core.body_rates(n),
                             core.reward.expand(n, 1), core.terminated.to(torch.float32).expand(n, 1),
                             core.truncated.to(torch.float32).expand(n, 1)], dim=1).cpu().numpy().astype(np.float64)
@@ -230,8 +246,7 @@ class BaseAviary(Env):
             print("\n[ERROR] it", self.step_counter, "in BaseAviary._normalizedActionToRPM(), out-of-bound action")
         return np.where(action <= 0, (action + 1) * self.HOVER_RPM, self.HOVER_RPM + (self.MAX_RPM - self.HOVER_RPM) * action)
 
-    ################################################################################
-    # engine configuration hooks (new) -------------------------------------------------------------
+    # engine configuration hooks (new)
 
     def _fusedActionCode(self):
         """Kernel action code when the action->RPM mapping runs inside the kernel, else None (the
@@ -245,8 +260,7 @@ class BaseAviary(Env):
         """Extra `SimCore` keyword arguments describing the task evaluated in the kernel."""
         return {}
 
-    ################################################################################
-    # the reference's subclass hooks ---------------------------------------------------------------
+    # the reference's subclass hooks
 
     def _actionSpace(self):
         raise NotImplementedError
@@ -272,7 +286,6 @@ class BaseAviary(Env):
     def _computeInfo(self):
         raise NotImplementedError
 
-    ################################################################################
 
     def _calculateNextStep(self, current_position, destination, step_size=1):
         """Waypoint at most `step_size` away from `current_position` towards `destination`."""

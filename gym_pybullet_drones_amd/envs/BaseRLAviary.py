@@ -37,7 +37,7 @@ class BaseRLAviary(BaseAviary):
                  device=None):
         if obs != ObservationType.KIN:
             raise NotImplementedError("ObservationType.RGB (camera rendering) is outside the MI355X hot path")
-        #### Create a buffer for the last .5 sec of actions ########
+        # the last half second of actions is part of every observation row
         self.ACTION_BUFFER_SIZE = int(ctrl_freq // 2)
         self.action_buffer = deque(maxlen=self.ACTION_BUFFER_SIZE)
         self.OBS_TYPE = obs
@@ -51,7 +51,6 @@ class BaseRLAviary(BaseAviary):
         if act == ActionType.VEL:
             self.SPEED_LIMIT = 0.03 * self.MAX_SPEED_KMH * (1000 / 3600)
 
-    ################################################################################
 
     def _fusedActionCode(self):
         if type(self)._preprocessAction is BaseRLAviary._preprocessAction:
@@ -61,7 +60,6 @@ class BaseRLAviary(BaseAviary):
     def _recordAction(self, action):
         self.action_buffer.append(np.array(action, dtype=np.float32).reshape(self.NUM_DRONES, -1))
 
-    ################################################################################
 
     def _actionSpace(self):
         """Box of shape (NUM_DRONES, 4 | 3 | 1) in [-1, 1]."""
@@ -72,7 +70,6 @@ class BaseRLAviary(BaseAviary):
             self.action_buffer.append(np.zeros((self.NUM_DRONES, size), dtype=np.float32))
         return spaces.Box(low=act_lower_bound, high=act_upper_bound, dtype=np.float32)
 
-    ################################################################################
 
     def _preprocessAction(self, action):
         """action (NUM_DRONES, A) -> RPMs (NUM_DRONES, 4).
@@ -90,7 +87,6 @@ class BaseRLAviary(BaseAviary):
         from ..control.DSLPIDControl import pid_rpm_for_action
         return pid_rpm_for_action(self, action)
 
-    ################################################################################
 
     def _observationSpace(self):
         """Box of shape (NUM_DRONES, 12 + ACTION_BUFFER_SIZE * A)."""
@@ -102,7 +98,6 @@ class BaseRLAviary(BaseAviary):
         obs_upper_bound = np.hstack([obs_upper_bound, +np.ones((self.NUM_DRONES, tail))])
         return spaces.Box(low=obs_lower_bound, high=obs_upper_bound, dtype=np.float32)
 
-    ################################################################################
 
     def _computeObs(self):
         """(NUM_DRONES, 12 + H*A) float32: pos | rpy | vel | ang_v, then the H most recent actions, oldest first."""

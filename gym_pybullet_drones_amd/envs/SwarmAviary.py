@@ -615,7 +615,8 @@ class SwarmAviary:
 
     def invalidate(self):
         """Tell the aviary that the state was changed without going through `reset()` / `core.set_state()` (e.g. by writing
-        into `core.kin`): the next step re-packs, re-bins and recomputes the downwash forces first."""
+        through the plane views `core.kin_P / kin_Q / kin_V / kin_W`, `core.positions()` ...; `core.kin` itself is a copy and rejects
+        writes): the next step re-packs, re-bins and recomputes the downwash forces first."""
         self._dw_version = -1
 
     def state_vectors(self) -> torch.Tensor:

@@ -39,7 +39,6 @@ class VelocityAviary(BaseAviary):
                          initial_xyzs=initial_xyzs, initial_rpys=initial_rpys, physics=physics, pyb_freq=pyb_freq,
                          ctrl_freq=ctrl_freq, gui=gui, record=record, obstacles=obstacles,
                          user_debug_gui=user_debug_gui, output_folder=output_folder, device=device)
-        #### Set a limit on the maximum target speed ###############
         self.SPEED_LIMIT = 0.03 * self.MAX_SPEED_KMH * (1000 / 3600)
 
     def _fusedActionCode(self):

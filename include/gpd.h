@@ -144,13 +144,15 @@ typedef struct GpdState {
                                 V  float4[ld] at kin + 8 ld   (vel x, vel y, vel z, body rate y)
                                 W  float [ld] at kin + 12 ld  body rate z
                               (body rates = the reference's rpy_rates, envs/BaseAviary.py:474).  A lane moves its drone with three
-                              16-byte accesses and one 4-byte access per direction instead of thirteen 4-byte ones */
+                              16-byte accesses and one 4-byte access per direction instead of thirteen 4-byte ones.
+                              ALIGNMENT: kin must be 16-byte aligned (hipMalloc / torch allocations are; a sub-allocation at a
+                              4-byte offset is not) -- every entry that moves the planes returns GPD_EINVAL otherwise */
     float* last_rpm;       /* [4][ld] last applied RPMs (last_clipped_action); NULL = not tracked
                               (required with GPD_PHYS_DRAG) */
     float* pid;            /* [9][ld]: integral_pos_e | last_rpy | integral_rpy_e; NULL unless a
                               PID action type is used */
     int32_t* step_counter; /* [num_envs] physics steps since reset (envs/BaseAviary.py:460,382) */
-    int64_t ld;            /* row pitch in floats */
+    int64_t ld;            /* row pitch in floats, 1 .. 2^32 - 1 (the kernels take it as a 32-bit argument; GPD_EINVAL beyond) */
     float* dw_force;       /* [ld] or NULL: body-z downwash force per drone computed OUTSIDE the step kernel
                               (gpd_downwash_global, for one aviary of more than 256 drones); used with
                               GPD_PHYS_DW when drones_per_env == 1, added in every sub-step of the call */

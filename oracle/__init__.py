@@ -3,7 +3,7 @@
 Float64 restatements of the reference algorithm (utiasDSL/gym-pybullet-drones, files cited per
 function) used ONLY by `tests/`, by `__graft_entry__.smoke()` and by the `cpu_baseline` leg of
 `bench.py`, as the checker the HIP path is compared with.  Nothing under
-`gym-pybullet-drones_amd/` imports this package; the product path fails loudly when the HIP
+`gym_pybullet_drones_amd/` imports this package; the product path fails loudly when the HIP
 library is missing instead of falling back to anything here.
 
 Modules

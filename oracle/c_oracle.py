@@ -201,7 +201,7 @@ def swarm_substep_seconds(xyz, threads=1, budget_s=10.0, urdf_path=None):
     """Seconds per all-pairs downwash pass over the drones at `xyz` (what dominates a sub-step of one large world on the CPU),
     averaged over the passes that fit `budget_s` -> (seconds, passes)."""
     import time
-    urdf_path = urdf_path or os.path.join(os.path.dirname(_HERE), "gym-pybullet-drones_amd", "assets", "cf2x.urdf")
+    urdf_path = urdf_path or os.path.join(os.path.dirname(_HERE), "gym_pybullet_drones_amd", "assets", "cf2x.urdf")
     downwash_all_pairs(urdf_path, xyz[:256], threads=threads)          # (page in)
     reps, t0 = 0, time.perf_counter()
     while reps == 0 or time.perf_counter() - t0 < budget_s:

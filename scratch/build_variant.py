@@ -7,7 +7,7 @@
 --flags-UNIT   replace the extra flags of one unit (UNIT = step_rollout | policy | swarm | abi), e.g. --flags-policy -mllvm -amdgpu-sched-strategy=max-ilp
 --patch        apply a patch (`patch -p1`, paths relative to the repo) to a COPY of csrc/ and include/ first: experiment scaffolding lives
                outside the product sources (the per-workgroup timeline instrumentation of rounds 3 / 4 -- `GPD_EXP_TS*`, read by
-               scratch/exp_r04/force_timeline.py / step_timeline.py -- left them in round 5; `git show fd66d7c:gym-pybullet-drones_amd/csrc/gpd.hip`
+               scratch/exp_r04/force_timeline.py / step_timeline.py -- left them in round 5; `git show fd66d7c:gym_pybullet_drones_amd/csrc/gpd.hip`
                has its last form)"""
 import os
 import shutil
@@ -32,12 +32,12 @@ csrc, include = _native.CSRC, _native.INCLUDE
 tmp = None
 if extra["--patch"]:
     tmp = tempfile.mkdtemp(prefix="gpd_variant_")
-    os.makedirs(os.path.join(tmp, "gym-pybullet-drones_amd"))
-    shutil.copytree(_native.CSRC, os.path.join(tmp, "gym-pybullet-drones_amd", "csrc"), ignore=shutil.ignore_patterns("*.so", "*.o"))
+    os.makedirs(os.path.join(tmp, "gym_pybullet_drones_amd"))
+    shutil.copytree(_native.CSRC, os.path.join(tmp, "gym_pybullet_drones_amd", "csrc"), ignore=shutil.ignore_patterns("*.so", "*.o"))
     shutil.copytree(_native.INCLUDE, os.path.join(tmp, "include"))
     for pf in extra["--patch"]:
         subprocess.run(["patch", "-p1", "-i", os.path.abspath(pf)], cwd=tmp, check=True)
-    csrc, include = os.path.join(tmp, "gym-pybullet-drones_amd", "csrc"), os.path.join(tmp, "include")
+    csrc, include = os.path.join(tmp, "gym_pybullet_drones_amd", "csrc"), os.path.join(tmp, "include")
 objs, procs = [], []
 for unit, flags in _native.UNITS:
     key = "--flags-" + unit.replace(".hip", "")

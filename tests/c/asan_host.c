@@ -49,6 +49,10 @@ int main(void) {
     C.act_type = GPD_ACT_PID; CHECK(STEP(DEV(3), DEV(4)) == GPD_EINVAL, "PID action without state.pid"); C.act_type = GPD_ACT_RPM;
     C.physics_flags = GPD_PHYS_DRAG; CHECK(STEP(DEV(3), DEV(4)) == GPD_EINVAL, "DRAG without last_rpm"); C.physics_flags = 0;
     C.lanes_per_wave = 48; CHECK(STEP(DEV(3), DEV(4)) == GPD_EINVAL, "lanes_per_wave 48"); C.lanes_per_wave = 0;
+    S.kin = (float*)((char*)DEV(1) + 4); CHECK(STEP(DEV(3), DEV(4)) == GPD_EINVAL && strstr(gpd_last_error(), "16-byte") != NULL, "state.kin at a 4-byte offset (the planes are float4)");
+    CHECK(gpd_reset(&S, DEV(5), 0, NULL, 65536, 1, 0, DEV(6), NULL) == GPD_EINVAL, "gpd_reset refuses a misaligned state.kin as well");
+    CHECK(gpd_state_vectors(&S, DEV(6), DEV(15), 65536, NULL) == GPD_EINVAL, "gpd_state_vectors refuses a misaligned state.kin as well"); S.kin = DEV(1);
+    S.ld = 1ll << 32; CHECK(STEP(DEV(3), DEV(4)) == GPD_EINVAL && strstr(gpd_last_error(), "state.ld") != NULL, "a pitch that does not fit the kernels' 32-bit argument"); S.ld = 65536;
     C.num_envs = (1 << 26) + 1; S.ld = (1ll << 26) + 64; CHECK(STEP(DEV(3), DEV(4)) == GPD_ERANGE, "more than 2^26 drones"); C.num_envs = 65536; S.ld = 65536;
 
     /* ---- launch geometry ---- */

@@ -9,7 +9,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
-ASSETS = os.path.join(REPO, "gym-pybullet-drones_amd", "assets")
+ASSETS = os.path.join(REPO, "gym_pybullet_drones_amd", "assets")
 
 
 def pytest_configure(config):

@@ -56,7 +56,7 @@ def load_reference():
     pd.getDataPath = lambda: "/nonexistent"
     sys.modules["pybullet_data"] = pd
     spec = importlib.util.spec_from_file_location(
-        "_gpd_gym_shim", os.path.join(REPO, "gym-pybullet-drones_amd", "_gym_shim.py"))
+        "_gpd_gym_shim", os.path.join(REPO, "gym_pybullet_drones_amd", "_gym_shim.py"))
     gs = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gs)
     gym = types.ModuleType("gymnasium")

@@ -140,12 +140,46 @@ def spill_runs(body):
     return [r for r in runs if len(r["regs"]) > 1]
 
 
+def preload_lengths(text):
+    """kernel name -> `.amdhsa_user_sgpr_kernarg_preload_length` (dwords of the argument block that arrive in SGPRs) of every kernel
+    descriptor in an assembly file."""
+    out = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)([\s\S]*?)\.end_amdhsa_kernel", text):
+        n = re.search(r"\.amdhsa_user_sgpr_kernarg_preload_length (\d+)", m.group(2))
+        out[m.group(1)] = int(n.group(1)) if n else 0
+    return out
+
+
+def kernarg_pointer_pairs(body):
+    """SGPR pairs that hold the kernel-argument segment pointer: s[0:1] (these kernels enable no dispatch / queue pointer, which
+    tests/test_kernel_isa.py asserts) and every pair an `s_mov_b64` copies it to, in textual order, until something else defines
+    the pair.  -> {line index: set of pairs valid at that line}"""
+    cur, out = {(0, 1)}, {}
+    for i, line in enumerate(body):
+        l = line.split(";")[0].strip()
+        out[i] = set(cur)
+        if not l or l.endswith(":"):
+            continue
+        mn, _, rest = l.partition(" ")
+        ops = split_ops(rest.strip())
+        d, _u = def_use(mn, ops)
+        m = re.match(r"s_mov_b64\s+s\[(\d+):(\d+)\],\s*s\[(\d+):(\d+)\]$", l)
+        if m and (int(m.group(3)), int(m.group(4))) in cur:
+            cur.add((int(m.group(1)), int(m.group(2))))
+            continue
+        cur = {pr for pr in cur if not (set(pr) & d)}
+    return out
+
+
 def torn_spills(body, unused_kernarg_offsets=()):
     """The miscompile proper: a scalar load A keeps some destination dwords alive and loses others to a later definition,
     and afterwards ONE spill run saves both kinds together as if A's tuple were intact (reachability over the kernel's control-flow graph).
     `unused_kernarg_offsets`: byte offsets of kernel-argument words NO device code reads (a host-only struct member): there is no
     s_load_dwordx3, so three used words next to such a member are fetched as an x4 whose fourth register the allocator is free to
-    reuse at once -- the same shape, and harmless; a finding all of whose dead dwords sit at such offsets is not reported."""
+    reuse at once -- the same shape, and harmless; a finding all of whose dead dwords sit at such offsets is not reported, PROVIDED
+    the load's base is the kernel-argument pointer (s[0:1] or a copy of it, `kernarg_pointer_pairs`): a load of the same offset
+    from any other base -- weights, a struct in memory -- is reported as ever."""
+    karg = kernarg_pointer_pairs(body) if unused_kernarg_offsets else {}
     dead_of = {n: (l, set(dead)) for n, l, dead in check(body)}
     out = []
     runs = spill_runs(body)
@@ -157,7 +191,10 @@ def torn_spills(body, unused_kernarg_offsets=()):
         if not alive:
             continue
         m_imm = re.search(r",\s*(0x[0-9a-fA-F]+|\d+)\s*$", rest)
-        if unused_kernarg_offsets and m_imm and all(int(m_imm.group(1), 0) + 4 * (r - min(dst)) in unused_kernarg_offsets for r in dead):
+        m_base = re.match(r"[^,]+,\s*s\[(\d+):(\d+)\]", rest)
+        from_kernarg = m_base is not None and (int(m_base.group(1)), int(m_base.group(2))) in karg.get(n, set())
+        if (unused_kernarg_offsets and from_kernarg and m_imm
+                and all(int(m_imm.group(1), 0) + 4 * (r - min(dst)) in unused_kernarg_offsets for r in dead)):
             continue
         for run in runs:
             if run["start"] < n:

@@ -247,6 +247,64 @@ def test_config4_524288_drones_240_steps_against_the_c_oracle(gpu_device):
         c_oracle.lib().orc_set_threads(1)
 
 
+def test_population_of_65536_closed_loop_hover_episodes_matches_the_float64_population(gpu_device):
+    """VERDICT r05 #1(b).  Past half a second of DSLPID at the reference's 30 Hz (HoverAviary's default, envs/HoverAviary.py:16-17;
+    control/DSLPIDControl.py:212-259 rides its torque clip) no two runs agree drone by drone -- two float64 runs do not -- so
+    what must hold is that the fp32 POPULATION behaves like the float64 one: 65 536 HoverAviaries spread over the 1.5 m box,
+    ActionType.PID towards one random waypoint each up to 0.5 m away (about a third of the episodes end early -- the first
+    lunge tilts the drone past 0.4 rad, or carries it over the edge of the box -- the rest at the 8 s limit), same-step auto-reset, 260 control steps = one full 8 s episode and the start of the next, fp32 HIP against
+    oracle/gpd_oracle.c.  Compared: the distributions of the first episode's return and of the step it ended at (relative
+    difference of the means < 1e-3, two-sample Kolmogorov-Smirnov p > 0.01), and at EVERY step the population mean and standard
+    deviation of position and attitude (within 1e-4 of the group's scale)."""
+    from scipy import stats
+    from oracle import c_oracle
+    rng = np.random.default_rng(20260)
+    E, S, T = 65536, 8, 260
+    xyz = (np.array([0, 0, 0.8]) + rng.uniform(-1, 1, size=(E, 1, 3)) * np.array([1.3, 1.3, 0.5])).astype(np.float32).astype(np.float64)
+    rpy = rng.uniform(-0.1, 0.1, size=(E, 1, 3)).astype(np.float32).astype(np.float64)
+    wp = (xyz + rng.uniform(-1, 1, size=(E, 1, 3)) * np.array([0.5, 0.5, 0.3])).astype(np.float32)
+    orc = CAviary(urdf("cf2x"), "cf2x", E, 1, initial_xyzs=xyz, initial_rpys=rpy, pyb_freq=240, ctrl_freq=30, act="pid", task="hover",
+                  auto_reset=True)
+    core = _core("cf2x", E, 1, 0, S, "pid", "hover", xyz, rpy, gpu_device, auto_reset=True, target=orc.TARGET_POS)
+    wp_dev, wp64 = torch.as_tensor(wp, device=gpu_device), wp.astype(np.float64)
+    ret = {"hip": np.zeros(E), "f64": np.zeros(E)}
+    end = {"hip": np.zeros(E, dtype=np.int64), "f64": np.zeros(E, dtype=np.int64)}
+    worst = {"pos_mean": 0.0, "pos_std": 0.0, "rpy_mean": 0.0, "rpy_std": 0.0}
+    c_oracle.lib().orc_set_threads(min(len(__import__("os").sched_getaffinity(0)), c_oracle.lib().orc_max_threads()))
+    try:
+        for k in range(T):
+            orc.step_in_place(wp64)
+            obs, rew, term, trunc = core.step(wp_dev)
+            o32 = obs.cpu().numpy().astype(np.float64).reshape(E, 12)
+            o64 = orc.obs.reshape(E, 12)
+            for side, r, done in (("hip", rew.cpu().numpy().astype(np.float64), (term | trunc).cpu().numpy()),
+                                  ("f64", orc.reward, (orc.terminated | orc.truncated).astype(bool))):
+                first = end[side] == 0
+                ret[side] += np.where(first, r, 0.0)
+                end[side] = np.where(first & done, k + 1, end[side])
+            # (the observation row of an aviary that ended in this step is its reset pose on both sides: same-step auto-reset)
+            for name, sl in (("pos", slice(0, 3)), ("rpy", slice(3, 6))):
+                scale = max(float(np.abs(o64[:, sl]).max()), 1.0)
+                worst[name + "_mean"] = max(worst[name + "_mean"], float(np.abs(o32[:, sl].mean(0) - o64[:, sl].mean(0)).max() / scale))
+                worst[name + "_std"] = max(worst[name + "_std"], float(np.abs(o32[:, sl].std(0) - o64[:, sl].std(0)).max() / scale))
+    finally:
+        c_oracle.lib().orc_set_threads(1)
+    assert (end["hip"] > 0).all() and (end["f64"] > 0).all()            # every aviary finished its first episode (time limit: step 241)
+    early = float((end["f64"] < 241).mean())
+    d_ret = abs(ret["hip"].mean() - ret["f64"].mean()) / abs(ret["f64"].mean())
+    d_end = abs(end["hip"].mean() - end["f64"].mean()) / end["f64"].mean()
+    ks_ret, ks_end = stats.ks_2samp(ret["hip"], ret["f64"]), stats.ks_2samp(end["hip"], end["f64"])
+    same_end = float((end["hip"] == end["f64"]).mean())
+    print(f"POPULATION 65536 x PID @ 30 Hz: {early:.3f} of the episodes end before the time limit; return mean {ret['f64'].mean():.3f} (f64) "
+          f"rel diff {d_ret:.2e}, KS D {ks_ret.statistic:.2e} p {ks_ret.pvalue:.3f}; end step mean {end['f64'].mean():.2f} rel diff {d_end:.2e}, "
+          f"KS D {ks_end.statistic:.2e} p {ks_end.pvalue:.3f}; same end step drone by drone {same_end:.4f}; per-step population moments "
+          + " ".join(f"{n}={v:.2e}" for n, v in worst.items()))
+    assert 0.15 < early < 0.8                                           # the scene does produce a distribution of episode lengths
+    assert d_ret < 1e-3 and d_end < 1e-3
+    assert ks_ret.pvalue > 0.01 and ks_end.pvalue > 0.01
+    assert max(worst.values()) < 1e-4, worst
+
+
 def _sync_c(core, orc):
     """CAviary has the same state attributes as BatchedAviary (the PID block aside, unused here)."""
     assert core.pid is None

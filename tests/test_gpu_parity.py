@@ -328,42 +328,56 @@ def test_closed_loop_pid_240hz(gpu_device):
         assert e["pos"] < 2e-6 and e["vel"] < 8e-6 and e["quat"] < 1e-5 and e["rates"] < 5e-6, (t, e)
 
 
+def _closed_loop_actions(rng, act, xyz):
+    """A constant command per drone for the DSLPID action types: a waypoint within 0.3 m (PID), a velocity and the fraction of the
+    speed limit it is flown at (VEL), a climb / descent rate (ONE_D_PID: target z = current z + 0.1 a, every control step)."""
+    E, D, _ = xyz.shape
+    if act == "pid":
+        return (xyz + rng.uniform(-0.3, 0.3, size=(E, D, 3))).astype(np.float32)
+    if act == "vel":
+        return np.concatenate([rng.uniform(-1, 1, size=(E, D, 3)), rng.uniform(0.2, 1.0, size=(E, D, 1))], axis=-1).astype(np.float32)
+    return rng.uniform(-1, 1, size=(E, D, 1)).astype(np.float32)
+
+
 @pytest.mark.parametrize("ctrl", [30, 48])
-def test_closed_loop_pid_low_rate_stays_inside_the_float64_envelope(gpu_device, ctrl):
-    """DSLPID at the reference's default 30 Hz (HoverAviary) and at 48 Hz (examples/pid.py): the attitude loop rides
-    its +-3200 torque clip and chatters, so ANY rounding-level difference grows ~10x per 4 control steps until it
-    saturates at the chatter amplitude -- two float64 runs do that too.  This test quantifies it: run the float64
-    oracle twice, the second time with its state nudged by half an fp32 ulp (relative 2^-24, random sign) after every
-    control step -- a float64 run that suffers exactly the input rounding the fp32 state array imposes -- and demand
-    that the fp32 HIP run stays within a small factor of that envelope at every checkpoint, per field group, on the
-    95th percentile and the median over 1024 drones."""
-    rng = np.random.default_rng(100 + ctrl)
-    E, D, S, T = 1024, 1, 240 // ctrl, 48
+@pytest.mark.parametrize("act,D", [("pid", 1), ("vel", 1), ("one_d_pid", 1), ("pid", 2), ("pid", 3)])
+def test_closed_loop_dslpid_low_rate_stays_inside_the_float64_envelope(gpu_device, ctrl, act, D):
+    """DSLPID at the reference's default 30 Hz (HoverAviary / MultiHoverAviary, envs/HoverAviary.py:16-17) and at 48 Hz
+    (examples/pid.py:101-113), through EVERY action type that closes the loop in the kernel -- PID, VEL, ONE_D_PID -- and for
+    MultiHover's 2 and 3 drones: the attitude loop (control/DSLPIDControl.py:212-259) rides its +-3200 torque clip and
+    chatters, so ANY rounding-level difference grows ~10x per 4 control steps until it saturates at the chatter amplitude --
+    two float64 runs do that too.  This test quantifies it: run the float64 oracle twice, the second time with its state
+    nudged by half an fp32 ulp (relative 2^-24, random sign) after every control step -- a float64 run that suffers exactly
+    the input rounding the fp32 state array imposes -- and demand that the fp32 HIP run stays within a small factor of that
+    envelope at every checkpoint, per field group, on the 95th percentile and the median over 1024 drones."""
+    rng = np.random.default_rng(100 + ctrl + 1000 * D + zlib.crc32(act.encode()) % 997)
+    E, S, T = 1024 // D, 240 // ctrl, 48
+    task = "hover" if D == 1 else "multihover"
     xyz, rpy = _random_scene(rng, E, D)
     mk = lambda: BatchedAviary(urdf("cf2x"), "cf2x", E, D, initial_xyzs=xyz, initial_rpys=rpy * 0.3, pyb_freq=240,  # noqa: E731
-                               ctrl_freq=ctrl, act="pid", task="hover")
+                               ctrl_freq=ctrl, act=act, task=task)
     b, bp = mk(), mk()
-    core = _core("cf2x", E, D, 0, S, "pid", "hover", xyz, rpy * 0.3, gpu_device, target=b.TARGET_POS)
+    core = _core("cf2x", E, D, 0, S, act, task, xyz, rpy * 0.3, gpu_device, target=b.TARGET_POS)
     _sync_from_oracle(core, b)
     for name in ("pos", "quat", "vel", "rpy_rates", "rpy", "last_rpm"):
         setattr(bp, name, getattr(b, name).copy())
     bp.pid.integral_pos_e, bp.pid.last_rpy, bp.pid.integral_rpy_e = (b.pid.integral_pos_e.copy(), b.pid.last_rpy.copy(),
                                                                     b.pid.integral_rpy_e.copy())
-    wp = (xyz + rng.uniform(-0.3, 0.3, size=(E, D, 3))).astype(np.float32)
+    cmd = _closed_loop_actions(rng, act, xyz)
     eps = 2.0 ** -24
     from oracle import bullet_math as bm
     rows = []
     for k in range(T):
-        b.step(wp.astype(np.float64))
-        bp.step(wp.astype(np.float64))
+        b.step(cmd.astype(np.float64))
+        bp.step(cmd.astype(np.float64))
         for name in ("pos", "quat", "vel", "rpy_rates"):
             arr = getattr(bp, name)
             arr *= 1.0 + eps * rng.choice([-1.0, 1.0], size=arr.shape)
         bp.rpy = bm.euler_from_quaternion_b(bp.quat)
-        core.step(torch.as_tensor(wp, device=gpu_device))
+        core.step(torch.as_tensor(cmd, device=gpu_device))
         if (k + 1) in (2, 4, 8, 12, 16, 24, 32, 48):
             ref, per = _oracle_kin(b), _oracle_kin(bp)
-            k32 = core.kin[:, :E].cpu().numpy().astype(np.float64)
+            k32 = core.kin[:, :E * D].cpu().numpy().astype(np.float64)
             for g, (sl, _) in GROUPS.items():
                 e32 = np.abs(k32[sl] - ref[sl]).max(axis=0)
                 env = np.abs(per[sl] - ref[sl]).max(axis=0)
@@ -371,6 +385,8 @@ def test_closed_loop_pid_low_rate_stays_inside_the_float64_envelope(gpu_device, 
                              np.percentile(env, 95), e32.max(), env.max()))
     for r in rows:
         print("t=%3d %-5s median fp32 %.2e envelope %.2e | p95 fp32 %.2e envelope %.2e | max fp32 %.2e envelope %.2e" % r)
+    print("ENVELOPE %s D=%d %d Hz: worst ratio median %.2f p95 %.2f" % (
+        act, D, ctrl, max(r[2] / (r[3] + 1.25e-7) for r in rows), max(r[4] / (r[5] + 1.25e-7) for r in rows)))
     for t, g, m32, menv, p32, penv, x32, xenv in rows:
         floor = 5e-7                     # one-step fp32 rounding of O(1) quantities
         # measured on the MI355X: the fp32 run sits 1.0-3.3x above the envelope at every checkpoint (profiles/r02_pid_envelope.txt)
@@ -443,15 +459,22 @@ def test_reference_fixture_multihover(gpu_device, name, act, n):
     # perturbation decorrelates by step 60 too, tests/test_oracle_batched.py) until it saturates at the
     # chatter amplitude (~2 cm): tight comparison on the first 12 steps, boundedness afterwards.
     horizon = 40 if act == "rpm" else 12
+    worst_pos = worst_rew = 0.0
     for k, a in enumerate(g["actions"][:60]):
         obs, rew, term, trunc, _ = env.step(a)
         assert obs.shape == (n, 12 + 15 * ACT_DIM[act])
         if k < horizon:
-            np.testing.assert_allclose(obs[:, :3], g["obs"][k, :, :3], rtol=0, atol=2e-5 if act == "pid" else 2e-4)
-            assert rew == pytest.approx(float(g["reward"][k]), rel=1e-5 if act == "pid" else 2e-3, abs=1e-3)
+            worst_pos = max(worst_pos, float(np.abs(obs[:, :3] - g["obs"][k, :, :3]).max()))
+            worst_rew = max(worst_rew, abs(rew - float(g["reward"][k])) / max(abs(float(g["reward"][k])), 1.0))
             assert trunc == bool(g["truncated"][k])
         elif act == "pid":
             assert np.abs(obs[:, :3] - g["obs"][k, :, :3]).max() < 0.06
+    print(f"MEASURED multihover fixture {act}: max |pos - reference| over the first {horizon} steps {worst_pos:.2e} m, reward {worst_rew:.2e} (relative)")
+    # bounds: <= 3x what the MI355X measures (round 6: RPM 8.9e-6 m / 1.7e-5, PID 2.6e-6 m / 2.1e-6), never above 1e-4 of the scale
+    assert worst_pos < POS_BOUND[act] and worst_rew < REW_BOUND[act]
+
+
+POS_BOUND, REW_BOUND = {"rpm": 1e-4, "pid": 2e-5}, {"rpm": 1e-4, "pid": 1e-5}
 
 
 @pytest.mark.parametrize("model", ["cf2x", "cf2p"])
@@ -524,6 +547,16 @@ def test_auto_reset_matches_oracle(gpu_device):
     assert obs.shape == (E, 1, 12)
     bias = rng.uniform(-1, 1, size=(E, 1, 1))
     n_done = 0
+    worst = {"obs": 0.0, "terminal_obs": 0.0}
+
+    def rel(x32, x64):
+        """SURVEY section 8(d)'s normalisation per observation group: max |x32 - x64| / max(max |x64|, 1)"""
+        out = 0.0
+        for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 12)):
+            if x64.size:
+                out = max(out, float(np.abs(x32[..., sl] - x64[..., sl]).max() / max(float(np.abs(x64[..., sl]).max()), 1.0)))
+        return out
+
     for k in range(260):
         a = np.clip(bias + 0.3 * rng.uniform(-1, 1, size=(E, 1, 1)), -1, 1).astype(np.float32)
         o64, r64, te64, tr64, tobs64 = b.step(a.astype(np.float64))
@@ -533,17 +566,23 @@ def test_auto_reset_matches_oracle(gpu_device):
         assert (done != done64).mean() < 0.003
         same = done == done64
         n_done += int(done.sum())
-        np.testing.assert_allclose(obs.cpu().numpy()[same], o64[same], rtol=1e-3, atol=3e-4)
+        worst["obs"] = max(worst["obs"], rel(obs.cpu().numpy()[same].astype(np.float64), o64[same]))
         tob = info["terminal_observation"].cpu().numpy()
         both = done & done64
         if both.any():
-            np.testing.assert_allclose(tob[both], tobs64[both], rtol=1e-3, atol=3e-4)
+            worst["terminal_obs"] = max(worst["terminal_obs"], rel(tob[both].astype(np.float64), tobs64[both]))
         np.testing.assert_array_equal(env.core.step_counter.cpu().numpy()[same], b.step_counter[same])
         # keep the two sides in lock-step where a threshold was crossed on one side only
         if (~same).any():
             b.pos, b.quat = b.pos.copy(), b.quat.copy()
             _sync_from_oracle_inverse(env.core, b)
+    print("MEASURED auto-reset run, 260 steps of 1024 aviaries at 30 Hz: " + " ".join(f"{n}={v:.2e}" for n, v in worst.items()))
     assert n_done > E        # every aviary finished at least one episode (time truncation at step 242)
+    # <= 3x what the MI355X measures (round 6: obs 1.3e-5, terminal_obs 1.2e-5 over a full 8 s open-loop episode), never above 1e-4
+    assert worst["obs"] < AUTO_RESET_BOUND and worst["terminal_obs"] < AUTO_RESET_BOUND, worst
+
+
+AUTO_RESET_BOUND = 1e-4
 
 
 def _sync_from_oracle_inverse(core, b):

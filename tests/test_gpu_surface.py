@@ -843,7 +843,109 @@ def test_kinematic_planes_are_writable_views_and_kin_is_their_logical_matrix(gpu
     np.testing.assert_allclose((c.positions()[:, 2] - z0).cpu().numpy(), 1.2 / 240, rtol=1e-4)
     with pytest.raises(TypeError, match="copy of the state"):      # (up to ABI 8 this assignment changed the device's state: now it says so)
         c.kin[8, 3] = 1.0
+    for lost_write in (lambda: c.kin[0:3].copy_(torch.zeros(3, c.ld, device=gpu_device)), lambda: c.kin[2].fill_(1.0),
+                       lambda: c.kin[:, 5].zero_()):         # in-place operations on the copy or on a view of it
+        with pytest.raises(TypeError, match="copy of the state"):
+            lost_write()
     snap = c.kin[:, :64].clone()
     snap[8] = -0.5
     c.set_state(kin=snap)
     assert torch.equal(c.kin[:, :64], snap) and float(c.kin_V[3, 1]) == -0.5
+
+
+@pytest.mark.parametrize("act,D,flags,S", [(0, 1, 0, 8), (1, 1, 0, 8), (0, 3, 7, 2), (2, 2, 2, 5)])
+def test_host_visible_core_is_bitwise_the_device_core(gpu_device, act, D, flags, S):
+    """`SimCore(host_visible=True)` -- what the reference-shaped single aviaries run on since round 6: state, action row and step
+    outputs in page-locked host memory the kernel addresses directly -- is the same kernels on the same bits: 60 steps, a masked
+    reset and a rollout in lock-step with a core whose state lives in HBM; state, observation rows, rewards, flags, counters and
+    the controllers' members equal bit for bit.  And a `step()` of it has drained the stream when it returns (the host reads
+    the buffers without a copy)."""
+    from gym_pybullet_drones_amd import engine
+    rng = np.random.default_rng(act + 10 * D)
+    xyz = rng.uniform(-0.3, 0.3, size=(D, 3)) + np.array([0, 0, 0.5]) + np.arange(D)[:, None] * np.array([0.15, 0, 0.3])
+    kw = dict(num_envs=1, drones_per_env=D, physics=flags, pyb_freq=240, ctrl_freq=240 // S, act_code=act, task=engine.TASK_HOVER if D == 1 else engine.TASK_MULTIHOVER,
+              initial_xyzs=xyz, initial_rpys=rng.uniform(-0.1, 0.1, size=(D, 3)), target_pos=xyz + np.array([0, 0, 0.3]), track_rpm=True,
+              nan_guard=True, device=gpu_device)
+    hv, dv = engine.SimCore(host_visible=True, **kw), engine.SimCore(**kw)
+    assert hv.kin_store.device.type == "cpu" and hv.kin_store.is_pinned() and hv.action_host.is_pinned() and dv.kin_store.device == gpu_device
+    A = hv.A
+
+    def same():
+        torch.cuda.synchronize()
+        for name in ("kin_store", "last_rpm", "pid", "step_counter", "obs12", "reward", "terminated", "truncated", "bad"):
+            a, b = getattr(hv, name), getattr(dv, name)
+            assert (a is None) == (b is None), name
+            if a is not None:
+                assert torch.equal(a, b.cpu()), name
+
+    same()
+    for k in range(60):
+        a = rng.uniform(-1, 1, size=(D, A)).astype(np.float32) * (0.3 if act != 1 else 1.0) + (np.array([0, 0, 0.8], dtype=np.float32) if act == 1 else 0)
+        hv.action_host.numpy()[...] = a
+        o, r, te, tr = hv.step(hv.action_host)
+        # no synchronisation here on purpose: the host-visible step returned after its stream drained
+        assert np.isfinite(o.numpy()).all() and o.numpy().shape == (D, 12)
+        dv.step(torch.as_tensor(a, device=gpu_device))
+        if k % 10 == 9:
+            same()
+        if k == 30:
+            hv.reset(mask=torch.ones(1, dtype=torch.uint8, device=gpu_device))
+            dv.reset(mask=torch.ones(1, dtype=torch.uint8, device=gpu_device))
+            same()
+    acts = torch.as_tensor(rng.uniform(-0.2, 0.2, size=(5, D, A)).astype(np.float32), device=gpu_device)
+    oh, rh, _, _ = hv.rollout(acts)
+    od, rd, _, _ = dv.rollout(acts)
+    assert torch.equal(oh.cpu(), od.cpu()) and torch.equal(rh.cpu(), rd.cpu())
+    same()
+    st = hv.get_state()
+    hv.step(hv.action_host)
+    hv.set_state(**st)
+    dv.set_state(**{k: v.to(gpu_device) for k, v in st.items()})
+    same()
+
+
+def test_dropin_aviary_step_is_one_launch_on_host_visible_state(gpu_device, monkeypatch):
+    """The reference-shaped `HoverAviary.step()`: the action row written where the kernel reads it, ONE gpd_step launch, no
+    gpd_state_vectors launch, no torch.cat / device-to-host copy -- and the same trajectory, float for float, as with
+    GPD_HOST_VISIBLE=0 (state in HBM, the round-5 path with its packed copy)."""
+    from gym_pybullet_drones_amd import _native
+    from gym_pybullet_drones_amd.envs import HoverAviary, MultiHoverAviary
+    from gym_pybullet_drones_amd.utils.enums import ActionType, Physics
+    rng = np.random.default_rng(4)
+    for make, A in ((lambda: HoverAviary(physics=Physics.DYN, act=ActionType.ONE_D_RPM, device=gpu_device), (1, 1)),
+                    (lambda: MultiHoverAviary(num_drones=3, physics=Physics.DYN, act=ActionType.PID, device=gpu_device), (3, 3))):
+        monkeypatch.setenv("GPD_HOST_VISIBLE", "1")
+        a = make()
+        monkeypatch.setenv("GPD_HOST_VISIBLE", "0")
+        b = make()
+        assert a._core.host_visible and not b._core.host_visible
+        oa, _ = a.reset(seed=1)
+        ob, _ = b.reset(seed=1)
+        np.testing.assert_array_equal(oa, ob)
+        L = _native.lib()
+        calls = {"gpd_step": 0, "gpd_state_vectors": 0}
+        real = {n: getattr(L, n) for n in calls}
+        for n in calls:
+            def counted(*args, _n=n):
+                calls[_n] += 1
+                return real[_n](*args)
+            monkeypatch.setattr(L, n, counted, raising=False)
+        acts = rng.uniform(-1, 1, size=(40,) + A).astype(np.float32) * 0.3 + (np.array([0, 0, 0.7], dtype=np.float32) if A[1] == 3 else 0)
+        for k in range(40):
+            ra = a.step(acts[k])
+            assert calls == {"gpd_step": k + 1, "gpd_state_vectors": 0}
+            n0 = dict(calls)
+            rb = b.step(acts[k])
+            calls.update(n0)
+            np.testing.assert_array_equal(ra[0], rb[0])
+            assert ra[1:4] == rb[1:4] and isinstance(ra[1], float) and isinstance(ra[2], bool)
+            for name in ("pos", "quat", "rpy", "vel", "ang_v", "rpy_rates", "last_clipped_action"):
+                x, y = getattr(a, name), getattr(b, name)
+                assert x.dtype == np.float64 and x.shape == y.shape
+                np.testing.assert_array_equal(x, y, err_msg=name)
+            np.testing.assert_array_equal(a._getDroneStateVector(0), b._getDroneStateVector(0))
+        for n in calls:
+            monkeypatch.setattr(L, n, real[n], raising=False)
+        text = a.render()
+        assert text.count("\n") == 1 + a.NUM_DRONES and "sim" in text.split("\n")[0]
+        a.close(); b.close()

@@ -140,7 +140,7 @@ def test_product_path_refuses_to_run_without_a_gpu():
 
 
 def test_product_never_imports_the_oracle():
-    pkg = os.path.join(REPO, "gym-pybullet-drones_amd")
+    pkg = os.path.join(REPO, "gym_pybullet_drones_amd")
     for root, _, files in os.walk(pkg):
         for f in files:
             if f.endswith(".py"):

@@ -30,7 +30,7 @@ def _asm(unit, extra):
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "unit.s")
         subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", "-I", os.path.join(REPO, "include"),
-                                          os.path.join(REPO, "gym-pybullet-drones_amd", "csrc", unit), "-o", out],
+                                          os.path.join(REPO, "gym_pybullet_drones_amd", "csrc", unit), "-o", out],
                        check=True, capture_output=True)
         return open(out).read().split("\n")
 
@@ -164,6 +164,26 @@ def test_spill_checker_recognises_the_miscompile_it_was_written_for():
     assert chk.torn_spills(body) == []
 
 
+def test_kernarg_exemption_needs_the_kernarg_pointer_as_base():
+    """The exemption for a host-only argument word covers loads off s[0:1] or an s_mov_b64 copy of it, nothing else: the torn shape
+    at the same immediate offset from another base register is still a finding."""
+    import isa_spill_check as chk
+    torn = TORN.format(lo=36, hi=51)
+    (name, body), = chk.kernels(torn)
+    first = chk.torn_spills(body)[0]
+    imm = int(re.search(r",\s*(0x[0-9a-fA-F]+|\d+)\s*$", first[1]).group(1), 0)
+    dst_lo = min(chk.sregs(chk.split_ops(first[1].split(None, 1)[1])[0]))
+    offs = {imm + 4 * (r - dst_lo) for r in first[2]}
+    base = re.match(r"\S+\s+[^,]+,\s*(s\[\d+:\d+\])", first[1]).group(1)
+    exempt = chk.torn_spills(body, unused_kernarg_offsets=offs)
+    if base == "s[0:1]":
+        assert exempt == []
+        moved = [l.replace(first[1], first[1].replace("s[0:1]", "s[90:91]")) for l in body]
+        assert len(chk.torn_spills(moved, unused_kernarg_offsets=offs)) == 1
+    else:
+        assert len(exempt) == 1
+
+
 def test_no_kernel_saves_a_half_overwritten_argument_tuple(gpd_asm, policy_asm, swarm_asm, abi_asm):
     """Every kernel of the four units, every instantiation: no scalar-load destination tuple is spilled after part of it was
     overwritten (backward SGPR liveness over the kernel's control-flow graph, tests/isa_spill_check.py).  All of these kernels
@@ -172,12 +192,17 @@ def test_no_kernel_saves_a_half_overwritten_argument_tuple(gpd_asm, policy_asm, 
     import isa_spill_check as chk
     n = 0
     for asm in (gpd_asm, policy_asm, swarm_asm, abi_asm):
-        for name, body in chk.kernels("\n".join(asm)):
+        text = "\n".join(asm)
+        preload = chk.preload_lengths(text)
+        for name, body in chk.kernels(text):
             n += 1
             # GpdParams.pid_kf (word 36 of the struct) is read by the HOST only (the "no controller for this airframe" check): its three
             # neighbours hover_resid / km_over_kf / pid_gravity are fetched as an x4 whose fourth register is reused at once.  The struct
-            # sits at byte 0 of the argument block, or at byte 56 behind the fourteen preloaded dwords of gpd_step_kernel / gpd_rollout1_kernel
-            found = chk.torn_spills(body, unused_kernarg_offsets={36 * 4, 56 + 36 * 4})
+            # sits at byte 0 of the argument block -- or at byte 56, behind the fourteen preloaded dwords, in the kernels whose
+            # descriptor says so (gpd_step_kernel / gpd_rollout1_kernel / the one-world kernels); only THAT word of THAT kernel, and
+            # only in a load off the kernel-argument pointer, is exempt
+            unused = {56 + 36 * 4} if preload.get(name, 0) == 14 else {36 * 4}
+            found = chk.torn_spills(body, unused_kernarg_offsets=unused)
             assert not found, (name, [(l, dead, run["lanes"]) for _, l, dead, run in found])
     assert n >= 180, n          # (every kernel of the four units, the preloaded-argument ones included)
 
