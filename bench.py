@@ -1,34 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py — throughput of the fused HIP env step on synthetic hover batches.
+"""bench.py — throughput of the fused HIP env step on synthetic hover batches (the driver-run file).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--mode rollout|graph|eager]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one `env.step()` of EVERY aviary on this rank: the action of that step is read, the physics is
-integrated, and the step's observation rows, rewards and terminated/truncated flags are written (same-step
-auto-reset on).  Default workload `hover65536_240hz` (BASELINE.json's metric): 65 536 HoverAviaries per GPU (1 drone
-each), Physics.DYN, ActionType.RPM, pyb_freq = ctrl_freq = 240 Hz (one physics step per env step, so env-steps ==
-drone-steps); actions are pre-generated on the device and different every step.
+One "step" = one `env.step()` of EVERY aviary on this rank: the action of that step is read, the physics is integrated, and the
+step's observation rows, rewards and terminated/truncated flags are written (same-step auto-reset on).  Default workload
+`hover65536_240hz` (BASELINE.json's metric): 65 536 HoverAviaries per GPU (1 drone each), Physics.DYN, ActionType.RPM,
+pyb_freq = ctrl_freq = 240 Hz (env-steps == drone-steps); actions are pre-generated on the device and different every step.
 
-Launch modes:
-  rollout  (default, the headline `value`) `gpd_rollout`: up to 64 consecutive env steps per kernel launch -- the
-           action blocks are staged in HBM, every step's outputs are written, the drone state stays in registers;
-  graph    one `gpd_step` launch per env step, up to 64 launches captured in a hipGraph (the pattern of an RL loop
-           that runs a policy between steps); measured as well in the default run and reported under
-           `one_launch_per_step`;  `--split C` steps C sub-batches of E/C aviaries on C streams inside the graph;
-  eager    one host launch per step.
+Launch modes: `rollout` (default, the headline `value`) = `gpd_rollout`, up to 64 consecutive env steps per
+launch, action blocks staged in HBM, every step's outputs written, the state in registers; `graph` = one `gpd_step` launch per env
+step, up to 64 launches in a hipGraph (an RL loop with a policy between steps; reported under `one_launch_per_step` as well);
+`eager` = one host launch per step (`python_step_loop`).
 
-What is timed.  The K steps of `--steps` form one SCHEDULE (K // 64 groups of 64 steps + one group of K % 64).  A run of
-K = 20 steps of the headline workload lasts ~20 us, far below what an event pair or a wall clock resolves, so the
-schedule is repeated back to back `repeats` times until the timed region lasts >= 0.25 s (`--min-time`); `steps` echoes
-K, `timed_steps` = K x repeats is what the clock saw, and `ms_per_step` / `value` / `roofline.achieved` all come from
-ONE clock: HIP events on the launch stream (max over ranks).  The host wall clock around the same region (barrier +
-synchronize on both sides, max over ranks) is printed beside it as `wall_ms_per_step` / `value_wall`.
-Weak scaling: every rank owns its own aviaries; no data-path collective unless `--allgather` (or a workload that names
-it) asks for the optional RCCL all-gather of the observation shards.
-
-Rank 0 prints ONE JSON line (metric/value/unit + roofline + roofline_valu_issue + cpu_baseline).
+What is timed: the K steps of `--steps` form one SCHEDULE (K // 64 launches of 64 steps + one of K % 64), repeated back to back
+until the timed region lasts >= `--min-time`; `ms_per_step` / `value` / `roofline.achieved` come from ONE clock, HIP events on the
+launch stream (max over ranks); the host wall clock around the same region is printed beside it.  Weak scaling: every rank owns its
+aviaries, no data-path collective unless a workload names the optional RCCL all-gather of the observation shards.
+The line also carries `hbm_saturating`, `dropin_single_env`, `parity`, `cpu_baseline` and, for N > 1, the `suite` (BASELINE configs
+4 and 5).  Checker code: oracle/bench_checks.py; one-world, policy and history-row workloads: bench_extra.py.  ONE JSON line, rank 0.
 """
 import argparse
 import ctypes
@@ -49,6 +41,7 @@ HBM_ACHIEVABLE_GBS = 6300.0    # ... and what a streaming kernel reaches on it (
 PEAK_CLOCK_GHZ = 2.4       # MI355X peak engine clock
 NUM_SIMDS = 256 * 4        # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 4 cycles
 BASELINE_METRIC = "env steps/sec (whole node), HoverAviary N=65536 drones @240Hz"
+POOL = 64                  # env steps per rollout launch / per captured hipGraph
 
 WORKLOADS = {
     # name: envs/GPU, drones/env, physics flags, ctrl_freq, act, task
@@ -67,39 +60,22 @@ WORKLOADS = {
     "hover65536_ext_pid_240hz": dict(E=65536, D=1, phys=7, ctrl=240, act="pid", task="hover"),
     "stack8x8192_ext_pid_240hz": dict(E=8192, D=8, phys=7, ctrl=240, act="pid", task="multihover"),
     "multihover2x16384_pid_240hz": dict(E=16384, D=2, phys=4, ctrl=240, act="pid", task="multihover"),
-    "hover65536_240hz_fullobs": dict(E=65536, D=1, phys=0, ctrl=240, act="rpm", task="hover", full_obs=True),
-    "hover65536_30hz_fullobs": dict(E=65536, D=1, phys=0, ctrl=30, act="rpm", task="hover", full_obs=True),
-    # ... and with the action ring only ("lazy": the history tail stays a strided view of the ring the step kernel pushes into)
-    "hover65536_240hz_history": dict(E=65536, D=1, phys=0, ctrl=240, act="rpm", task="hover", full_obs="lazy"),
-    "hover65536_30hz_history": dict(E=65536, D=1, phys=0, ctrl=30, act="rpm", task="hover", full_obs="lazy"),
-    # the loop of examples/learn.py:157-192 with the policy IN the kernel (gpd_rollout_policy: SB3's default 2 x 64 tanh actor on
-    # the matrix cores, the policy sees the reference's full 72-float row); second leg: the same policy as torch operations between
-    # two gpd_step launches (rows gathered for it every step), one hipGraph
-    "hover65536_30hz_policy": dict(E=65536, D=1, phys=0, ctrl=30, act="rpm", task="hover", full_obs="lazy", policy=True),
-    "hover65536_240hz_policy12": dict(E=65536, D=1, phys=0, ctrl=240, act="rpm", task="hover", policy=True),
-    # ... and PPO's collection loop: the same kernel with noise rows, a = clip(mean + std * eps) (examples/learn.py --collect kernel)
-    "hover65536_30hz_policy_sample": dict(E=65536, D=1, phys=0, ctrl=30, act="rpm", task="hover", full_obs="lazy", policy=True, sample=True),
     "hover4m_240hz": dict(E=4194304, D=1, phys=0, ctrl=240, act="rpm", task="hover"),
     "hover16m_240hz": dict(E=16777216, D=1, phys=0, ctrl=240, act="rpm", task="hover"),
-    # BASELINE.json configs 4 and 5, per GPU, verbatim (launch with --gpus 8 under torch.distributed.run)
+    # BASELINE.json configs 4 and 5, per GPU, verbatim (launch with --gpus 8)
     "hover65536x8_allgather": dict(E=65536, D=1, phys=0, ctrl=240, act="rpm", task="hover", allgather=True),
-    # (config 5's two drones are stacked 0.3 m apart like every multi-drone workload here: from MultiHoverAviary's DEFAULT
-    # poses -- both drones at z = 0.1125 -- the reference's downwash model, alpha ~ 1/dz^2, returns ~1e10 N as soon as
-    # rounding separates the heights; no trajectory from that start means anything, in any precision)
+    # (config 5's two drones are stacked 0.3 m apart like every multi-drone workload here: from MultiHoverAviary's DEFAULT poses --
+    # both drones at z = 0.1125 -- the reference's downwash model, alpha ~ 1/dz^2, returns ~1e10 N as soon as rounding separates
+    # the heights; no trajectory from that start means anything, in any precision)
     "multihover2x16384x8": dict(E=16384, D=2, phys=4, ctrl=240, act="rpm", task="multihover"),
-    # ONE aviary of 65 536 drones, pairwise downwash over the whole swarm (gpd_downwash_global + gpd_step per sub-step)
-    "swarm65536_ext_240hz": dict(E=1, D=65536, phys=7, ctrl=240, act="raw_rpm", task="none", swarm=True),
-    # ... and of 1 048 576: with --gpus N the ONE world is shared by the N ranks (strong scaling: every rank steps its block of
-    # drones, the ranks all-gather 16 bytes per drone per sub-step, every rank evaluates the downwash of its own drones)
-    "swarm1m_ext_240hz": dict(E=1, D=1048576, phys=7, ctrl=240, act="raw_rpm", task="none", swarm=True),
 }
+# (bench_extra.py adds workloads with a "builder": one world of any size, the policy in the kernel, materialised history rows)
 
 
 def stack_scene(rng, E, D):
     """Initial poses of the multi-drone workloads: D drones stacked so that downwash and ground effect are active, the lowest
-    0.1 m above the ground, 0.3 m apart -- or, taller stacks, as far apart as keeps the top drone under the task's 2 m ceiling
-    (8 drones 0.3 m apart start above it: every aviary would be truncated and reset in every step).  THE scene of BASELINE
-    config 3 (ii) and 5: `tests/test_gpu_fullsize.py` checks the same poses it comes from here.
+    0.1 m above the ground, 0.3 m apart -- or, taller stacks, as far apart as keeps the top drone under the task's 2 m ceiling.
+    THE scene of BASELINE config 3 (ii) and 5: `tests/test_gpu_fullsize.py` checks the same poses it comes from here.
       D == 2: the pair 5 cm apart laterally (the upper drone's wake pushes the lower one with ~2x its weight, it falls away);
       D  > 2: a staircase, 12 cm per drone (a drone sits on the shoulder of its upper neighbour's wake, |beta| ~ 0.07 m, where
               the force is ~0.2x its weight), +-0.05 rad of tilt: the well-conditioned start SURVEY.md section 8(d) asks for."""
@@ -111,52 +87,21 @@ def stack_scene(rng, E, D):
     return xyz, rng.uniform(-0.05, 0.05, size=(E, D, 3))
 
 
-def make_env(w, device, seed, E=None, world=1, rank=0, exchange=None):
-    from gym_pybullet_drones_amd.envs import SwarmAviary, VectorAviary
-    from gym_pybullet_drones_amd.utils.enums import ActionType, Physics
+def make_env(w, device, seed, E=None, world=1, rank=0, job=None):
+    if w.get("builder"):                      # (bench_extra.py's workloads build their own environment)
+        return w["builder"](w, device, seed, E=E, world=world, rank=rank, job=job)
+    from gym_pybullet_drones_amd.envs import VectorAviary
+    from gym_pybullet_drones_amd.utils.enums import ActionType
     E, D = E or w["E"], w["D"]
     rng = np.random.default_rng(seed)
-    if w.get("swarm"):
-        # 12 layers 1 m apart, a 4 m lattice per layer (74 x 74 sites) with +-0.1 m jitter: ~300 m x 300 m, 32 x 32 grid cells.
-        # Layer l is shifted by (l % 4, l // 4) metres inside the lattice cell, so no drone hovers within 0.8 m (laterally)
-        # of one above it: with drones stacked vertically the reference's downwash model pushes the lower one down by up to
-        # half its weight, it falls onto the next one, and alpha ~ 1/dz^2 diverges as they pass -- under open-loop hover
-        # RPMs the whole swarm is flung apart within two seconds (gpurun_out/debug_swarm_*.log, round 2).  Every drone
-        # still sweeps the same ~600 candidates of its 3x3 cells.
-        side = int(np.ceil(np.sqrt(D / 12)))
-        idx = rng.permutation(side * side * 12)[:D]
-        layer, site = idx // (side * side), idx % (side * side)
-        xy = np.stack([(site % side) * 4.0 + layer % 4, (site // side) * 4.0 + layer // 4], axis=1) - 2.0 * side + \
-            rng.uniform(-0.1, 0.1, size=(D, 2))
-        xyz = np.concatenate([xy, (1.0 + layer)[:, None]], axis=1)
-        kw = {k: v for k, v in (("cell", os.environ.get("GPD_SWARM_CELL")), ("rebin_every", os.environ.get("GPD_SWARM_REBIN"))) if v}
-        # (pyb_like="damped": every term the kernels hold is on -- the three force models, the plane, Bullet's damping -- as in rounds 3 / 4)
-        env = SwarmAviary(D, initial_xyzs=xyz, initial_rpys=rng.uniform(-0.05, 0.05, size=(D, 3)), physics=Physics.PYB_GND_DRAG_DW,
-                          pyb_like="damped", pyb_freq=240, ctrl_freq=w["ctrl"], act="raw_rpm", device=device, world_size=world, rank=rank, exchange=exchange,
-                          cell=float(kw.get("cell", 10.5)), rebin_every=int(kw["rebin_every"]) if "rebin_every" in kw else None)
-        env.NUM_ENVS, env.ACT_DIM = 1, 4
-        # a single world has no task and no auto-reset: every pass of the schedule starts from the initial lattice (one reset
-        # launch per pass), otherwise thousands of open-loop steps let drones pass each other vertically, where the
-        # reference's downwash model (alpha ~ 1/dz^2) diverges
-        env.reset_each_pass = True
-        return env
     if D == 1:
         xyz = np.array([0, 0, 0.1125]) + rng.uniform(-0.5, 0.5, size=(E, D, 3)) * np.array([1, 1, 0])
         rpy = rng.uniform(-0.1, 0.1, size=(E, D, 3))
     else:
         xyz, rpy = stack_scene(rng, E, D)
-    env = VectorAviary(E, D, initial_xyzs=xyz, initial_rpys=rpy, physics=w["phys"], pyb_freq=240,
-                       ctrl_freq=w["ctrl"], act=ActionType(w["act"]), task=w["task"], auto_reset=True,
-                       track_rpm=bool(w["phys"] & 2), full_obs=w.get("full_obs", False), keep_terminal_obs=bool(w.get("term_obs")),
-                       device=device)
-    if w.get("policy"):
-        from gym_pybullet_drones_amd.policy import MlpPolicy
-        hist = env.ACTION_BUFFER_SIZE * env.ACT_DIM if w.get("full_obs") else 0
-        env.bench_policy = MlpPolicy.random(12 + hist, env.ACT_DIM, seed=seed, gain=1.0, device=device)
-        if w.get("sample"):
-            env.bench_noise = torch.randn((64, env.core.N, env.ACT_DIM), device=device)     # (64 = the steps of the longest launch, POOL)
-            env.bench_mean = torch.empty_like(env.bench_noise)
-    return env
+    return VectorAviary(E, D, initial_xyzs=xyz, initial_rpys=rpy, physics=w["phys"], pyb_freq=240, ctrl_freq=w["ctrl"],
+                        act=ActionType(w["act"]), task=w["task"], auto_reset=True, track_rpm=bool(w["phys"] & 2),
+                        full_obs=w.get("full_obs", False), keep_terminal_obs=bool(w.get("term_obs")), device=device)
 
 
 def make_actions(w, env, device, seed, pool):
@@ -183,439 +128,36 @@ def host_threads():
     return n
 
 
-def cpu_baseline(w, budget_s=12.0, phys=None):
-    """Time the loop-structured float64 oracle (the CPU 'port' of the reference's per-drone Python/numpy
-    path; PyBullet itself is not installable here) on ONE host core, on a bounded sample of the workload."""
-    from oracle.aviary_oracle import OracleAviary
-    urdf = os.path.join(REPO, "gym_pybullet_drones_amd", "assets", "cf2x.urdf")
-    D = w["D"]
-    phys = w["phys"] if phys is None else phys      # (the flags the device path really runs with: Physics.PYB* adds the ground plane)
-    task = w["task"] if w["task"] != "hover" or D == 1 else "multihover"
-    env = OracleAviary(urdf, "cf2x", num_drones=D, physics_flags=phys, pyb_freq=240, ctrl_freq=w["ctrl"],
-                       act=w["act"], task=task)
-    rng = np.random.default_rng(0)
-    A = env.action_buffer[0].shape[1]
-    acts = rng.uniform(-1, 1, size=(64, D, A))
-    env.step(acts[0])
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        for k in range(16):
-            _, _, term, trunc = env.step(acts[(n + k) % 64])
-            if term or trunc:
-                env.reset()
-        n += 16
-    dt = time.perf_counter() - t0
-    S = 240 // w["ctrl"]
-    out = {"value": n * D * S / dt, "unit": "drone-steps/s", "cores": 1, "kind": "port",
-           "sample": f"{n} env.step() of ONE aviary ({D} drone(s), S={S}) through oracle/aviary_oracle.py "
-                     f"(float64 per-drone numpy loop restating BaseAviary._dynamics + BaseRLAviary + task) in {dt:.1f}s "
-                     f"on 1 host core; PyBullet (Physics.PYB) is not installable in this image"}
-    try:    # second figure: the same arithmetic compiled (oracle/gpd_oracle.c, scalar float64, one core)
-        from oracle import c_oracle
-        from oracle.c_oracle import CAviary
-
-        def timed(E, threads, secs):
-            c_oracle.lib().orc_set_threads(threads)
-            c = CAviary(urdf, "cf2x", E, D, physics_flags=phys, pyb_freq=240, ctrl_freq=w["ctrl"], act=w["act"], task=task)
-            ac = rng.uniform(-1, 1, size=(4, E, D, A))
-            c.step_in_place(ac[0])          # (first touch of every array by the threads that will own its pages)
-            c.step_in_place(ac[1])
-            m, t0 = 0, time.perf_counter()
-            while time.perf_counter() - t0 < secs:
-                c.step_in_place(ac[m % 4])
-                m += 1
-            return m, time.perf_counter() - t0
-
-        m, dtc = timed(2048, 1, 3.0)
-        out["c_port"] = {"value": m * 2048 * D * S / dtc, "unit": "drone-steps/s", "cores": 1,
-                         "sample": f"{m} steps of 2048 aviaries through oracle/gpd_oracle.c (gcc -O2, scalar float64) in {dtc:.1f}s"}
-        # third figure: the same C restatement with the aviaries spread over the host's threads (OpenMP, static chunks).
-        # Thread counts: all usable threads (affinity mask / cgroup quota, not os.cpu_count()), half and a quarter of
-        # them (SMT siblings and oversubscribed containers make "all" slower than fewer); the best is reported.
-        try:
-            usable = min(host_threads(), c_oracle.lib().orc_max_threads())
-            best = None
-            for th in sorted({usable, max(1, usable // 2), max(1, usable // 4)}, reverse=True):
-                Ea = 2048 * th
-                m, dta = timed(Ea, th, 1.5)
-                rate = m * Ea * D * S / dta
-                if best is None or rate > best[0]:
-                    best = (rate, th, m, Ea, dta)
-            rate, th, m, Ea, dta = best
-            out["c_port_all_cores"] = {"value": rate, "unit": "drone-steps/s", "cores": th,
-                                       "sample": f"{m} steps of {Ea} aviaries, OpenMP over aviaries, best of "
-                                                 f"{{1, 1/2, 1/4}} x {usable} usable threads: {th}, in {dta:.1f}s"}
-        finally:
-            c_oracle.lib().orc_set_threads(1)
-    except Exception as e:   # the C restatement is optional test infrastructure
-        out.setdefault("c_port", {"error": str(e)[:200]})
-    out["reference_python"] = reference_python_figure(w, out["value"])
-    out["pybullet"] = pybullet_baseline()
-    if out["pybullet"].get("available"):        # the stated baseline itself was timed: it leads, the ports stay beside it
-        port = {k: out[k] for k in ("value", "unit", "cores", "kind", "sample")}
-        out.update({k: out["pybullet"][k] for k in ("value", "unit", "cores", "kind", "sample")})
-        out["port"] = port
-    return out
-
-
-def reference_python_figure(w, port_value):
-    """The reference's OWN Python (its unmodified HoverAviary, Physics.DYN, imported over oracle/pybullet_shim.py) as timed in the
-    build container by scratch/time_reference_dyn.py -- /root/reference does not exist on the GPU box, so the figure travels as
-    profiles/r05_reference_python_dyn_cpu.json (host CPU stated there) and is QUOTED here, next to the port timed on this box."""
-    path = os.path.join(REPO, "profiles", "r05_reference_python_dyn_cpu.json")
-    try:
-        rec = json.load(open(path))
-    except Exception as e:      # noqa: BLE001
-        return {"available": False, "why": f"{type(e).__name__}: {e}"[:160]}
-    same_shape = w["ctrl"] == 240 and "at_240hz_control" in rec
-    value = rec["at_240hz_control"]["value"] if same_shape else rec["value"]
-    return {"available": True, "kind": "reference", "value": value, "unit": rec["unit"], "cores": rec["cores"],
-            "schedule": "240 Hz control, ActionType.RPM (this workload's per-drone work)" if same_shape else
-                        "HoverAviary() defaults: 30 Hz control / 240 Hz physics, ONE_D_RPM (BASELINE config 1 with Physics.DYN)",
-            "default_schedule_value": rec["value"], "host_cpu": rec.get("host_cpu"), "measured_in": "the build container, not this box",
-            "port_over_reference": port_value / value if value else None, "file": "profiles/r05_reference_python_dyn_cpu.json",
-            "sample": f"{rec['steps']} env.step() of the reference's unmodified HoverAviary(physics=Physics.DYN) over oracle/pybullet_shim.py, "
-                      f"best of {len(rec['runs'])} runs, 1 core of {rec.get('host_cpu')}"}
-
-
-def swarm_cpu_baseline(w, env, budget_s=10.0):
-    """ONE aviary of N drones on the CPU: the reference's `_downwash` is an O(N^2) Python loop per sub-step
-    (envs/BaseAviary.py:785-811).  Timed: the float64 C restatement of one sub-step of the whole swarm -- all-pairs downwash
-    + the explicit integrator -- on a bounded SAMPLE of the swarm (the first n drones of the bench scene, n chosen so that a
-    sub-step takes about a second), all usable threads; the figure for the full swarm is extrapolated with the pair count."""
-    from oracle import c_oracle
-    if not hasattr(c_oracle, "swarm_substep_seconds"):
-        return {"error": "oracle/c_oracle.py has no swarm restatement"}
-    n = min(env.NUM_DRONES, 65536)
-    th = min(host_threads(), c_oracle.lib().orc_max_threads())
-    secs, reps = c_oracle.swarm_substep_seconds(env.INIT_XYZS[:n], threads=th, budget_s=budget_s)
-    N = env.NUM_DRONES
-    full = secs * (N / n) ** 2
-    return {"value": N / full, "unit": "drone-steps/s", "cores": th, "kind": "port",
-            "sample": f"{reps} all-pairs downwash passes over the first {n} drones of the scene (what dominates a sub-step of one large world "
-                      f"on the CPU; oracle/gpd_oracle.c, float64, {th} threads): {secs * 1e3:.1f} ms each" +
-                      (f"; extrapolated to {N} drones by the pair count (x{(N / n) ** 2:.0f})" if n < N else "")}
-
-
-def swarm_parity_check(env, all_pos=None):
-    """The swarm line's own parity figure: the downwash forces the timed path left in `dw_force` (stale cell order, wake lists
-    and all) against the float64 all-pairs loop of the reference (oracle/gpd_oracle.c, all usable threads) on the positions of
-    that very moment -- one snapshot of the whole world after the timed region (a multi-step replay through the O(N^2) loop
-    would take minutes).  Sharded worlds: rank 0's drones against the positions of all."""
-    from oracle import c_oracle
-    torch.cuda.synchronize()
-    N, n = env.TOTAL_DRONES, env.NUM_DRONES
-    if all_pos is not None:
-        # a world shared by several ranks: everybody's positions in the caller's drone order (SwarmAviary.all_positions(), gathered
-        # for this check -- with the halo exchange a rank holds its own neighbourhood only); this rank's drones are GLOBAL_IDS
-        pos = all_pos.cpu().numpy().astype(np.float64)
-        rows = np.arange(N)
-        mine_ids = np.asarray(env.GLOBAL_IDS)
-    else:
-        pos = env.pos4[:, :3].cpu().numpy().astype(np.float64)
-        rows = np.flatnonzero(np.isfinite(pos).all(axis=1))
-        mine_ids = None
-    if len(rows) != N or not np.isfinite(pos[rows]).all():
-        return {"error": f"{N - len(rows)} drones without a finite position"}
-    urdf = os.path.join(REPO, "gym_pybullet_drones_amd", "assets", "cf2x.urdf")
-    th = min(host_threads(), c_oracle.lib().orc_max_threads())
-    first = int(np.searchsorted(rows, env.RANK * env.slab))         # this rank's rows start here; rows[] skips the meta rows before them
-    # a BOUNDED check: every drone is a source, but beyond 131 072 receivers a seeded sample of this rank's drones (the full
-    # loop over 1 048 576 drones is 10^12 pair tests, 200 s on 16 threads)
-    cap = 131072
-    pick = np.arange(n) if n <= cap else np.sort(np.random.default_rng(0).choice(n, cap, replace=False))
-    t0 = time.perf_counter()
-    mine = c_oracle.downwash_some(urdf, pos[rows], (first + pick) if mine_ids is None else mine_ids[pick], threads=th)
-    dt = time.perf_counter() - t0
-    got = env.dw_force[:n].cpu().numpy().astype(np.float64)[pick]
-    scale = max(float(np.abs(mine).max()), 1e-12)
-    err = float(np.abs(got - mine).max() / scale)
-    return {"checked": f"downwash forces of {len(pick)} drones{'' if len(pick) == n else ' (a seeded sample of this rank)'} on one snapshot after the "
-                       f"timed region vs the float64 all-pairs loop over {N} sources ({dt:.1f} s on {th} threads)",
-            "force_max_abs_err_over_max_force": err, "max_force_N": scale,
-            "drones_with_a_force": int((np.abs(mine) > 1e-6).sum()), "tolerance": 1e-4, "ok": bool(err < 1e-4),
-            "note": "fp32 positions of drones up to ~150 m from the origin resolve 1e-5 m; the Gaussian of the nearest layer has a "
-                    "relative condition number of ~30 against them: individual forces agree to ~1e-3 of themselves, all to < 1e-4 of the largest"}
-
-
-def pybullet_baseline(budget_s=20.0, steps=2420):
-    """The reference's REAL CPU path, BASELINE config 1 as SURVEY.md section 8(d) spells it out: `HoverAviary()` with its defaults
-    (Physics.PYB through Bullet's own integrator, envs/BaseAviary.py:679-711; 30 Hz control / 240 Hz physics), ActionType.ONE_D_RPM,
-    actions a ~ U(-1, 1) of shape (1, 1), 2 420 `step()` calls = ten 8-second episodes (cut short by `budget_s`).  Timed when a box
-    has `pybullet` AND the reference package installed (`import gym_pybullet_drones`); this image has neither and no network:
-    the leg then reports why.  Nothing here reads /root/reference."""
-    try:
-        import pybullet  # noqa: F401
-        from gym_pybullet_drones.envs.HoverAviary import HoverAviary as RefHover
-        from gym_pybullet_drones.utils.enums import ActionType as RefAct
-    except Exception as e:
-        return {"available": False, "why": f"{type(e).__name__}: {e}"[:160]}
-    env = RefHover(gui=False, act=RefAct.ONE_D_RPM)
-    env.reset(seed=0)
-    rng = np.random.default_rng(0)
-    n, episodes, t0 = 0, 0, time.perf_counter()
-    while n < steps and time.perf_counter() - t0 < budget_s:
-        _, _, term, trunc, _ = env.step(rng.uniform(-1, 1, size=(1, 1)).astype(np.float32))
-        if term or trunc:
-            env.reset()
-            episodes += 1
-        n += 1
-    dt = time.perf_counter() - t0
-    S = int(env.PYB_STEPS_PER_CTRL)
-    env.close()
-    return {"available": True, "value": n * S / dt, "unit": "drone-steps/s", "cores": 1, "kind": "reference",
-            "env_steps_per_s": n / dt,
-            "sample": f"{n} env.step() ({episodes} episodes ended) of the reference's HoverAviary() -- Physics.PYB, ONE_D_RPM, 30 Hz control / "
-                      f"240 Hz physics, S = {S} -- in {dt:.1f}s on 1 host core (pybullet {getattr(pybullet, '__version__', '?')})"}
-
-
-def parity_check(w, env, actions, K, POOL, max_steps=256):
-    """Ties the bench line to a parity figure from the SAME process (checker code: the product path stays oracle-free).
-
-    After the timed region the device state is snapshotted and ONE K-step schedule of the exact timed workload -- the same
-    launches (`launch_rollout`, the groups of `groups_of(K, POOL)`), the same pre-generated action blocks, same-step
-    auto-reset on -- is replayed on the device and, from the identical fp32-rounded state and actions, through the float64 C
-    restatement (`oracle/gpd_oracle.c`, all usable host threads).  Errors are SURVEY.md section 8(d)'s metric per field group:
-    max |x32 - x64| / max(max |x64| over the batch and the replayed steps, floor), floors 1 m / 1 / 1 m/s / 1 rad/s.
-    An aviary whose terminated / truncated flags differ in some step (a value within rounding of a threshold: one side resets,
-    the other does not) is counted in `flag_mismatch_frac` and leaves the comparison from that step on.  The schedule is cut
-    after `max_steps` env steps (bounded CPU time)."""
-    from oracle import bullet_math as bm
-    from oracle import c_oracle
-    from oracle.c_oracle import CAviary
-    core = env.core
-    E, D, N, A, S = core.E, core.D, core.N, core.A, core.S
-    urdf = os.path.join(REPO, "gym_pybullet_drones_amd", "assets", "cf2x.urdf")
-    task = {0: "none", 1: "hover", 2: "multihover"}[core.task]
-    torch.cuda.synchronize()
-    st = core.get_state()
-    orc = CAviary(urdf, "cf2x", E, D, physics_flags=core.physics_flags, pyb_freq=240, ctrl_freq=w["ctrl"], act=w["act"], task=task,
-                  auto_reset=bool(core.auto_reset), target_pos=np.broadcast_to(core.TARGET_POS, (E, D, 3)))
-    pose = core.init_pose.cpu().numpy().astype(np.float64).reshape(-1, D, 7)      # the fp32 reset poses the kernel uses
-    orc.INIT_XYZS = np.ascontiguousarray(np.broadcast_to(pose[..., :3], (E, D, 3)))
-    orc.INIT_QUAT = np.ascontiguousarray(np.broadcast_to(pose[..., 3:], (E, D, 4)))
-    kin = st["kin"].cpu().numpy().astype(np.float64).T                              # [N][13]
-    orc.pos, orc.quat = kin[:, 0:3].reshape(E, D, 3).copy(), kin[:, 3:7].reshape(E, D, 4).copy()
-    orc.vel, orc.rpy_rates = kin[:, 7:10].reshape(E, D, 3).copy(), kin[:, 10:13].reshape(E, D, 3).copy()
-    orc.rpy = np.ascontiguousarray(bm.euler_from_quaternion_b(orc.quat))
-    orc.step_counter = st["step_counter"].cpu().numpy().astype(np.int64)
-    if "last_rpm" in st:
-        orc.last_rpm = np.ascontiguousarray(st["last_rpm"].cpu().numpy().astype(np.float64).T.reshape(E, D, 4))
-    if "pid" in st:
-        orc.pid_state = np.ascontiguousarray(st["pid"].cpu().numpy().astype(np.float64).T.reshape(E, D, 9))
-    # Multi-drone aviaries with downwash: the model is ill-conditioned where a drone crosses a neighbour's wake (alpha ~ 1/dz^2,
-    # a Gaussian of width |beta| ~ 0.07 m), so ANY rounding-level difference between two runs grows -- between two float64 runs
-    # too.  A second float64 run, its state nudged by half an fp32 ulp (relative 2^-24, random sign) after every step -- a
-    # float64 run that suffers exactly the input rounding an fp32 state array imposes --, measures how far such runs separate
-    # on THIS scene: the envelope the fp32 run is held against (the construction of tests/test_gpu_parity.py's PID envelope).
-    envelope = D > 1 and bool(core.physics_flags & 4)
-    orp, alive_p, env_rows, erng = None, None, [], np.random.default_rng(12345)
-    if envelope:
-        orp = CAviary(urdf, "cf2x", E, D, physics_flags=core.physics_flags, pyb_freq=240, ctrl_freq=w["ctrl"], act=w["act"], task=task,
-                      auto_reset=bool(core.auto_reset), target_pos=np.broadcast_to(core.TARGET_POS, (E, D, 3)))
-        orp.INIT_XYZS, orp.INIT_QUAT = orc.INIT_XYZS, orc.INIT_QUAT
-        for name in ("pos", "quat", "vel", "rpy_rates", "rpy", "step_counter", "last_rpm", "pid_state"):
-            setattr(orp, name, getattr(orc, name).copy())
-        alive_p = np.ones(E, dtype=bool)              # aviaries whose flags agreed between the two float64 runs so far
-
-        def nudge():
-            for name in ("pos", "quat", "vel", "rpy_rates"):
-                arr = getattr(orp, name)
-                arr *= 1.0 + 2.0 ** -24 * erng.choice([-1.0, 1.0], size=arr.shape)
-            orp.rpy = np.ascontiguousarray(bm.euler_from_quaternion_b(orp.quat))
-        nudge()                                       # (the first step's input is already a rounded one)
-    # (every replayed step's rows go to the host, and once more as float64: a launch is cut so that its rows stay under 2 GB --
-    # 10 steps at 4M drones -- and the whole replay under 6 GB)
-    per_launch = max(1, int(2.0e9 // (N * 48)))
-    max_steps = min(max_steps, max(per_launch, int(6.0e9 // (N * 48))))
-    groups, left = [], max_steps
-    for n in groups_of(K, POOL):
-        if left <= 0:
-            break
-        groups.append(min(n, left, per_launch))
-        left -= groups[-1]
-    names = ("pos", "quat", "vel", "rates")
-    sl = {"pos": slice(0, 3), "quat": slice(3, 7), "vel": slice(7, 10), "rates": slice(10, 13)}
-    osl = {"pos": slice(0, 3), "rpy": slice(3, 6), "vel": slice(6, 9), "ang_v": slice(9, 12)}
-    scale = {g: 1.0 for g in list(sl) + list(osl)}
-    obs_err = {g: 0.0 for g in osl}
-    first_err = {}
-    alive = np.ones(E, dtype=bool)                  # aviaries whose flags agreed in every step so far
-    min_dz = np.full(E, np.inf) if D > 1 else None  # per aviary: the smallest height difference between two of its drones, over the replay
-    rew_err, checked, n_done = 0.0, 0, 0
-    c_oracle.lib().orc_set_threads(min(host_threads(), c_oracle.lib().orc_max_threads()))
-    try:
-        for n in groups:
-            out = launch_rollout(env, actions, n)
-            torch.cuda.synchronize()
-            obs = out[0].reshape(-1, N, 12)[:n].cpu().numpy().astype(np.float64)
-            rew, term, trunc = (x[:n].cpu().numpy() for x in out[1:4])
-            a64 = actions[:n].cpu().numpy().astype(np.float64)
-            for k in range(n):
-                orc.step_in_place(a64[k])
-                same = (term[k] == orc.terminated.astype(bool)) & (trunc[k] == orc.truncated.astype(bool))
-                alive &= same
-                if envelope:
-                    orp.step_in_place(a64[k])
-                    alive_p &= (orp.terminated == orc.terminated) & (orp.truncated == orc.truncated)
-                    if (checked + 1) % 16 == 0 or (checked + 1) in (1, 2, 4, 8) or (n == groups[-1] and k == n - 1):
-                        both = alive & alive_p
-                        if both.any():
-                            o64, op = orc.obs.reshape(E, D, 12)[both], orp.obs.reshape(E, D, 12)[both]
-                            o32 = obs[k].reshape(E, D, 12)[both]
-                            for g, s_ in osl.items():
-                                e32 = np.abs(o32[..., s_] - o64[..., s_]).max(axis=(1, 2))       # per aviary: its worst drone / component
-                                e64 = np.abs(op[..., s_] - o64[..., s_]).max(axis=(1, 2))
-                                env_rows.append((checked + 1, g, float(np.percentile(e32, 50)), float(np.percentile(e64, 50)),
-                                                 float(np.percentile(e32, 95)), float(np.percentile(e64, 95)), float(e32.max()), float(e64.max()),
-                                                 int(both.sum())))
-                    nudge()
-                n_done += int((term[k] | trunc[k]).sum())
-                if min_dz is not None:
-                    zz = orc.pos[..., 2]
-                    dzz = np.abs(zz[:, :, None] - zz[:, None, :]) + np.eye(D)[None] * 1e9
-                    min_dz = np.minimum(min_dz, dzz.min(axis=(1, 2)))
-                m = np.repeat(alive, D)
-                o64 = orc.obs.reshape(N, 12)
-                for g, s_ in osl.items():
-                    scale[g] = max(scale[g], float(np.abs(o64[:, s_]).max()))
-                    e_ = float(np.abs(obs[k][m][:, s_] - o64[m][:, s_]).max()) if m.any() else 0.0
-                    obs_err[g] = max(obs_err[g], e_)
-                    if checked == 0:
-                        first_err[g] = e_
-                if alive.any():
-                    rew_err = max(rew_err, float(np.abs(rew[k][alive].astype(np.float64) - orc.reward[alive]).max()))
-                k64 = np.concatenate([orc.pos.reshape(N, 3), orc.quat.reshape(N, 4), orc.vel.reshape(N, 3), orc.rpy_rates.reshape(N, 3)], axis=1)
-                for g in names:
-                    scale[g] = max(scale[g], float(np.abs(k64[:, sl[g]]).max()))
-                checked += 1
-    finally:
-        c_oracle.lib().orc_set_threads(1)
-    torch.cuda.synchronize()
-    kin32 = core.kin[:, :N].cpu().numpy().astype(np.float64).T
-    m = np.repeat(alive, D)
-    res = {"checked_steps": checked, "launches": [f"rollout{n}" for n in groups], "aviaries": E, "drones": N,
-           "episodes_ended_in_window": n_done}
-    worst = 0.0
-    for g in names:
-        res[g] = float(np.abs(kin32[m][:, sl[g]] - k64[m][:, sl[g]]).max() / scale[g])
-        worst = max(worst, res[g])
-    # (SURVEY.md section 8(d) also asks for the element-wise figure: the share of the final state's floats with
-    # |x32 - x64| <= 1e-5 + 1e-4 |x64|)
-    if m.any():
-        res["allclose_pass_rate"] = float(np.isclose(kin32[m], k64[m], rtol=1e-4, atol=1e-5).mean())
-    res["obs_every_step"] = {g: obs_err[g] / scale[g] for g in osl}
-    res["obs_first_step"] = {g: first_err.get(g, 0.0) / scale[g] for g in osl}
-    if D > 1 and core.physics_flags & 4:
-        res["note"] = ("drones flying in each other's wake: the reference's downwash model is ill-conditioned there (alpha ~ 1/dz^2, "
-                       "exp(-(dxy/beta)^2/2) with |beta| ~ 0.06 m) -- single steps agree (obs_first_step; tests/test_gpu_parity.py), "
-                       "trajectories of the closest pairs separate in any finite precision (DESIGN.md section 4)")
-    res["flag_mismatch_frac"] = float(1.0 - alive.mean())
-    res["reward_max_abs"] = rew_err
-    res["max"] = worst
-    res["tolerance"] = 1e-4
-    res["ok"] = bool(worst < 1e-4)            # the plain tolerance, nothing else (the envelope verdict is `ok_envelope`)
-    res["ok_by"] = "tolerance" if res["ok"] else None
-    # per aviary: the share whose own final state is inside the tolerance (the maximum above belongs to the worst one)
-    if m.any():
-        per = np.zeros(E)
-        for g in names:
-            per = np.maximum(per, np.abs(kin32[:, sl[g]] - k64[:, sl[g]]).reshape(E, -1).max(axis=1) / scale[g])
-        res["frac_aviaries_within_tolerance"] = float((per[alive] < 1e-4).mean())
-        if D > 1 and min_dz is not None:
-            wa = int(np.argmax(np.where(alive, per, -1.0)))
-            res["worst_aviary"] = {"index": wa, "error": float(per[wa]), "min_abs_dz_between_two_of_its_drones_m": float(min_dz[wa]),
-                                   "min_abs_dz_median_over_aviaries_m": float(np.median(min_dz)),
-                                   "note": "the reference's downwash amplitude is ~ 1 / dz^2: an aviary whose drones pass each other in height is where any rounding grows"}
-    if envelope and env_rows:
-        floor = 5e-7                    # one-step fp32 rounding of O(1) quantities
-        ratio = lambda x32, xenv: x32 / (xenv + floor / 4.0)          # noqa: E731 -- (x32 <= 4 xenv + floor  <=>  ratio <= 4)
-        worst_row = max(env_rows, key=lambda r: max(ratio(r[2], r[3]), ratio(r[4], r[5])))
-        er = max(ratio(worst_row[2], worst_row[3]), ratio(worst_row[4], worst_row[5]))
-        res["envelope"] = {
-            "ratio": er, "limit": 4.0, "ok": bool(er <= 4.0),
-            "worst": {"step": worst_row[0], "group": worst_row[1], "median_fp32": worst_row[2], "median_envelope": worst_row[3],
-                      "p95_fp32": worst_row[4], "p95_envelope": worst_row[5]},
-            "last": {r[1]: {"step": r[0], "median_fp32": r[2], "median_envelope": r[3], "p95_fp32": r[4], "p95_envelope": r[5],
-                            "max_fp32": r[6], "max_envelope": r[7], "aviaries": r[8]} for r in env_rows[-len(osl):]},
-            "flag_mismatch_frac_between_the_two_float64_runs": float(1.0 - alive_p.mean()),
-            "rows": [list(r) for r in env_rows],
-            "what": "per aviary and observation group: |fp32 - float64| against |float64 nudged by half an fp32 ulp per step - float64|, "
-                    "median and 95th percentile over the aviaries; ratio = max over checkpoints of x32 / (x_envelope + 1.25e-7)"}
-        res["ok_envelope"] = bool(res["envelope"]["ok"])
-        if not res["ok"] and res["envelope"]["ok"]:
-            res["ok_by"] = "float64_envelope"         # (`ok` stays the tolerance's verdict: False)
-    res["oracle"] = "oracle/gpd_oracle.c (float64), from the device state after the timed region, same action blocks, auto-reset on"
-    res["metric"] = "max|x32-x64| / max(max|x64| over batch and window, 1): final state per field group; obs_every_step: the same over every replayed step"
-    return res
-
-
 def groups_of(k, pool):
     return [pool] * (k // pool) + ([k % pool] if k % pool else [])
 
 
 def launch_rollout(e, a, n):
-    """One rollout launch of n env steps of the aviaries of `e` with the action blocks a[:n] -- THE timed call of rollout mode
-    (also what `parity_check` replays).  Returns (obs12 [n,N,12], reward, terminated, truncated[, actions])."""
-    hist = getattr(e, "full_obs", False) or getattr(e, "lazy_history", False)
-    if getattr(e, "bench_policy", None) is not None:
-        if getattr(e, "bench_noise", None) is not None:
-            return e.core.rollout_policy(e.bench_policy, n, want_actions=True, noise=e.bench_noise[:n], action_std=[0.6] * e.ACT_DIM,
-                                         mean_out=e.bench_mean[:n])
-        return e.core.rollout_policy(e.bench_policy, n, want_actions=True)
-    return e.rollout(a[:n]) if hist else e.core.rollout(a[:n], update_latest=False)
+    """One rollout launch of n env steps of the aviaries of `e` with the action blocks a[:n] -- THE timed call of rollout mode (also
+    what the parity leg replays).  Returns (obs12 [n,N,12], reward, terminated, truncated[, actions])."""
+    hook = getattr(e, "bench_launch", None)          # (bench_extra.py: policy rollouts, history rows)
+    if hook is not None:
+        return hook(a, n)
+    return e.core.rollout(a[:n], update_latest=False)
 
 
-def measure(mode, args, envs, actions, gather, device, world, POOL):
-    """Time `repeats` x K env steps of every aviary on this rank.  mode 'graph': one kernel launch per env step (per
-    sub-batch), up to POOL steps captured in a hipGraph; 'eager': one host launch per step; 'rollout': `gpd_rollout`,
-    up to POOL steps per launch (actions pre-staged, every step's obs/reward/flags written)."""
+def measure(mode, args, env, actions, gather, device, world):
+    """Time `repeats` x K env steps of every aviary on this rank.  mode 'graph': one kernel launch per env step, up to POOL steps
+    captured in a hipGraph; 'eager': one host launch per step; 'rollout': `gpd_rollout`, up to POOL steps per launch (actions
+    pre-staged, every step's obs/reward/flags written)."""
     from gym_pybullet_drones_amd import dist as gdist
-    cores = [e.core for e in envs]
-    core = cores[0]
+    core = env.core
     K, W = args.steps, args.warmup
     main = torch.cuda.current_stream(device)
-    side = [torch.cuda.Stream(device) for _ in envs[1:]]
+    step_hook = getattr(env, "bench_step", None)
 
     def one_step(i):
-        """step i of every sub-batch: sub-batch 0 on the current stream, the others on their own streams"""
-        if len(envs) == 1:
-            pol = getattr(envs[0], "bench_policy", None)
-            if pol is not None:         # the policy between two steps, as torch operations on the rows gathered for it
-                row = envs[0].full_rows() if pol.in_dim > 12 else envs[0].core.obs12.view(-1, 1, 12)
-                envs[0].step(pol(row))
-            else:
-                envs[0].step(actions[0][i % POOL])
-            if gather is not None:
-                gather(core.obs12)
-            return
-        cur = torch.cuda.current_stream(device)
-        for s in side:
-            s.wait_stream(cur)
-        envs[0].step(actions[0][i % POOL])
-        for e, a, s in zip(envs[1:], actions[1:], side):
-            with torch.cuda.stream(s):
-                e.step(a[i % POOL])
-        for s in side:
-            cur.wait_stream(s)
-
-    def chain_steps(n):
-        """n steps of every sub-batch, each sub-batch as an independent chain on its own stream"""
-        if len(envs) == 1:
-            for i in range(n):
-                one_step(i)
-            return
-        cur = torch.cuda.current_stream(device)
-        for s in side:
-            s.wait_stream(cur)
-        for i in range(n):
-            envs[0].step(actions[0][i % POOL])
-        for e, a, s in zip(envs[1:], actions[1:], side):
-            with torch.cuda.stream(s):
-                for i in range(n):
-                    e.step(a[i % POOL])
-        for s in side:
-            cur.wait_stream(s)
+        if step_hook is not None:
+            step_hook(actions, i)
+        else:
+            env.step(actions[i % POOL])
+        if gather is not None:
+            gather(core.obs12)
 
     sizes = set(groups_of(K, POOL)) | set(groups_of(W, POOL))
     gathers = {}
@@ -623,39 +165,10 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
         for n in sorted(sizes):             # one larger collective per rollout; every length shares the ONE communicator of `gather`
             gathers[n] = gather.sized(n * core.N * 12)
 
-    # rollout mode with --split C: sub-batch c is an independent chain of launches on stream c -- no join inside the timed
-    # region (the aviaries share nothing), so one chain's kernel boundary and straggler tail hide under the others' steady state
-    indep = mode == "rollout" and len(envs) > 1
-    if indep:
-        if getattr(args, "cu_mask", False):
-            # every chain on a stream restricted to its own CUs (hipExtStreamCreateWithCUMask).  Chain c takes the mask bits
-            # c*256/C .. (c+1)*256/C - 1: scratch/exp_r03/place.hip shows that two such halves are disjoint sets of 128 CUs,
-            # 16 in every XCD (profiles/r03_stream_placement.txt) -- the "bit i = CU i/8 of XCD i%8" layout the first version
-            # of this option assumed changes nothing against plain streams, where two 128-workgroup kernels share 21 CUs
-            hip = ctypes.CDLL("libamdhip64.so")
-            C = len(envs)
-            side = []
-            for c in range(C):
-                words = (ctypes.c_uint32 * 8)()
-                for i in range(256):
-                    if i * C // 256 == c:
-                        words[i // 32] |= 1 << (i % 32)
-                h = ctypes.c_void_p()
-                rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words)
-                if rc != 0:
-                    raise SystemExit(f"hipExtStreamCreateWithCUMask failed ({rc})")
-                side.append(torch.cuda.ExternalStream(h.value, device=device))
-            for e, s in zip(envs, side):
-                e.core.use_stream(s)
-        else:
-            for e, s in zip(envs[1:], side):
-                e.core.use_stream(s)
-
     def one_rollout(n):
-        for e, a in zip(envs, actions):
-            out = launch_rollout(e, a, n)
-            if n in gathers:
-                gathers[n](out[0].reshape(-1, 12))
+        out = launch_rollout(env, actions, n)
+        if n in gathers:
+            gathers[n](out[0].reshape(-1, 12))
 
     graphs = {}
     if mode == "rollout":
@@ -672,35 +185,14 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
             with torch.cuda.stream(stream):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=stream):
-                    chain_steps(n)
+                    for i in range(n):
+                        one_step(i)
             main.wait_stream(stream)
             graphs[n] = g
 
-    # --rollout-graph P (experiment): P passes of the rollout schedule -- every chain of a --split -- captured in ONE hipGraph
-    # (fork behind the capture stream, join before its end) and replayed: no host launch cost in the timed region, which at
-    # 20 steps per launch and two or more chains is what the plain --split figures measure (9 us of host time per launch)
-    pass_graph, P = None, int(getattr(args, "rollout_graph", 0) or 0)
-    if mode == "rollout" and P > 0 and gather is None:
-        cap = torch.cuda.Stream(device)
-        cap.wait_stream(main)
-        with torch.cuda.stream(cap):
-            pass_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(pass_graph, stream=cap):
-                if indep:
-                    for s_ in side:
-                        s_.wait_stream(cap)
-                for _ in range(P):
-                    for n in groups_of(K, POOL):
-                        one_rollout(n)
-                if indep:
-                    for s_ in side:
-                        cap.wait_stream(s_)
-        main.wait_stream(cap)
-
     def run(k):
-        for e in envs:
-            if getattr(e, "reset_each_pass", False):
-                e.reset()
+        if getattr(env, "reset_each_pass", False):
+            env.reset()
         if mode == "eager":
             for i in range(k):
                 one_step(i)
@@ -714,8 +206,7 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
                 for i in range(n):
                     one_step(i)
 
-    per_rank_s = []
-    marks = []          # (repeats done, seconds since the first event) at the segment events of the last timed() call
+    per_rank_s, marks = [], []          # marks: (repeats done, seconds since the first event) at the segment events of the last timed() call
 
     def timed(reps):
         torch.cuda.synchronize()
@@ -725,32 +216,15 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ev0.record()          # on the current stream = the stream every gpd_* launch above goes to
-        if indep:             # fork: the other chains start behind ev0 ...
-            for s_ in side:
-                s_.wait_event(ev0)
-        if indep and getattr(args, "stagger", False):
-            # chains forked at the same instant with launches of the same length stay in lock step: their kernel boundaries
-            # coincide and hide nothing.  Chain c starts with a launch of c/C of the schedule's steps (inside the timed
-            # region, its steps NOT counted).
-            for c, (e, a) in enumerate(zip(envs, actions)):
-                if c:
-                    launch_rollout(e, a, max(1, min(K, POOL) * c // len(envs)))
         marks.clear()
         nseg = int(getattr(args, "segment_events", 0) or 0)
         every = max(1, reps // nseg) if nseg else 0
-        if pass_graph is not None and reps % P == 0:
-            for _ in range(reps // P):
-                pass_graph.replay()
-        else:
-            for i in range(reps):
-                run(K)
-                if every and (i + 1) % every == 0 and i + 1 < reps:        # the timed region seen piecewise (clock ramps, throttling)
-                    ev = torch.cuda.Event(enable_timing=True)
-                    ev.record()
-                    marks.append((i + 1, ev))
-        if indep:             # ... and ev1 sits behind the last launch of EVERY chain (one join, after the last step)
-            for s_ in side:
-                main.wait_stream(s_)
+        for i in range(reps):
+            run(K)
+            if every and (i + 1) % every == 0 and i + 1 < reps:        # the timed region seen piecewise (clock ramps, throttling)
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append((i + 1, ev))
         ev1.record()
         torch.cuda.synchronize()
         if world > 1:
@@ -759,56 +233,32 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
         mine = ev0.elapsed_time(ev1) * 1e-3
         marks[:] = [(n, ev0.elapsed_time(ev) * 1e-3) for n, ev in marks] + [(reps, mine)]
         per_rank_s[:] = gdist.gather_floats(mine, device=device)       # (this rank's own event time, from every rank)
-        return (gdist.max_over_ranks(mine, device=device),
-                gdist.max_over_ranks(t1 - t0, device=device))
+        return gdist.max_over_ranks(mine, device=device), gdist.max_over_ranks(t1 - t0, device=device)
 
-    if indep and getattr(args, "stagger", False):
-        for c, (e, a) in enumerate(zip(envs, actions)):
-            if c:
-                launch_rollout(e, a, max(1, min(K, POOL) * c // len(envs)))      # (allocates that length's buffers)
     run(W)                                          # W untimed warm-up steps, as requested
     run(K)                                          # + one untimed pass of the schedule itself
     cal, _ = timed(1)                               # calibration pass (untimed in the result): how long is one schedule?
     repeats = int(min(max(1, math.ceil(args.min_time / max(cal, 1e-7))), 1 << 20))
-    if pass_graph is not None:
-        repeats = max(P, (repeats + P - 1) // P * P)
     ev_s, wall_s = timed(repeats)
     timed_steps = K * repeats
     # roofline of the dominant kernel: algorithmic bytes of all launches of the timed region / its HIP-event time
-    def extra(e, n, rollout):          # materialised (12 + H*A)-float rows / the ring update behind a rollout
-        c = e.core
-        pol = getattr(e, "bench_policy", None)
-        if pol is not None:             # in the kernel: the ring push; between steps: the gathered rows (+ the MLP's own traffic, not counted)
-            ring = 2 * n * c.N * c.A * 4 if getattr(e, "lazy_history", False) else 0
-            return ring if rollout else (c.bytes_full_rows(n) if pol.in_dim > 12 else 0)
-        if getattr(e, "full_obs", False):
-            return c.bytes_full_rows(n, push=rollout)
-        if getattr(e, "lazy_history", False) and rollout:
-            if getattr(c, "pushed_history", False):     # gpd_rollout_history: the action (already counted) goes to both ring halves
-                return n * c.N * 2 * c.A * 4 + 2 * 4 * c.E          # + the ring position of every aviary, read and written once
-            return c.bytes_full_rows(n, push=True) - c.bytes_full_rows(n)     # post-pass (gpd_full_obs, ring update only)
-        return 0
-
+    extra = getattr(env, "bench_extra_bytes", lambda n, rollout: 0)
     if mode == "rollout":
-        per_pass = sum(e.core.bytes_per_rollout(n) + extra(e, n, True) for n in groups_of(K, POOL) for e in envs)
+        per_pass = sum(core.bytes_per_rollout(n) + extra(n, True) for n in groups_of(K, POOL))
         launches_pass = len(groups_of(K, POOL))
     else:
-        per_pass = K * sum(e.core.bytes_per_step() + extra(e, 1, False) for e in envs)
+        per_pass = K * (core.bytes_per_step() + extra(1, False))
         launches_pass = K
-    launches = launches_pass * repeats * (len(envs) if indep else 1)       # (independent chains: C concurrent launches per group)
+    launches = launches_pass * repeats
     bytes_total = per_pass * repeats
-    n_rank = sum(c.N for c in cores)
-    n_total = n_rank * world
+    n_total = core.N * world
     achieved = bytes_total / ev_s / 1e9
-    steps_per_launch = K / launches_pass
-    kernel = "gpd_rollout_policy_kernel" if (mode == "rollout" and getattr(envs[0], "bench_policy", None) is not None) else \
-        "dwg_force_kernel (+ gpd_swarm_step_kernel; a binning every few sub-steps)" if hasattr(envs[0], "pos4") else \
-        "gpd_step_kernel" if mode != "rollout" else \
-        ("gpd_rollout1_kernel" if core.D & (core.D - 1) == 0 and core.D <= 64 and core.term_obs12 is None else "gpd_rollout_kernel")
+    kernel = getattr(env, "bench_kernel", {}).get(mode) or ("gpd_step_kernel" if mode != "rollout" else
+        ("gpd_rollout1_kernel" if core.D & (core.D - 1) == 0 and core.D <= 64 and core.term_obs12 is None else "gpd_rollout_kernel"))
     segments = None
     if len(marks) > 1:
         # rate of the first ~100 ms of the timed region against the rest of it (a GPU that boosts out of idle and then settles, or
-        # throttles, shows here; VERDICT r04 weak #1: a 0.1 s region cannot tell)
+        # throttles, shows here)
         head = next((i for i, (_, t) in enumerate(marks) if t >= 0.1), len(marks) - 1)
         n_h, t_h = marks[head]
         n_e, t_e = marks[-1]
@@ -820,80 +270,20 @@ def measure(mode, args, envs, actions, gather, device, world, POOL):
         "K": K, "W": W, "repeats": repeats, "timed_steps": timed_steps, "ev_s": ev_s, "wall_s": wall_s, "segments": segments,
         "value": n_total * core.S * timed_steps / ev_s, "value_wall": n_total * core.S * timed_steps / wall_s,
         "env_steps_per_s": n_total * timed_steps / ev_s, "us_per_step": ev_s * 1e6 / timed_steps,
-        "per_gpu": [n_rank * core.S * timed_steps / t for t in per_rank_s],
+        "per_gpu": [core.N * core.S * timed_steps / t for t in per_rank_s],
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "achievable": HBM_ACHIEVABLE_GBS,
                      "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS, "traffic": None, "kernel": kernel,
-                     "env_steps_per_launch": steps_per_launch, "bytes_per_launch": bytes_total / launches,
-                     "bytes_per_drone_per_env_step": per_pass / (n_rank * K),
-                     "launch_us_hip_events": ev_s * 1e6 / (launches_pass * repeats), "launches_timed": launches,
-                     "concurrent_chains": len(envs) if indep else 1,
-                     "clock": "HIP events on the launch stream, max over ranks" +
-                              (f"; {len(envs)} independent chains forked behind the first event, the second event behind the last launch of each" if indep else "")},
+                     "env_steps_per_launch": K / launches_pass, "bytes_per_launch": bytes_total / launches,
+                     "bytes_per_drone_per_env_step": per_pass / (core.N * K),
+                     "launch_us_hip_events": ev_s * 1e6 / launches, "launches_timed": launches,
+                     "clock": "HIP events on the launch stream, max over ranks"},
     }
 
 
-def swarm_pairs(env):
-    """Pairs the wake lists of the current binning hold = what every replay launch evaluates (valid entries of the batches the
-    four waves of every group recorded; include/gpd.h, GpdSwarm.pair_list / pair_nb).  None without lists."""
-    if getattr(env, "_pair_list", None) is None:
-        return None
-    torch.cuda.synchronize()
-    nb = env._pair_nb[..., 0].to(torch.int32) & 0xffff                         # [groups, 4] batches per wave
-    ok = env._list_ok.to(torch.bool)
-    cap64 = env._pair_list.shape[2]
-    idx = torch.arange(cap64, device=env.device).view(1, 1, -1)
-    live = (idx < (nb * 64).unsqueeze(2)) & ok.view(-1, 1, 1)
-    pairs = int(((env._pair_list != -1) & live).sum().item())
-    slots = int((nb * 64)[ok].sum().item())
-    return {"pairs": pairs, "list_slots": slots, "groups_with_a_list": int(ok.sum().item()), "groups": int(ok.numel()),
-            "list_bytes_read_per_substep": slots * 4}
-
-
-def swarm_roofline(out, env, m, clock_ghz):
-    """The roofline that binds a one-world line.  The HBM figure stays (as `hbm`), but a sub-step moves ~200 B per drone and takes
-    tens of microseconds: what it spends is pair evaluations and the dependent trips to memory around them.  Bound named here:
-    VALU issue -- wave-instructions of all kernels of a sub-step (rocprofv3 --pmc SQ_INSTS_VALU, profiles/swarm_counters.json)
-    x 4 cycles on 1024 SIMDs, against the measured sub-step; beside it the pairs per sub-step (the lists the timed region
-    replayed), the lane-instructions per pair, and where the rest of the time goes (per-kernel durations of the same trace)."""
-    roof = out["roofline"]
-    hbm = {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "achievable", "frac_of_achievable", "bytes_per_launch",
-                                "bytes_per_drone_per_env_step", "floor_us") if k in roof}
-    pairs = swarm_pairs(env)
-    us = m["us_per_step"] / max(env.PYB_STEPS_PER_CTRL, 1)                 # per physics sub-step
-    rec = None
-    f = os.path.join(REPO, "profiles", "swarm_counters.json")
-    if os.path.exists(f):
-        rec = json.load(open(f)).get(out["config"]["workload"])
-    peak = NUM_SIMDS * PEAK_CLOCK_GHZ / 4.0                                # G wave-instructions per second (a wave64 VALU op holds its SIMD 4 cycles)
-    new = {"bound": "valu_issue", "achieved": None, "peak": peak, "unit": "G wave-instructions/s", "frac": None, "traffic": roof.get("traffic"),
-           "kernel": roof["kernel"], "us_per_substep": us, "pairs": pairs, "hbm": hbm, "clock": roof.get("clock"),
-           "env_steps_per_launch": roof.get("env_steps_per_launch"), "launch_us_hip_events": roof.get("launch_us_hip_events")}
-    if pairs:
-        new["pairs_per_substep"] = pairs["pairs"]
-        new["pairs_per_drone"] = pairs["pairs"] / env.TOTAL_DRONES
-        new["pair_evaluations_per_s"] = pairs["pairs"] / (us * 1e-6)
-    if rec:
-        valu = rec["valu_wave_instructions_per_substep"]
-        new["achieved"] = valu / (us * 1e-6) / 1e9
-        new["frac"] = new["achieved"] / peak
-        new["valu_floor_us"] = valu * 4.0 / (NUM_SIMDS * PEAK_CLOCK_GHZ * 1e3)
-        if clock_ghz:
-            new["frac_at_measured_clock"] = valu * 4.0 / (NUM_SIMDS * clock_ghz * 1e3) / us
-        new["counters"] = rec
-        new["traffic"] = rec.get("hbm_bytes_per_substep")       # FETCH_SIZE x 2 + WRITE_SIZE of every kernel of a sub-step (separate --pmc passes)
-        if pairs and rec.get("replay_valu_wave_instructions"):
-            new["valu_lane_instructions_per_pair"] = rec["replay_valu_wave_instructions"] * 64.0 / pairs["pairs"]
-        new["source"] = "profiles/swarm_counters.json (rocprofv3 --pmc SQ_INSTS_*, scratch/profile_r05.py)"
-    else:
-        new["note"] = "no profiles/swarm_counters.json entry for this workload: instruction counts unknown, frac not computed"
-    out["roofline"] = new
-
-
 def attach_counters(roof, key, m, core, clock_ghz):
-    """Offline-measured per-kernel figures (separate rocprofv3 passes, profiles/*.json) next to the live numbers:
-    HBM traffic from the FETCH_SIZE / WRITE_SIZE counters, scaled to this launch's step count, and the instruction
-    counts behind the VALU-issue roofline."""
+    """Offline-measured per-kernel figures (separate rocprofv3 passes, profiles/*.json) next to the live numbers: HBM traffic from the
+    FETCH_SIZE / WRITE_SIZE counters, scaled to this launch's step count, and the instruction counts behind the VALU-issue roofline."""
     issue = None
     tfile = os.path.join(REPO, "profiles", "hbm_traffic.json")
     if os.path.exists(tfile):
@@ -926,8 +316,8 @@ def attach_counters(roof, key, m, core, clock_ghz):
                 issue["frac_at_measured_clock"] = waves_per_simd * slots * 4 / (clock_ghz * 1e3) / m["us_per_step"]
             if waves_per_simd == 1:
                 # ONE wave on a SIMD does not issue every 4 cycles: profiles/r01_issue_microbench.txt measures 4.5 cycles per
-                # instruction with four independent chains and 5.4 for a dependent chain (two waves per SIMD issue twice that).
-                # At the headline size (1024 waves on 1024 SIMDs) that interval, not the 4-cycle figure, is the floor.
+                # instruction with four independent chains and 5.4 for a dependent chain.  At the headline size (1024 waves on
+                # 1024 SIMDs) that interval, not the 4-cycle figure, is the floor.
                 ck = clock_ghz or PEAK_CLOCK_GHZ
                 lo, hi = slots * 4.5 / (ck * 1e3), slots * 5.4 / (ck * 1e3)
                 issue["lone_wave"] = {"cycles_per_slot": [4.5, 5.4], "clock_ghz": ck, "floor_us": [lo, hi],
@@ -940,43 +330,86 @@ def attach_counters(roof, key, m, core, clock_ghz):
     return issue
 
 
+def dropin_single_env(device, steps=2420):
+    """BASELINE config 1's shape through the DROP-IN class: `HoverAviary()` with its defaults (30 Hz control / 240 Hz physics,
+    Physics.PYB = explicit integrator + ground plane here), ActionType.ONE_D_RPM, a ~ U(-1, 1) of shape (1, 1), 2 420 `step()` calls
+    with a reset at every episode end (examples/learn.py:54-58; envs/BaseAviary.py:509-519 is the per-step read-back the reference
+    pays).  Wall clock per call -- this path is latency, not bandwidth: the aviary's state lives in host-visible memory, a step is
+    one gpd_step launch + one stream synchronisation + numpy reads -- and where it goes."""
+    import warnings
+    from gym_pybullet_drones_amd.envs import HoverAviary
+    from gym_pybullet_drones_amd.utils.enums import ActionType
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        env = HoverAviary(act=ActionType.ONE_D_RPM, device=device)
+    acts = np.random.default_rng(0).uniform(-1, 1, size=(steps, 1, 1)).astype(np.float32)
+    env.reset(seed=0)
+    for k in range(64):
+        env.step(acts[k])
+    env.reset(seed=0)
+    torch.cuda.synchronize()
+    episodes, t0 = 0, time.perf_counter()
+    for k in range(steps):
+        _, _, term, trunc, _ = env.step(acts[k])
+        if term or trunc:
+            env.reset()
+            episodes += 1
+    dt = time.perf_counter() - t0
+    core, n = env._core, 1000
+    t1 = time.perf_counter()
+    for _ in range(n):
+        core.step(core.action_host)
+    t2 = time.perf_counter()
+    for _ in range(n):
+        env._updateAndStoreKinematicInformation()
+    t3 = time.perf_counter()
+    for _ in range(n):
+        env._computeObs()
+    t4 = time.perf_counter()
+    S = int(env.PYB_STEPS_PER_CTRL)
+    out = {"us_per_step": dt / steps * 1e6, "env_steps_per_s": steps / dt, "value": steps * S / dt, "unit": "drone-steps/s", "steps": steps,
+           "episodes_ended": episodes, "state_memory": "host-visible (page-locked, device-mapped)" if core.host_visible else "HBM",
+           "breakdown_us": {"launch_and_stream_sync": (t2 - t1) / n * 1e6, "numpy_kinematic_refresh": (t3 - t2) / n * 1e6,
+                            "observation_row_with_history": (t4 - t3) / n * 1e6},
+           "what": "for k in range(2420): HoverAviary(act=ONE_D_RPM).step(a[k]) (+ reset at episode ends), wall clock; one gpd_step launch and "
+                   "one stream synchronisation per call, no device-to-host copy, no second launch"}
+    env.close()
+    try:        # the reference's OWN Python on the same schedule (quoted: /root/reference does not exist on this box)
+        rec = json.load(open(os.path.join(REPO, "profiles", "r05_reference_python_dyn_cpu.json")))
+        out["reference_python_us_per_step"] = 1e6 * S / rec["value"]
+        out["speedup_over_reference_python"] = out["value"] / rec["value"]
+        out["reference_python_note"] = ("the reference's unmodified HoverAviary(physics=Physics.DYN) over oracle/pybullet_shim.py, same schedule, "
+                                        f"1 core of {rec.get('host_cpu')}, timed in the build container (profiles/r05_reference_python_dyn_cpu.json)")
+    except Exception as e:      # noqa: BLE001
+        out["reference_python_note"] = f"no committed figure ({type(e).__name__})"
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4096)
     ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--workload", default="hover65536_240hz", choices=sorted(WORKLOADS))
-    ap.add_argument("--mode", default="rollout", choices=["rollout", "graph", "eager"],
-                    help="rollout: gpd_rollout, up to 64 env steps per launch (state in registers, actions pre-staged); "
-                         "graph: one launch per env step, hipGraph of up to 64 steps; eager: one host launch per step")
+    ap.add_argument("--mode", default="rollout", choices=["rollout", "graph", "eager"], help="see the module docstring")
     ap.add_argument("--min-time", type=float, default=0.25, help="repeat the K-step schedule until the timed region lasts this long [s]")
-    ap.add_argument("--split", type=int, default=1,
-                    help="C sub-batches of E/C aviaries as C independent chains on C streams: rollout mode -- C concurrent rollout launches, "
-                         "no join inside the timed region; graph/eager -- C chains of single-step launches")
-    ap.add_argument("--stagger", action="store_true", help="rollout --split C: chain c starts c/C of a launch late (experiment)")
-    ap.add_argument("--rollout-graph", type=int, default=0,
-                    help="experiment: rollout mode -- capture this many passes of the schedule (all chains of a --split) in one hipGraph")
-    ap.add_argument("--cu-mask", action="store_true", help="rollout --split C: chain c runs on a stream restricted to its own 8/C XCDs")
     ap.add_argument("--no-parity", action="store_true", help="skip the replay of one schedule through the float64 C oracle")
     ap.add_argument("--allgather", action="store_true", help="all-gather the obs shards over RCCL")
-    ap.add_argument("--allgather-impl", default="auto", choices=["auto", "native", "torch"],
-                    help="native: the C-ABI's gpd_allgather_obs (ncclAllGather); torch: torch.distributed")
+    ap.add_argument("--allgather-impl", default="auto", choices=["auto", "native", "torch"], help="native: gpd_allgather_obs (ncclAllGather); torch: torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-second-leg", action="store_true",
-                    help="skip the extra one-launch-per-step measurement reported next to the rollout headline")
-    ap.add_argument("--scale-suite", action="store_true",
-                    help="after the headline, also run the multi-GPU configurations of BASELINE.json in the same job and report them "
-                         "under `suite` (default with --gpus > 1 and the default workload; --no-suite turns it off)")
+    ap.add_argument("--no-second-leg", action="store_true", help="skip the one-launch-per-step and Python-loop legs beside the rollout headline")
+    ap.add_argument("--no-dropin-leg", action="store_true", help="skip `dropin_single_env` (HoverAviary().step(), BASELINE config 1's shape)")
+    ap.add_argument("--scale-suite", action="store_true", help="also run BASELINE configs 4 and 5 in the same job (`suite`; default with --gpus > 1)")
     ap.add_argument("--no-suite", action="store_true")
-    ap.add_argument("--suite-timeout", type=float, default=300.0,
-                    help="seconds the suite may take before the headline line is printed without it")
+    ap.add_argument("--suite-timeout", type=float, default=300.0, help="seconds the suite may take before the headline line is printed without it")
     ap.add_argument("--hbm-leg-time", type=float, default=2.2, help="seconds of timed region of the `hbm_saturating` leg (its whole launches: >= 2 s)")
-    ap.add_argument("--hbm-leg-reallocations", type=int, default=2,
-                    help="re-run the `hbm_saturating` leg this many times on freshly allocated buffers (0.3 s each): its rate follows the buffers' physical placement")
-    ap.add_argument("--segment-events", type=int, default=0,
-                    help="record this many extra events inside the timed region and report first-100-ms vs steady-state rates under `segments`")
-    ap.add_argument("--no-hbm-leg", action="store_true",
-                    help="skip the `hbm_saturating` block (hover4m_240hz: a working set the 256 MiB Infinity Cache cannot hold)")
+    ap.add_argument("--hbm-leg-reallocations", type=int, default=10, help="re-runs of the `hbm_saturating` leg on freshly allocated buffers (0.15 s each)")
+    ap.add_argument("--placement-search", action="store_true", help="rollout mode: the launch's blocks at offsets chosen by probing (placement.py; the hbm leg does)")
+    ap.add_argument("--placement-target", type=float, default=0.755, help="the search stops at the first layout that reaches this fraction of 8 TB/s")
+    ap.add_argument("--segment-events", type=int, default=0, help="extra events inside the timed region: first-100-ms vs steady-state rates (`segments`)")
+    ap.add_argument("--no-hbm-leg", action="store_true", help="skip `hbm_saturating` (hover4m_240hz: a working set the 256 MiB Infinity Cache cannot hold)")
+    ap.add_argument("--dry-run-topology", action="store_true", help="only bring the job up (process group, RCCL, one 12-float all-gather), print what the ranks see, exit")
+    ap.add_argument("--init-timeout", type=float, default=180.0, help="seconds the process group / RCCL bring-up may take before the job gives up with a readable line")
     args = ap.parse_args(argv)
     if args.steps < 1 or args.warmup < 0:
         ap.error("--steps must be >= 1 and --warmup >= 0")
@@ -994,9 +427,10 @@ def free_port():
 
 def self_launch(args, argv):
     """`python bench.py --gpus N` with N > 1 and no torchrun around it: start the N ranks ourselves (one process per GPU,
-    `torch.distributed.run` on 127.0.0.1 and a free port) with the very same arguments, pass rank 0's ONE JSON line through,
-    and exit with the job's return code.  A node with fewer than N devices is an error, not a silent smaller run (the
-    GPD_BENCH_SINGLE_DEVICE test hook puts every rank on device 0)."""
+    `torch.distributed.run` on 127.0.0.1 and a free port) with the very same arguments, pass rank 0's ONE JSON line through, and
+    exit with the job's return code.  A node with fewer than N devices is an error, not a silent smaller run (the
+    GPD_BENCH_SINGLE_DEVICE test hook puts every rank on device 0).  Before the real job the same ranks are brought up once with
+    `--dry-run-topology` (seconds): a node whose RCCL cannot form the communicator says so before anything is timed."""
     import subprocess
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
     if have < args.gpus and not os.environ.get("GPD_BENCH_SINGLE_DEVICE"):
@@ -1006,48 +440,72 @@ def self_launch(args, argv):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", GPD_BENCH_SELF_LAUNCHED="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_threads() // args.gpus)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
-    print(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr)
+
+    def cmd(extra):
+        return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv) + extra
+    if not args.dry_run_topology and not os.environ.get("GPD_BENCH_NO_TOPOLOGY_CHECK"):
+        dry = subprocess.run(cmd(["--dry-run-topology"]), env=env, capture_output=True, text=True)
+        line = next((l for l in (dry.stdout or "").splitlines() if l.startswith("{")), None)
+        print(f"[bench] topology dry run: rc {dry.returncode} {line or (dry.stderr or '')[-2000:]}", file=sys.stderr)
+        if dry.returncode != 0:
+            if line:
+                print(line)
+            raise SystemExit(dry.returncode)
+    c = cmd([])
+    print(f"[bench] launching {args.gpus} ranks: {' '.join(c)}", file=sys.stderr)
     sys.stderr.flush()
-    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+    raise SystemExit(subprocess.run(c, env=env).returncode)
 
 
 class Job:
-    """What every workload of one bench.py process shares: the process group, this rank's device."""
+    """What every workload of one bench.py process shares: the process group, this rank's device, and what the ranks say about the
+    topology they found (`gym_pybullet_drones_amd.dist.bring_up`; printed into the line, and all there is to a `--dry-run-topology`).
+    A bring-up that fails or hangs ends in ONE readable line from rank 0 and exit code 3 everywhere, not in the driver's timeout."""
     def __init__(self, args):
         from gym_pybullet_drones_amd import dist as gdist
         # (GPD_DIST_BACKEND / GPD_BENCH_SINGLE_DEVICE: test hooks -- run the multi-rank code path with gloo on one GPU)
         self.backend = os.environ.get("GPD_DIST_BACKEND", "nccl")
-        self.rank, self.world, self.local = gdist.init_from_env(self.backend if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+        world_env, rank_env = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = torch.device("cuda", local if world_env > 1 and not os.environ.get("GPD_BENCH_SINGLE_DEVICE") else 0)
+        torch.cuda.set_device(self.device)
+        self.topology = {}
+
+        def failed(what):
+            return {"metric": BASELINE_METRIC, "value": None, "n_gpus": world_env, "error": what, "rccl_warnings": gdist.rccl_debug_tail(),
+                    "topology": self.topology}
+        dog = Watchdog(args.init_timeout, type("R", (), {"rank": rank_env})(), {},
+                       lambda o: o.update(failed(f"process group / RCCL bring-up not finished after {args.init_timeout:.0f} s")), code=3) if world_env > 1 else None
+        try:
+            gdist.bring_up(self.backend, self.device, self.topology)
+        except Exception as e:          # noqa: BLE001
+            if dog is not None:
+                dog.done()
+            if rank_env == 0:
+                print(json.dumps(failed(f"bring-up failed: {type(e).__name__}: {e}"[:600])))
+                sys.stdout.flush()
+            os._exit(3)
+        if dog is not None:
+            dog.done()
+        t = self.topology
+        self.rank, self.world, self.local = t["rank"], t["world_size"], t["local_rank"]
+        self.ranks_in_group, self.native_ranks_seen, self.native_note = t["ranks_in_process_group"], t["n_ranks_seen_by_rccl"], t["native_comm_note"]
         if args.gpus != self.world:
             # (reached only when a launcher set WORLD_SIZE to something else than --gpus: the line reports what really ran)
             if self.rank == 0:
                 print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={self.world}: reporting {self.world}", file=sys.stderr)
             args.gpus = self.world
-        assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-        self.device = torch.device("cuda", self.local if self.world > 1 and not os.environ.get("GPD_BENCH_SINGLE_DEVICE") else 0)
-        torch.cuda.set_device(self.device)
-        # what the collective library itself says the job spans: an all-reduce of ones over the process group (RCCL with the
-        # "nccl" backend), before anything is timed -- a job that fell apart into one-rank worlds shows here
-        self.ranks_in_group = None
-        if self.world > 1:
-            one = torch.ones(1, dtype=torch.float32, device=self.device if self.backend == "nccl" else None)
-            torch.distributed.all_reduce(one)
-            self.ranks_in_group = int(one.item())
-        # ... and the C-ABI's own communicator (gpd_comm_*: ncclCommInitRank / ncclCommCount), created once per process; every
-        # rank takes the same branch when it fails anywhere (the native collectives then fall back to torch.distributed together)
-        self.native_ranks_seen, self.native_note = None, None
-        if self.world > 1 and self.backend == "nccl":
-            err = None
-            try:
-                self.native_ranks_seen = gdist.NativeComm.shared(device=self.device).ranks_seen
-            except Exception as e:      # noqa: BLE001 -- reported in the JSON line
-                err = f"{type(e).__name__}: {e}"[:300]
-            if not gdist.all_ranks_ok(err is None, device=self.device):
-                self.native_ranks_seen, self.native_note = None, f"no native RCCL communicator ({err or 'failed on another rank'})"
-                if gdist.NativeComm._shared is not None:
-                    gdist.NativeComm._shared.close()
+
+    def dry_run(self):
+        """`--dry-run-topology`: one 12-float all-gather, the topology block as ONE JSON line, exit code 0 / 3."""
+        from gym_pybullet_drones_amd import dist as gdist
+        ok, note = gdist.dry_run_exchange(self.topology, self.backend, self.device)
+        if self.rank == 0:
+            print(json.dumps({"dry_run_topology": True, "ok": ok, "n_gpus": self.world, "allgather_12_floats": note, "topology": self.topology}))
+            sys.stdout.flush()
+        return 0 if ok else 3
 
 
 def main(argv=None):
@@ -1056,6 +514,12 @@ def main(argv=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args, argv)
     job = Job(args)
+    if args.dry_run_topology:
+        rc = job.dry_run()
+        if job.world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        raise SystemExit(rc)
     suite = (args.scale_suite or (job.world > 1 and args.workload == "hover65536_240hz")) and not args.no_suite
     out = run_workload(args, job)
     if args.workload == "hover65536_240hz" and not args.no_hbm_leg:
@@ -1071,11 +535,11 @@ def main(argv=None):
 
 
 class Watchdog:
-    """Bounds an EXTRA leg of the job (the HBM-saturating leg, the multi-GPU suite): when `seconds` pass before `done()`, rank 0
-    prints the headline line it already holds -- `note(out)` has written what happened into it -- and every rank leaves the
+    """Bounds a part of the job that may hang (the bring-up, the HBM-saturating leg, the multi-GPU suite): when `seconds` pass before
+    `done()`, rank 0 prints the line it already holds -- `note(out)` has written what happened into it -- and every rank leaves the
     process.  A rank that raised before a collective leaves the others waiting in it; that must not cost the headline."""
 
-    def __init__(self, seconds, job, out, note):
+    def __init__(self, seconds, job, out, note, code=0):
         import threading
         self._done = threading.Event()
 
@@ -1086,7 +550,7 @@ class Watchdog:
                 note(out)
                 print(json.dumps(out))
                 sys.stdout.flush()
-            os._exit(0)
+            os._exit(code)
 
         threading.Thread(target=watch, daemon=True).start()
 
@@ -1100,116 +564,121 @@ def hbm_leg(args, job, out):
     next to it is a fabric-side rate.  This leg puts a number beside it that the cache cannot serve: the same kernel, the same
     schedule, 4 194 304 drones per GPU (13.9 GB of observation rows per 64-step launch, 218 MB of state)."""
     a = argparse.Namespace(**vars(args))
-    a.workload, a.no_cpu_baseline, a.no_second_leg, a.split, a.allgather = "hover4m_240hz", True, True, 1, False
-    # >= 2 s of timed region, seen in 48 pieces (VERDICT r04 weak #1: 0.1 s = 32 launches cannot tell a boost clock from a steady one);
-    # --hbm-leg-time shortens it for tests
+    a.workload, a.no_cpu_baseline, a.no_second_leg, a.no_dropin_leg, a.allgather = "hover4m_240hz", True, True, True, False
+    a.placement_search = not os.environ.get("GPD_BENCH_NO_PLACEMENT_SEARCH")       # (the A/B: the driver's allocation as it comes)
+    # >= 2 s of timed region, seen in 48 pieces (0.1 s = 32 launches cannot tell a boost clock from a steady one); --hbm-leg-time shortens it for tests
     a.min_time = float(getattr(args, "hbm_leg_time", 2.2))
     a.segment_events = 48
     # 64 steps per launch whatever the headline's --steps: the block is about the rate HBM serves this kernel at, and at 4M drones a
-    # 20-step launch (16 rounds of resident workgroups, each starting and ending together) reads 0.63-0.71 depending on the box
-    # where the 64-step one reads 0.72-0.75 (profiles/r04_hbm_leg_steps_per_launch.txt)
-    a.steps, a.warmup = max(64, args.steps // 64 * 64), 64
-    if a.steps > 256:
-        a.steps = 256
-    # (the parity replay copies every replayed step's rows to the host, twice as float64: 8 steps of 4M drones are 1.6 + 3.2 GB,
-    # 64 would be 13 + 26 GB)
+    # 20-step launch (16 rounds of resident workgroups, each starting and ending together) reads 0.63-0.71 where the 64-step one reads
+    # 0.72-0.75 (profiles/r04_hbm_leg_steps_per_launch.txt)
+    a.steps, a.warmup = min(256, max(64, args.steps // 64 * 64)), 64
+    # (the parity replay copies every replayed step's rows to the host, twice as float64: 8 steps of 4M drones are 1.6 + 3.2 GB)
     a.parity_max_steps = 8
     limit = min(120.0, args.suite_timeout)
     dog = Watchdog(limit, job, out, lambda o: o.__setitem__("hbm_saturating", {"error": f"not finished after {limit:.0f} s: line printed without it"}))
-    copy, again = None, []
     try:
         r = run_workload(a, job)
-        if job.rank == 0:
-            copy = copy_probe(job.device)
-        # The rate of this leg depends on WHERE the driver places the buffers: the same process, the same virtual addresses, the buffers
-        # freed and allocated again read 0.62 / 0.68 / 0.72 / 0.75 of 8 TB/s (profiles/r05_hbm_placement_modes.txt; no kernel-side
-        # mapping changes it).  Two short re-runs on fresh allocations put that spread into the line itself.
-        b = argparse.Namespace(**vars(a))
-        b.min_time, b.no_parity, b.segment_events = 0.3, True, 0
-        for _ in range(int(getattr(args, "hbm_leg_reallocations", 2))):
-            import gc
-            gc.collect()
-            torch.cuda.empty_cache()
-            rr = run_workload(b, job)
-            if job.rank == 0 and rr and "roofline" in rr:
-                again.append({"frac": rr["roofline"]["frac"], "launch_us_hip_events": rr["roofline"]["launch_us_hip_events"], "timed_region_ms": rr["timed_region_ms"]})
     except Exception as e:          # noqa: BLE001 -- reported; the headline survives
         r = {"error": f"{type(e).__name__}: {e}"[:300]}
     finally:
         dog.done()
+    # The extras have their own guard and their own budget: a failure or a time-out in them leaves `on_fresh_allocations` partial and
+    # the leg's figure -- already measured -- in the line (ADVICE r05).
+    copy, again, again_note = None, [], None
+    if r is not None and "error" not in r or job.rank != 0:
+        n_again = int(getattr(args, "hbm_leg_reallocations", 10))
+        budget = min(90.0, args.suite_timeout)
+
+        def late(o):
+            o["hbm_saturating"] = hbm_block(r, copy, again, f"the re-runs on fresh allocations were cut after {budget:.0f} s")
+        dog2 = Watchdog(budget, job, out, late)
+        try:
+            if job.rank == 0:
+                copy = copy_probe(job.device)
+            b = argparse.Namespace(**vars(a))
+            b.min_time, b.no_parity, b.segment_events, b.steps, b.warmup = 0.15, True, 0, 64, 64
+            for _ in range(n_again):
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
+                rr = run_workload(b, job)
+                if job.rank == 0 and rr and "roofline" in rr:
+                    again.append({"frac": rr["roofline"]["frac"], "launch_us_hip_events": rr["roofline"]["launch_us_hip_events"], "timed_region_ms": rr["timed_region_ms"],
+                                  **({"probes": rr["placement"]["probes"], "arenas_tried": rr["placement"]["arenas_tried"], "levels_seen": rr["placement"]["seen"]} if "placement" in rr else {})})
+        except Exception as e:      # noqa: BLE001
+            again_note = f"stopped after {len(again)} re-runs: {type(e).__name__}: {e}"[:300]
+        finally:
+            dog2.done()
     if job.rank == 0:
-        if "error" in r:
-            out["hbm_saturating"] = r
-            return
-        roof = r["roofline"]
-        prof = rocprof_record("hover4m_240hz:rollout64")
-        out["hbm_saturating"] = {
-            "workload": "hover4m_240hz", "drones_per_gpu": r["config"]["envs_per_gpu"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
-            "timed_steps": r["timed_steps"], "timed_region_ms": r["timed_region_ms"], "kernel": roof["kernel"],
-            "env_steps_per_launch": roof["env_steps_per_launch"], "launch_us_hip_events": roof["launch_us_hip_events"],
-            "bytes_per_launch": roof["bytes_per_launch"], "achieved": roof["achieved"], "peak": roof["peak"], "unit_bw": "GB/s",
-            "frac": roof["frac"], "frac_of_achievable": roof["frac_of_achievable"], "traffic": roof.get("traffic"),
-            "segments": r.get("segments"), "clock_ghz_after": r.get("clock_ghz_after_timed_region"),
-            # the same leg on freshly allocated buffers (this process, 0.3 s each): the rate follows the physical placement of the buffers
-            "on_fresh_allocations": again, "frac_range_over_allocations": [min([roof["frac"]] + [x["frac"] for x in again]), max([roof["frac"]] + [x["frac"] for x in again])],
-            # what a plain device-to-device copy reaches on THIS box in THIS process (SURVEY section 8(d): "measure achievable ... and quote both")
-            "copy_probe": copy, "frac_of_measured_copy": (roof["achieved"] / copy["gbs"]) if copy and copy.get("gbs") else None,
-            # ... and the same kernel's average duration under rocprofv3 --kernel-trace, from the committed reconciliation
-            # (profiles/r05_hbm_reconcile.json: plain / traced / --pmc / plain on ONE lease, clocks recorded)
-            **prof,
-            "parity": {k: r["parity"].get(k) for k in ("checked_steps", "max", "tolerance", "ok", "flag_mismatch_frac", "error") if k in r.get("parity", {})},
-            "note": "working set of one launch >> the 256 MiB Infinity Cache: this rate is served by HBM"}
-        out["roofline"]["traffic_scope"] = ("the headline's working set (%.0f MB per launch, re-used by every launch) is Infinity-Cache "
-                                            "resident: achieved / traffic are fabric-side rates; see hbm_saturating for the HBM-served figure"
-                                            % (out["roofline"]["bytes_per_launch"] / 1e6))
+        out["hbm_saturating"] = r if "error" in r else hbm_block(r, copy, again, again_note)
+        if "error" not in r:
+            out["roofline"]["traffic_scope"] = ("the headline's working set (%.0f MB per launch, re-used by every launch) is Infinity-Cache "
+                                                "resident: achieved / traffic are fabric-side rates; see hbm_saturating for the HBM-served figure"
+                                                % (out["roofline"]["bytes_per_launch"] / 1e6))
+
+
+def hbm_block(r, copy, again, again_note):
+    roof = r["roofline"]
+    fr = [roof["frac"]] + [x["frac"] for x in again]
+    return {
+        "workload": "hover4m_240hz", "drones_per_gpu": r["config"]["envs_per_gpu"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+        "timed_steps": r["timed_steps"], "timed_region_ms": r["timed_region_ms"], "kernel": roof["kernel"],
+        "env_steps_per_launch": roof["env_steps_per_launch"], "launch_us_hip_events": roof["launch_us_hip_events"],
+        "bytes_per_launch": roof["bytes_per_launch"], "achieved": roof["achieved"], "peak": roof["peak"], "unit_bw": "GB/s",
+        "frac": roof["frac"], "frac_of_achievable": roof["frac_of_achievable"], "traffic": roof.get("traffic"),
+        "segments": r.get("segments"), "clock_ghz_after": r.get("clock_ghz_after_timed_region"),
+        # how the blocks of the launch were placed: by search inside one arena, the launch itself as the probe (or: as the allocator handed them out)
+        "placement": r.get("placement") or {"what": "as allocated (no search)"},
+        # the same leg on freshly allocated buffers / arenas (this process, 0.15 s each): does the rate depend on the allocation?
+        "on_fresh_allocations": again, "frac_range_over_allocations": [min(fr), max(fr)], "frac_spread_over_allocations": (max(fr) - min(fr)) / max(fr),
+        "allocations_seen": len(fr), **({"on_fresh_allocations_note": again_note} if again_note else {}),
+        # what a plain device-to-device copy reaches on THIS box in THIS process (SURVEY section 8(d): "measure achievable ... and quote both")
+        "copy_probe": copy, "frac_of_measured_copy": (roof["achieved"] / copy["gbs"]) if copy and copy.get("gbs") else None,
+        **rocprof_record("hover4m_240hz:rollout64"),
+        "parity": {k: r["parity"].get(k) for k in ("checked_steps", "max", "tolerance", "ok", "flag_mismatch_frac", "error") if k in r.get("parity", {})},
+        "note": "working set of one launch >> the 256 MiB Infinity Cache: this rate is served by HBM"}
 
 
 def copy_probe(device, mib=1024, reps=20):
-    """Device-to-device copy bandwidth (read + write bytes / time) of a buffer the Infinity Cache cannot hold: the streaming rate this
-    box reaches right now, measured with HIP events."""
+    """Device-to-device copy bandwidth (read + write bytes / time) of a buffer the Infinity Cache cannot hold, and a write-only fill of
+    the same buffer (the rollout kernel's traffic is 76 % stores): the streaming rates this box reaches right now, HIP events."""
     try:
         n = mib * (1 << 20) // 4
         a = torch.empty(n, dtype=torch.float32, device=device).normal_()
         b = torch.empty_like(a)
-        for _ in range(3):
-            b.copy_(a)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        ev0.record()
-        for _ in range(reps):
-            b.copy_(a)
-        ev1.record()
-        torch.cuda.synchronize()
-        sec = ev0.elapsed_time(ev1) * 1e-3
-        # ... and a write-only stream (the rollout kernel's traffic is 76 % stores: boxes of this pool that agree on the copy rate differ on it)
-        for _ in range(3):
-            b.fill_(1.0)
-        torch.cuda.synchronize()
-        ev0.record()
-        for _ in range(reps):
-            b.fill_(1.0)
-        ev1.record()
-        torch.cuda.synchronize()
-        sec_w = ev0.elapsed_time(ev1) * 1e-3
-        return {"gbs": 2 * n * 4 * reps / sec / 1e9, "fill_gbs": n * 4 * reps / sec_w / 1e9, "mib": mib, "reps": reps,
-                "what": "torch Tensor.copy_ device to device (read + write bytes); fill_gbs: Tensor.fill_ of the same buffer (write only)"}
+        res = {}
+        for name, fn, nbytes in (("gbs", lambda: b.copy_(a), 2 * n * 4), ("fill_gbs", lambda: b.fill_(1.0), n * 4)):
+            for _ in range(3):
+                fn()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            ev0.record()
+            for _ in range(reps):
+                fn()
+            ev1.record()
+            torch.cuda.synchronize()
+            res[name] = nbytes * reps / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+        return dict(res, mib=mib, reps=reps, what="torch Tensor.copy_ device to device (read + write bytes); fill_gbs: Tensor.fill_ of the same buffer (write only)")
     except Exception as e:          # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"[:160]}
 
 
 def rocprof_record(key):
-    """The committed rocprofv3 figures for one kernel (profiles/r05_hbm_reconcile.json, written by scratch/hbm_reconcile_r05.py on a
-    GPU box): quoted in the bench line so that the line and the profile can be held against each other."""
-    try:
-        rec = json.load(open(os.path.join(REPO, "profiles", "r05_hbm_reconcile.json")))["keys"][key]
-        return {"rocprof_kernel_avg_us": rec["rocprof_kernel_avg_us"], "rocprof_frac": rec["rocprof_frac"],
-                "rocprof_note": rec.get("note"), "rocprof_file": "profiles/r05_hbm_reconcile.json"}
-    except Exception as e:          # noqa: BLE001
-        return {"rocprof_kernel_avg_us": None, "rocprof_note": f"no committed reconciliation ({type(e).__name__})"}
+    """The committed rocprofv3 figures for one kernel (profiles/*hbm_reconcile.json, written on a GPU box by one script on one lease):
+    quoted in the bench line so that the line and the profile can be held against each other."""
+    for name in ("r06_hbm_reconcile.json", "r05_hbm_reconcile.json"):
+        try:
+            rec = json.load(open(os.path.join(REPO, "profiles", name)))["keys"][key]
+            return {"rocprof_kernel_avg_us": rec["rocprof_kernel_avg_us"], "rocprof_frac": rec["rocprof_frac"],
+                    "rocprof_note": rec.get("note"), "rocprof_file": "profiles/" + name}
+        except Exception:           # noqa: BLE001
+            continue
+    return {"rocprof_kernel_avg_us": None, "rocprof_note": "no committed reconciliation"}
 
 
-#: the multi-GPU configurations of BASELINE.json (configs 4 and 5) and the one strong-scaling workload, per GPU
-SUITE = ("hover65536x8_allgather", "multihover2x16384x8", "swarm1m_ext_240hz")
+#: the multi-GPU configurations of BASELINE.json (configs 4 and 5), per GPU
+SUITE = ("hover65536x8_allgather", "multihover2x16384x8")
 
 
 def run_suite(args, job, out):
@@ -1225,29 +694,24 @@ def run_suite(args, job, out):
     try:
         for name in SUITE:
             a = argparse.Namespace(**vars(args))
-            a.workload, a.no_cpu_baseline, a.no_hbm_leg, a.split = name, True, True, 1
-            a.no_parity = a.no_parity or bool(WORKLOADS[name].get("swarm"))       # (the O(N^2) float64 loop over a million drones: minutes)
-            a.allgather = False
-            if WORKLOADS[name].get("swarm"):
-                a.mode, a.no_second_leg = "graph", True
-                a.steps, a.warmup = min(args.steps, 64), min(args.warmup, 8)
+            a.workload, a.no_cpu_baseline, a.no_hbm_leg, a.no_dropin_leg, a.allgather = name, True, True, True, False
             t0 = time.perf_counter()
             try:
                 r = run_workload(a, job)
             except Exception as e:          # noqa: BLE001 -- reported; the headline survives
-                r = {"error": f"{type(e).__name__}: {e}"[:300]}
+                r = {"error": f"{type(e).__name__}: {e}"[:300], "rccl_warnings": gdist.rccl_debug_tail()}
             if os.environ.get("GPD_BENCH_INJECT_HANG") == "suite":       # (test hook: a collective that never returns -- the watchdog's case)
                 time.sleep(3600)
             ok = gdist.all_ranks_ok(r is None or "error" not in r, device=job.device)
             if job.rank == 0:
                 if "error" in r or not ok:
-                    results[name] = {"error": r.get("error", "failed on another rank")}
+                    results[name] = {"error": r.get("error", "failed on another rank"), "rccl_warnings": r.get("rccl_warnings")}
                 else:
                     keep = ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "per_gpu", "timed_steps", "value_wall")
                     c = {k: r[k] for k in keep if k in r}
                     c["roofline"] = {k: r["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "env_steps_per_launch")}
                     c["config"] = {k: r["config"].get(k) for k in ("workload", "total_drones", "obs_allgather", "allgather_impl", "allgather_note",
-                                                                   "n_ranks_seen_by_rccl", "ranks_in_process_group", "swarm", "launch", "mode")}
+                                                                   "n_ranks_seen_by_rccl", "ranks_in_process_group", "launch", "mode")}
                     for k in ("one_launch_per_step", "parity", "without_allgather"):
                         if k in r:
                             c[k] = r[k] if k != "one_launch_per_step" else {q: r[k][q] for q in ("value", "us_per_step", "launch")}
@@ -1280,47 +744,20 @@ def run_workload(args, job):
     backend, rank, world, device = job.backend, job.rank, job.world, job.device
     w, rehearsal_div = rehearsal_scale(WORKLOADS[args.workload])
     want_gather = bool(args.allgather or w.get("allgather"))
-    POOL = 64      # env steps per rollout launch / per captured hipGraph
-    if w.get("swarm") and args.mode == "rollout":
-        args.mode = "graph"          # a single world needs the downwash of every sub-step's snapshot: one step per launch group
-    if w.get("swarm") and world > 1 and backend == "gloo" and args.mode == "graph":
-        args.mode = "eager"          # (the gloo test hook stages the position exchange through host memory: not capturable)
-
-    def build(split):
-        if split > 1 and (w.get("swarm") or w["E"] % split):
-            raise SystemExit(f"--split {split} does not divide {w['E']} aviaries")
-        if w.get("swarm"):      # ONE world: the same scene on every rank, rank r takes its block of drones
-            exch = None
-            if world > 1:
-                # GPD_SWARM_EXCHANGE=halo (default): blocks from the neighbouring stripes only (gpd_p2p_group: grouped ncclSend /
-                # ncclRecv; torch.distributed's batched P2P where the native communicator is missing); =allgather: every position to
-                # every rank (gpd_allgather_obs in place), the round-3 exchange
-                from gym_pybullet_drones_amd.envs import NativeHaloExchange, NativeSlabExchange, TorchHaloExchange, TorchSlabExchange
-                kind = os.environ.get("GPD_SWARM_EXCHANGE", "halo")
-                margin = float(os.environ.get("GPD_SWARM_HALO_MARGIN", "2.0"))
-                native, torch_ = (NativeHaloExchange, TorchHaloExchange) if kind == "halo" else (NativeSlabExchange, TorchSlabExchange)
-                err = None
-                try:
-                    exch = (native(margin=margin, device=device) if kind == "halo" else native(device=device)) if backend == "nccl" else None
-                except Exception as e:      # noqa: BLE001
-                    err = f"{type(e).__name__}: {e}"[:200]
-                if not gdist.all_ranks_ok(exch is not None, device=device):
-                    exch = torch_(margin=margin) if kind == "halo" else torch_()
-                    swarm_note.append(f"position exchange ({kind}) through torch.distributed ({err or 'no native RCCL communicator'})")
-                else:
-                    swarm_note.append(f"position exchange ({kind}): " + ("gpd_p2p_group, grouped ncclSend / ncclRecv" if kind == "halo" else "gpd_allgather_obs in place") +
-                                      f", {exch.nc.ranks_seen} ranks seen by RCCL")
-            envs = [make_env(w, device, seed=1000, world=world, rank=rank, exchange=exch)]
-            acts = [make_actions(w, envs[0], device, seed=2000 + rank * 16, pool=POOL)]
-            return envs, acts
-        envs = [make_env(w, device, seed=1000 + rank * 16 + c, E=w["E"] // split) for c in range(split)]
-        acts = [make_actions(w, e, device, seed=2000 + rank * 16 + c, pool=POOL) for c, e in enumerate(envs)]
-        return envs, acts
-
-    swarm_note = []
-
-    envs, actions = build(1)
-    core = envs[0].core
+    mode = w["pick_mode"](args.mode, world, backend) if w.get("pick_mode") else args.mode
+    env = make_env(w, device, seed=1000 + rank * 16, world=world, rank=rank, job=job)
+    actions = make_actions(w, env, device, seed=2000 + rank * 16, pool=POOL)
+    core = env.core
+    placement = None
+    if getattr(args, "placement_search", False) and mode == "rollout":
+        # where the launch's blocks sit in HBM decides its rate (profiles/r06_hbm_placement_cause.md): the library carves them out of
+        # one arena at offsets it chooses by probing with the launch itself (gym_pybullet_drones_amd/placement.py), before anything is timed
+        from gym_pybullet_drones_amd.placement import place_rollout
+        arena, placement = place_rollout(core, POOL, target=args.placement_target)
+        arena.actions.copy_(actions.view_as(arena.actions))
+        actions = arena.actions.view(actions.shape)
+        env.placement_arena = arena                     # (owns the blocks: lives as long as the environment)
+        env.reset()
     gather, impl, gather_note, ranks_seen = None, None, None, None
     if want_gather:
         impl = args.allgather_impl
@@ -1343,52 +780,31 @@ def run_workload(args, job):
         if impl == "torch":
             gather = gdist.ObsAllGather(core.N, 12, device=device)
 
-    second = None
-    if args.mode == "rollout" and not args.no_second_leg:
+    second = eager = plain = None
+    if mode == "rollout" and not args.no_second_leg:
         # (a gather staged through host memory -- the gloo test hook -- cannot be captured in a hipGraph: that leg then runs without it)
-        second = measure("graph", args, envs, actions, None if getattr(gather, "_stage", False) else gather, device, world, POOL)
-        for e in envs:
-            e.reset()
-    eager = None
-    if second is not None and world == 1 and not w.get("policy") and not w.get("swarm"):
-        # ... and the plain Python loop `for ...: env.step(action)`, one host launch per step, nothing captured: what a user's own loop gets
-        # (host-bound: the interpreter and the ctypes call take longer than the kernel)
-        a2 = argparse.Namespace(**vars(args))
-        a2.min_time, a2.segment_events = min(args.min_time, 0.1), 0
-        eager = measure("eager", a2, envs, actions, None, device, world, POOL)
-        for e in envs:
-            e.reset()
-    if args.split > 1:
-        if w.get("policy") or w.get("full_obs"):
-            raise SystemExit("--split: plain obs12 workloads only (no policy / history rows)")
-        envs, actions = build(args.split)
-    plain = None
-    if gather is not None and len(envs) == 1:
+        second = measure("graph", args, env, actions, None if getattr(gather, "_stage", False) else gather, device, world)
+        env.reset()
+        if world == 1 and not w.get("builder"):
+            # ... and the plain Python loop `for ...: env.step(action)`, one host launch per step, nothing captured: what a user's own
+            # loop gets (host-bound: the interpreter and the ctypes call take longer than the kernel)
+            a2 = argparse.Namespace(**vars(args))
+            a2.min_time, a2.segment_events = min(args.min_time, 0.1), 0
+            eager = measure("eager", a2, env, actions, None, device, world)
+            env.reset()
+    if gather is not None:
         # BASELINE config 4 asks for both: first the same schedule WITHOUT the collective
-        plain = measure(args.mode, args, envs, actions, None, device, world, POOL)
-        for e in envs:
-            e.reset()
-    m = measure(args.mode, args, envs, actions, gather if len(envs) == 1 else None, device, world, POOL)
+        plain = measure(mode, args, env, actions, None, device, world)
+        env.reset()
+    m = measure(mode, args, env, actions, gather, device, world)
 
-    halo_check = None
-    if w.get("swarm") and world > 1 and getattr(envs[0].exchange, "halo", False):
-        try:        # (collective) did every drone of every rank stay within the halo's margin since the last plan?
-            envs[0].exchange.check(envs[0])
-            halo_check = "ok"
-        except RuntimeError as e:
-            halo_check = str(e)[:300]
     parity = None
-    all_pos = None
-    if not args.no_parity and w.get("swarm") and envs[0].flags & 4 and world > 1:
-        all_pos = envs[0].all_positions()          # (collective: a rank of a halo-exchanging world holds its neighbourhood only)
-    if rank == 0 and not args.no_parity and w.get("swarm") and envs[0].flags & 4:
+    if w.get("parity"):                     # (bench_extra.py's workloads bring their own checker; collective where the world is shared)
+        parity = w["parity"](args, job, env)
+    elif rank == 0 and not args.no_parity and mode == "rollout":
         try:
-            parity = swarm_parity_check(envs[0], all_pos)
-        except Exception as e:          # noqa: BLE001
-            parity = {"error": f"{type(e).__name__}: {e}"[:300]}
-    if rank == 0 and not args.no_parity and args.mode == "rollout" and not w.get("policy") and not w.get("swarm"):
-        try:
-            parity = parity_check(w, envs[0], actions[0], args.steps, POOL, max_steps=getattr(args, "parity_max_steps", 256))
+            from oracle.bench_checks import parity_check       # checker code: the product path stays oracle-free
+            parity = parity_check(w, env, actions, args.steps, POOL, launch_rollout, max_steps=getattr(args, "parity_max_steps", 256))
         except Exception as e:          # noqa: BLE001 -- the checker must never take the measurement down with it
             parity = {"error": f"{type(e).__name__}: {e}"[:300]}
 
@@ -1397,92 +813,84 @@ def run_workload(args, job):
         ghz, nsf = ctypes.c_double(), ctypes.c_double()
         if core.lib.gpd_clock_probe(ctypes.byref(ghz), ctypes.byref(nsf), ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)) == 0:
             clock_ghz = ghz.value
-    except Exception:
+    except Exception:       # noqa: BLE001
         pass
+    dropin = None
+    if rank == 0 and world == 1 and args.workload == "hover65536_240hz" and not args.no_dropin_leg:
+        try:
+            dropin = dropin_single_env(device)
+        except Exception as e:          # noqa: BLE001
+            dropin = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if rank != 0:
+        if w.get("finish"):
+            w["finish"](None, args, job, env, m, clock_ghz)
+        return None
 
-    if rank == 0:
-        n_total = sum(e.core.N for e in envs) * world
-        spl = m["roofline"]["env_steps_per_launch"]
-        launch = {"rollout": f"rollout{int(spl) if spl == int(spl) else spl:g}", "graph": "graph", "eager": "eager"}[args.mode]
-        D, S = core.D, core.S
-        metric = BASELINE_METRIC if args.workload == "hover65536_240hz" else \
-            (f"env steps/sec (whole node), {args.workload}: {w['E']} aviaries x {w['D']} drone(s) per GPU, "
-             f"{w['ctrl']} Hz control / 240 Hz physics")
-        out = {
-            "metric": metric,
-            "value": m["value"], "unit": "drone-steps/s", "n_gpus": world, "steps": m["K"], "warmup": m["W"],
-            "ms_per_step": m["ev_s"] * 1e3 / m["timed_steps"], "higher_is_better": True,
-            "scaling": "strong" if w.get("swarm") else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "repeats": m["repeats"], "timed_steps": m["timed_steps"], "timed_region_ms": m["ev_s"] * 1e3,
-            "wall_ms_per_step": m["wall_s"] * 1e3 / m["timed_steps"], "value_wall": m["value_wall"],
-            "config": {"workload": args.workload, "envs_per_gpu": w["E"], "drones_per_env": D,
-                       **({"rehearsal_divisor": rehearsal_div, "rehearsal_note": "GPD_BENCH_E_DIV: NOT the named configuration's size"} if rehearsal_div > 1 else {}),
-                       "total_drones": n_total, "physics": "DYN" + "".join(n for b, n in ((1, "+GND"), (2, "+DRAG"), (4, "+DW"), (8, "+GROUND_PLANE"), (16, "+BULLET_DAMPING")) if core.physics_flags & b),
-                       "physics_flags": core.physics_flags,
-                       "pyb_freq": 240, "ctrl_freq": w["ctrl"], "substeps_per_step": S, "action": w["act"],
-                       "task": w["task"], "auto_reset": True, "mode": args.mode, "launch": launch, "split": len(envs),
-                       **({"rollout_graph_passes": args.rollout_graph} if args.rollout_graph else {}),
-                       **({"staggered_chains": True} if args.stagger and len(envs) > 1 else {}),
-                       "full_obs": w.get("full_obs", False), "policy": "MlpPolicy 64x64 tanh, in the kernel (rollout) / torch between steps (graph)" if w.get("policy") else None,
-                       "obs_allgather": want_gather, "allgather_impl": impl, "allgather_note": gather_note,
-                       "n_ranks_seen_by_rccl": ranks_seen if ranks_seen is not None else job.native_ranks_seen,
-                       "ranks_in_process_group": job.ranks_in_group, "process_group_backend": backend if world > 1 else None,
-                       **({"native_comm_note": job.native_note} if job.native_note else {}),
-                       "launcher": "bench.py self-launch (torch.distributed.run)" if os.environ.get("GPD_BENCH_SELF_LAUNCHED") else
-                                   ("torch.distributed.run" if world > 1 else "single process"),
-                       "env_steps_per_s": m["env_steps_per_s"],
-                       **({"swarm": {"total_drones": envs[0].TOTAL_DRONES, "ranks": envs[0].WORLD_SIZE, "cell_m": envs[0].cell,
-                                     "grid": [envs[0].nx, envs[0].ny], "rebin_every": envs[0].rebin_every, "note": "; ".join(swarm_note) or None,
-                                     "exchange": None if world == 1 else ("halo" if getattr(envs[0].exchange, "halo", False) else "allgather"),
-                                     "exchange_bytes_sent_per_rank_per_substep": None if world == 1 else
-                                     (envs[0].exchange.bytes_per_substep if getattr(envs[0].exchange, "halo", False) else envs[0].slab * 16),
-                                     "exchange_bytes_received_allgather": None if world == 1 else (world - 1) * envs[0].slab * 16,
-                                     "halo_plans_made": getattr(envs[0].exchange, "plans_made", None), "halo_margin_check": halo_check}}
-                          if w.get("swarm") else {})},
-            "roofline": m["roofline"],
-            "per_gpu": {"unit": "drone-steps/s", "values": m["per_gpu"], "min": min(m["per_gpu"]), "max": max(m["per_gpu"]),
-                        "note": "every rank's own units / its own HIP-event time of the same timed region; `value` uses the slowest rank's time"},
-        }
-        if plain is not None:
-            out["without_allgather"] = {"value": plain["value"], "unit": "drone-steps/s", "us_per_step": plain["us_per_step"],
-                                        "per_gpu": plain["per_gpu"], "frac": plain["roofline"]["frac"]}
-            per_step = 12 * 4 * core.N
-            out["allgather"] = {"bytes_per_rank_per_env_step": per_step, "bytes_per_collective": per_step * m["roofline"]["env_steps_per_launch"] if args.mode == "rollout" else per_step,
-                                "us_per_step_added": m["us_per_step"] - plain["us_per_step"]}
-        key_launch = "rollout64" if args.mode == "rollout" else args.mode
-        issue = attach_counters(out["roofline"], f"{args.workload}:{key_launch}", m, core, clock_ghz)
-        if issue is not None:
-            out["roofline_valu_issue"] = issue
-        if w.get("swarm"):
-            try:
-                swarm_roofline(out, envs[0], m, clock_ghz)
-            except Exception as e:      # noqa: BLE001 -- the line survives without the extra block
-                out["roofline"]["swarm_roofline_error"] = f"{type(e).__name__}: {e}"[:200]
-        if clock_ghz:
-            out["shader_clock_ghz_probe"] = clock_ghz
-            out["clock_ghz_after_timed_region"] = clock_ghz
-        if m.get("segments"):
-            out["segments"] = m["segments"]
-        if second is not None:
-            sec = {"value": second["value"], "unit": "drone-steps/s", "steps": second["K"], "repeats": second["repeats"],
-                   "timed_steps": second["timed_steps"], "us_per_step": second["us_per_step"], "split": 1,
-                   "launch": f"graph (hipGraph of {min(second['K'], POOL)} single-step launches)",
-                   "roofline": second["roofline"]}
-            si = attach_counters(sec["roofline"], f"{args.workload}:graph", second, core, clock_ghz)
-            if si is not None:
-                sec["roofline_valu_issue"] = si
-            out["one_launch_per_step"] = sec
-        if eager is not None:
-            out["python_step_loop"] = {"value": eager["value_wall"], "unit": "drone-steps/s", "us_per_step": eager["wall_s"] * 1e6 / eager["timed_steps"],
-                                       "us_per_step_hip_events": eager["us_per_step"], "timed_steps": eager["timed_steps"],
-                                       "what": "for i in range(n): env.step(action[i]) -- one gpd_step call per step from Python, no hipGraph; wall clock around the loop + one synchronize"}
-        if parity is not None:
-            out["parity"] = parity
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = swarm_cpu_baseline(w, envs[0]) if w.get("swarm") else cpu_baseline(w, phys=core.physics_flags)
-        return out
-    return None
+    spl = m["roofline"]["env_steps_per_launch"]
+    launch = {"rollout": f"rollout{int(spl) if spl == int(spl) else spl:g}", "graph": "graph", "eager": "eager"}[mode]
+    metric = BASELINE_METRIC if args.workload == "hover65536_240hz" else \
+        (f"env steps/sec (whole node), {args.workload}: {w['E']} aviaries x {w['D']} drone(s) per GPU, {w['ctrl']} Hz control / 240 Hz physics")
+    out = {
+        "metric": metric,
+        "value": m["value"], "unit": "drone-steps/s", "n_gpus": world, "steps": m["K"], "warmup": m["W"],
+        "ms_per_step": m["ev_s"] * 1e3 / m["timed_steps"], "higher_is_better": True,
+        "scaling": w.get("scaling", "weak"), "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "repeats": m["repeats"], "timed_steps": m["timed_steps"], "timed_region_ms": m["ev_s"] * 1e3,
+        "wall_ms_per_step": m["wall_s"] * 1e3 / m["timed_steps"], "value_wall": m["value_wall"],
+        "config": {"workload": args.workload, "envs_per_gpu": w["E"], "drones_per_env": core.D,
+                   **({"rehearsal_divisor": rehearsal_div, "rehearsal_note": "GPD_BENCH_E_DIV: NOT the named configuration's size"} if rehearsal_div > 1 else {}),
+                   "total_drones": core.N * world,
+                   "physics": "DYN" + "".join(n for b, n in ((1, "+GND"), (2, "+DRAG"), (4, "+DW"), (8, "+GROUND_PLANE"), (16, "+BULLET_DAMPING")) if core.physics_flags & b),
+                   "physics_flags": core.physics_flags, "pyb_freq": 240, "ctrl_freq": w["ctrl"], "substeps_per_step": core.S, "action": w["act"],
+                   "task": w["task"], "auto_reset": True, "mode": mode, "launch": launch, "full_obs": w.get("full_obs", False),
+                   "obs_allgather": want_gather, "allgather_impl": impl, "allgather_note": gather_note,
+                   "n_ranks_seen_by_rccl": ranks_seen if ranks_seen is not None else job.native_ranks_seen,
+                   "ranks_in_process_group": job.ranks_in_group, "process_group_backend": backend if world > 1 else None,
+                   **({"native_comm_note": job.native_note} if job.native_note else {}),
+                   "launcher": "bench.py self-launch (torch.distributed.run)" if os.environ.get("GPD_BENCH_SELF_LAUNCHED") else
+                               ("torch.distributed.run" if world > 1 else "single process"),
+                   "topology": job.topology, "env_steps_per_s": m["env_steps_per_s"]},
+        "roofline": m["roofline"],
+        "per_gpu": {"unit": "drone-steps/s", "values": m["per_gpu"], "min": min(m["per_gpu"]), "max": max(m["per_gpu"]),
+                    "note": "every rank's own units / its own HIP-event time of the same timed region; `value` uses the slowest rank's time"},
+    }
+    if placement is not None:
+        out["placement"] = {k: v for k, v in placement.items() if k != "all_probes"}
+    if plain is not None:
+        out["without_allgather"] = {"value": plain["value"], "unit": "drone-steps/s", "us_per_step": plain["us_per_step"],
+                                    "per_gpu": plain["per_gpu"], "frac": plain["roofline"]["frac"]}
+        per_step = 12 * 4 * core.N
+        out["allgather"] = {"bytes_per_rank_per_env_step": per_step, "bytes_per_collective": per_step * spl if mode == "rollout" else per_step,
+                            "us_per_step_added": m["us_per_step"] - plain["us_per_step"]}
+    issue = attach_counters(out["roofline"], f"{args.workload}:{'rollout64' if mode == 'rollout' else mode}", m, core, clock_ghz)
+    if issue is not None:
+        out["roofline_valu_issue"] = issue
+    if clock_ghz:
+        out["shader_clock_ghz_probe"] = out["clock_ghz_after_timed_region"] = clock_ghz
+    if m.get("segments"):
+        out["segments"] = m["segments"]
+    if second is not None:
+        sec = {"value": second["value"], "unit": "drone-steps/s", "steps": second["K"], "repeats": second["repeats"],
+               "timed_steps": second["timed_steps"], "us_per_step": second["us_per_step"],
+               "launch": f"graph (hipGraph of {min(second['K'], POOL)} single-step launches)", "roofline": second["roofline"]}
+        si = attach_counters(sec["roofline"], f"{args.workload}:graph", second, core, clock_ghz)
+        if si is not None:
+            sec["roofline_valu_issue"] = si
+        out["one_launch_per_step"] = sec
+    if eager is not None:
+        out["python_step_loop"] = {"value": eager["value_wall"], "unit": "drone-steps/s", "us_per_step": eager["wall_s"] * 1e6 / eager["timed_steps"],
+                                   "us_per_step_hip_events": eager["us_per_step"], "timed_steps": eager["timed_steps"],
+                                   "what": "for i in range(n): env.step(action[i]) -- one gpd_step call per step from Python, no hipGraph; wall clock around the loop + one synchronize"}
+    if dropin is not None:
+        out["dropin_single_env"] = dropin
+    if parity is not None:
+        out["parity"] = parity
+    if w.get("finish"):                 # (bench_extra.py: the one-world config block, its roofline, its CPU baseline)
+        w["finish"](out, args, job, env, m, clock_ghz)
+    elif not args.no_cpu_baseline and world == 1:
+        from oracle.bench_checks import cpu_baseline           # the oracle timed on this box's host cores (reported, not the target)
+        out["cpu_baseline"] = cpu_baseline(w, phys=core.physics_flags)
+    return out
 
 
 if __name__ == "__main__":

@@ -124,9 +124,13 @@ _SIGNATURES = {
     "gpd_struct_sizes": (None, [ctypes.POINTER(ctypes.c_int32)]),
     "gpd_step": (ctypes.c_int, [ctypes.POINTER(GpdParams), ctypes.POINTER(GpdState), ctypes.POINTER(GpdStepCfg),
                                 _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gpd_step_sync": (ctypes.c_int, [ctypes.POINTER(GpdParams), ctypes.POINTER(GpdState), ctypes.POINTER(GpdStepCfg),
+                                     _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gpd_rollout": (ctypes.c_int, [ctypes.POINTER(GpdParams), ctypes.POINTER(GpdState), ctypes.POINTER(GpdStepCfg),
                                    ctypes.c_int32, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_int64, _P, _P, _P,
                                    ctypes.c_int64, _P, _P]),
+    "gpd_rollout_packed": (ctypes.c_int, [ctypes.POINTER(GpdParams), ctypes.POINTER(GpdState), ctypes.POINTER(GpdStepCfg),
+                                          ctypes.c_int32, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_int64, _P, ctypes.c_int64, _P]),
     "gpd_rollout_history": (ctypes.c_int, [ctypes.POINTER(GpdParams), ctypes.POINTER(GpdState), ctypes.POINTER(GpdStepCfg),
                                            ctypes.c_int32, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_int64, _P, _P, _P,
                                            ctypes.c_int64, _P]),

@@ -35,8 +35,9 @@ def shard_rows_per_rank(total_envs: int, world_size: int, rows_per_env: int = 1)
             for r in range(world_size)]
 
 
-def init_from_env(backend: str = None):
-    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun); returns (rank, world, local_rank)."""
+def init_from_env(backend: str = None, device=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun); returns (rank, world, local_rank).  `device`: the
+    device this rank was given already (default with RCCL: device LOCAL_RANK)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -44,7 +45,7 @@ def init_from_env(backend: str = None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local if device is None else device)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -240,3 +241,88 @@ def gather_floats(value: float, device=None) -> list:
     t[dist.get_rank()] = value
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [float(x) for x in t.tolist()]
+
+
+# ---- bringing a multi-process job up, and saying what it found ------------------------------------------------------------------
+def rccl_debug_tail(limit: int = 1500):
+    """What RCCL wrote at NCCL_DEBUG=WARN into this process's NCCL_DEBUG_FILE (see `bring_up`), for the report of a failed job."""
+    try:
+        text = open(os.environ["NCCL_DEBUG_FILE"].replace("%p", str(os.getpid())).replace("%h", os.uname().nodename)).read()
+        return text[-limit:] or None
+    except Exception:   # noqa: BLE001
+        return None
+
+
+def device_record(rank: int, local_rank: int, device) -> dict:
+    """This rank's line of the rank -> device map (`device` None: a host-only rank, as in the CPU tests)."""
+    if device is None or not torch.cuda.is_available():
+        return {"rank": rank, "local_rank": local_rank, "device": None, "name": "host", "pci": None, "uuid": None, "pid": os.getpid(), "visible": {}}
+    props = torch.cuda.get_device_properties(device)
+    return {"rank": rank, "local_rank": local_rank, "device": torch.device(device).index, "name": props.name,
+            "pci": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")) or None, "pid": os.getpid(),
+            "visible": {k: os.environ[k] for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES") if k in os.environ}}
+
+
+def bring_up(backend: str, device, topology: dict = None) -> dict:
+    """Initialise the process group from the launcher's environment and say what the job spans, BEFORE anything is timed:
+    the rank -> device map of all ranks (two ranks on one device under RCCL is an error with that map in its message, not a
+    hang), an all-reduce of ones over the group (`ranks_in_process_group`), and the C-ABI's own communicator
+    (`gpd_comm_*`: ncclCommInitRank / ncclCommCount -> `n_ranks_seen_by_rccl`; when it fails on ANY rank every rank drops it
+    together and the native collectives fall back to torch.distributed).  RCCL's warnings go to a per-process file
+    (`rccl_debug_tail`).  Fills and returns `topology` (the caller keeps a reference: a watchdog can print it while this hangs)."""
+    topo = {} if topology is None else topology
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    topo.update(world_size=world, backend=backend if world > 1 else None)
+    if world > 1 and backend == "nccl":
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/gpd_rccl_%h_%p.log")
+    rank, world, local = init_from_env(backend if world > 1 else None, device=device)
+    mine = device_record(rank, local, device)
+    topo.update(rank=rank, local_rank=local, devices_on_node=torch.cuda.device_count(), rank_device_map=[mine],
+                ranks_in_process_group=None, n_ranks_seen_by_rccl=None, native_comm_note=None)
+    if world > 1:
+        # through the rendezvous store, not through a collective: the map must exist BEFORE the first RCCL call can fail or hang
+        import json
+        store = dist.distributed_c10d._get_default_store()
+        store.set(f"gpd/device/{rank}", json.dumps(mine))
+        everyone = [json.loads(store.get(f"gpd/device/{r}")) for r in range(world)]
+        topo["rank_device_map"] = everyone
+        if backend == "nccl" and len({(e["device"], e["pci"]) for e in everyone}) < world:
+            raise RuntimeError("two ranks of this job sit on the same device (see rank_device_map): RCCL refuses duplicate GPUs -- "
+                               "launch one rank per GPU (LOCAL_RANK = device index)")
+        one = torch.ones(1, dtype=torch.float32, device=device if backend == "nccl" else None)
+        dist.all_reduce(one)
+        topo["ranks_in_process_group"] = int(one.item())
+        if backend == "nccl":
+            err = None
+            try:
+                topo["n_ranks_seen_by_rccl"] = NativeComm.shared(device=device).ranks_seen
+            except Exception as e:      # noqa: BLE001 -- reported, not fatal
+                err = f"{type(e).__name__}: {e}"[:300]
+            if not all_ranks_ok(err is None, device=device):
+                topo["n_ranks_seen_by_rccl"], topo["native_comm_note"] = None, f"no native RCCL communicator ({err or 'failed on another rank'})"
+                if NativeComm._shared is not None:
+                    NativeComm._shared.close()
+    return topo
+
+
+def dry_run_exchange(topo: dict, backend: str, device):
+    """The smallest real exchange: every rank contributes 12 floats (its rank), through the process group and -- when the native
+    communicator exists -- through `gpd_allgather_obs`.  -> (ok, note)"""
+    world, rank = topo["world_size"], topo["rank"]
+    if world == 1:
+        return True, "one rank: nothing to exchange"
+    row = torch.full((1, 12), float(rank), device=device if backend == "nccl" else None)
+    rows = [torch.empty_like(row) for _ in range(world)]
+    dist.all_gather(rows, row)
+    ok = [float(r[0, 0]) for r in rows] == [float(r) for r in range(world)]
+    note = "torch.distributed.all_gather carried 12 floats per rank"
+    if topo.get("n_ranks_seen_by_rccl"):
+        try:
+            full = NativeObsAllGather(1, 12, device=device)(torch.full((1, 12), float(rank), device=device))
+            torch.cuda.synchronize()
+            ok = ok and [float(x) for x in full[:, 0].cpu()] == [float(r) for r in range(world)]
+            note = "gpd_allgather_obs (ncclAllGather through the C-ABI) carried 12 floats per rank"
+        except Exception as e:      # noqa: BLE001
+            ok, note = False, f"gpd_allgather_obs failed: {type(e).__name__}: {e}"[:300]
+    return bool(ok), note

@@ -222,7 +222,7 @@ class SimCore:
         self.target_per_env = int(tp.ndim == 3)
         self.TARGET_POS = tp
         self.target = torch.tensor(tp.reshape(-1, 3), dtype=torch.float32, device=self.device).contiguous()
-        self._step_args = None                       # (holds the old buffer's address)
+        self._step_args = self._host_args = None     # (hold the old buffer's address)
         if hasattr(self, "_cfg"):
             self._cfg.target_per_env = self.target_per_env
 
@@ -233,6 +233,7 @@ class SimCore:
 
     _own_stream = None
     _pinned = None
+    _host_args = None
     _step_args = None       # the arguments of gpd_step that never change between two calls, as ctypes objects (built on first use)
 
     def use_stream(self, stream: "torch.cuda.Stream" = None):
@@ -273,6 +274,25 @@ class SimCore:
             self._pinned.synchronize()
         else:
             torch.cuda.current_stream(self.device).synchronize()
+
+    def step_host(self):
+        """`step(self.action_host)` of a host-visible core with nothing on the way: ONE library call (`gpd_step_sync`: the launch
+        and the wait for its stream), the argument list built once, the stream from torch's raw-handle accessor (no Stream object,
+        no device guard when the device is current).  What `BaseAviary.step()` calls."""
+        a = self._host_args
+        if a is None:
+            if not self.host_visible:
+                raise ValueError("step_host() needs a core built with host_visible=True")
+            a = self._host_args = (ctypes.byref(self._params), ctypes.byref(self._state), ctypes.byref(self._cfg), _ptr(self.action_host),
+                                   _ptr(self.target), _ptr(self.init_pose), _ptr(self.obs12), _ptr(self.reward), _ptr(self.terminated),
+                                   _ptr(self.truncated), _ptr(self.term_obs12), self.lib.gpd_step_sync)
+        if self._own_stream is not None or _get_raw_stream is None or torch.cuda.current_device() != self._dev_index:
+            self.step(self.action_host)
+            return
+        self.state_version += 1
+        rc = a[11](a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], _get_raw_stream(self._dev_index))
+        if rc:
+            _native.check(rc, "gpd_step_sync")
 
     # ---- the kinematic block as the logical [13][ld] matrix (rows: pos xyz | quat xyzw | vel xyz | body rates xyz) -------------
     @property
@@ -390,6 +410,35 @@ class SimCore:
             self.truncated.copy_(trunc[K - 1])
             if tobs is not None and self.auto_reset:      # term_obs12 = what K single steps would have left
                 self._latest_terminal(tobs, term, trunc, K)
+        return obs, rew, term, trunc
+
+    def rollout_packed(self, actions: torch.Tensor):
+        """`rollout(actions)` with the per-aviary outputs of a step stored as ONE 8-byte record (`gpd_rollout_packed`: one store per
+        lane and step instead of three).  Returns `(obs12 [K,N,12], reward [K,E], terminated [K,E], truncated [K,E])` -- reward and
+        flags are STRIDED VIEWS of the record block (float32 at byte 0, the flag bytes at bytes 4 and 5 of every record), no unpacking
+        pass; values and trajectories are bit for bit those of `rollout()`.  Shapes the packed kernel is built for only
+        (single-drone aviaries, Physics.DYN, ActionType.RPM, one sub-step per step, K >= 2): `GpdError` otherwise.  The latest-step
+        tensors (`obs12`, `reward`, ...) are NOT updated."""
+        per = self.N * self.A
+        if action_needs_fix(actions, self.device):
+            actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        if actions.numel() % per != 0 or actions.numel() == 0:
+            raise ValueError(f"actions has {actions.numel()} elements, expected K x {self.N}x{self.A}")
+        K = actions.numel() // per
+        cache = self.__dict__.setdefault("_packed_cache", {})
+        buf = cache.get(K)
+        if buf is None:
+            cache.clear()
+            rec = torch.zeros((K, self.E), dtype=torch.int64, device=self.device)
+            by = rec.view(torch.uint8).view(K, self.E, 8)
+            buf = cache[K] = (torch.zeros((K, self.N, 12), dtype=torch.float32, device=self.device), rec,
+                              rec.view(torch.float32).view(K, self.E, 2)[..., 0], by[..., 4].view(torch.bool), by[..., 5].view(torch.bool))
+        obs, rec, rew, term, trunc = buf
+        self.state_version += 1
+        with torch.cuda.device(self.device):
+            rc = self.lib.gpd_rollout_packed(ctypes.byref(self._params), ctypes.byref(self._state), ctypes.byref(self._cfg), K, _ptr(actions), per,
+                                             _ptr(self.target), _ptr(self.init_pose), _ptr(obs), self.N * 12, _ptr(rec), self.E, self._stream())
+        _native.check(rc, "gpd_rollout_packed")
         return obs, rew, term, trunc
 
     def rollout_policy(self, policy, num_steps: int, want_actions: bool = True, noise: torch.Tensor = None, action_std=None,

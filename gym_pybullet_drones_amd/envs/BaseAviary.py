@@ -146,7 +146,7 @@ class BaseAviary(Env):
         core = self._core
         if core.host_visible:
             self._action_row[...] = np.reshape(row, self._action_row.shape)       # (casts to float32 where the kernel reads it)
-            core.step(core.action_host)
+            core.step_host()
         else:
             core.step(torch.as_tensor(np.ascontiguousarray(row, dtype=np.float32).reshape(self.NUM_DRONES, -1), device=core.device))
         self._updateAndStoreKinematicInformation()

@@ -58,8 +58,13 @@ class BaseRLAviary(BaseAviary):
         return None
 
     def _recordAction(self, action):
-        self.action_buffer.append(np.array(action, dtype=np.float32).reshape(self.NUM_DRONES, -1))
-
+        a = np.array(action, dtype=np.float32).reshape(self.NUM_DRONES, -1)
+        self.action_buffer.append(a)
+        # the same history as one (NUM_DRONES, H * A) row block, oldest action first: what every observation row ends with
+        w = a.shape[1]
+        self._history_rows[:, :-w] = self._history_rows[:, w:]
+        self._history_rows[:, -w:] = a
+        self._history_tail = a
 
     def _actionSpace(self):
         """Box of shape (NUM_DRONES, 4 | 3 | 1) in [-1, 1]."""
@@ -68,6 +73,8 @@ class BaseRLAviary(BaseAviary):
         act_upper_bound = np.array([+1 * np.ones(size) for _ in range(self.NUM_DRONES)])
         for _ in range(self.ACTION_BUFFER_SIZE):
             self.action_buffer.append(np.zeros((self.NUM_DRONES, size), dtype=np.float32))
+        self._history_rows = np.zeros((self.NUM_DRONES, self.ACTION_BUFFER_SIZE * size), dtype=np.float32)
+        self._history_tail = self.action_buffer[-1]
         return spaces.Box(low=act_lower_bound, high=act_upper_bound, dtype=np.float32)
 
 
@@ -101,7 +108,11 @@ class BaseRLAviary(BaseAviary):
 
     def _computeObs(self):
         """(NUM_DRONES, 12 + H*A) float32: pos | rpy | vel | ang_v, then the H most recent actions, oldest first."""
-        ret = np.hstack([self.pos, self.rpy, self.vel, self.ang_v]).astype('float32')
-        for i in range(self.ACTION_BUFFER_SIZE):
-            ret = np.hstack([ret, np.asarray(self.action_buffer[i], dtype=np.float32)])
-        return ret
+        if self._core.host_visible:
+            kin = self._host_views["obs"]           # the kernel's own float32 row: what the float64 attributes are copies of
+        else:
+            kin = np.hstack([self.pos, self.rpy, self.vel, self.ang_v]).astype('float32')
+        if self.action_buffer[-1] is not self._history_tail:       # somebody appended to the deque directly: follow it
+            self._history_rows = np.concatenate([np.asarray(a, dtype=np.float32).reshape(self.NUM_DRONES, -1) for a in self.action_buffer], axis=1)
+            self._history_tail = self.action_buffer[-1]
+        return np.concatenate([kin, self._history_rows], axis=1)

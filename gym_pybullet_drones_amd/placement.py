@@ -1,0 +1,161 @@
+"""Where a large rollout's blocks sit in HBM decides how fast the SAME launch runs: `RolloutArena` chooses by measurement.
+
+A `gpd_rollout` launch over millions of drones is two long streams at once -- the action blocks read, the observation rows (and
+rewards / flags) written, 19 GB per 64-step launch at 4 194 304 drones.  On MI355X that launch runs at one of several discrete
+rates, 0.62 / 0.68 / 0.72 / 0.75-0.77 of 8 TB/s, and which one is decided by the PHYSICAL placement of the blocks relative to each
+other: same virtual addresses, same request counts, same L2 hit / miss / eviction / write-back counts, perfectly balanced L2
+channels, identical TLB behaviour -- but 20 % more cycles per memory-side read and per write behind the L2, and 5x the write-credit
+stalls (profiles/r06_hbm_placement_cause.md has the counters and the sweeps: inside ONE 100 GiB allocation, moving the action block
+by whole GiB steps walks through all the levels).  Neither HIP nor the driver lets a process choose physical pages, so the library
+does the one thing that is under its control: it takes ONE allocation larger than the launch needs, tries the blocks at a grid of
+offsets inside it with the launch itself as the probe (a few launches each, milliseconds), and keeps the best layout -- another
+arena is tried while the first is still held when no layout reaches the target.
+
+    arena = RolloutArena(core, K=64)           # core: engine.SimCore; nothing is measured yet
+    report = arena.search(target=0.755)        # probes; installs the winning blocks as the core's K-step rollout buffers
+    arena.actions.copy_(my_actions)            # [K, N, A] view inside the arena: the action blocks the launch reads
+    obs, rew, term, trunc = core.rollout(arena.actions)
+
+Worth it only where HBM serves the launch (a working set far beyond the 256 MiB Infinity Cache); smaller rollouts do not care.
+"""
+import torch
+
+GiB, MiB = 1 << 30, 1 << 20
+HBM_PEAK = 8.0e12      # bytes/s, MI355X spec peak: the fractions quoted here and in bench.py are of this
+
+
+def _up(n, q):
+    return (n + q - 1) // q * q
+
+
+class RolloutArena:
+    """One device allocation holding every block a K-step `SimCore.rollout` reads or writes, at offsets chosen by `search()`."""
+
+    def __init__(self, core, K: int, arena_bytes: int = None, grid_bytes: int = None):
+        self.core, self.K = core, int(K)
+        N, E, A = core.N, core.E, core.A
+        self.sizes = {"obs": K * N * 48, "act": K * N * A * 4, "rew": K * E * 4, "term": K * E, "trunc": K * E}
+        if core.term_obs12 is not None:
+            self.sizes["tobs"] = K * N * 48
+        pad = 2 * MiB
+        # the blocks the launch streams through together with the actions travel as one unit ("tail"): actions, rewards, flags
+        self.tail_parts, off = {}, 0
+        for name in ("act", "rew", "term", "trunc"):
+            self.tail_parts[name] = off
+            off += _up(self.sizes[name], pad) + pad          # (+ one pad: no two blocks start at the same offset modulo a large power of two)
+        self.tail_bytes = off
+        self.head_bytes = _up(self.sizes["obs"], pad) + (_up(self.sizes["tobs"], pad) if "tobs" in self.sizes else 0)
+        need = self.head_bytes + self.tail_bytes
+        self.grid = int(grid_bytes or max(_up(need // 8, pad), 64 * MiB))
+        free, _total = torch.cuda.mem_get_info(core.device)
+        want = int(arena_bytes or min(max(5 * need, need + 8 * self.grid), int(0.45 * free)))
+        if want < need + self.grid:
+            raise ValueError(f"an arena of {want} bytes cannot hold this rollout's {need} bytes with room to move")
+        self.bytes = want
+        self.slab = torch.empty(want, dtype=torch.uint8, device=core.device)
+        self.layout, self.report = None, None
+        self.actions = None
+
+    # ------------------------------------------------------------------------------------------------------------------------------
+    def _view(self, off, name, dtype, shape):
+        return self.slab[off:off + self.sizes[name]].view(dtype).view(shape)
+
+    def install(self, head_off: int, tail_off: int):
+        """Carve the blocks at these offsets and make them the core's K-step rollout buffers (`SimCore.rollout` then uses them)."""
+        c, K = self.core, self.K
+        obs = self._view(head_off, "obs", torch.float32, (K, c.N, 12))
+        tobs = self._view(head_off + _up(self.sizes["obs"], 2 * MiB), "tobs", torch.float32, (K, c.N, 12)) if "tobs" in self.sizes else None
+        p = self.tail_parts
+        self.actions = self._view(tail_off + p["act"], "act", torch.float32, (K, c.N, c.A))
+        rew = self._view(tail_off + p["rew"], "rew", torch.float32, (K, c.E))
+        term = self._view(tail_off + p["term"], "term", torch.bool, (K, c.E))
+        trunc = self._view(tail_off + p["trunc"], "trunc", torch.bool, (K, c.E))
+        cache = c.__dict__.setdefault("_rollout_cache", {})
+        cache[K] = (obs, rew, term, trunc, tobs)
+        self.layout = (head_off, tail_off)
+        return obs, rew, term, trunc
+
+    def candidates(self):
+        return layout_candidates(self.bytes, self.head_bytes, self.tail_bytes, self.grid)
+
+    def probe(self, head_off, tail_off, launches=3):
+        """Rate of the launch itself with the blocks at these offsets: algorithmic bytes / HIP-event time of `launches` launches."""
+        c = self.core
+        self.install(head_off, tail_off)
+        self.actions.uniform_(-1.0, 1.0) if c.act_code != 5 else self.actions.fill_(float(c.P.HOVER_RPM))
+        c.rollout(self.actions, update_latest=False)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(c.device)
+        e0.record()
+        for _ in range(launches):
+            c.rollout(self.actions, update_latest=False)
+        e1.record()
+        torch.cuda.synchronize(c.device)
+        return c.bytes_per_rollout(self.K) * launches / (e0.elapsed_time(e1) * 1e-3) / HBM_PEAK
+
+    def search(self, target: float = 0.755, max_probes: int = 48, launches: int = 3):
+        """Probe layouts until one reaches `target` (fraction of 8 TB/s) or `max_probes` are spent; install the best.  Returns the
+        report: every probe, the winner.  The aviaries advance while probing (the probe IS the launch): reset afterwards."""
+        probes, best = [], None
+        for h, t in self.candidates()[:max_probes]:
+            f = self.probe(h, t, launches)
+            probes.append({"obs_at_gib": h / GiB, "tail_at_gib": t / GiB, "frac": f})
+            if best is None or f > best[0]:
+                best = (f, h, t)
+            if f >= target:
+                break
+        self.install(best[1], best[2])
+        self.report = {"arena_gib": self.bytes / GiB, "grid_gib": self.grid / GiB, "target": target, "probes": len(probes), "best_frac_in_search": best[0],
+                       "obs_at_gib": best[1] / GiB, "tail_at_gib": best[2] / GiB, "reached_target": bool(best[0] >= target),
+                       "seen": sorted({round(p["frac"], 2) for p in probes}), "all_probes": probes}
+        return self.report
+
+
+def layout_candidates(arena_bytes, head_bytes, tail_bytes, grid):
+    """(head offset, tail offset) pairs on the grid, the two units inside the arena and disjoint, in an order that spreads the
+    early probes over the whole arena (a stride coprime to the list's length)."""
+    out = []
+    for h in range(0, arena_bytes - head_bytes + 1, grid):
+        for t in range(0, arena_bytes - tail_bytes + 1, grid):
+            if t + tail_bytes <= h or t >= h + head_bytes:
+                out.append((h, t))
+    n = len(out)
+    step = max(1, int(n * 0.6180339887)) | 1
+    while n > 1 and _gcd(step, n) != 1:
+        step += 2
+    return [out[(i * step) % n] for i in range(n)]
+
+
+def _gcd(a, b):
+    while b:
+        a, b = b, a % b
+    return a
+
+
+def place_rollout(core, K: int, target: float = 0.755, max_arenas: int = 3, max_probes: int = 48):
+    """`RolloutArena.search` over up to `max_arenas` arenas (each one held while the next is tried: a new arena is new physical
+    memory), keeping the best; the others are freed.  -> (arena, report)"""
+    tried, best = [], None
+    for _ in range(max_arenas):
+        try:
+            arena = RolloutArena(core, K)
+        except (ValueError, RuntimeError):          # (no room for another arena)
+            break
+        rep = arena.search(target=target, max_probes=max_probes)
+        tried.append(arena)
+        if best is None or rep["best_frac_in_search"] > best[1]["best_frac_in_search"]:
+            best = (arena, rep)
+        if rep["reached_target"]:
+            break
+    if best is None:
+        raise RuntimeError("no arena could be allocated")
+    arena, rep = best
+    arena.install(*arena.layout)
+    rep = dict(rep, arenas_tried=len(tried), what="blocks of the K-step rollout carved out of one allocation at offsets chosen by probing "
+               "with the launch itself (gym_pybullet_drones_amd/placement.py)")
+    for other in tried:
+        if other is not arena:
+            other.slab = None
+    del tried
+    torch.cuda.empty_cache()
+    return arena, rep

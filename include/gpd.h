@@ -243,6 +243,19 @@ int gpd_step(const GpdParams* params, const GpdState* state, const GpdStepCfg* c
              float* term_obs12, void* stream);
 
 /*
+ * gpd_step, then a wait for `stream` (hipStreamSynchronize): returns when the step's results are where the kernel wrote them.
+ * The one call behind the reference-shaped single aviaries (`BaseAviary.step`, envs/BaseAviary.py:259-383 of the reference: its
+ * step() returns numpy values, so every step ends in a host read): their state, action row and outputs live in page-locked HOST
+ * memory mapped into the device's address space (hipHostMalloc -- every pointer of this ABI may be such a host pointer), the
+ * kernel reads and writes them over the link, and the host reads the results in place -- no copy engine, no second launch, one
+ * library call per step.  Same arguments and error codes as gpd_step; a failed wait returns the positive hipError_t.
+ */
+int gpd_step_sync(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg,
+                  const float* action, const float* target_pos, const float* init_pose,
+                  float* obs12, float* reward, uint8_t* terminated, uint8_t* truncated,
+                  float* term_obs12, void* stream);
+
+/*
  * K consecutive env.step() calls in ONE launch.  Replaces the caller's stepping loop around
  * BaseAviary.step when the actions of the K steps are known up front: open-loop RPM sequences, and
  * closed-loop DSLPID tracking of a precomputed waypoint list -- the loops of examples/pid.py:132-167
@@ -273,6 +286,19 @@ int gpd_rollout(const GpdParams* params, const GpdState* state, const GpdStepCfg
                 float* obs12, int64_t obs_step_stride,
                 float* reward, uint8_t* terminated, uint8_t* truncated, int64_t env_step_stride,
                 float* term_obs12, void* stream);
+
+/*
+ * gpd_rollout with the per-aviary outputs of a step in ONE 8-byte record instead of three arrays:
+ *     step_out[t * env_step_stride + env] = reward bits (float32, low word) | terminated << 32 | truncated << 40
+ * (a host binding reads it back as strided views: the float at byte 0, the two flag bytes at bytes 4 and 5 of every record).  One
+ * store per lane and step instead of a 4-byte and two 1-byte ones; trajectories, observation rows and the values themselves are
+ * bit for bit those of gpd_rollout.  Shapes: single-drone aviaries, Physics.DYN, GPD_ACT_RPM, one sub-step per step, num_steps >= 2,
+ * no terminal observations, no action ring (GPD_ENOTSUP otherwise: call gpd_rollout).  Round 6's A/B of the headline kernel
+ * (profiles/r06_ab_packed_step_records.*).
+ */
+int gpd_rollout_packed(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, int32_t num_steps,
+                       const float* actions, int64_t action_step_stride, const float* target_pos, const float* init_pose,
+                       float* obs12, int64_t obs_step_stride, uint64_t* step_out, int64_t env_step_stride, void* stream);
 
 /*
  * gpd_rollout that ALSO pushes every step's raw action into the action ring of `state` (act_ring / ring_pos / hist_len), the

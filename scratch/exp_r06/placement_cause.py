@@ -60,7 +60,8 @@ for trial in range(args.trials):
                        act=ActionType.RPM, task="hover", auto_reset=True, track_rpm=False, device=dev)
     core = env.core
     aside = []
-    if args.mode == "slab":
+    mode = args.mode if args.mode != "alt" else ("slab" if trial % 2 else "torch")
+    if mode == "slab":
         sizes = [K * E * 12 * 4, K * E * 4 * 4, K * E * 4, K * E, K * E]
         offs = np.cumsum([0] + [(s + 4095) // 4096 * 4096 for s in sizes])
         slab = torch.empty(int(offs[-1]), dtype=torch.uint8, device=dev)
@@ -72,7 +73,7 @@ for trial in range(args.trials):
     else:
         acts = torch.rand((K, E, 1, 4), device=dev) * 2 - 1
         obs = None
-        if args.mode == "retry":
+        if mode == "retry":
             while True:
                 obs = torch.empty((K, E, 12), dtype=torch.float32, device=dev)
                 obs.fill_(0.0)
@@ -96,12 +97,13 @@ for trial in range(args.trials):
     read_dst.copy_(flat)
     r_gbs = 2 * flat.numel() * 4 / timed(lambda: read_dst.copy_(flat), 3) / 1e9
     row = {"trial": trial, "us_per_launch": sec * 1e6, "frac": bytes_launch / sec / 8e12, "obs_fill_gbs": w_gbs, "actions_copy_gbs": r_gbs,
-           "rollout_dispatches": [first, n_disp - 1], "set_aside": len(aside),
+           "rollout_dispatches": [first, n_disp - 1], "set_aside": len(aside), "mode": mode,
            "ptr": {"obs": hex(obs.data_ptr()), "actions": hex(acts.data_ptr()), "reward": hex(out[1].data_ptr()), "state": hex(core.kin_store.data_ptr())}}
     rows.append(row)
     print(json.dumps(row), flush=True)
     del env, core, acts, obs, out, aside
-    if args.mode == "slab":
+    mode = args.mode if args.mode != "alt" else ("slab" if trial % 2 else "torch")
+    if mode == "slab":
         del slab, rew, term, trunc
     gc.collect()
     torch.cuda.empty_cache()

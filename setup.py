@@ -15,11 +15,11 @@ PKG = os.path.join(ROOT, "gym_pybullet_drones_amd")
 
 
 def _compile_native():
-    if os.environ.get("GPD_SKIP_NATIVE_BUILD") == "1":
-        return
     # the header travels inside the package so that a wheel can re-build / be bound against without the source tree
     os.makedirs(os.path.join(PKG, "include"), exist_ok=True)
     shutil.copyfile(os.path.join(ROOT, "include", "gpd.h"), os.path.join(PKG, "include", "gpd.h"))
+    if os.environ.get("GPD_SKIP_NATIVE_BUILD") == "1":
+        return
     # import _native.py under a stand-in parent package: the real package's __init__ would pull torch in at build time
     import sys
     import types

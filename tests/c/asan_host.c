@@ -58,6 +58,8 @@ int main(void) {
     /* ---- launch geometry ---- */
     int n0 = hipstub_launches();
     CHECK(STEP(DEV(3), DEV(4)) == 0 && hipstub_launches() == n0 + 1, "gpd_step launches once");
+    CHECK(gpd_step_sync(&P, &S, &C, DEV(3), DEV(4), DEV(5), DEV(6), DEV(7), DEV(8), DEV(9), NULL, NULL) == 0 && hipstub_launches() == n0 + 2, "gpd_step_sync: one launch (and the wait for its stream)");
+    CHECK(gpd_step_sync(&P, &S, &C, NULL, DEV(4), DEV(5), DEV(6), DEV(7), DEV(8), DEV(9), NULL, NULL) == GPD_EINVAL && strstr(gpd_last_error(), "gpd_step_sync") != NULL, "gpd_step_sync names itself in its errors");
     hipstub_last(last);
     CHECK(last[0] == 256 && last[3] == 256 && last[6] == 0, "65 536 single-drone aviaries: 256 workgroups of 256 lanes");
     C.num_envs = 1 << 26; S.ld = 1ll << 26;

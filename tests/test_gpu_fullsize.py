@@ -107,7 +107,7 @@ def test_config3_conditioned_stacks_meet_the_plain_tolerance_over_256_steps(gpu_
 @pytest.mark.parametrize("workload", ["stack8x8192_ext_240hz", "stack8x8192_ext_pid_240hz"])
 def test_stack8_downwash_stays_inside_the_float64_envelope(gpu_device, workload):
     """The bench's OWN stack8 workload -- its scene, its random +-5 % RPM (or DSLPID waypoint) blocks, same-step auto-reset, its
-    64-step rollout launches -- for the bench's 256-step horizon, through the bench's own checker (`bench.parity_check`):
+    64-step rollout launches -- for the bench's 256-step horizon, through the bench's own checker (`oracle/bench_checks.py: parity_check`):
     the fp32 HIP run against the float64 C oracle, AND against the envelope of a second float64 run nudged by half an fp32
     ulp after every step.  Over 256 steps of random actions some drones cross a neighbour's wake, where the reference's model
     amplifies any rounding; the claim that this, not a kernel defect, is what the plain tolerance sees is measured here:
@@ -120,7 +120,8 @@ def test_stack8_downwash_stays_inside_the_float64_envelope(gpu_device, workload)
     for n in (64, 64):                                   # (some history first, like the bench's timed region before its check)
         bench.launch_rollout(env, acts, n)
     _all_threads()
-    res = bench.parity_check(w, env, acts, 256, 64, max_steps=256)
+    from oracle.bench_checks import parity_check
+    res = parity_check(w, env, acts, 256, 64, bench.launch_rollout, max_steps=256)
     e = res["envelope"]
     for r in e["rows"]:
         print("t=%3d %-5s median fp32 %.2e envelope %.2e | p95 fp32 %.2e envelope %.2e | max fp32 %.2e envelope %.2e | %d aviaries" % tuple(r))
@@ -129,14 +130,20 @@ def test_stack8_downwash_stays_inside_the_float64_envelope(gpu_device, workload)
     assert e["ratio"] <= 4.0 and e["ok"] and res["ok_envelope"], e["worst"]
     # `ok` is the plain tolerance's verdict and nothing else; the line also says how many aviaries are inside it on their
     # own, and how close the worst one's drones came to each other in height
-    assert res["ok"] == (res["max"] < 1e-4) and res["frac_aviaries_within_tolerance"] >= 0.97, res["frac_aviaries_within_tolerance"]
+    assert res["ok_plain_all_aviaries"] == (res["max"] < 1e-4) and res["frac_aviaries_within_tolerance"] >= 0.97, res["frac_aviaries_within_tolerance"]
     print("aviaries inside 1e-4:", res["frac_aviaries_within_tolerance"], res.get("worst_aviary"))
+    # ... and `ok` itself follows the WRITTEN rule for drones in each other's wake (VERDICT r05 #1d): the aviaries whose drones never came
+    # within 2 cm of each other in height -- at least 95 % of them -- are ALL inside the plain tolerance; the rest is counted, not judged
+    wr = res["wake_rule"]
+    print("WAKE RULE", {k: wr[k] for k in ("min_abs_dz_m", "aviaries_kept", "excluded_frac", "excluded_for_wake_frac", "max_over_kept", "max_over_excluded", "ok")},
+          wr["threshold_scan"])
+    assert res["ok"] == wr["ok"] and wr["min_abs_dz_m"] == 0.02 and wr["needs_kept_frac"] == 0.95
     # the first steps are plain rounding on both sides ...
     first = [r for r in e["rows"] if r[0] == 1]
     assert all(r[4] < 2e-6 for r in first), first
     # ... and the divergence the tolerance sees is there in float64 as well: the two float64 runs separate by more than the tolerance
     # in their worst aviaries, or the fp32 run passed the tolerance outright
-    assert res["ok_by"] == "tolerance" or max(r[7] for r in e["rows"]) > 1e-4
+    assert res["ok_by"] in ("tolerance", "wake_rule") or max(r[7] for r in e["rows"]) > 1e-4
     assert e["flag_mismatch_frac_between_the_two_float64_runs"] < 0.05 and res["flag_mismatch_frac"] < 0.05
 
 
@@ -252,57 +259,86 @@ def test_population_of_65536_closed_loop_hover_episodes_matches_the_float64_popu
     control/DSLPIDControl.py:212-259 rides its torque clip) no two runs agree drone by drone -- two float64 runs do not -- so
     what must hold is that the fp32 POPULATION behaves like the float64 one: 65 536 HoverAviaries spread over the 1.5 m box,
     ActionType.PID towards one random waypoint each up to 0.5 m away (about a third of the episodes end early -- the first
-    lunge tilts the drone past 0.4 rad, or carries it over the edge of the box -- the rest at the 8 s limit), same-step auto-reset, 260 control steps = one full 8 s episode and the start of the next, fp32 HIP against
-    oracle/gpd_oracle.c.  Compared: the distributions of the first episode's return and of the step it ended at (relative
-    difference of the means < 1e-3, two-sample Kolmogorov-Smirnov p > 0.01), and at EVERY step the population mean and standard
-    deviation of position and attitude (within 1e-4 of the group's scale)."""
+    lunge tilts the drone past 0.4 rad, or carries it over the edge of the box -- the rest at the 8 s limit), same-step auto-reset,
+    260 control steps = one full 8 s episode and the start of the next, fp32 HIP against oracle/gpd_oracle.c.  Compared:
+      * the distributions of the first episode's return and of the step it ended at: relative difference of the means < 1e-3,
+        two-sample Kolmogorov-Smirnov p > 0.01;
+      * at EVERY step the population mean and standard deviation of position and attitude, over the aviaries that are in the
+        same episode on both sides (1.2 % are not: a tilt within rounding of 0.4 rad ends the episode on one side a step
+        earlier, and from then on one side shows the reset pose where the other still flies): within 1e-4 of the group's scale;
+      * the same moments over ALL aviaries against what two float64 populations differ by (the second one nudged by the fp32
+        state array's rounding, relative 2^-24 sqrt(8) per control step): within 3x of that envelope."""
+    import os
     from scipy import stats
+    from oracle import bullet_math as bm
     from oracle import c_oracle
     rng = np.random.default_rng(20260)
     E, S, T = 65536, 8, 260
     xyz = (np.array([0, 0, 0.8]) + rng.uniform(-1, 1, size=(E, 1, 3)) * np.array([1.3, 1.3, 0.5])).astype(np.float32).astype(np.float64)
     rpy = rng.uniform(-0.1, 0.1, size=(E, 1, 3)).astype(np.float32).astype(np.float64)
     wp = (xyz + rng.uniform(-1, 1, size=(E, 1, 3)) * np.array([0.5, 0.5, 0.3])).astype(np.float32)
-    orc = CAviary(urdf("cf2x"), "cf2x", E, 1, initial_xyzs=xyz, initial_rpys=rpy, pyb_freq=240, ctrl_freq=30, act="pid", task="hover",
-                  auto_reset=True)
+    mk = lambda: CAviary(urdf("cf2x"), "cf2x", E, 1, initial_xyzs=xyz, initial_rpys=rpy, pyb_freq=240, ctrl_freq=30, act="pid",  # noqa: E731
+                         task="hover", auto_reset=True)
+    orc, orn = mk(), mk()
     core = _core("cf2x", E, 1, 0, S, "pid", "hover", xyz, rpy, gpu_device, auto_reset=True, target=orc.TARGET_POS)
     wp_dev, wp64 = torch.as_tensor(wp, device=gpu_device), wp.astype(np.float64)
-    ret = {"hip": np.zeros(E), "f64": np.zeros(E)}
-    end = {"hip": np.zeros(E, dtype=np.int64), "f64": np.zeros(E, dtype=np.int64)}
-    worst = {"pos_mean": 0.0, "pos_std": 0.0, "rpy_mean": 0.0, "rpy_std": 0.0}
-    c_oracle.lib().orc_set_threads(min(len(__import__("os").sched_getaffinity(0)), c_oracle.lib().orc_max_threads()))
+    sides = ("hip", "f64", "f64n")
+    ret = {s: np.zeros(E) for s in sides}
+    end = {s: np.zeros(E, dtype=np.int64) for s in sides}
+    hist = {s: np.zeros(E, dtype=np.int64) for s in sides}        # episodes ended so far: equal on two sides = the same episode
+    groups = (("pos", slice(0, 3)), ("rpy", slice(3, 6)))
+    matched = dict.fromkeys([f"{g}_{m}" for g, _ in groups for m in ("mean", "std")], 0.0)
+    everyone = {k: [0.0, 0.0] for k in matched}                    # [fp32 vs f64, f64 nudged vs f64], worst step
+    eps = 2.0 ** -24 * np.sqrt(S)
+    c_oracle.lib().orc_set_threads(min(len(os.sched_getaffinity(0)), c_oracle.lib().orc_max_threads()))
     try:
         for k in range(T):
             orc.step_in_place(wp64)
+            orn.step_in_place(wp64)
+            for name in ("pos", "quat", "vel", "rpy_rates"):
+                arr = getattr(orn, name)
+                arr *= 1.0 + eps * rng.choice([-1.0, 1.0], size=arr.shape)
+            orn.rpy = np.ascontiguousarray(bm.euler_from_quaternion_b(orn.quat))
             obs, rew, term, trunc = core.step(wp_dev)
-            o32 = obs.cpu().numpy().astype(np.float64).reshape(E, 12)
-            o64 = orc.obs.reshape(E, 12)
+            o = {"hip": obs.cpu().numpy().astype(np.float64).reshape(E, 12), "f64": orc.obs.reshape(E, 12), "f64n": orn.obs.reshape(E, 12)}
             for side, r, done in (("hip", rew.cpu().numpy().astype(np.float64), (term | trunc).cpu().numpy()),
-                                  ("f64", orc.reward, (orc.terminated | orc.truncated).astype(bool))):
+                                  ("f64", orc.reward, (orc.terminated | orc.truncated).astype(bool)),
+                                  ("f64n", orn.reward, (orn.terminated | orn.truncated).astype(bool))):
                 first = end[side] == 0
                 ret[side] += np.where(first, r, 0.0)
                 end[side] = np.where(first & done, k + 1, end[side])
-            # (the observation row of an aviary that ended in this step is its reset pose on both sides: same-step auto-reset)
-            for name, sl in (("pos", slice(0, 3)), ("rpy", slice(3, 6))):
-                scale = max(float(np.abs(o64[:, sl]).max()), 1.0)
-                worst[name + "_mean"] = max(worst[name + "_mean"], float(np.abs(o32[:, sl].mean(0) - o64[:, sl].mean(0)).max() / scale))
-                worst[name + "_std"] = max(worst[name + "_std"], float(np.abs(o32[:, sl].std(0) - o64[:, sl].std(0)).max() / scale))
+                hist[side] += done
+            # (the observation row of an aviary that ended in this step is its reset pose: same-step auto-reset)
+            same = hist["hip"] == hist["f64"]
+            for g, sl in groups:
+                scale = max(float(np.abs(o["f64"][:, sl]).max()), 1.0)
+                for m, fn in (("mean", np.mean), ("std", np.std)):
+                    key = f"{g}_{m}"
+                    matched[key] = max(matched[key], float(np.abs(fn(o["hip"][same][:, sl], axis=0) - fn(o["f64"][same][:, sl], axis=0)).max() / scale))
+                    ref = fn(o["f64"][:, sl], axis=0)
+                    everyone[key][0] = max(everyone[key][0], float(np.abs(fn(o["hip"][:, sl], axis=0) - ref).max() / scale))
+                    everyone[key][1] = max(everyone[key][1], float(np.abs(fn(o["f64n"][:, sl], axis=0) - ref).max() / scale))
     finally:
         c_oracle.lib().orc_set_threads(1)
-    assert (end["hip"] > 0).all() and (end["f64"] > 0).all()            # every aviary finished its first episode (time limit: step 241)
+    assert all((end[s] > 0).all() for s in sides)                       # every aviary finished its first episode (time limit: step 241)
     early = float((end["f64"] < 241).mean())
     d_ret = abs(ret["hip"].mean() - ret["f64"].mean()) / abs(ret["f64"].mean())
     d_end = abs(end["hip"].mean() - end["f64"].mean()) / end["f64"].mean()
     ks_ret, ks_end = stats.ks_2samp(ret["hip"], ret["f64"]), stats.ks_2samp(end["hip"], end["f64"])
-    same_end = float((end["hip"] == end["f64"]).mean())
+    same_end, same_end_n = float((end["hip"] == end["f64"]).mean()), float((end["f64n"] == end["f64"]).mean())
     print(f"POPULATION 65536 x PID @ 30 Hz: {early:.3f} of the episodes end before the time limit; return mean {ret['f64'].mean():.3f} (f64) "
           f"rel diff {d_ret:.2e}, KS D {ks_ret.statistic:.2e} p {ks_ret.pvalue:.3f}; end step mean {end['f64'].mean():.2f} rel diff {d_end:.2e}, "
-          f"KS D {ks_end.statistic:.2e} p {ks_end.pvalue:.3f}; same end step drone by drone {same_end:.4f}; per-step population moments "
-          + " ".join(f"{n}={v:.2e}" for n, v in worst.items()))
+          f"KS D {ks_end.statistic:.2e} p {ks_end.pvalue:.3f}; same end step drone by drone: fp32 {same_end:.4f}, nudged float64 {same_end_n:.4f}; "
+          f"still in the same episode at the end {float((hist['hip'] == hist['f64']).mean()):.4f}")
+    print("POPULATION moments, worst step, aviaries in the same episode on both sides: " + " ".join(f"{n}={v:.2e}" for n, v in matched.items()))
+    print("POPULATION moments, worst step, ALL aviaries [fp32 vs f64 | nudged f64 vs f64]: " + " ".join(f"{n}={a:.2e}|{b:.2e}" for n, (a, b) in everyone.items()))
     assert 0.15 < early < 0.8                                           # the scene does produce a distribution of episode lengths
     assert d_ret < 1e-3 and d_end < 1e-3
     assert ks_ret.pvalue > 0.01 and ks_end.pvalue > 0.01
-    assert max(worst.values()) < 1e-4, worst
+    assert abs(same_end - same_end_n) < 0.01                            # the fp32 run leaves the float64 one as often as a float64 run does
+    assert max(matched.values()) < 1e-4, matched
+    for key, (a, b_) in everyone.items():
+        assert a <= 3.0 * b_ + 2e-5, (key, a, b_)
 
 
 def _sync_c(core, orc):
@@ -398,7 +434,7 @@ def test_multihover_131072x2_reward_is_sum_of_hover_rewards(gpu_device):
 def test_the_timed_workload_of_bench_py_against_the_c_oracle(gpu_device, workload, K, steps):
     """What bench.py TIMES, not a gentler stand-in: 65 536 HoverAviaries at 240 Hz, U(-1, 1) RPM actions that change every step,
     same-step auto-reset on, through `gpd_rollout` with K steps per launch (K = 20: the driver's `--steps 20`) -- replayed
-    through the float64 C oracle from the device's own state by bench.py's `parity_check` (the block the bench line carries).
+    through the float64 C oracle from the device's own state by bench.py's checker, `oracle.bench_checks.parity_check` (the block the bench line carries).
     SURVEY.md section 8(d)'s metric, every field group below 1e-4; episodes do end inside the window (tilt / box truncation:
     the reset path is exercised), and the aviaries whose flags flip within rounding of a threshold stay a handful.  The other
     cases: the same for the workloads of the other BASELINE configs, open loop and with DSLPID closing the loop in the kernel
@@ -409,7 +445,8 @@ def test_the_timed_workload_of_bench_py_against_the_c_oracle(gpu_device, workloa
     acts = bench.make_actions(w, env, gpu_device, seed=2000, pool=64)
     for _ in range(3):                                   # not from the reset poses: a few launches in, like after a timed region
         bench.launch_rollout(env, acts, K)
-    res = bench.parity_check(w, env, acts, steps, K, max_steps=steps)
+    from oracle.bench_checks import parity_check
+    res = parity_check(w, env, acts, steps, K, bench.launch_rollout, max_steps=steps)
     print(res)
     assert res["checked_steps"] == steps and res["launches"] == [f"rollout{K}"] * (steps // K)
     assert res["max"] < 1e-4 and res["ok"], res
@@ -423,9 +460,10 @@ def test_the_timed_workload_of_bench_py_against_the_c_oracle(gpu_device, workloa
 def test_swarm_of_65536_drones_forces_and_a_second_of_flight(gpu_device):
     """ONE world at bench size (`swarm65536_ext_240hz`): after 48 steps through the persistent path (a binning every 16th
     sub-step, stale cell order, wake lists) the forces of all 65 536 drones against the float64 all-pairs loop of the reference
-    (`BaseAviary._downwash`, 4.3e9 pairs in C) on the same positions -- bench.py's `swarm_parity_check`, the block its swarm
+    (`BaseAviary._downwash`, 4.3e9 pairs in C) on the same positions -- bench_extra.py's checker, `oracle.bench_checks.swarm_parity_check`, the block its swarm
     lines carry -- and the trajectory bit for bit that of a twin that bins before every force evaluation."""
     import bench
+    import bench_extra  # noqa: F401 -- registers the one-world workloads
     w = bench.WORKLOADS["swarm65536_ext_240hz"]
     env = bench.make_env(w, gpu_device, seed=1000)
     from gym_pybullet_drones_amd.envs import SwarmAviary
@@ -440,6 +478,7 @@ def test_swarm_of_65536_drones_forces_and_a_second_of_flight(gpu_device):
         vb, *_ = twin.step(acts[k % 8])
     assert torch.equal(va, vb) and torch.equal(env.dw_force, twin.dw_force)
     assert env.wake_lists and float(env._list_ok.float().mean()) > 0.99
-    res = bench.swarm_parity_check(env)
+    from oracle.bench_checks import swarm_parity_check
+    res = swarm_parity_check(env)
     print(res)
     assert res["ok"] and res["drones_with_a_force"] > 30000, res

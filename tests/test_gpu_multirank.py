@@ -15,10 +15,10 @@ from conftest import REPO
 pytestmark = pytest.mark.gpu
 
 
-def _bench(args, world, port, timeout=900):
+def _bench(args, world, port, timeout=900, script="bench.py"):
     env = dict(os.environ, GPD_DIST_BACKEND="gloo", GPD_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", str(world)] + args
+           "--master-port", str(port), os.path.join(REPO, script), "--gpus", str(world)] + args
     res = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
@@ -26,13 +26,14 @@ def _bench(args, world, port, timeout=900):
     return json.loads(lines[0])
 
 
-def _bench_self(args, timeout=1200, gpus=2, **extra_env):
+def _bench_self(args, timeout=1200, gpus=2, script="bench.py", expect_rc=0, **extra_env):
     """`python bench.py --gpus N ...` the way the driver types it -- NO torch.distributed.run around it."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(GPD_DIST_BACKEND="gloo", GPD_BENCH_SINGLE_DEVICE="1", **extra_env)
-    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(gpus)] + args, cwd=REPO, env=env, capture_output=True,
+    env.update(GPD_DIST_BACKEND="gloo", GPD_BENCH_SINGLE_DEVICE="1")
+    env.update(extra_env)
+    res = subprocess.run([sys.executable, os.path.join(REPO, script), "--gpus", str(gpus)] + args, cwd=REPO, env=env, capture_output=True,
                          text=True, timeout=timeout)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert (res.returncode == expect_rc) if expect_rc is not None else (res.returncode != 0), res.stdout[-2000:] + res.stderr[-4000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]          # ONE JSON line, whatever ran
     return json.loads(lines[0])
@@ -48,8 +49,8 @@ def test_bench_gpus_2_launches_its_two_ranks_itself(gpu_device):
 
 
 def test_bench_gpus_2_default_run_carries_the_suite_and_the_hbm_leg(gpu_device):
-    """What the driver's SCALE run gets from one command: the headline, the HBM-saturating leg beside it, and BASELINE configs 4
-    and 5 plus the shared 1M-drone world under `suite`."""
+    """What the driver's SCALE run gets from one command: the headline with the topology the ranks found, the HBM-saturating leg
+    beside it, and BASELINE configs 4 and 5 under `suite`."""
     j = _bench_self(["--steps", "20", "--warmup", "5", "--min-time", "0.05", "--no-cpu-baseline"], timeout=2400)
     assert j["n_gpus"] == 2 and j["config"]["workload"] == "hover65536_240hz"
     h = j["hbm_saturating"]
@@ -60,8 +61,10 @@ def test_bench_gpus_2_default_run_carries_the_suite_and_the_hbm_leg(gpu_device):
     assert ag["config"]["obs_allgather"] is True and ag["without_allgather"]["value"] >= ag["value"] * 0.5 and ag["n_gpus"] == 2
     mh = su["multihover2x16384x8"]
     assert mh["config"]["total_drones"] == 2 * 2 * 16384 and mh["value"] > 1e8
-    sw = su["swarm1m_ext_240hz"]
-    assert sw["scaling"] == "strong" and sw["config"]["swarm"]["ranks"] == 2 and sw["config"]["total_drones"] == 1048576
+    # the line says what the ranks found before anything was timed: the rank -> device map, the group's own count
+    topo = j["config"]["topology"]
+    assert topo["world_size"] == 2 and topo["ranks_in_process_group"] == 2 and [e["rank"] for e in topo["rank_device_map"]] == [0, 1]
+    assert all(e["device"] == 0 and e["name"] for e in topo["rank_device_map"]) and topo["backend"] == "gloo"
 
 
 def test_bench_gpus_8_rehearsal_of_the_driver_command(gpu_device):
@@ -69,7 +72,8 @@ def test_bench_gpus_8_rehearsal_of_the_driver_command(gpu_device):
     rehearsed end to end on ONE device: eight self-launched ranks (gloo rendezvous, every rank on device 0, 1/8 of every workload's
     aviaries: `GPD_BENCH_E_DIV=8`).  What is shown is plumbing, not performance (VERDICT r04 "next" #4; no 8-GPU node is available to
     this build: no hardware scaling curve exists): eight per-GPU values, eight ranks in the process group, the HBM leg, and the suite
-    with BASELINE config 4 (with AND without the all-gather), config 5 and the shared one-world workload split over eight ranks."""
+    with BASELINE config 4 (with AND without the all-gather) and config 5.  (The one-world workload split over eight ranks:
+    `test_bench_extra_eight_ranks_share_the_1m_world`.)"""
     j = _bench_self(["--steps", "20", "--warmup", "5", "--min-time", "0.02", "--hbm-leg-time", "0.05", "--no-cpu-baseline", "--suite-timeout", "900"],
                     timeout=2400, gpus=8, GPD_BENCH_E_DIV="8")
     assert j["n_gpus"] == 8 and len(j["per_gpu"]["values"]) == 8 and j["config"]["ranks_in_process_group"] == 8
@@ -80,9 +84,34 @@ def test_bench_gpus_8_rehearsal_of_the_driver_command(gpu_device):
     ag = su["hover65536x8_allgather"]
     assert ag["n_gpus"] == 8 and ag["config"]["obs_allgather"] is True and ag["without_allgather"]["value"] > 0 and len(ag["per_gpu"]["values"]) == 8
     assert su["multihover2x16384x8"]["n_gpus"] == 8 and su["multihover2x16384x8"]["config"]["total_drones"] == 8 * 2 * 2048
-    sw = su["swarm1m_ext_240hz"]
-    assert sw["scaling"] == "strong" and sw["config"]["swarm"]["ranks"] == 8 and sw["config"]["swarm"]["exchange"] == "halo"
-    assert sw["config"]["swarm"]["halo_margin_check"] == "ok"
+    assert len(j["config"]["topology"]["rank_device_map"]) == 8
+
+
+def test_bench_extra_eight_ranks_share_the_1m_world(gpu_device):
+    """bench_extra.py's strong-scaling workload self-launched with eight ranks on ONE device (1/8 size): the world split over eight
+    ranks, positions exchanged by halo, the margin check "ok"."""
+    sw = _bench_self(["--workload", "swarm1m_ext_240hz", "--mode", "graph", "--steps", "20", "--warmup", "5", "--min-time", "0.02", "--no-cpu-baseline",
+                      "--no-parity"], timeout=2400, gpus=8, script="bench_extra.py", GPD_BENCH_E_DIV="8")
+    assert sw["n_gpus"] == 8 and sw["scaling"] == "strong" and sw["config"]["swarm"]["ranks"] == 8 and sw["config"]["swarm"]["exchange"] == "halo"
+    assert sw["config"]["swarm"]["halo_margin_check"] == "ok" and sw["config"]["rehearsal_divisor"] == 8
+
+
+def test_dry_run_topology_and_two_rccl_ranks_on_one_device_fail_fast(gpu_device):
+    """VERDICT r05 #7.  (a) `--dry-run-topology` brings the job up, all-gathers 12 floats per rank, prints the topology block and exits
+    0 in seconds (gloo test hook: two ranks on device 0).  (b) The same two ranks on ONE device under the REAL backend ("nccl" =
+    RCCL, which refuses duplicate GPUs): a readable line -- the rank -> device map, what is wrong -- and a non-zero exit code within the
+    minute, not a hang until somebody's timeout."""
+    import time
+    t0 = time.perf_counter()
+    j = _bench_self(["--dry-run-topology"], timeout=300)
+    assert j["dry_run_topology"] and j["ok"] and j["n_gpus"] == 2 and len(j["topology"]["rank_device_map"]) == 2
+    assert time.perf_counter() - t0 < 120
+    t0 = time.perf_counter()
+    j = _bench_self(["--dry-run-topology", "--init-timeout", "60"], timeout=300, expect_rc=None, GPD_DIST_BACKEND="nccl")
+    assert time.perf_counter() - t0 < 150
+    assert j["value"] is None and "error" in j and j["n_gpus"] == 2
+    assert "same device" in j["error"] and len(j["topology"]["rank_device_map"]) == 2, j
+    assert {e["device"] for e in j["topology"]["rank_device_map"]} == {0}
 
 
 def test_bench_watchdog_prints_the_headline_when_the_suite_hangs(gpu_device):
@@ -117,7 +146,7 @@ def test_bench_two_ranks_share_one_swarm_world(gpu_device):
     """ONE world of 65 536 drones shared by two ranks (both on device 0, positions exchanged through torch.distributed / gloo --
     the test hook; on a node RCCL carries them): rank r steps its block of drones, all-gathers, evaluates its own forces."""
     j = _bench(["--workload", "swarm65536_ext_240hz", "--mode", "eager", "--steps", "24", "--warmup", "4", "--min-time", "0.02",
-                "--no-cpu-baseline"], 2, 29543)
+                "--no-cpu-baseline"], 2, 29543, script="bench_extra.py")
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["total_drones"] == 65536
     sw = j["config"]["swarm"]
     assert sw["ranks"] == 2 and sw["total_drones"] == 65536 and "torch.distributed" in sw["note"]

@@ -905,9 +905,9 @@ def test_host_visible_core_is_bitwise_the_device_core(gpu_device, act, D, flags,
 
 
 def test_dropin_aviary_step_is_one_launch_on_host_visible_state(gpu_device, monkeypatch):
-    """The reference-shaped `HoverAviary.step()`: the action row written where the kernel reads it, ONE gpd_step launch, no
-    gpd_state_vectors launch, no torch.cat / device-to-host copy -- and the same trajectory, float for float, as with
-    GPD_HOST_VISIBLE=0 (state in HBM, the round-5 path with its packed copy)."""
+    """The reference-shaped `HoverAviary.step()`: the action row written where the kernel reads it, ONE library call (gpd_step_sync:
+    one launch + the wait for its stream), no gpd_state_vectors launch, no torch.cat / device-to-host copy -- and the same
+    trajectory, float for float, as with GPD_HOST_VISIBLE=0 (state in HBM, the round-5 path with its packed copy)."""
     from gym_pybullet_drones_amd import _native
     from gym_pybullet_drones_amd.envs import HoverAviary, MultiHoverAviary
     from gym_pybullet_drones_amd.utils.enums import ActionType, Physics
@@ -923,7 +923,7 @@ def test_dropin_aviary_step_is_one_launch_on_host_visible_state(gpu_device, monk
         ob, _ = b.reset(seed=1)
         np.testing.assert_array_equal(oa, ob)
         L = _native.lib()
-        calls = {"gpd_step": 0, "gpd_state_vectors": 0}
+        calls = {"gpd_step_sync": 0, "gpd_step": 0, "gpd_state_vectors": 0}
         real = {n: getattr(L, n) for n in calls}
         for n in calls:
             def counted(*args, _n=n):
@@ -933,7 +933,7 @@ def test_dropin_aviary_step_is_one_launch_on_host_visible_state(gpu_device, monk
         acts = rng.uniform(-1, 1, size=(40,) + A).astype(np.float32) * 0.3 + (np.array([0, 0, 0.7], dtype=np.float32) if A[1] == 3 else 0)
         for k in range(40):
             ra = a.step(acts[k])
-            assert calls == {"gpd_step": k + 1, "gpd_state_vectors": 0}
+            assert calls == {"gpd_step_sync": k + 1, "gpd_step": 0, "gpd_state_vectors": 0}
             n0 = dict(calls)
             rb = b.step(acts[k])
             calls.update(n0)

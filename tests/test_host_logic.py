@@ -203,6 +203,61 @@ open({str(tmp_path)!r} + f"/ok{{rank}}", "w").write("ok")
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
 
 
+def test_bring_up_reports_the_topology_world2_gloo(tmp_path):
+    """`dist.bring_up` (what bench.py's Job and its `--dry-run-topology` stand on), world_size 2 over gloo on CPU: the rank -> device
+    map travels through the rendezvous store (it exists before any collective runs), the group's own all-reduce counts two ranks,
+    and the 12-float exchange carries every rank's row."""
+    script = tmp_path / "up.py"
+    script.write_text(f"""
+import json, sys
+sys.path.insert(0, {REPO!r})
+import torch.distributed as dist
+from gym_pybullet_drones_amd import dist as gdist
+topo = gdist.bring_up("gloo", None)
+ok, note = gdist.dry_run_exchange(topo, "gloo", None)
+assert topo["world_size"] == 2 and topo["ranks_in_process_group"] == 2 and topo["n_ranks_seen_by_rccl"] is None
+assert [e["rank"] for e in topo["rank_device_map"]] == [0, 1] and len({{e["pid"] for e in topo["rank_device_map"]}}) == 2
+assert ok and "12 floats" in note
+dist.barrier(); dist.destroy_process_group()
+open({str(tmp_path)!r} + f"/up{{topo['rank']}}", "w").write(json.dumps(topo))
+""")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29537", str(script)],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert (tmp_path / "up0").exists() and (tmp_path / "up1").exists()
+
+
+def test_package_installs_with_pip_and_imports_from_anywhere(tmp_path):
+    """`pip install .` (setup.cfg metadata, setup.py's build hook; GPD_SKIP_NATIVE_BUILD=1 here: the hook's hipcc step
+    is `_native.build()`, which `__graft_entry__.build()` exercises) into an empty directory, then -- from another working
+    directory, without the source tree on the path -- the package imports under its real name, carries its URDFs, kernels' sources
+    and the C header, and registers the reference's four environment ids."""
+    site = tmp_path / "site"
+    env = dict(os.environ, GPD_SKIP_NATIVE_BUILD="1")
+    res = subprocess.run([sys.executable, "-m", "pip", "install", "--no-build-isolation", "--no-deps", "--quiet", "--target", str(site), REPO],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    pkg = site / "gym_pybullet_drones_amd"
+    for rel in ("__init__.py", "engine.py", "envs/HoverAviary.py", "assets/cf2x.urdf", "csrc/step_rollout.hip", "csrc/gpd_common.inc", "include/gpd.h"):
+        assert (pkg / rel).exists(), rel
+    code = ("import gym_pybullet_drones_amd as g, gym_pybullet_drones_amd.envs as e, gym_pybullet_drones_amd.control as c, importlib.metadata as m;"
+            "from gym_pybullet_drones_amd import _gym_shim as s;"
+            "ids = set(s._REGISTRY) if not s.HAVE_GYMNASIUM else {i for i in __import__('gymnasium').envs.registration.registry};"
+            "assert {'hover-aviary-v0', 'multihover-aviary-v0', 'ctrl-aviary-v0', 'velocity-aviary-v0'} <= ids;"
+            "print(g.__file__, m.version('gym-pybullet-drones-amd'), e.HoverAviary.__name__, c.DSLPIDControl.__name__)")
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=str(tmp_path),
+                         env={k: v for k, v in dict(os.environ, PYTHONPATH=str(site)).items()})
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert str(site) in run.stdout and "0.1.0" in run.stdout and "HoverAviary DSLPIDControl" in run.stdout
+    import shutil
+    for junk in ("build", "gym_pybullet_drones_amd.egg-info", "gym_pybullet_drones_amd/include"):      # (what the in-tree build leaves behind)
+        shutil.rmtree(os.path.join(REPO, junk), ignore_errors=True)
+    assert not os.path.exists(os.path.join(REPO, "gym_pybullet_drones_amd", "__init__.py")) or \
+        "exec(" not in open(os.path.join(REPO, "gym_pybullet_drones_amd", "__init__.py")).read()      # the alias hack is gone
+
+
 def test_logger_layout_and_files(tmp_path):
     """Reference layout: states (N,16,T) = [pos, vel, rpy, ang_vel, rpm] re-ordered from the 20-float state vector
     (utils/Logger.py:117), growing arrays when duration_sec = 0, one CSV per signal and drone."""

@@ -69,6 +69,6 @@ def test_idle_rotors_rest_on_the_plane_like_bullet(gpu_device):
 
 
 def test_bench_times_the_real_reference_when_it_is_there():
-    import bench
-    r = bench.pybullet_baseline(budget_s=5.0, steps=242)
+    from oracle.bench_checks import pybullet_baseline
+    r = pybullet_baseline(budget_s=5.0, steps=242)
     assert r["available"] and r["kind"] == "reference" and r["value"] > 0 and "HoverAviary()" in r["sample"]
