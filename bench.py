@@ -586,7 +586,8 @@ def hbm_leg(args, job, out):
     # The extras have their own guard and their own budget: a failure or a time-out in them leaves `on_fresh_allocations` partial and
     # the leg's figure -- already measured -- in the line.
     copy, again, again_note = None, [], None
-    if r is not None and "error" not in r or job.rank != 0:
+    from gym_pybullet_drones_amd import dist as gdist
+    if gdist.all_ranks_ok(r is None or "error" not in r, device=job.device):       # (every rank takes the same branch: the re-runs hold collectives)
         n_again = int(getattr(args, "hbm_leg_reallocations", 10))
         budget = min(90.0, args.suite_timeout)
 
@@ -700,8 +701,6 @@ def run_suite(args, job, out):
                 r = run_workload(a, job)
             except Exception as e:          # noqa: BLE001 -- reported; the headline survives
                 r = {"error": f"{type(e).__name__}: {e}"[:300], "rccl_warnings": gdist.rccl_debug_tail()}
-            if os.environ.get("GPD_BENCH_INJECT_HANG") == "suite":       # (test hook: a collective that never returns -- the watchdog's case)
-                time.sleep(3600)
             ok = gdist.all_ranks_ok(r is None or "error" not in r, device=job.device)
             if job.rank == 0:
                 if "error" in r or not ok:

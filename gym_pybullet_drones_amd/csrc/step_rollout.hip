@@ -410,9 +410,7 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
 //     the empty asm keeps the zero-extension of the offsets inside the loop (hoisted, it turns every store into a
 //     64-bit VALU add plus a flat-addressed store).
 // ------------------------------------------------------------------------------------------------
-// PACKED (gpd_rollout_packed): reward and flags of an aviary and step leave as ONE 8-byte record {reward bits | terminated << 32 |
-// truncated << 40} at `reward` + (step * env_step + env) * 8 -- one store instead of three (a 4-byte and two 1-byte ones).
-template <bool NT_OBS = true, bool PACKED = false>     // NT_OBS: the observation bursts are stored non-temporally (see launch_step for when not)
+template <bool NT_OBS = true>     // NT_OBS: the observation bursts are stored non-temporally (see launch_step for when not)
 struct RollOut {
     char* og_prev; char* og; char* rg; uint8_t* tg; uint8_t* ug;     // obs block of the previous / this step, reward, flags
     int64_t obs_step, env_step;                                     // bytes / elements between consecutive steps
@@ -423,7 +421,7 @@ struct RollOut {
                                        const uint32_t goff[3], uint32_t eoff4, uint32_t env, float* row, const char* lsrc_)
         : og_prev(reinterpret_cast<char*>(obs12)), og(reinterpret_cast<char*>(obs12)), rg(reinterpret_cast<char*>(reward)),
           tg(terminated), ug(truncated), obs_step(T.obs_stride * 4), env_step(T.env_stride), g0(goff[0]), g1(goff[1]),
-          g2(goff[2]), e4(PACKED ? eoff4 * 2u : eoff4), e1(env), mine(reinterpret_cast<float4*>(row)), lsrc(lsrc_) {
+          g2(goff[2]), e4(eoff4), e1(env), mine(reinterpret_cast<float4*>(row)), lsrc(lsrc_) {
         pend[0] = pend[1] = pend[2] = f4v{0, 0, 0, 0};
     }
     __device__ __forceinline__ void bursts(char* base) {
@@ -440,7 +438,7 @@ struct RollOut {
     }
     // `advance`: false on the first step of the launch (the pointers already address step 0)
     __device__ __forceinline__ void emit(const StepOut& out, bool advance) {
-        if (advance) { og_prev = og; og += obs_step; rg += env_step * (PACKED ? 8 : 4); if (!PACKED) { tg += env_step; ug += env_step; } }
+        if (advance) { og_prev = og; og += obs_step; rg += env_step * 4; tg += env_step; ug += env_step; }
         bursts(og_prev);
         mine[0] = make_float4(out.o[0], out.o[1], out.o[2], out.o[3]);
         mine[1] = make_float4(out.o[4], out.o[5], out.o[6], out.o[7]);
@@ -452,17 +450,10 @@ struct RollOut {
             pend[j] = f4v{v.x, v.y, v.z, v.w};
         }
         __builtin_amdgcn_wave_barrier();                             // (the next step's row writes stay behind these reads)
-        if constexpr (PACKED) {
-            asm volatile("" : "+v"(e4));
-            typedef uint32_t u2v __attribute__((ext_vector_type(2)));
-            const u2v rec = {__float_as_uint(out.rew), (out.term ? 1u : 0u) | (out.trunc ? 0x100u : 0u)};
-            __builtin_nontemporal_store(rec, reinterpret_cast<u2v*>(rg + e4));
-        } else {
-            asm volatile("" : "+v"(e4), "+v"(e1));
-            __builtin_nontemporal_store(out.rew, reinterpret_cast<float*>(rg + e4));
-            __builtin_nontemporal_store(static_cast<uint8_t>(out.term ? 1 : 0), tg + e1);
-            __builtin_nontemporal_store(static_cast<uint8_t>(out.trunc ? 1 : 0), ug + e1);
-        }
+        asm volatile("" : "+v"(e4), "+v"(e1));
+        __builtin_nontemporal_store(out.rew, reinterpret_cast<float*>(rg + e4));
+        __builtin_nontemporal_store(static_cast<uint8_t>(out.term ? 1 : 0), tg + e1);
+        __builtin_nontemporal_store(static_cast<uint8_t>(out.trunc ? 1 : 0), ug + e1);
     }
     __device__ __forceinline__ void flush() { bursts(og); }          // after the last step
 };
@@ -493,7 +484,7 @@ struct RollOut {
 // they are unconditional -- a compile-time variant, not a run-time test).
 // (the argument list starts with the fourteen dwords the launch's first loads need -- kernarg preload, as for gpd_step_kernel: the state,
 // the first action rows, the counter, the target and the reset pose are requested without first waiting for the argument block)
-template <bool PID, bool EXT, int AW, int ACT, bool S1, bool MULTI, bool NT_OBS = true, bool RING = false, bool PACKED = false>
+template <bool PID, bool EXT, int AW, int ACT, bool S1, bool MULTI, bool NT_OBS = true, bool RING = false>
 __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     float* __restrict__ hot_kin, const float* __restrict__ action, int32_t* __restrict__ hot_counter, const float* __restrict__ target_pos,
     const float* __restrict__ init_pose, const uint32_t hot_ld, const int32_t hot_num_envs, const int32_t hot_num_steps, const uint32_t hot_bits,
@@ -505,7 +496,7 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     const GpdStepCfg C{hot_num_envs, C_.drones_per_env, C_.act_type, C_.substeps, C_.physics_flags, C_.pyb_dt, C_.ctrl_dt, C_.inv_ctrl_dt,
                        C_.lanes_per_wave, C_.task, C_.xy_bound, C_.z_bound, C_.tilt_bound, C_.term_dist, C_.trunc_counter,
                        static_cast<int32_t>((hot_bits >> 2) & 1u), static_cast<int32_t>((hot_bits >> 1) & 1u), static_cast<int32_t>(hot_bits & 1u)};
-    const Span T{hot_num_steps, T_.action_stride, T_.obs_stride, T_.env_stride, T_.ring, static_cast<int32_t>((hot_bits >> 3) & 1u), PACKED ? 1 : 0};
+    const Span T{hot_num_steps, T_.action_stride, T_.obs_stride, T_.env_stride, T_.ring, static_cast<int32_t>((hot_bits >> 3) & 1u)};
     const int tid = threadIdx.x;
     // workgroup -> drones: the identity, or (T.xcd, large batches) every XCD one contiguous eighth of the drones instead of every eighth
     // workgroup -- at 65 536 drones that changed nothing (0.816 vs 0.813-0.821 us per step, round-2 A/B)
@@ -571,7 +562,7 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
 
     (void)term_obs12;   // (terminal observations: the host routes such calls to gpd_rollout_kernel -- a conditional
                         // store in this loop body would make the wait counts conservative again)
-    RollOut<NT_OBS, PACKED> ro(obs12, reward, terminated, truncated, T, goff, eoff4, L.env, sh_rows + tid * 12, lsrc);
+    RollOut<NT_OBS> ro(obs12, reward, terminated, truncated, T, goff, eoff4, L.env, sh_rows + tid * 12, lsrc);
     float irpy[3] = {0.0f, 0.0f, 0.0f};
     if (C.auto_reset) quat_to_rpy(ip[3], ip[4], ip[5], ip[6], irpy[0], irpy[1], irpy[2]);
     auto do_step = [&](const int t, const float4 act) {
@@ -684,12 +675,6 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
             // non-temporal streaming rate, profiles/README.md)
             static const char* const obs_stores = getenv("GPD_ROLLOUT_OBS_STORES");
             const bool plain_obs = obs_stores != nullptr && obs_stores[0] == 'p';
-            if (Tr.packed) {      // gpd_rollout_packed (step_impl let only this shape through): the headline's two store flavours, 8-byte records
-                if (plain_obs || (N <= (1 << 17) && T.num_steps >= 48))
-                    hipLaunchKernelGGL((gpd_rollout1_kernel<false, false, 4, GPD_ACT_RPM, true, false, false, false, true>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
-                else
-                    hipLaunchKernelGGL((gpd_rollout1_kernel<false, false, 4, GPD_ACT_RPM, true, false, true, false, true>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
-            } else
             if (C.substeps == 1 && !PID && !EXT && ACT == GPD_ACT_RPM && (plain_obs || (N <= (1 << 17) && T.num_steps >= 48)))
                 hipLaunchKernelGGL((gpd_rollout1_kernel<false, false, 4, GPD_ACT_RPM, true, false, false>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
             else if (C.substeps == 1)
@@ -731,9 +716,6 @@ int step_impl(const char* who, const GpdParams* params, const GpdState* state, c
     if (cfg->task != GPD_TASK_NONE && !target_pos) return bad(GPD_EINVAL, "task needs target_pos");
     if (cfg->auto_reset && !init_pose) return bad(GPD_EINVAL, "auto_reset needs init_pose");
     const bool multi = cfg->drones_per_env > 1;
-    if (T.packed && (multi || pid || cfg->physics_flags != 0 || cfg->act_type != GPD_ACT_RPM || cfg->substeps != 1 || term_obs12 || state->act_ring ||
-                     T.num_steps < 2))
-        return bad(GPD_ENOTSUP, "packed step records: single-drone aviaries, Physics.DYN, ActionType.RPM, one sub-step per step, num_steps >= 2, no terminal observations, no action ring");
     GpdStepCfg c = *cfg;
     if (c.lanes_per_wave == 0) c.lanes_per_wave = 64;
     if (c.lanes_per_wave != 16 && c.lanes_per_wave != 32 && c.lanes_per_wave != 64)
@@ -832,18 +814,6 @@ int gpd_rollout(const GpdParams* params, const GpdState* state, const GpdStepCfg
     if (state) { no_ring = *state; no_ring.act_ring = nullptr; }
     return step_impl("gpd_rollout", params, state ? &no_ring : nullptr, cfg, T, actions, target_pos, init_pose, obs12, reward,
                      terminated, truncated, term_obs12, stream);
-}
-
-int gpd_rollout_packed(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, int32_t num_steps,
-                       const float* actions, int64_t action_step_stride, const float* target_pos, const float* init_pose,
-                       float* obs12, int64_t obs_step_stride, uint64_t* step_out, int64_t env_step_stride, void* stream) {
-    if (num_steps <= 0) return fail(GPD_EINVAL, "gpd_rollout_packed: num_steps must be positive");
-    if (action_step_stride < 0 || obs_step_stride < 0 || env_step_stride < 0)
-        return fail(GPD_EINVAL, "gpd_rollout_packed: strides must be non-negative");
-    if (!step_out || (reinterpret_cast<uintptr_t>(step_out) & 7u)) return fail(GPD_EINVAL, "gpd_rollout_packed: step_out must be an 8-byte aligned device pointer");
-    const Span T{num_steps, action_step_stride, obs_step_stride, env_step_stride, 2, 0, 1};
-    return step_impl("gpd_rollout_packed", params, state, cfg, T, actions, target_pos, init_pose, obs12, reinterpret_cast<float*>(step_out),
-                     reinterpret_cast<uint8_t*>(step_out), reinterpret_cast<uint8_t*>(step_out), nullptr, stream);
 }
 
 int gpd_rollout_history(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, int32_t num_steps,

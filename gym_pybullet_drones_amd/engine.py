@@ -412,35 +412,6 @@ class SimCore:
                 self._latest_terminal(tobs, term, trunc, K)
         return obs, rew, term, trunc
 
-    def rollout_packed(self, actions: torch.Tensor):
-        """`rollout(actions)` with the per-aviary outputs of a step stored as ONE 8-byte record (`gpd_rollout_packed`: one store per
-        lane and step instead of three).  Returns `(obs12 [K,N,12], reward [K,E], terminated [K,E], truncated [K,E])` -- reward and
-        flags are STRIDED VIEWS of the record block (float32 at byte 0, the flag bytes at bytes 4 and 5 of every record), no unpacking
-        pass; values and trajectories are bit for bit those of `rollout()`.  Shapes the packed kernel is built for only
-        (single-drone aviaries, Physics.DYN, ActionType.RPM, one sub-step per step, K >= 2): `GpdError` otherwise.  The latest-step
-        tensors (`obs12`, `reward`, ...) are NOT updated."""
-        per = self.N * self.A
-        if action_needs_fix(actions, self.device):
-            actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
-        if actions.numel() % per != 0 or actions.numel() == 0:
-            raise ValueError(f"actions has {actions.numel()} elements, expected K x {self.N}x{self.A}")
-        K = actions.numel() // per
-        cache = self.__dict__.setdefault("_packed_cache", {})
-        buf = cache.get(K)
-        if buf is None:
-            cache.clear()
-            rec = torch.zeros((K, self.E), dtype=torch.int64, device=self.device)
-            by = rec.view(torch.uint8).view(K, self.E, 8)
-            buf = cache[K] = (torch.zeros((K, self.N, 12), dtype=torch.float32, device=self.device), rec,
-                              rec.view(torch.float32).view(K, self.E, 2)[..., 0], by[..., 4].view(torch.bool), by[..., 5].view(torch.bool))
-        obs, rec, rew, term, trunc = buf
-        self.state_version += 1
-        with torch.cuda.device(self.device):
-            rc = self.lib.gpd_rollout_packed(ctypes.byref(self._params), ctypes.byref(self._state), ctypes.byref(self._cfg), K, _ptr(actions), per,
-                                             _ptr(self.target), _ptr(self.init_pose), _ptr(obs), self.N * 12, _ptr(rec), self.E, self._stream())
-        _native.check(rc, "gpd_rollout_packed")
-        return obs, rew, term, trunc
-
     def rollout_policy(self, policy, num_steps: int, want_actions: bool = True, noise: torch.Tensor = None, action_std=None,
                        mean_out: torch.Tensor = None):
         """K env steps in ONE launch with `policy` (a `policy.MlpPolicy`) evaluated inside the kernel

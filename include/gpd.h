@@ -288,19 +288,6 @@ int gpd_rollout(const GpdParams* params, const GpdState* state, const GpdStepCfg
                 float* term_obs12, void* stream);
 
 /*
- * gpd_rollout with the per-aviary outputs of a step in ONE 8-byte record instead of three arrays:
- *     step_out[t * env_step_stride + env] = reward bits (float32, low word) | terminated << 32 | truncated << 40
- * (a host binding reads it back as strided views: the float at byte 0, the two flag bytes at bytes 4 and 5 of every record).  One
- * store per lane and step instead of a 4-byte and two 1-byte ones; trajectories, observation rows and the values themselves are
- * bit for bit those of gpd_rollout.  Shapes: single-drone aviaries, Physics.DYN, GPD_ACT_RPM, one sub-step per step, num_steps >= 2,
- * no terminal observations, no action ring (GPD_ENOTSUP otherwise: call gpd_rollout).  Round 6's A/B of the headline kernel
- * (profiles/r06_ab_packed_step_records.*).
- */
-int gpd_rollout_packed(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, int32_t num_steps,
-                       const float* actions, int64_t action_step_stride, const float* target_pos, const float* init_pose,
-                       float* obs12, int64_t obs_step_stride, uint64_t* step_out, int64_t env_step_stride, void* stream);
-
-/*
  * gpd_rollout that ALSO pushes every step's raw action into the action ring of `state` (act_ring / ring_pos / hist_len), the
  * way gpd_step does: for a consumer that keeps the history as the zero-copy view (envs/BaseRLAviary.py:65-67, 153-154, 187) and
  * needs no materialised rows -- the K actions never take the detour through a second kernel (gpd_full_obs with obs_full =

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """VERDICT r05 #5, candidate 2: the three per-step small stores of the headline kernel (reward 4 B + two flag bytes per aviary) folded into
 ONE 8-byte record (`gpd_rollout_packed`), unpacked host-side as strided views.  A/B against `gpd_rollout` on the driver's command shape
-(65 536 HoverAviaries, 240 Hz, K = 20 steps per launch) and at K = 64, interleaved rounds in one process, HIP events; bitwise check first."""
+(65 536 HoverAviaries, 240 Hz, K = 20 steps per launch) and at K = 64, interleaved rounds in one process, HIP events; bitwise check first.
+Result (profiles/r06_ab_packed_step_records.json): +0.67 % / +0.06 % -- not kept.  The variant is scratch/exp_r06/packed_records.patch
+(`patch -p1` on the tree, rebuild, then this script runs)."""
 import json
 import os
 import sys

@@ -263,11 +263,16 @@ def test_population_of_65536_closed_loop_hover_episodes_matches_the_float64_popu
     260 control steps = one full 8 s episode and the start of the next, fp32 HIP against oracle/gpd_oracle.c.  Compared:
       * the distributions of the first episode's return and of the step it ended at: relative difference of the means < 1e-3,
         two-sample Kolmogorov-Smirnov p > 0.01;
-      * at EVERY step the population mean and standard deviation of position and attitude, over the aviaries that are in the
-        same episode on both sides (1.2 % are not: a tilt within rounding of 0.4 rad ends the episode on one side a step
-        earlier, and from then on one side shows the reset pose where the other still flies): within 1e-4 of the group's scale;
-      * the same moments over ALL aviaries against what two float64 populations differ by (the second one nudged by the fp32
-        state array's rounding, relative 2^-24 sqrt(8) per control step): within 3x of that envelope."""
+      * at EVERY step the population mean and standard deviation of position and attitude against what two float64 populations
+        differ by (the second one nudged by the fp32 state array's rounding, relative 2^-24 sqrt(8) per control step): within 3x of
+        that envelope -- over ALL aviaries, and over the aviaries that are in the same episode on both sides (1.2 % are not: a tilt
+        within rounding of 0.4 rad ends the episode on one side a step earlier, and from then on one side shows the reset pose where
+        the other still flies).  VERDICT r05 asked for "within 1e-4 of the scale" here; two float64 populations do not meet that
+        (measured, round 6, nudged float64 against float64 over all aviaries: rpy mean 6.6e-4, rpy std 4.3e-4, pos mean 1.8e-4, pos
+        std 1.9e-4 of the scale -- 65 536 chattering attitude loops average to ~1e-4 rad, not to zero), so the float64 pair is the
+        yardstick: the fp32 population reads 6.3e-4 / 4.3e-4 / 1.5e-4 / 1.7e-4, 0.84 - 0.99 of it; over the aviaries in the same episode
+        fp32 | float64 pair: rpy mean 4.6e-4 | 5.7e-4, rpy std 2.7e-4 | 2.3e-4, pos mean 9.4e-5 | 6.8e-5, pos std 1.2e-4 | 1.3e-4
+        (profiles/r06_parity_measured.log)."""
     import os
     from scipy import stats
     from oracle import bullet_math as bm
@@ -287,8 +292,9 @@ def test_population_of_65536_closed_loop_hover_episodes_matches_the_float64_popu
     end = {s: np.zeros(E, dtype=np.int64) for s in sides}
     hist = {s: np.zeros(E, dtype=np.int64) for s in sides}        # episodes ended so far: equal on two sides = the same episode
     groups = (("pos", slice(0, 3)), ("rpy", slice(3, 6)))
-    matched = dict.fromkeys([f"{g}_{m}" for g, _ in groups for m in ("mean", "std")], 0.0)
-    everyone = {k: [0.0, 0.0] for k in matched}                    # [fp32 vs f64, f64 nudged vs f64], worst step
+    keys = [f"{g}_{m}" for g, _ in groups for m in ("mean", "std")]
+    matched = {k: [0.0, 0.0] for k in keys}                        # [fp32 vs f64, f64 nudged vs f64], worst step, aviaries in the same episode
+    everyone = {k: [0.0, 0.0] for k in keys}                       # the same over all aviaries
     eps = 2.0 ** -24 * np.sqrt(S)
     c_oracle.lib().orc_set_threads(min(len(os.sched_getaffinity(0)), c_oracle.lib().orc_max_threads()))
     try:
@@ -309,15 +315,16 @@ def test_population_of_65536_closed_loop_hover_episodes_matches_the_float64_popu
                 end[side] = np.where(first & done, k + 1, end[side])
                 hist[side] += done
             # (the observation row of an aviary that ended in this step is its reset pose: same-step auto-reset)
-            same = hist["hip"] == hist["f64"]
+            same = {"hip": hist["hip"] == hist["f64"], "f64n": hist["f64n"] == hist["f64"]}
             for g, sl in groups:
                 scale = max(float(np.abs(o["f64"][:, sl]).max()), 1.0)
                 for m, fn in (("mean", np.mean), ("std", np.std)):
                     key = f"{g}_{m}"
-                    matched[key] = max(matched[key], float(np.abs(fn(o["hip"][same][:, sl], axis=0) - fn(o["f64"][same][:, sl], axis=0)).max() / scale))
                     ref = fn(o["f64"][:, sl], axis=0)
-                    everyone[key][0] = max(everyone[key][0], float(np.abs(fn(o["hip"][:, sl], axis=0) - ref).max() / scale))
-                    everyone[key][1] = max(everyone[key][1], float(np.abs(fn(o["f64n"][:, sl], axis=0) - ref).max() / scale))
+                    for j, side in enumerate(("hip", "f64n")):
+                        sel = same[side]
+                        matched[key][j] = max(matched[key][j], float(np.abs(fn(o[side][sel][:, sl], axis=0) - fn(o["f64"][sel][:, sl], axis=0)).max() / scale))
+                        everyone[key][j] = max(everyone[key][j], float(np.abs(fn(o[side][:, sl], axis=0) - ref).max() / scale))
     finally:
         c_oracle.lib().orc_set_threads(1)
     assert all((end[s] > 0).all() for s in sides)                       # every aviary finished its first episode (time limit: step 241)
@@ -330,15 +337,16 @@ def test_population_of_65536_closed_loop_hover_episodes_matches_the_float64_popu
           f"rel diff {d_ret:.2e}, KS D {ks_ret.statistic:.2e} p {ks_ret.pvalue:.3f}; end step mean {end['f64'].mean():.2f} rel diff {d_end:.2e}, "
           f"KS D {ks_end.statistic:.2e} p {ks_end.pvalue:.3f}; same end step drone by drone: fp32 {same_end:.4f}, nudged float64 {same_end_n:.4f}; "
           f"still in the same episode at the end {float((hist['hip'] == hist['f64']).mean()):.4f}")
-    print("POPULATION moments, worst step, aviaries in the same episode on both sides: " + " ".join(f"{n}={v:.2e}" for n, v in matched.items()))
-    print("POPULATION moments, worst step, ALL aviaries [fp32 vs f64 | nudged f64 vs f64]: " + " ".join(f"{n}={a:.2e}|{b:.2e}" for n, (a, b) in everyone.items()))
+    for name, table in (("aviaries in the same episode on both sides", matched), ("ALL aviaries", everyone)):
+        print(f"POPULATION moments, worst step, {name} [fp32 vs f64 | nudged f64 vs f64]: " + " ".join(f"{n}={a:.2e}|{b:.2e}" for n, (a, b) in table.items()))
     assert 0.15 < early < 0.8                                           # the scene does produce a distribution of episode lengths
     assert d_ret < 1e-3 and d_end < 1e-3
     assert ks_ret.pvalue > 0.01 and ks_end.pvalue > 0.01
     assert abs(same_end - same_end_n) < 0.01                            # the fp32 run leaves the float64 one as often as a float64 run does
-    assert max(matched.values()) < 1e-4, matched
-    for key, (a, b_) in everyone.items():
-        assert a <= 3.0 * b_ + 2e-5, (key, a, b_)
+    for table in (matched, everyone):
+        for key, (a, b_) in table.items():
+            assert a <= 3.0 * b_ + 2e-5, (key, a, b_)
+            assert a < 1e-3, (key, a)                                   # ... and small in absolute terms whatever the yardstick reads
 
 
 def _sync_c(core, orc):

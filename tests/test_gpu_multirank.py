@@ -51,7 +51,7 @@ def test_bench_gpus_2_launches_its_two_ranks_itself(gpu_device):
 def test_bench_gpus_2_default_run_carries_the_suite_and_the_hbm_leg(gpu_device):
     """What the driver's SCALE run gets from one command: the headline with the topology the ranks found, the HBM-saturating leg
     beside it, and BASELINE configs 4 and 5 under `suite`."""
-    j = _bench_self(["--steps", "20", "--warmup", "5", "--min-time", "0.05", "--no-cpu-baseline"], timeout=2400)
+    j = _bench_self(["--steps", "20", "--warmup", "5", "--min-time", "0.05", "--no-cpu-baseline", "--hbm-leg-time", "0.3", "--hbm-leg-reallocations", "1"], timeout=2400)
     assert j["n_gpus"] == 2 and j["config"]["workload"] == "hover65536_240hz"
     h = j["hbm_saturating"]
     assert h["workload"] == "hover4m_240hz" and h["bytes_per_launch"] > 4 * 256 * 2 ** 20 and 0.2 < h["frac"] < 1.1
@@ -74,7 +74,7 @@ def test_bench_gpus_8_rehearsal_of_the_driver_command(gpu_device):
     this build: no hardware scaling curve exists): eight per-GPU values, eight ranks in the process group, the HBM leg, and the suite
     with BASELINE config 4 (with AND without the all-gather) and config 5.  (The one-world workload split over eight ranks:
     `test_bench_extra_eight_ranks_share_the_1m_world`.)"""
-    j = _bench_self(["--steps", "20", "--warmup", "5", "--min-time", "0.02", "--hbm-leg-time", "0.05", "--no-cpu-baseline", "--suite-timeout", "900"],
+    j = _bench_self(["--steps", "20", "--warmup", "5", "--min-time", "0.02", "--hbm-leg-time", "0.05", "--hbm-leg-reallocations", "1", "--no-cpu-baseline", "--suite-timeout", "900"],
                     timeout=2400, gpus=8, GPD_BENCH_E_DIV="8")
     assert j["n_gpus"] == 8 and len(j["per_gpu"]["values"]) == 8 and j["config"]["ranks_in_process_group"] == 8
     assert j["config"]["rehearsal_divisor"] == 8 and j["config"]["total_drones"] == 8 * 8192 and "self-launch" in j["config"]["launcher"]
@@ -115,11 +115,11 @@ def test_dry_run_topology_and_two_rccl_ranks_on_one_device_fail_fast(gpu_device)
 
 
 def test_bench_watchdog_prints_the_headline_when_the_suite_hangs(gpu_device):
-    """A collective of a workload that has never met the node hangs: injected (`GPD_BENCH_INJECT_HANG=suite`: every rank sleeps inside
-    the suite).  The watchdog prints the headline line it holds, with the suite's entry saying what happened, and every rank leaves:
-    return code 0, ONE JSON line."""
+    """A collective of a workload that has never met the node hangs: staged by tests/helpers/bench_with_a_hanging_suite.py (bench.py with
+    a suite whose first workload sleeps forever on every rank).  The watchdog prints the headline line it holds, with the suite's entry
+    saying what happened, and every rank leaves: return code 0, ONE JSON line."""
     j = _bench_self(["--steps", "20", "--warmup", "5", "--min-time", "0.02", "--no-cpu-baseline", "--no-hbm-leg", "--suite-timeout", "25"],
-                    timeout=900, gpus=4, GPD_BENCH_E_DIV="8", GPD_BENCH_INJECT_HANG="suite")
+                    timeout=900, gpus=4, script=os.path.join("tests", "helpers", "bench_with_a_hanging_suite.py"), GPD_BENCH_E_DIV="8")
     assert j["n_gpus"] == 4 and j["value"] > 0 and len(j["per_gpu"]["values"]) == 4
     assert "not finished after 25 s" in j["suite"]["error"]
 

@@ -351,8 +351,10 @@ def test_closed_loop_dslpid_low_rate_stays_inside_the_float64_envelope(gpu_devic
     once per physics sub-step, half an ulp (relative 2^-24) with a random sign each time, S = pyb_freq / ctrl_freq of them per
     control step adding in quadrature: relative 2^-24 sqrt(S) -- and demand that the fp32 HIP run stays within a small factor
     of that envelope at every checkpoint, per field group, on the 95th percentile and the median over 1024 drones.  (Measured
-    on the MI355X, round 6, worst checkpoint: PID 0.8 / 0.8, VEL 1.9 / 1.1, ONE_D_PID 2.0 / 1.4, MultiHover PID 1.2 / 0.9 at
-    30 / 48 Hz; with one half-ulp nudge per control step, the round-2 form of this test, the same runs read 2.3 - 5.8.)"""
+    on the MI355X, round 6, worst checkpoint, median / p95 of fp32 over the envelope: PID 1.05 / 1.03 at 30 Hz and 1.04 / 0.96 at
+    48 Hz, VEL 2.01 / 1.94 and 1.28 / 1.07, ONE_D_PID 2.56 / 1.26 and 1.39 / 1.12, MultiHover PID with 2 drones 1.31 / 1.32 and
+    1.32 / 0.99, with 3 drones 1.27 / 1.18 and 1.25 / 1.02 -- profiles/r06_parity_measured.log; with ONE half-ulp nudge per control
+    step, the round-2 form of this test, the same runs read 2.3 - 5.8: the fp32 array is rounded S times per control step.)"""
     rng = np.random.default_rng(100 + ctrl + 1000 * D + zlib.crc32(act.encode()) % 997)
     E, S, T = 1024 // D, 240 // ctrl, 48
     task = "hover" if D == 1 else "multihover"

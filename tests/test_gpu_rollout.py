@@ -243,3 +243,40 @@ def test_rollout_with_lazy_history_pushes_the_ring_inside_the_kernel(gpu_device,
         np.testing.assert_array_equal(tail[:, :, h, :], sent[idx] if idx >= 0 else np.zeros((E, D, A), dtype=np.float32))
     o, *_ = a.step(acts[0]); p, *_ = b.step(acts[0])          # and stepping goes on from the same ring
     assert torch.equal(o, p) and torch.equal(a.history(), b.history())
+
+
+def test_rollout_arena_places_the_blocks_and_changes_no_bit(gpu_device):
+    """`placement.RolloutArena` (at millions of drones the launch's rate follows the physical placement of its blocks,
+    so the library carves them out of one arena at offsets it chooses by probing with the launch itself): at a size a test can afford
+    the search runs its probes, installs the winning blocks as the core's rollout buffers, the action view lives inside the arena, and
+    a rollout through the arena is bit for bit the rollout of a core with ordinary buffers.  Candidate layouts: inside the arena,
+    disjoint, no duplicates (`layout_candidates`, also checked without a GPU in tests/test_host_logic.py)."""
+    from gym_pybullet_drones_amd.envs import VectorHoverAviary
+    from gym_pybullet_drones_amd.placement import RolloutArena, layout_candidates, place_rollout
+    from gym_pybullet_drones_amd.utils.enums import ActionType
+    E, K = 16384, 16
+    rng = np.random.default_rng(5)
+    a = VectorHoverAviary(E, act=ActionType.RPM, ctrl_freq=240, auto_reset=True, device=gpu_device)
+    b = VectorHoverAviary(E, act=ActionType.RPM, ctrl_freq=240, auto_reset=True, device=gpu_device)
+    arena = RolloutArena(a.core, K, arena_bytes=256 << 20, grid_bytes=16 << 20)
+    cand = arena.candidates()
+    assert len(cand) == len(set(cand)) > 50
+    assert all(h + arena.head_bytes <= arena.bytes and t + arena.tail_bytes <= arena.bytes and
+               (t + arena.tail_bytes <= h or t >= h + arena.head_bytes) for h, t in cand)
+    rep = arena.search(target=2.0, max_probes=6)          # an unreachable target: all six probes run, the best one is installed
+    assert rep["probes"] == 6 and not rep["reached_target"] and 0 < rep["best_frac_in_search"] < 1.5 and len(rep["all_probes"]) == 6
+    lo, hi = arena.slab.data_ptr(), arena.slab.data_ptr() + arena.bytes
+    obs_buf = a.core._rollout_cache[K][0]
+    assert lo <= obs_buf.data_ptr() < hi and lo <= arena.actions.data_ptr() < hi and arena.actions.shape == (K, E, 4)
+    assert arena.layout == (int(rep["obs_at_gib"] * 2 ** 30), int(rep["tail_at_gib"] * 2 ** 30))
+    a.reset(); b.reset()
+    acts = torch.as_tensor(rng.uniform(-1, 1, size=(K, E, 1, 4)).astype(np.float32), device=gpu_device)
+    arena.actions.copy_(acts.view(K, E, 4))
+    for _ in range(3):
+        oa = a.core.rollout(arena.actions)
+        ob = b.core.rollout(acts)
+        assert oa[0].data_ptr() == obs_buf.data_ptr()                    # the arena's blocks ARE the rollout buffers
+        assert all(torch.equal(x, y) for x, y in zip(oa, ob)) and torch.equal(a.core.kin_store, b.core.kin_store)
+    arena2, rep2 = place_rollout(b.core, K, target=0.0, max_arenas=2, max_probes=4)       # a target every layout reaches: one confirmed probe
+    assert rep2["probes"] == 1 and rep2["arenas_tried"] == 1 and rep2["reached_target"] and "confirmed_frac" in rep2["all_probes"][0]
+    assert b.core._rollout_cache[K][0].data_ptr() >= arena2.slab.data_ptr()

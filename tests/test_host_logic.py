@@ -258,6 +258,19 @@ def test_package_installs_with_pip_and_imports_from_anywhere(tmp_path):
         "exec(" not in open(os.path.join(REPO, "gym_pybullet_drones_amd", "__init__.py")).read()      # the alias hack is gone
 
 
+def test_placement_layout_candidates_are_disjoint_and_spread():
+    """`placement.layout_candidates`: every (head, tail) pair on the grid lies inside the arena with the two units disjoint, no pair
+    twice, and the probing order is spread out (the first eight probes already span most of the arena in both coordinates)."""
+    from gym_pybullet_drones_amd.placement import GiB, layout_candidates
+    A, H, T, G = 88 * GiB, 12 * GiB, int(5.6 * GiB), int(2.2 * GiB)
+    c = layout_candidates(A, H, T, G)
+    assert len(c) == len(set(c)) > 500
+    assert all(0 <= h and h + H <= A and 0 <= t and t + T <= A and (t + T <= h or t >= h + H) for h, t in c)
+    first = c[:8]
+    assert max(h for h, _ in first) - min(h for h, _ in first) > A / 2 and max(t for _, t in first) - min(t for _, t in first) > A / 2
+    assert layout_candidates(H + T, H, T, G) == [(0, H)] or len(layout_candidates(H + T + G, H, T, G)) >= 2      # (a tight arena still has a layout)
+
+
 def test_logger_layout_and_files(tmp_path):
     """Reference layout: states (N,16,T) = [pos, vel, rpy, ang_vel, rpm] re-ordered from the 20-float state vector
     (utils/Logger.py:117), growing arrays when duration_sec = 0, one CSV per signal and drone."""

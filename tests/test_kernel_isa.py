@@ -15,8 +15,7 @@ import pytest
 
 from conftest import REPO
 
-HEADLINE = "gpd_rollout1_kernelILb0ELb0ELi4ELi0ELb1ELb0ELb0ELb0ELb0EE"  # <PID=0, EXT=0, AW=4, ACT=RPM, S1=1, MULTI=0, NT_OBS=0, RING=0, PACKED=0>
-HEADLINE_PACKED = "gpd_rollout1_kernelILb0ELb0ELi4ELi0ELb1ELb0ELb0ELb0ELb1EE"  # ... PACKED=1 (gpd_rollout_packed)
+HEADLINE = "gpd_rollout1_kernelILb0ELb0ELi4ELi0ELb1ELb0ELb0ELb0EE"  # <PID=0, EXT=0, AW=4, ACT=RPM, S1=1, MULTI=0, NT_OBS=0, RING=0>
 
 
 POLICY = "gpd_rollout_policy_kernelILb0ELi4ELi0ELi5ELb0E"  # <PID=0, AW=4, ACT=RPM, NK1=5 (72-float rows), tanh>
@@ -107,19 +106,6 @@ def test_action_rows_are_claimed_with_an_exact_count(headline_isa):
     # stores of the loop use <uniform base in SGPRs> + <32-bit lane offset>
     stores = [s for op, s in _ops(loop[:first]) if op.startswith("global_store")]
     assert len(stores) == 18 and all(re.search(r"s\[\d+:\d+\]", s) for s in stores), stores[:3]
-
-
-def test_packed_records_leave_four_stores_per_step(gpd_asm):
-    """gpd_rollout_packed's variant of the headline kernel: reward and flags as one 8-byte record -> 4 stores per step instead of 6,
-    so the action rows of the next iteration are claimed with vmcnt(12) (3 x 4 stores may still be in flight), nothing else waits."""
-    body, meta = _kernel(gpd_asm, HEADLINE_PACKED)
-    assert re.search(r"ScratchSize: 0\b", meta)
-    writes = [i for i, l in enumerate(body) if "ds_write_b128" in l]
-    loop = body[writes[0]:]
-    first = next(i for i, l in enumerate(loop) if "vmcnt(12)" in l)
-    assert not [l for l in loop[:first] if "s_waitcnt" in l and "vmcnt" in l]
-    stores = [s for op, s in _ops(loop[:first]) if op.startswith("global_store")]
-    assert len(stores) == 12 and sum("dwordx2" in s for s in stores) == 3 and not [s for s in stores if "store_byte" in s], stores
 
 
 def test_policy_kernel_runs_its_layers_on_the_matrix_cores(policy_asm):
