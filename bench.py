@@ -299,7 +299,7 @@ def attach_counters(roof, key, m, core, clock_ghz):
                 roof["traffic"] = rec["traffic_bytes"] / rec["algorithmic_bytes"] * roof["bytes_per_launch"]
                 roof["traffic_note"] = (f"counters of the {prof_steps}-step profile launch scaled by the algorithmic bytes to this "
                                         f"launch's {spl:g} steps (profiles/hbm_traffic.json)")
-            roof["rocprof_kernel_avg_us"] = rec.get("rocprof_kernel_avg_ns", 0) / 1e3 if spl == prof_steps else None
+            roof["rocprof_kernel_avg_us"], roof["rocprof_note"] = (rec.get("rocprof_kernel_avg_ns", 0) / 1e3 if spl == prof_steps else None), rec.get("rocprof_note")
     cfile = os.path.join(REPO, "profiles", "kernel_counters.json")
     if os.path.exists(cfile):
         rec = json.load(open(cfile)).get(key)
@@ -355,24 +355,21 @@ def dropin_single_env(device, steps=2420):
             env.reset()
             episodes += 1
     dt = time.perf_counter() - t0
-    core, n = env._core, 1000
-    t1 = time.perf_counter()
-    for _ in range(n):
-        core.step(core.action_host)
-    t2 = time.perf_counter()
-    for _ in range(n):
-        env._updateAndStoreKinematicInformation()
-    t3 = time.perf_counter()
-    for _ in range(n):
-        env._computeObs()
-    t4 = time.perf_counter()
+    core = env._core
+
+    def per_call_us(fn, n=1000):
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        return (time.perf_counter() - t) / n * 1e6
+    parts = {"launch_and_stream_sync": per_call_us(core.step_host), "numpy_kinematic_refresh": per_call_us(env._updateAndStoreKinematicInformation),
+             "observation_row_with_history": per_call_us(env._computeObs)}
     S = int(env.PYB_STEPS_PER_CTRL)
     out = {"us_per_step": dt / steps * 1e6, "env_steps_per_s": steps / dt, "value": steps * S / dt, "unit": "drone-steps/s", "steps": steps,
            "episodes_ended": episodes, "state_memory": "host-visible (page-locked, device-mapped)" if core.host_visible else "HBM",
-           "breakdown_us": {"launch_and_stream_sync": (t2 - t1) / n * 1e6, "numpy_kinematic_refresh": (t3 - t2) / n * 1e6,
-                            "observation_row_with_history": (t4 - t3) / n * 1e6},
-           "what": "for k in range(2420): HoverAviary(act=ONE_D_RPM).step(a[k]) (+ reset at episode ends), wall clock; one gpd_step launch and "
-                   "one stream synchronisation per call, no device-to-host copy, no second launch"}
+           "breakdown_us": parts,
+           "what": "for k in range(2420): HoverAviary(act=ONE_D_RPM).step(a[k]) (+ reset at episode ends), wall clock; one gpd_step_sync call "
+                   "(launch + stream wait) per step, no device-to-host copy, no second launch"}
     env.close()
     try:        # the reference's OWN Python on the same schedule (quoted: /root/reference does not exist on this box)
         rec = json.load(open(os.path.join(REPO, "profiles", "r05_reference_python_dyn_cpu.json")))
@@ -584,33 +581,39 @@ def hbm_leg(args, job, out):
     finally:
         dog.done()
     # The extras have their own guard and their own budget: a failure or a time-out in them leaves `on_fresh_allocations` partial and
-    # the leg's figure -- already measured -- in the line.
+    # the leg's figure -- already measured -- in the line.  Every rank re-runs on its own (no collective inside): the same
+    # environment, its rollout blocks freed and placed again -- a new arena searched (or, without the search, new plain allocations).
     copy, again, again_note = None, [], None
-    from gym_pybullet_drones_amd import dist as gdist
-    if gdist.all_ranks_ok(r is None or "error" not in r, device=job.device):       # (every rank takes the same branch: the re-runs hold collectives)
-        n_again = int(getattr(args, "hbm_leg_reallocations", 10))
-        budget = min(90.0, args.suite_timeout)
-
-        def late(o):
-            o["hbm_saturating"] = hbm_block(r, copy, again, f"the re-runs on fresh allocations were cut after {budget:.0f} s")
-        dog2 = Watchdog(budget, job, out, late)
+    if (r is None or "error" not in r) and getattr(job, "last_env", None) is not None:
+        n_again, budget = int(getattr(args, "hbm_leg_reallocations", 10)), min(90.0, args.suite_timeout)
+        dog2 = Watchdog(budget, job, out, lambda o: o.__setitem__("hbm_saturating", hbm_block(r, copy, again, f"the re-runs on fresh allocations were cut after {budget:.0f} s")))
         try:
+            import gc
             if job.rank == 0:
                 copy = copy_probe(job.device)
-            b = argparse.Namespace(**vars(a))
-            b.min_time, b.no_parity, b.segment_events, b.steps, b.warmup = 0.15, True, 0, 64, 64
+            env, core = job.last_env, job.last_env.core
             for _ in range(n_again):
-                import gc
+                env.placement_arena = acts = None
+                core.__dict__.get("_rollout_cache", {}).clear()
                 gc.collect()
                 torch.cuda.empty_cache()
-                rr = run_workload(b, job)
-                if job.rank == 0 and rr and "roofline" in rr:
-                    again.append({"frac": rr["roofline"]["frac"], "launch_us_hip_events": rr["roofline"]["launch_us_hip_events"], "timed_region_ms": rr["timed_region_ms"],
-                                  **({"probes": rr["placement"]["probes"], "arenas_tried": rr["placement"]["arenas_tried"], "levels_seen": rr["placement"]["seen"]} if "placement" in rr else {})})
+                rep = None
+                if a.placement_search:
+                    from gym_pybullet_drones_amd.placement import place_rollout
+                    env.placement_arena, rep = place_rollout(core, POOL, target=args.placement_target)
+                    acts = env.placement_arena.actions
+                else:
+                    acts = torch.rand((POOL, core.N, core.A), device=job.device) * 2 - 1
+                core.rollout(acts, update_latest=False)
+                n = 45                                                      # (0.15 s of 64-step launches)
+                sec = event_seconds(lambda: core.rollout(acts, update_latest=False), n)
+                again.append({"frac": core.bytes_per_rollout(POOL) / sec / (HBM_PEAK_GBS * 1e9), "launch_us_hip_events": sec * 1e6, "launches": n,
+                              **({"probes": rep["probes"], "arenas_tried": rep["arenas_tried"], "levels_seen": rep["seen"]} if rep else {})})
         except Exception as e:      # noqa: BLE001
             again_note = f"stopped after {len(again)} re-runs: {type(e).__name__}: {e}"[:300]
         finally:
             dog2.done()
+            job.last_env = None
     if job.rank == 0:
         out["hbm_saturating"] = r if "error" in r else hbm_block(r, copy, again, again_note)
         if "error" not in r:
@@ -631,7 +634,8 @@ def hbm_block(r, copy, again, again_note):
         "segments": r.get("segments"), "clock_ghz_after": r.get("clock_ghz_after_timed_region"),
         # how the blocks of the launch were placed: by search inside one arena, the launch itself as the probe (or: as the allocator handed them out)
         "placement": r.get("placement") or {"what": "as allocated (no search)"},
-        # the same leg on freshly allocated buffers / arenas (this process, 0.15 s each): does the rate depend on the allocation?
+        # the same environment with its blocks freed and placed again (a fresh arena searched / fresh plain allocations), 0.15 s each:
+        # does the rate depend on the allocation?
         "on_fresh_allocations": again, "frac_range_over_allocations": [min(fr), max(fr)], "frac_spread_over_allocations": (max(fr) - min(fr)) / max(fr),
         "allocations_seen": len(fr), **({"on_fresh_allocations_note": again_note} if again_note else {}),
         # what a plain device-to-device copy reaches on THIS box in THIS process ("measure achievable ... and quote both")
@@ -639,6 +643,18 @@ def hbm_block(r, copy, again, again_note):
         **rocprof_record("hover4m_240hz:rollout64"),
         "parity": {k: r["parity"].get(k) for k in ("checked_steps", "max", "tolerance", "ok", "flag_mismatch_frac", "error") if k in r.get("parity", {})},
         "note": "working set of one launch >> the 256 MiB Infinity Cache: this rate is served by HBM"}
+
+
+def event_seconds(fn, reps):
+    """seconds per call of `fn`, HIP events on the current stream around `reps` back-to-back calls"""
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(reps):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) * 1e-3 / reps
 
 
 def copy_probe(device, mib=1024, reps=20):
@@ -650,16 +666,8 @@ def copy_probe(device, mib=1024, reps=20):
         b = torch.empty_like(a)
         res = {}
         for name, fn, nbytes in (("gbs", lambda: b.copy_(a), 2 * n * 4), ("fill_gbs", lambda: b.fill_(1.0), n * 4)):
-            for _ in range(3):
-                fn()
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            ev0.record()
-            for _ in range(reps):
-                fn()
-            ev1.record()
-            torch.cuda.synchronize()
-            res[name] = nbytes * reps / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+            event_seconds(fn, 3)
+            res[name] = nbytes / event_seconds(fn, reps) / 1e9
         return dict(res, mib=mib, reps=reps, what="torch Tensor.copy_ device to device (read + write bytes); fill_gbs: Tensor.fill_ of the same buffer (write only)")
     except Exception as e:          # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"[:160]}
@@ -729,12 +737,7 @@ def rehearsal_scale(w):
     k = int(os.environ.get("GPD_BENCH_E_DIV", "1") or 1)
     if k <= 1:
         return w, 1
-    w = dict(w)
-    if w.get("swarm"):
-        w["D"] = max(4096, w["D"] // k)
-    else:
-        w["E"] = max(256, w["E"] // k)
-    return w, k
+    return dict(w, **({"D": max(4096, w["D"] // k)} if w.get("swarm") else {"E": max(256, w["E"] // k)})), k
 
 
 def run_workload(args, job):
@@ -796,6 +799,7 @@ def run_workload(args, job):
         plain = measure(mode, args, env, actions, None, device, world)
         env.reset()
     m = measure(mode, args, env, actions, gather, device, world)
+    job.last_env = env                      # (the hbm leg re-places this environment's blocks for its re-runs)
 
     parity = None
     if w.get("parity"):                     # (bench_extra.py's workloads bring their own checker; collective where the world is shared)

@@ -61,26 +61,16 @@ class BaseAviary(Env):
         if gui or record or vision_attributes:
             raise NotImplementedError("GUI, video recording and camera observations are outside the MI355X hot path")
         # constants, under the reference's names
-        self.G = 9.8
-        self.RAD2DEG = 180 / np.pi
-        self.DEG2RAD = np.pi / 180
-        self.CTRL_FREQ = ctrl_freq
-        self.PYB_FREQ = pyb_freq
-        if self.PYB_FREQ % self.CTRL_FREQ != 0:
+        if pyb_freq % ctrl_freq:
             raise ValueError('[ERROR] in BaseAviary.__init__(), pyb_freq is not divisible by env_freq.')
-        self.PYB_STEPS_PER_CTRL = int(self.PYB_FREQ / self.CTRL_FREQ)
-        self.CTRL_TIMESTEP = 1. / self.CTRL_FREQ
-        self.PYB_TIMESTEP = 1. / self.PYB_FREQ
-        self.NUM_DRONES = num_drones
-        self.NEIGHBOURHOOD_RADIUS = neighbourhood_radius
-        self.DRONE_MODEL = drone_model
-        self.GUI, self.RECORD = False, False
+        self.G, self.RAD2DEG, self.DEG2RAD = 9.8, 180 / np.pi, np.pi / 180
+        self.CTRL_FREQ, self.PYB_FREQ, self.PYB_STEPS_PER_CTRL = ctrl_freq, pyb_freq, pyb_freq // ctrl_freq
+        self.CTRL_TIMESTEP, self.PYB_TIMESTEP = 1.0 / ctrl_freq, 1.0 / pyb_freq
+        self.NUM_DRONES, self.NEIGHBOURHOOD_RADIUS, self.DRONE_MODEL = num_drones, neighbourhood_radius, drone_model
+        self.GUI, self.RECORD, self.OBSTACLES, self.USER_DEBUG = False, False, obstacles, user_debug_gui
         self.PHYSICS = physics
         warn_if_pyb(physics)                  # Physics.PYB* runs the explicit integrator here: say so, once
-        self.OBSTACLES = obstacles
-        self.USER_DEBUG = user_debug_gui
-        self.URDF = self.DRONE_MODEL.value + ".urdf"
-        self.OUTPUT_FOLDER = output_folder
+        self.URDF, self.OUTPUT_FOLDER = drone_model.value + ".urdf", output_folder
         self.CLIENT = -1                      # there is no PyBullet client
         P = DroneParams(drone_model)
         for name in ("M", "L", "THRUST2WEIGHT_RATIO", "J", "J_INV", "KF", "KM", "COLLISION_H", "COLLISION_R",
@@ -96,13 +86,12 @@ class BaseAviary(Env):
         else:
             raise ValueError("[ERROR] invalid initial_xyzs in BaseAviary.__init__(), try initial_xyzs.reshape(NUM_DRONES,3)")
         if initial_rpys is None:
-            self.INIT_RPYS = np.zeros((self.NUM_DRONES, 3))
-        elif np.array(initial_rpys).shape == (self.NUM_DRONES, 3):
+            self.INIT_RPYS = np.zeros_like(self.INIT_XYZS)
+        elif np.shape(initial_rpys) == (num_drones, 3):
             self.INIT_RPYS = np.array(initial_rpys, dtype=np.float64)
         else:
             raise ValueError("[ERROR] invalid initial_rpys in BaseAviary.__init__(), try initial_rpys.reshape(NUM_DRONES,3)")
-        self.action_space = self._actionSpace()
-        self.observation_space = self._observationSpace()
+        self.action_space, self.observation_space = self._actionSpace(), self._observationSpace()
         # the engine: one aviary of NUM_DRONES drones; GPD_HOST_VISIBLE=0 keeps its state in HBM instead (A/B)
         fused = self._fusedActionCode()
         self._fused_action = fused is not None
@@ -150,13 +139,10 @@ class BaseAviary(Env):
         else:
             core.step(torch.as_tensor(np.ascontiguousarray(row, dtype=np.float32).reshape(self.NUM_DRONES, -1), device=core.device))
         self._updateAndStoreKinematicInformation()
-        obs = self._computeObs()
-        reward = self._computeReward()
-        terminated = self._computeTerminated()
-        truncated = self._computeTruncated()
-        info = self._computeInfo()
-        self.step_counter = self.step_counter + (1 * self.PYB_STEPS_PER_CTRL)
-        return obs, reward, terminated, truncated, info
+        # the hooks, in the reference's order (a subclass may rely on it): obs, reward, terminated, truncated, info
+        result = (self._computeObs(), self._computeReward(), self._computeTerminated(), self._computeTruncated(), self._computeInfo())
+        self.step_counter += self.PYB_STEPS_PER_CTRL
+        return result
 
 
     def render(self, mode='human', close=False):
@@ -231,9 +217,8 @@ class BaseAviary(Env):
 
     def _getDroneStateVector(self, nth_drone):
         """(20,) state vector: pos3 | quat4 | rpy3 | vel3 | ang_v3 | last_clipped_action4."""
-        state = np.hstack([self.pos[nth_drone, :], self.quat[nth_drone, :], self.rpy[nth_drone, :],
-                           self.vel[nth_drone, :], self.ang_v[nth_drone, :], self.last_clipped_action[nth_drone, :]])
-        return state.reshape(20,)
+        i = nth_drone
+        return np.concatenate((self.pos[i], self.quat[i], self.rpy[i], self.vel[i], self.ang_v[i], self.last_clipped_action[i]))
 
     def _getAdjacencyMatrix(self):
         """(NUM_DRONES, NUM_DRONES) adjacency matrix for NEIGHBOURHOOD_RADIUS (BaseAviary.py:658-675)."""
@@ -242,8 +227,8 @@ class BaseAviary(Env):
 
     def _normalizedActionToRPM(self, action):
         """[-1, 1] -> [0, MAX_RPM], non-linear (BaseAviary.py:896-914; unused by the RL aviaries)."""
-        if np.any(np.abs(action) > 1):
-            print("\n[ERROR] it", self.step_counter, "in BaseAviary._normalizedActionToRPM(), out-of-bound action")
+        if np.abs(action).max() > 1:
+            print(f"[ERROR] BaseAviary._normalizedActionToRPM() at step {self.step_counter}: an action outside [-1, 1]")
         return np.where(action <= 0, (action + 1) * self.HOVER_RPM, self.HOVER_RPM + (self.MAX_RPM - self.HOVER_RPM) * action)
 
     # engine configuration hooks (new)
