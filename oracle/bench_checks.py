@@ -37,7 +37,7 @@ def groups_of(k, pool):
     return [pool] * (k // pool) + ([k % pool] if k % pool else [])
 
 
-def cpu_baseline(w, budget_s=12.0, phys=None):
+def cpu_baseline(w, budget_s=10.0, phys=None):
     """Time the loop-structured float64 oracle (the CPU 'port' of the reference's per-drone Python/numpy
     path; PyBullet itself is not installable here) on ONE host core, on a bounded sample of the workload."""
     from oracle.aviary_oracle import OracleAviary
@@ -80,7 +80,7 @@ def cpu_baseline(w, budget_s=12.0, phys=None):
                 m += 1
             return m, time.perf_counter() - t0
 
-        m, dtc = timed(2048, 1, 3.0)
+        m, dtc = timed(2048, 1, 2.0)
         out["c_port"] = {"value": m * 2048 * D * S / dtc, "unit": "drone-steps/s", "cores": 1,
                          "sample": f"{m} steps of 2048 aviaries through oracle/gpd_oracle.c (gcc -O2, scalar float64) in {dtc:.1f}s"}
         # third figure: the same C restatement with the aviaries spread over the host's threads (OpenMP, static chunks).
@@ -91,7 +91,7 @@ def cpu_baseline(w, budget_s=12.0, phys=None):
             best = None
             for th in sorted({usable, max(1, usable // 2), max(1, usable // 4)}, reverse=True):
                 Ea = 2048 * th
-                m, dta = timed(Ea, th, 1.5)
+                m, dta = timed(Ea, th, 1.0)
                 rate = m * Ea * D * S / dta
                 if best is None or rate > best[0]:
                     best = (rate, th, m, Ea, dta)
