@@ -137,9 +137,11 @@ def _gcd(a, b):
     return a
 
 
-def place_rollout(core, K: int, target: float = 0.755, max_arenas: int = 3, max_probes: int = 48):
+def place_rollout(core, K: int, target: float = 0.755, max_arenas: int = 3, max_probes: int = 48, accept: float = None):
     """`RolloutArena.search` over up to `max_arenas` arenas (each one held while the next is tried: a new arena is new physical
-    memory), keeping the best; the others are freed.  -> (arena, report)"""
+    memory), keeping the best; the others are freed.  `accept` (default: `target`): an arena whose best layout reaches it is good
+    enough not to try another one -- with `target` above it the search inside an arena still looks for the better level.
+    -> (arena, report)"""
     tried, best = [], None
     for _ in range(max_arenas):
         try:
@@ -150,7 +152,7 @@ def place_rollout(core, K: int, target: float = 0.755, max_arenas: int = 3, max_
         tried.append(arena)
         if best is None or rep["best_frac_in_search"] > best[1]["best_frac_in_search"]:
             best = (arena, rep)
-        if rep["reached_target"]:
+        if rep["reached_target"] or rep["best_frac_in_search"] >= (target if accept is None else accept):
             break
     if best is None:
         raise RuntimeError("no arena could be allocated")
