@@ -11,56 +11,28 @@ import numpy as np
 
 from .._gym_shim import spaces
 from ..utils.enums import ActionType, DroneModel, Physics
-from .BaseAviary import BaseAviary
+from ._state_vector_aviary import StateVectorAviary
 
 
-class VelocityAviary(BaseAviary):
+class VelocityAviary(StateVectorAviary):
     """Multi-drone environment class for high-level planning."""
 
-    def __init__(self,
-                 drone_model: DroneModel = DroneModel.CF2X,
-                 num_drones: int = 1,
-                 neighbourhood_radius: float = np.inf,
-                 initial_xyzs=None,
-                 initial_rpys=None,
-                 physics: Physics = Physics.PYB,
-                 pyb_freq: int = 240,
-                 ctrl_freq: int = 240,
-                 gui=False,
-                 record=False,
-                 obstacles=False,
-                 user_debug_gui=True,
-                 output_folder='results',
-                 device=None):
+    _STOCK_ACTION_CODE = ActionType.VEL.code
+
+    def __init__(self, drone_model: DroneModel = DroneModel.CF2X, num_drones: int = 1, neighbourhood_radius: float = np.inf,
+                 initial_xyzs=None, initial_rpys=None, physics: Physics = Physics.PYB, pyb_freq: int = 240, ctrl_freq: int = 240,
+                 gui=False, record=False, obstacles=False, user_debug_gui=True, output_folder='results', device=None):
+        # (the reference's argument list, `envs/VelocityAviary.py:16-30`, + `device`)
         if drone_model not in (DroneModel.CF2X, DroneModel.CF2P):
             # the reference builds no controller for other models and fails at the first step (:59-60, :152)
             raise ValueError("[ERROR] in VelocityAviary.__init__(), no controller is available for the specified drone_model")
-        super().__init__(drone_model=drone_model, num_drones=num_drones, neighbourhood_radius=neighbourhood_radius,
-                         initial_xyzs=initial_xyzs, initial_rpys=initial_rpys, physics=physics, pyb_freq=pyb_freq,
-                         ctrl_freq=ctrl_freq, gui=gui, record=record, obstacles=obstacles,
-                         user_debug_gui=user_debug_gui, output_folder=output_folder, device=device)
+        super().__init__(drone_model, num_drones, neighbourhood_radius, initial_xyzs, initial_rpys, physics, pyb_freq, ctrl_freq,
+                         gui, record, obstacles, user_debug_gui, output_folder=output_folder, device=device)
         self.SPEED_LIMIT = 0.03 * self.MAX_SPEED_KMH * (1000 / 3600)
 
-    def _fusedActionCode(self):
-        if type(self)._preprocessAction is VelocityAviary._preprocessAction:
-            return ActionType.VEL.code
-        return None
-
     def _actionSpace(self):
-        lo = np.array([[-1, -1, -1, 0] for _ in range(self.NUM_DRONES)])
-        hi = np.array([[1, 1, 1, 1] for _ in range(self.NUM_DRONES)])
-        return spaces.Box(low=lo, high=hi, dtype=np.float32)
-
-    def _observationSpace(self):
-        inf, pi = np.inf, np.pi
-        lo = np.array([[-inf, -inf, 0., -1., -1., -1., -1., -pi, -pi, -pi, -inf, -inf, -inf, -inf, -inf, -inf, 0., 0., 0., 0.]
-                       for _ in range(self.NUM_DRONES)])
-        hi = np.array([[inf, inf, inf, 1., 1., 1., 1., pi, pi, pi, inf, inf, inf, inf, inf, inf,
-                        self.MAX_RPM, self.MAX_RPM, self.MAX_RPM, self.MAX_RPM] for _ in range(self.NUM_DRONES)])
-        return spaces.Box(low=lo, high=hi, dtype=np.float32)
-
-    def _computeObs(self):
-        return np.array([self._getDroneStateVector(i) for i in range(self.NUM_DRONES)])
+        low = np.tile(np.array([-1., -1., -1., 0.]), (self.NUM_DRONES, 1))
+        return spaces.Box(low=low, high=np.ones((self.NUM_DRONES, 4)), dtype=np.float32)
 
     def _preprocessAction(self, action):
         """(NUM_DRONES, 4) velocity commands -> (NUM_DRONES, 4) RPMs.  `step()` does not call this (the mapping
@@ -68,15 +40,3 @@ class VelocityAviary(BaseAviary):
         from ..control.DSLPIDControl import pid_rpm_for_action
         return pid_rpm_for_action(self, np.asarray(action, dtype=np.float64).reshape(self.NUM_DRONES, 4),
                                   act_type=ActionType.VEL)
-
-    def _computeReward(self):
-        return -1
-
-    def _computeTerminated(self):
-        return False
-
-    def _computeTruncated(self):
-        return False
-
-    def _computeInfo(self):
-        return {"answer": 42}

@@ -730,3 +730,40 @@ def test_kin_planes_round_trip_on_the_host():
     np.testing.assert_array_equal(kin_rows_from_planes(store, ld), rows)
     import torch
     np.testing.assert_array_equal(kin_rows_from_planes(torch.as_tensor(store), ld).numpy(), rows)
+
+
+def test_state_vector_aviaries_spaces_and_stock_action_code():
+    """`CtrlAviary` / `VelocityAviary` (reference envs/CtrlAviary.py:83-144, envs/VelocityAviary.py:87-127): the spaces the
+    reference advertises, and the rule that only a class whose `_preprocessAction` is still the stock one lets the kernel map the
+    action (a subclass that overrides the hook gets its own mapping called instead).  No device: the hooks are called on bare objects."""
+    from gym_pybullet_drones_amd.envs import CtrlAviary, VelocityAviary
+    from gym_pybullet_drones_amd.utils.enums import ACT_RAW_RPM, ActionType
+
+    def bare(cls, n=3, max_rpm=21702.64):
+        o = object.__new__(cls)
+        o.NUM_DRONES, o.MAX_RPM = n, max_rpm
+        return o
+    c, v = bare(CtrlAviary), bare(VelocityAviary)
+    for env in (c, v):
+        box = env._observationSpace()
+        assert box.shape == (3, 20) and box.dtype == np.float32
+        inf, pi = np.inf, np.pi
+        np.testing.assert_array_equal(box.low[1], np.float32([-inf, -inf, 0, -1, -1, -1, -1, -pi, -pi, -pi] + [-inf] * 6 + [0] * 4))
+        np.testing.assert_array_equal(box.high[2], np.float32([inf] * 3 + [1] * 4 + [pi] * 3 + [inf] * 6 + [env.MAX_RPM] * 4))
+        assert env._computeReward() == -1 and env._computeTerminated() is False and env._computeTruncated() is False
+        assert env._computeInfo() == {"answer": 42}
+    a = c._actionSpace()
+    assert a.shape == (3, 4) and (a.low == 0).all() and np.allclose(a.high, c.MAX_RPM)
+    a = v._actionSpace()
+    np.testing.assert_array_equal(a.low, np.float32([[-1, -1, -1, 0]] * 3))
+    np.testing.assert_array_equal(a.high, np.ones((3, 4), np.float32))
+    np.testing.assert_array_equal(c._preprocessAction(np.array([[-5.0, 1e9, 3.0, 4.0]] * 3)), [[0, c.MAX_RPM, 3, 4]] * 3)
+    assert c._fusedActionCode() == ACT_RAW_RPM and v._fusedActionCode() == ActionType.VEL.code
+
+    class Plain(CtrlAviary):
+        pass
+
+    class Mine(CtrlAviary):
+        def _preprocessAction(self, action):
+            return np.asarray(action) * 2
+    assert bare(Plain)._fusedActionCode() == ACT_RAW_RPM and bare(Mine)._fusedActionCode() is None
