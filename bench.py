@@ -466,7 +466,8 @@ class Job:
         world_env, rank_env = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
         assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
         local = int(os.environ.get("LOCAL_RANK", "0"))
-        self.device = torch.device("cuda", local if world_env > 1 and not os.environ.get("GPD_BENCH_SINGLE_DEVICE") else 0)
+        # (LOCAL_RANK modulo the visible devices: a launcher that gives every rank ONE visible device means index 0 on each)
+        self.device = torch.device("cuda", local % max(torch.cuda.device_count(), 1) if world_env > 1 and not os.environ.get("GPD_BENCH_SINGLE_DEVICE") else 0)
         torch.cuda.set_device(self.device)
         self.topology = {}
 
@@ -545,8 +546,7 @@ class Watchdog:
                 return
             if job.rank == 0:
                 note(out)
-                print(json.dumps(out))
-                sys.stdout.flush()
+                print(json.dumps(out), flush=True)
             os._exit(code)
 
         threading.Thread(target=watch, daemon=True).start()

@@ -287,7 +287,8 @@ def bring_up(backend: str, device, topology: dict = None) -> dict:
         store.set(f"gpd/device/{rank}", json.dumps(mine))
         everyone = [json.loads(store.get(f"gpd/device/{r}")) for r in range(world)]
         topo["rank_device_map"] = everyone
-        if backend == "nccl" and len({(e["device"], e["pci"]) for e in everyone}) < world:
+        # (a duplicate has the same index, bus id AND uuid: ranks that were each given ONE visible device all say "device 0")
+        if backend == "nccl" and len({(e["device"], e["pci"], e["uuid"]) for e in everyone}) < world:
             raise RuntimeError("two ranks of this job sit on the same device (see rank_device_map): RCCL refuses duplicate GPUs -- "
                                "launch one rank per GPU (LOCAL_RANK = device index)")
         one = torch.ones(1, dtype=torch.float32, device=device if backend == "nccl" else None)
