@@ -335,7 +335,7 @@ def dropin_single_env(device, steps=2420):
     Physics.PYB = explicit integrator + ground plane here), ActionType.ONE_D_RPM, a ~ U(-1, 1) of shape (1, 1), 2 420 `step()` calls
     with a reset at every episode end (examples/learn.py:54-58; envs/BaseAviary.py:509-519 is the per-step read-back the reference
     pays).  Wall clock per call -- this path is latency, not bandwidth: the aviary's state lives in host-visible memory, a step is
-    one gpd_step launch + one stream synchronisation + numpy reads -- and where it goes."""
+    one gpd_step_sync call (the launch + a spin on the word the kernel writes when it is done) + numpy reads -- and where it goes."""
     import warnings
     from gym_pybullet_drones_amd.envs import HoverAviary
     from gym_pybullet_drones_amd.utils.enums import ActionType
@@ -362,14 +362,14 @@ def dropin_single_env(device, steps=2420):
         for _ in range(n):
             fn()
         return (time.perf_counter() - t) / n * 1e6
-    parts = {"launch_and_stream_sync": per_call_us(core.step_host), "numpy_kinematic_refresh": per_call_us(env._updateAndStoreKinematicInformation),
+    parts = {"gpd_step_sync_launch_and_wait": per_call_us(core.step_host), "numpy_kinematic_refresh": per_call_us(env._updateAndStoreKinematicInformation),
              "observation_row_with_history": per_call_us(env._computeObs)}
     S = int(env.PYB_STEPS_PER_CTRL)
     out = {"us_per_step": dt / steps * 1e6, "env_steps_per_s": steps / dt, "value": steps * S / dt, "unit": "drone-steps/s", "steps": steps,
            "episodes_ended": episodes, "state_memory": "host-visible (page-locked, device-mapped)" if core.host_visible else "HBM",
            "breakdown_us": parts,
            "what": "for k in range(2420): HoverAviary(act=ONE_D_RPM).step(a[k]) (+ reset at episode ends), wall clock; one gpd_step_sync call "
-                   "(launch + stream wait) per step, no device-to-host copy, no second launch"}
+                   "(launch + wait on the kernel's completion word) per step, no device-to-host copy, no second launch"}
     env.close()
     try:        # the reference's OWN Python on the same schedule (quoted: /root/reference does not exist on this box)
         rec = json.load(open(os.path.join(REPO, "profiles", "r05_reference_python_dyn_cpu.json")))

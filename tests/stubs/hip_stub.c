@@ -46,6 +46,7 @@ int hipGetDevice(int* dev) { *dev = 0; return 0; }
 int hipDeviceGetAttribute(int* value, int attr, int dev) { (void)attr; (void)dev; *value = 100000; return 0; }
 int hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? 0 : 2; }
 int hipFree(void* p) { free(p); return 0; }
+int hipHostMalloc(void** p, size_t n, unsigned flags) { (void)flags; *p = calloc(1, n ? n : 1); return *p ? 0 : 2; }
 int hipMemcpyAsync(void* dst, const void* src, size_t n, int kind, void* stream) { (void)kind; (void)stream; memcpy(dst, src, n); return 0; }
 int hipStreamSynchronize(void* stream) { (void)stream; return 0; }
 int hipMemcpyFromSymbolAsync(void* dst, const void* sym, size_t n, size_t off, int kind, void* stream) {

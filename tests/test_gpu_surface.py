@@ -949,3 +949,38 @@ def test_dropin_aviary_step_is_one_launch_on_host_visible_state(gpu_device, monk
         text = a.render()
         assert text.count("\n") == 1 + a.NUM_DRONES and "sim" in text.split("\n")[0]
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("D,act", [(1, "one_d_rpm"), (3, "pid"), (70, "rpm")])
+def test_step_sync_returns_only_when_the_results_are_readable(gpu_device, D, act):
+    """`gpd_step_sync` (what `BaseAviary.step()` calls) learns that the step is done from a word the kernel itself writes into
+    page-locked memory when the aviary fits one wavefront, and from hipStreamSynchronize otherwise (70 drones: two waves; every 256th
+    call; a stream with work queued ahead).  Whatever the way: when it returns, the buffers hold THIS step's results -- 700 steps
+    read back at once, each compared bit for bit with a core in HBM that is synchronised the slow way, across the 256-call
+    boundary, a reset in between, and once with a large kernel queued ahead on the stream."""
+    from gym_pybullet_drones_amd import engine
+    rng = np.random.default_rng(D)
+    code = {"rpm": 0, "pid": 1, "one_d_rpm": 3}[act]
+    xyz = rng.uniform(-0.3, 0.3, size=(D, 3)) * np.array([1, 1, 0]) + np.array([0, 0, 0.5]) + np.arange(D)[:, None] * np.array([0.3, 0.1, 0.0])
+    kw = dict(num_envs=1, drones_per_env=D, physics=0, pyb_freq=240, ctrl_freq=30, act_code=code, task=engine.TASK_HOVER if D == 1 else engine.TASK_MULTIHOVER,
+              initial_xyzs=xyz, initial_rpys=np.zeros((D, 3)), target_pos=xyz + np.array([0, 0, 0.3]), track_rpm=True, device=gpu_device)
+    hv, dv = engine.SimCore(host_visible=True, **kw), engine.SimCore(**kw)
+    obs_h, rew_h, kin_h = hv.obs12.numpy(), hv.reward.numpy(), hv.kin_store.numpy()
+    ballast = torch.empty(1 << 28, dtype=torch.float32, device=gpu_device)              # 1 GiB: a fill of it takes ~0.2 ms
+    for k in range(700):
+        a = (rng.uniform(-1, 1, size=(D, hv.A)) * 0.05).astype(np.float32) + (np.array([0, 0, 0.8], dtype=np.float32) if act == "pid" else 0)
+        hv.action_host.numpy()[...] = a
+        if k == 400:
+            for _ in range(20):
+                ballast.fill_(float(k))                                                  # ~4 ms of work ahead of the step on its stream
+        hv.step_host()
+        got = (obs_h.copy(), rew_h.copy(), kin_h.copy())                                # read at once: no synchronisation of ours
+        dv.step(torch.as_tensor(a, device=gpu_device))
+        torch.cuda.synchronize()
+        assert np.array_equal(got[0], dv.obs12.cpu().numpy()), k
+        assert np.array_equal(got[1], dv.reward.cpu().numpy()), k
+        assert np.array_equal(got[2], dv.kin_store.cpu().numpy()), k
+        if k == 300:
+            hv.reset()
+            dv.reset()
+    assert np.isfinite(got[0]).all()
