@@ -151,6 +151,8 @@ _SIGNATURES = {
                                  ctypes.c_int32, _P, _P]),
     "gpd_pid": (ctypes.c_int, [ctypes.POINTER(GpdParams), _P, ctypes.c_int64, ctypes.c_float, _P, _P, _P, _P, _P, _P,
                                _P, _P, _P, _P, ctypes.c_int32, _P]),
+    "gpd_pid_sync": (ctypes.c_int, [ctypes.POINTER(GpdParams), _P, ctypes.c_int64, ctypes.c_float, _P, _P, _P, _P, _P, _P,
+                                    _P, _P, _P, _P, ctypes.c_int32, _P]),
     "gpd_state_vectors": (ctypes.c_int, [ctypes.POINTER(GpdState), _P, _P, ctypes.c_int32, _P]),
     "gpd_comm_unique_id": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint8)]),
     "gpd_comm_init": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32,

@@ -5,8 +5,8 @@ return triple); `DSLPIDControlBatch` runs n independent controllers per call on 
 Both call `gpd_pid` (include/gpd.h) — the same device function the fused step kernel uses for
 `ActionType.PID/VEL/ONE_D_PID`.  Controller state (integral_pos_e, last_rpy, integral_rpy_e)
 lives in a [9][ld] float32 block: in HBM for the batch class, in page-locked host memory the
-device addresses directly for the single-drone class, whose call is then one launch and one stream
-synchronisation (inputs written and outputs read by the host in place; no copies).
+device addresses directly for the single-drone class, whose call is then ONE library call (`gpd_pid_sync`:
+the launch and the wait for it; inputs written and outputs read by the host in place; no copies).
 """
 import ctypes
 
@@ -138,12 +138,10 @@ class DSLPIDControl(DSLPIDControlBatch):
         io[self._TRPY:self._TRPY + 3] = target_rpy
         io[self._TVEL:self._TVEL + 3] = target_vel
         io[self._TRATES:self._TRATES + 3] = target_rpy_rates
-        stream = torch.cuda.current_stream(self.device)
-        with torch.cuda.device(self.device):
-            rc = self.lib.gpd_pid(ctypes.byref(self._params), a[0], a[1], float(control_timestep), a[2], a[3], a[4], a[5], a[6], a[7], a[8],
-                                  a[9], a[10], a[11], 1, ctypes.c_void_p(stream.cuda_stream))
-        _native.check(rc, "gpd_pid")
-        stream.synchronize()
+        with torch.cuda.device(self.device):        # ONE library call: the launch and the wait for it (include/gpd.h: gpd_pid_sync)
+            rc = self.lib.gpd_pid_sync(ctypes.byref(self._params), a[0], a[1], float(control_timestep), a[2], a[3], a[4], a[5], a[6], a[7], a[8],
+                                       a[9], a[10], a[11], 1, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        _native.check(rc, "gpd_pid_sync")
         out = io.astype(np.float64)
         return out[self._RPM:self._RPM + 4], out[self._POS_E:self._POS_E + 3], float(out[self._YAW_E])
 

@@ -1,6 +1,52 @@
 // abi.hip -- the small kernels (masked reset, action-history rows, batched DSLPID, state vectors, clock probe), RCCL, and the library-level
 // entries of the C ABI (version, last error, struct sizes, debug status)
+#include <chrono>
 #include "gpd_common.inc"
+
+// the completion word of the `*_sync` entries (gpd_common.inc: GpdDone)
+namespace {
+struct DoneWord { uint32_t* p = nullptr; uint32_t seq = 0; uint32_t unsynced = 0; bool tried = false; };
+DoneWord& done_word() {
+    static thread_local DoneWord w;        // (never freed: 64 page-locked bytes per calling thread; the runtime may be gone when a thread ends)
+    if (!w.tried) {
+        w.tried = true;
+        void* q = nullptr;
+        if (hipHostMalloc(&q, 64, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess && q != nullptr) {
+            w.p = static_cast<uint32_t*>(q);
+            *w.p = 0u;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    return w;
+}
+}  // namespace
+
+GpdDone gpd_detail_done_begin() {
+    static const char* const how = getenv("GPD_STEP_SYNC_WAIT");
+    DoneWord& w = done_word();
+    const bool word = w.p != nullptr && !(how != nullptr && how[0] == 's');
+    return GpdDone{word ? w.p : nullptr, ++w.seq, false};
+}
+
+int gpd_detail_done_wait(const GpdDone& d, void* stream, const char* who) {
+    DoneWord& w = done_word();
+    if (d.used && d.flag != nullptr && ++w.unsynced < 256u) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 1;; ++spins) {
+            if (__atomic_load_n(d.flag, __ATOMIC_ACQUIRE) == d.seq) return 0;
+            __builtin_ia32_pause();
+            if ((spins & 0xfffu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+    }
+    w.unsynced = 0;
+    hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        gpd_detail_last_error() = std::string(who) + ": hipStreamSynchronize: " + hipGetErrorString(e);
+        return static_cast<int>(e);
+    }
+    return 0;
+}
 
 std::string& gpd_detail_last_error() {
     thread_local std::string e;
@@ -154,7 +200,7 @@ __global__ __launch_bounds__(kBlock) void gpd_pid_kernel(
     const float* __restrict__ cur_quat, const float* __restrict__ cur_vel, const float* __restrict__ target_pos,
     const float* __restrict__ target_rpy, const float* __restrict__ target_vel,
     const float* __restrict__ target_rpy_rates, float* __restrict__ rpm_out, float* __restrict__ pos_e_out,
-    float* __restrict__ yaw_e_out, int n_total) {
+    float* __restrict__ yaw_e_out, int n_total, uint32_t* __restrict__ done_flag, const uint32_t done_seq) {
     const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (n >= n_total) return;
     Kin k{};
@@ -184,6 +230,7 @@ __global__ __launch_bounds__(kBlock) void gpd_pid_kernel(
     reinterpret_cast<float4*>(rpm_out)[n] = make_float4(rpm[0], rpm[1], rpm[2], rpm[3]);
     if (pos_e_out) { pos_e_out[n * 3] = pe[0]; pos_e_out[n * 3 + 1] = pe[1]; pos_e_out[n * 3 + 2] = pe[2]; }
     if (yaw_e_out) yaw_e_out[n] = ye;
+    signal_done(done_flag, done_seq, n == 0);            // (gpd_pid_sync with n <= 64: one wave; NULL otherwise)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -378,21 +425,43 @@ int gpd_reset(const GpdState* state, const float* init_pose, int32_t init_per_en
     return 0;
 }
 
+namespace {
+int pid_impl(const char* who, const GpdParams* params, float* pid, int64_t ld, float ctrl_dt, const float* cur_pos,
+             const float* cur_quat, const float* cur_vel, const float* target_pos, const float* target_rpy,
+             const float* target_vel, const float* target_rpy_rates, float* rpm, float* pos_e, float* yaw_e,
+             int32_t n, void* stream, GpdDone* done) {
+    auto bad = [&](int code, const char* msg) { return fail(code, (std::string(who) + ": " + msg).c_str()); };
+    if (!params || !pid || !cur_pos || !cur_quat || !cur_vel || !target_pos || !rpm) return bad(GPD_EINVAL, "NULL argument");
+    if (n <= 0 || ld < n) return bad(GPD_EINVAL, "need 0 < n <= ld");
+    if (params->pid_kf <= 0.0f) return bad(GPD_ENOTSUP, "no DSLPID controller for this airframe");
+    const int blocks = (n + kBlock - 1) / kBlock;
+    if (done != nullptr) done->used = done->flag != nullptr && n <= 64;          // one wave: see GpdDone
+    hipLaunchKernelGGL(gpd_pid_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), *params, pid,
+                       ld, ctrl_dt, cur_pos, cur_quat, cur_vel, target_pos, target_rpy, target_vel, target_rpy_rates,
+                       rpm, pos_e, yaw_e, n, (done != nullptr && done->used) ? done->flag : nullptr, done != nullptr ? done->seq : 0u);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, (std::string(who) + " launch").c_str());
+    return 0;
+}
+}  // namespace
+
 int gpd_pid(const GpdParams* params, float* pid, int64_t ld, float ctrl_dt, const float* cur_pos,
             const float* cur_quat, const float* cur_vel, const float* target_pos, const float* target_rpy,
             const float* target_vel, const float* target_rpy_rates, float* rpm, float* pos_e, float* yaw_e,
             int32_t n, void* stream) {
-    if (!params || !pid || !cur_pos || !cur_quat || !cur_vel || !target_pos || !rpm)
-        return fail(GPD_EINVAL, "gpd_pid: NULL argument");
-    if (n <= 0 || ld < n) return fail(GPD_EINVAL, "gpd_pid: need 0 < n <= ld");
-    if (params->pid_kf <= 0.0f) return fail(GPD_ENOTSUP, "gpd_pid: no DSLPID controller for this airframe");
-    const int blocks = (n + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(gpd_pid_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), *params, pid,
-                       ld, ctrl_dt, cur_pos, cur_quat, cur_vel, target_pos, target_rpy, target_vel, target_rpy_rates,
-                       rpm, pos_e, yaw_e, n);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "gpd_pid launch");
-    return 0;
+    return pid_impl("gpd_pid", params, pid, ld, ctrl_dt, cur_pos, cur_quat, cur_vel, target_pos, target_rpy, target_vel,
+                    target_rpy_rates, rpm, pos_e, yaw_e, n, stream, nullptr);
+}
+
+int gpd_pid_sync(const GpdParams* params, float* pid, int64_t ld, float ctrl_dt, const float* cur_pos,
+                 const float* cur_quat, const float* cur_vel, const float* target_pos, const float* target_rpy,
+                 const float* target_vel, const float* target_rpy_rates, float* rpm, float* pos_e, float* yaw_e,
+                 int32_t n, void* stream) {
+    GpdDone done = gpd_detail_done_begin();
+    if (int rc = pid_impl("gpd_pid_sync", params, pid, ld, ctrl_dt, cur_pos, cur_quat, cur_vel, target_pos, target_rpy, target_vel,
+                          target_rpy_rates, rpm, pos_e, yaw_e, n, stream, &done))
+        return rc;
+    return gpd_detail_done_wait(done, stream, "gpd_pid_sync");
 }
 
 int gpd_state_vectors(const GpdState* state, const float* obs12, float* state20, int32_t n, void* stream) {

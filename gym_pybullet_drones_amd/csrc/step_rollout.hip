@@ -1,5 +1,4 @@
 // step_rollout.hip -- gpd_step / gpd_rollout / gpd_rollout_history: one env step per launch, K env steps per launch (DESIGN.md sections 3.1, 3.2)
-#include <chrono>
 #include "gpd_common.inc"
 #include "policy_kernel.inc"
 
@@ -140,14 +139,7 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     // miss the XCD-private L2 either way (round 5 A/B, profiles/r05_ab_step_kernel_round2.log: 3.95 -> 3.93 us per step at 65 536 drones,
     // 2.91 -> 2.87 at 4 096, equal at 4 194 304; rounds 1-4 kept ordinary stores up to 2^22 drones)
     store_carry<PID, true>(S, L, c);
-    // gpd_step_sync on a launch with ONE active wave (the host checks that): the wave's last act is a system-scope release store of
-    // the call's sequence number into a host-visible word -- everything this wave stored above is visible to a host that has
-    // read it (one wave issues its memory operations in order; the release waits for all of them and writes the L2 back).
-    // A NULL pointer (every other caller) costs one scalar compare.
-    if (__builtin_expect(done_flag != nullptr, 0)) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-        if (L.n == 0u) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    signal_done(done_flag, done_seq, L.n == 0u);         // (gpd_step_sync on a one-wave launch; NULL otherwise -- gpd_common.inc)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -627,14 +619,10 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     if constexpr (RING) { if (L.active && L.d == 0) S.ring_pos[L.env] = ring_q; }
 }
 
-// gpd_step_sync: where the kernel reports that it is done (a host-visible word, the call's sequence number), and whether this launch's
-// shape lets it (`used`, set by launch_step)
-struct StepDone { uint32_t* flag; uint32_t seq; bool used; };
-
 template <bool PID, bool EXT, int AW, int ACT>
 hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const GpdState& S, const GpdStepCfg& C,
                        const Span& T, const float* action, const float* target_pos, const float* init_pose,
-                       float* obs12, float* reward, uint8_t* terminated, uint8_t* truncated, float* term_obs12, StepDone* done) {
+                       float* obs12, float* reward, uint8_t* terminated, uint8_t* truncated, float* term_obs12, GpdDone* done) {
     const int64_t N = static_cast<int64_t>(C.num_envs) * C.drones_per_env;
     if (T.num_steps == 1) {      // gpd_step, or a rollout of one step: the low-latency single-step kernel
         const int lanes = multi ? (kBlock / C.drones_per_env) * C.drones_per_env : (kBlock / 64) * C.lanes_per_wave;
@@ -709,7 +697,7 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
 // argument checks + launch shared by gpd_step (K = 1) and gpd_rollout
 int step_impl(const char* who, const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, const Span& T,
               const float* action, const float* target_pos, const float* init_pose, float* obs12, float* reward,
-              uint8_t* terminated, uint8_t* truncated, float* term_obs12, void* stream, StepDone* done = nullptr) {
+              uint8_t* terminated, uint8_t* truncated, float* term_obs12, void* stream, GpdDone* done = nullptr) {
     auto bad = [&](int code, const char* msg) { return fail(code, (std::string(who) + ": " + msg).c_str()); };
     if (!params || !state || !cfg) return bad(GPD_EINVAL, "NULL params/state/cfg");
     if (!state->kin || !state->step_counter) return bad(GPD_EINVAL, "NULL state.kin/step_counter");
@@ -808,44 +796,12 @@ int gpd_step(const GpdParams* params, const GpdState* state, const GpdStepCfg* c
 int gpd_step_sync(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, const float* action,
                   const float* target_pos, const float* init_pose, float* obs12, float* reward, uint8_t* terminated,
                   uint8_t* truncated, float* term_obs12, void* stream) {
-    // How the host learns that the step is done.  hipStreamSynchronize costs a barrier packet behind the kernel, its completion signal
-    // and the runtime's wait: 12.4 us for an EMPTY kernel on MI355X against 7.6 when the kernel itself writes a sequence number into
-    // host-visible memory and the host spins on it (scratch/exp_r06/sync_latency.hip).  So: a launch whose drones sit in one wave
-    // (every reference-shaped aviary of up to 64 drones) reports through a word of page-locked memory owned by the calling thread;
-    // other shapes, a word that could not be allocated, and a word that has not changed after 2 ms (work queued ahead on the stream,
-    // a capture in progress) take hipStreamSynchronize.  Every 256th call takes it as well: the runtime retires its bookkeeping
-    // of the launches at a synchronisation.
-    struct Word { uint32_t* p = nullptr; uint32_t seq = 0; uint32_t unsynced = 0; bool tried = false; };
-    static thread_local Word w;            // (never freed: 64 bytes per calling thread; the runtime may be gone when a thread ends)
-    if (!w.tried) {
-        w.tried = true;
-        void* q = nullptr;
-        if (hipHostMalloc(&q, 64, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess && q != nullptr) {
-            w.p = static_cast<uint32_t*>(q);
-            *w.p = 0u;
-        } else {
-            (void)hipGetLastError();
-        }
-    }
-    static const char* const how = getenv("GPD_STEP_SYNC_WAIT");          // (diagnostics: "stream" = always hipStreamSynchronize, the A/B)
-    const bool word = w.p != nullptr && !(how != nullptr && how[0] == 's');
-    StepDone done{w.p, ++w.seq, false};
+    GpdDone done = gpd_detail_done_begin();              // (how the wait works: gpd_common.inc)
     const Span T{1, 0, 0, 0, 2};
     if (int rc = step_impl("gpd_step_sync", params, state, cfg, T, action, target_pos, init_pose, obs12, reward, terminated,
-                           truncated, term_obs12, stream, word ? &done : nullptr))
+                           truncated, term_obs12, stream, done.flag != nullptr ? &done : nullptr))
         return rc;
-    if (done.used && ++w.unsynced < 256u) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (uint32_t spins = 1;; ++spins) {
-            if (__atomic_load_n(w.p, __ATOMIC_ACQUIRE) == done.seq) return 0;
-            __builtin_ia32_pause();
-            if ((spins & 0xfffu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
-        }
-    }
-    w.unsynced = 0;
-    hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
-    if (e != hipSuccess) return hip_fail(e, "gpd_step_sync: hipStreamSynchronize");
-    return 0;
+    return gpd_detail_done_wait(done, stream, "gpd_step_sync");
 }
 
 int gpd_rollout(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, int32_t num_steps,

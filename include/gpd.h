@@ -559,6 +559,18 @@ int gpd_pid(const GpdParams* params, float* pid, int64_t ld, float ctrl_dt,
             int32_t n, void* stream);
 
 /*
+ * gpd_pid, then a wait for it on `stream` (as gpd_step_sync waits: up to 64 controllers report through a page-locked word the
+ * calling thread spins on, more take hipStreamSynchronize): the call behind the reference-shaped single-drone
+ * `DSLPIDControl.computeControl` (control/DSLPIDControl.py:82-145 returns numpy values: every call ends in a host read), whose
+ * operands and controller state live in page-locked host memory.  Same arguments and error codes as gpd_pid.
+ */
+int gpd_pid_sync(const GpdParams* params, float* pid, int64_t ld, float ctrl_dt,
+                 const float* cur_pos, const float* cur_quat, const float* cur_vel,
+                 const float* target_pos, const float* target_rpy, const float* target_vel,
+                 const float* target_rpy_rates, float* rpm, float* pos_e, float* yaw_e,
+                 int32_t n, void* stream);
+
+/*
  * Gather the 20-float state vectors of BaseAviary._getDroneStateVector
  * (envs/BaseAviary.py:541-561): pos3 | quat4 | rpy3 | vel3 | ang_v3 | last_clipped_action4,
  * from the SoA state and the obs12 rows of the latest step.  state20 is [n][20].

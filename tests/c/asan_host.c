@@ -110,6 +110,11 @@ int main(void) {
     CHECK(gpd_reset(&S, DEV(5), 0, NULL, 4096, 1, 1, DEV(6), NULL) == 0, "gpd_reset");
     CHECK(gpd_state_vectors(&S, DEV(6), DEV(23), 4096, NULL) == 0, "gpd_state_vectors");
     CHECK(gpd_pid(&P, DEV(11), 4096, 1.0f / 240, DEV(24), DEV(25), DEV(26), DEV(27), NULL, NULL, NULL, DEV(28), NULL, NULL, 4096, NULL) == 0, "gpd_pid");
+    n0 = hipstub_launches();
+    CHECK(gpd_pid_sync(&P, DEV(11), 4096, 1.0f / 240, DEV(24), DEV(25), DEV(26), DEV(27), NULL, NULL, NULL, DEV(28), NULL, NULL, 1, NULL) == 0 && hipstub_launches() == n0 + 1,
+          "gpd_pid_sync: one launch (the stub never writes the completion word: the 2 ms fallback to the stream wait)");
+    CHECK(gpd_pid_sync(&P, DEV(11), 4096, 1.0f / 240, DEV(24), DEV(25), DEV(26), DEV(27), NULL, NULL, NULL, DEV(28), NULL, NULL, 4096, NULL) == 0, "gpd_pid_sync, 4096 controllers (stream wait)");
+    CHECK(gpd_pid_sync(&P, DEV(11), 4096, 1.0f / 240, NULL, DEV(25), DEV(26), DEV(27), NULL, NULL, NULL, DEV(28), NULL, NULL, 1, NULL) == GPD_EINVAL && strstr(gpd_last_error(), "gpd_pid_sync") != NULL, "gpd_pid_sync names itself in its errors");
 
     /* ---- one world ---- */
     CHECK(gpd_downwash_global(&P, DEV(1), 65536, 65536, 10.5f, -170.0f, -170.0f, 32, 32, 0.0f, 1.0f, 1, NULL, DEV(30), DEV(31), DEV(32), DEV(33), DEV(34), NULL, NULL, NULL, NULL) == 0,

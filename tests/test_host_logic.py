@@ -111,6 +111,7 @@ def test_library_exports_every_declared_symbol():
     assert L.gpd_step(None, None, None, None, None, None, None, None, None, None, None, None) == -1
     assert b"NULL" in L.gpd_last_error()
     assert L.gpd_pid(None, None, 0, ctypes.c_float(0.0), None, None, None, None, None, None, None, None, None, None, 0, None) == -1
+    assert L.gpd_pid_sync(None, None, 0, ctypes.c_float(0.0), None, None, None, None, None, None, None, None, None, None, 0, None) == -1
 
 
 def test_struct_mirrors_match_the_header_layout():
