@@ -112,6 +112,10 @@ class BaseAviary(Env):
                                 "W": c.kin_W.numpy()[:n], "rpm": c.last_rpm.numpy()[:, :n], "reward": c.reward.numpy(),
                                 "terminated": c.terminated.numpy(), "truncated": c.truncated.numpy()}
             self._action_row = c.action_host.numpy()
+            # the body rates sit in three planes of the state block (P[:, 3] | V[:, 3] | W): one gather instead of a stack of three slices
+            i = np.arange(n)
+            self._host_views["kin_flat"] = c.kin_store.numpy().reshape(-1)
+            self._rates_at = np.stack([4 * i + 3, 8 * c.ld + 4 * i + 3, 12 * c.ld + i], axis=1).reshape(-1)
         self._housekeeping()
         self._updateAndStoreKinematicInformation()
 
@@ -185,7 +189,7 @@ class BaseAviary(Env):
             obs = v["obs"].astype(np.float64)                      # pos | rpy | vel | ang_v, as the kernel's observation row has them
             self.pos, self.rpy, self.vel, self.ang_v = obs[:, 0:3], obs[:, 3:6], obs[:, 6:9], obs[:, 9:12]
             self.quat = v["Q"].astype(np.float64)
-            self.rpy_rates = np.stack([v["P"][:, 3], v["V"][:, 3], v["W"]], axis=1).astype(np.float64)
+            self.rpy_rates = v["kin_flat"][self._rates_at].astype(np.float64).reshape(n, 3)
             self.last_clipped_action = v["rpm"].T.astype(np.float64)
             self._k_reward = float(v["reward"][0])
             self._k_terminated = bool(v["terminated"][0])

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""The downwash model of aviaries of 4 .. 64 drones evaluated for two mates per packed instruction (gpd_common.inc, `two_mates`):
+(1) bit for bit the library before the change (scratch/exp_r06/libgpd_before_pairs.so) -- 64-step rollouts and single steps of stacks of
+4, 8, 16, 64 drones with every force term, RPM and DSLPID actions, one and two sub-steps; (2) the time per launch, interleaved."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+LIBS = {"before": "scratch/exp_r06/libgpd_before_pairs.so", "pairs": "gym_pybullet_drones_amd/csrc/libgpd.so"}
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    sys.path.insert(0, R)
+    import numpy as np
+    import torch
+    import bench
+    from gym_pybullet_drones_amd.envs import VectorAviary
+    from gym_pybullet_drones_amd.utils.enums import ActionType
+    out = {}
+    dev = torch.device("cuda", 0)
+    for D in (4, 8, 16, 64):
+        for act, S in (("rpm", 1), ("pid", 1), ("rpm", 2)):
+            E = 4096 // D
+            rng = np.random.default_rng(D)
+            xyz, rpy = bench.stack_scene(rng, E, D)
+            env = VectorAviary(E, D, initial_xyzs=xyz, initial_rpys=rpy, physics=7, pyb_freq=240, ctrl_freq=240 // S, act=ActionType(act),
+                               task="multihover", auto_reset=True, track_rpm=True, device=dev)
+            g = torch.Generator(device=dev); g.manual_seed(5)
+            a = torch.rand((64, E, D, env.ACT_DIM), generator=g, device=dev) * 2 - 1
+            if act == "pid":
+                a = a * 0.5; a[..., 2] += 1.0
+            h = hashlib.sha256()
+            o, r, te, tr = env.core.rollout(a.contiguous(), update_latest=False)
+            for t in (o, r, te, tr, env.core.kin_store):
+                h.update(t.cpu().numpy().tobytes())
+            for k in range(8):
+                o, r, te, tr = env.core.step(a[k].contiguous())
+                for t in (o, r, te, tr):
+                    h.update(t.cpu().numpy().tobytes())
+            out[f"D{D}_{act}_S{S}"] = h.hexdigest()[:16]
+    print(json.dumps(out))
+    raise SystemExit(0)
+
+digests = {}
+for v, lib in LIBS.items():
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, GPD_LIB=os.path.join(R, lib)), capture_output=True, text=True)
+    line = next((l for l in p.stdout.splitlines() if l.startswith("{")), None)
+    if line is None:
+        print(v, "FAILED", p.stderr[-800:])
+        raise SystemExit(1)
+    digests[v] = json.loads(line)
+same = {k: digests["before"][k] == digests["pairs"][k] for k in digests["before"]}
+print("bitwise equal:", all(same.values()), json.dumps(same))
+res = {}
+WORK = [("stack8x8192_ext_240hz", ["--steps", "64", "--warmup", "64"]), ("stack8x8192_ext_240hz", ["--steps", "20", "--warmup", "5"]),
+        ("stack8x8192_ext_pid_240hz", ["--steps", "64", "--warmup", "64"]), ("multihover2x16384_240hz", ["--steps", "64", "--warmup", "64"])]
+for rnd in range(3):
+    for wl, extra in WORK:
+        for mode in ("rollout", "graph"):
+            if mode == "graph" and (rnd or wl != "stack8x8192_ext_240hz" or extra[1] != "64"):
+                continue
+            for v, lib in LIBS.items():
+                cmd = [sys.executable, os.path.join(R, "bench.py"), "--workload", wl, "--mode", mode, "--no-cpu-baseline", "--no-hbm-leg", "--no-parity", "--no-second-leg",
+                       "--no-dropin-leg", "--min-time", "0.5"] + extra
+                p = subprocess.run(cmd, env=dict(os.environ, GPD_LIB=os.path.join(R, lib)), capture_output=True, text=True, timeout=300)
+                line = next((l for l in reversed(p.stdout.splitlines()) if l.startswith("{")), None)
+                if not line:
+                    print(wl, v, "FAILED", p.stderr[-300:], flush=True)
+                    continue
+                j = json.loads(line)
+                key = f"{wl} {mode} K={extra[1]}"
+                res.setdefault(key, {}).setdefault(v, []).append(j["ms_per_step"] * 1e3)
+                print(f"round {rnd} {key:44s} {v:7s}: {j['ms_per_step'] * 1e3:.4f} us per step", flush=True)
+print("\nus per env step (min .. max over rounds)")
+for k, d in res.items():
+    print(f"{k:46s} " + "   ".join(f"{v}: {min(x):.4f}..{max(x):.4f}" for v, x in d.items()))
+os.makedirs(os.path.join(R, "gpurun_out", "r06p"), exist_ok=True)
+json.dump({"bitwise_equal": same, "us_per_env_step": res}, open(os.path.join(R, "gpurun_out", "r06p", "ab_pairs.json"), "w"), indent=1)
