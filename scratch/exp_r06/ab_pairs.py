@@ -19,9 +19,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     from gym_pybullet_drones_amd.utils.enums import ActionType
     out = {}
     dev = torch.device("cuda", 0)
-    for D in (4, 8, 16, 64):
+    for D in (4, 8, 16, 64, 3, 5, 6, 7, 12, 100, 255, 256):
         for act, S in (("rpm", 1), ("pid", 1), ("rpm", 2)):
-            E = 4096 // D
+            E = max(4096 // D, 2)
             rng = np.random.default_rng(D)
             xyz, rpy = bench.stack_scene(rng, E, D)
             env = VectorAviary(E, D, initial_xyzs=xyz, initial_rpys=rpy, physics=7, pyb_freq=240, ctrl_freq=240 // S, act=ActionType(act),
@@ -39,6 +39,17 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
                 for t in (o, r, te, tr):
                     h.update(t.cpu().numpy().tobytes())
             out[f"D{D}_{act}_S{S}"] = h.hexdigest()[:16]
+    # time per env step of a 64-step rollout, 65 536 drones in aviaries of D (HIP events, 30 launches)
+    for D in (3, 8, 12, 100, 256):
+        E = 65536 // D
+        rng = np.random.default_rng(D)
+        xyz, rpy = bench.stack_scene(rng, E, D)
+        env = VectorAviary(E, D, initial_xyzs=xyz, initial_rpys=rpy, physics=7, pyb_freq=240, ctrl_freq=240, act=ActionType("rpm"),
+                           task="multihover", auto_reset=True, track_rpm=True, device=dev)
+        a = (torch.rand((64, E, D, 4), device=dev) * 2 - 1).contiguous()
+        for _ in range(3):
+            env.core.rollout(a, update_latest=False)
+        out[f"us_per_step_D{D}"] = bench.event_seconds(lambda: env.core.rollout(a, update_latest=False), 30) * 1e6 / 64
     print(json.dumps(out))
     raise SystemExit(0)
 
@@ -50,12 +61,14 @@ for v, lib in LIBS.items():
         print(v, "FAILED", p.stderr[-800:])
         raise SystemExit(1)
     digests[v] = json.loads(line)
-same = {k: digests["before"][k] == digests["pairs"][k] for k in digests["before"]}
+same = {k: digests["before"][k] == digests["pairs"][k] for k in digests["before"] if not k.startswith("us_per_step")}
 print("bitwise equal:", all(same.values()), json.dumps(same))
+times = {k: {v: digests[v][k] for v in digests} for k in digests["before"] if k.startswith("us_per_step")}
+print("65 536 drones in aviaries of D, all force terms, 64-step rollout, us per env step:", json.dumps(times))
 res = {}
 WORK = [("stack8x8192_ext_240hz", ["--steps", "64", "--warmup", "64"]), ("stack8x8192_ext_240hz", ["--steps", "20", "--warmup", "5"]),
         ("stack8x8192_ext_pid_240hz", ["--steps", "64", "--warmup", "64"]), ("multihover2x16384_240hz", ["--steps", "64", "--warmup", "64"])]
-for rnd in range(3):
+for rnd in range(2):
     for wl, extra in WORK:
         for mode in ("rollout", "graph"):
             if mode == "graph" and (rnd or wl != "stack8x8192_ext_240hz" or extra[1] != "64"):
@@ -76,4 +89,4 @@ print("\nus per env step (min .. max over rounds)")
 for k, d in res.items():
     print(f"{k:46s} " + "   ".join(f"{v}: {min(x):.4f}..{max(x):.4f}" for v, x in d.items()))
 os.makedirs(os.path.join(R, "gpurun_out", "r06p"), exist_ok=True)
-json.dump({"bitwise_equal": same, "us_per_env_step": res}, open(os.path.join(R, "gpurun_out", "r06p", "ab_pairs.json"), "w"), indent=1)
+json.dump({"bitwise_equal": same, "us_per_env_step_by_aviary_size": times, "us_per_env_step": res}, open(os.path.join(R, "gpurun_out", "r06p", "ab_pairs.json"), "w"), indent=1)
