@@ -254,7 +254,7 @@ def measure(mode, args, env, actions, gather, device, world):
     n_total = core.N * world
     achieved = bytes_total / ev_s / 1e9
     kernel = getattr(env, "bench_kernel", {}).get(mode) or ("gpd_step_kernel" if mode != "rollout" else
-        ("gpd_rollout1_kernel" if core.D & (core.D - 1) == 0 and core.D <= 64 and core.term_obs12 is None else "gpd_rollout_kernel"))
+        ("gpd_rollout1_kernel" if core.D <= 64 and core.term_obs12 is None else "gpd_rollout_kernel"))
     segments = None
     if len(marks) > 1:
         # rate of the first ~100 ms of the timed region against the rest of it (a GPU that boosts out of idle and then settles, or

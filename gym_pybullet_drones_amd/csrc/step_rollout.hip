@@ -47,6 +47,7 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     L.d = MULTI ? (L.active ? tid - L.le * D : 0) : 0;
     L.env = MULTI ? (L.active ? blockIdx.x * (lanes / D) + L.le : 0u) : L.n;
     L.shfl = MULTI && D <= 64 && (D & (D - 1)) == 0;
+    L.base = MULTI ? L.le * D : tid;
 
     __shared__ __attribute__((aligned(16))) float sh_pos[MULTI ? 4 * kBlock : 4];   // downwash: positions of the env's drones
     __shared__ __attribute__((aligned(16))) float sh_red[MULTI ? 4 * kBlock : 4];   // reward | distance | out-of-bounds per drone
@@ -309,6 +310,7 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
     L.d = MULTI ? (L.active ? tid - L.le * D : 0) : 0;
     L.env = MULTI ? (L.active ? env_base + L.le : 0u) : L.n;
     L.shfl = shfl;
+    L.base = MULTI ? L.le * D : tid;
 
     Carry c;
     float tgx, tgy, tgz, ip[7];
@@ -476,10 +478,10 @@ struct RollOut {
 // addresses: a benign duplicate write instead of a branch around the stores.  (Calls that ask for terminal observations -- conditional stores -- use
 // the compute-wave + store-wave kernel above.)
 // ------------------------------------------------------------------------------------------------
-// MULTI: aviaries of D = 2, 4, ..., 64 drones (a power of two: D aligned lanes of one wave, wave-local exchange inside
-// env_step, no workgroup barrier).  Every lane of an aviary ends a step with the aviary's reward and flags and stores
-// them to the aviary's slot -- D identical writes instead of a branch; a lane without a drone is a clone of the drone with
-// the same index d in its workgroup's first aviary, so whole clone aviaries replay that aviary bit for bit.
+// MULTI: aviaries of D = 2 .. 64 drones, WHOLE aviaries per wave ((64 / D) D lanes of a wave hold a drone: D consecutive lanes of one
+// wave per aviary, wave-local exchange inside env_step, no workgroup barrier).  Every lane of an aviary ends a step with the
+// aviary's reward and flags and stores them to the aviary's slot -- D identical writes instead of a branch; a lane without a drone
+// is a clone (the lane mapping in the kernel says of whom), so clones replay their originals bit for bit.
 // RING (gpd_rollout_history): every step's raw action is also pushed into the action ring, like gpd_step does (slots q and
 // q + H of the double ring; two more stores per lane and step, which the explicit wait counts of the loop include because
 // they are unconditional -- a compile-time variant, not a run-time test).
@@ -504,21 +506,35 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     uint32_t bid = blockIdx.x;
     if (T.xcd) { const uint32_t per = gridDim.x >> 3; bid = (blockIdx.x & 7u) * per + (blockIdx.x >> 3); }
     const int D = MULTI ? C.drones_per_env : 1;
-    const uint32_t dmask = static_cast<uint32_t>(D - 1);
     const uint32_t N = static_cast<uint32_t>(C.num_envs) * static_cast<uint32_t>(D);
-    const uint32_t n_raw = bid * static_cast<uint32_t>(kBlock) + tid;
     const int K = T.num_steps;
     const uint32_t flags = EXT ? C.physics_flags : 0u;
+    // lane -> drone.  A wave holds W = (64 / D) D drones: WHOLE aviaries, so that an aviary's exchange never leaves its wave (64 when D
+    // divides 64 -- every lane has a drone; 63 for D = 3, 60 for D = 12 ...: the last 64 - W < D lanes of the wave are "pad" lanes).  A lane
+    // without a drone -- a pad lane, or a lane past the end of the batch -- is an exact CLONE: same state, same action rows, same
+    // arithmetic, hence the same bits, stored to its original's addresses (a benign duplicate write instead of a branch around the
+    // stores).  Whole aviaries past the end clone the first aviary of their wave (of their workgroup, when the wave has none) and are
+    // self-contained: they exchange through their own LDS slots.  A pad lane clones drone (lane - W) of its wave's first aviary and
+    // reads that aviary's slots (same wave: in order).
+    const int wave0 = tid & ~63, lane = tid & 63;
+    const int W = MULTI ? (64 / D) * D : 64;
+    const uint32_t block_base = bid * static_cast<uint32_t>(4 * W);                                   // first drone of this workgroup (< N)
+    const uint32_t n0 = block_base + static_cast<uint32_t>((tid >> 6) * W);                           // first drone of this wave
+    const uint32_t rows = n0 < N ? ((N - n0 < static_cast<uint32_t>(W)) ? N - n0 : static_cast<uint32_t>(W)) : 0u;   // lanes of this wave that own a drone
+    const uint32_t first = rows ? n0 : block_base;                                                    // the aviary this wave's clones copy
+    // the drone a row r of this wave's patch belongs to (r = lane index): its own, or its original's
+    auto drone_of = [&](uint32_t r) {
+        if (!MULTI) return r < rows ? n0 + r : block_base;
+        const uint32_t rw = static_cast<uint32_t>(W);
+        return r < rows ? n0 + r : first + (r < rw ? r - (r / static_cast<uint32_t>(D)) * static_cast<uint32_t>(D) : r - rw);
+    };
     Lane L;
     L.tid = tid; L.shfl = MULTI;
     L.le = MULTI ? tid / D : tid;
-    L.d = MULTI ? static_cast<int>(tid & dmask) : 0;
-    L.active = n_raw < N;
-    // a lane without a drone (ragged last workgroup) clones a drone of ITS OWN workgroup -- the one with the same index d
-    // in the workgroup's first aviary (which exists: the grid covers N, and N and 256 are multiples of D).  Owner and
-    // clone are co-resident, and the barrier behind load_carry orders the clone's loads before the owner's store_carry.
-    const uint32_t block_base = bid * static_cast<uint32_t>(kBlock);
-    L.n = L.active ? n_raw : block_base + (tid & dmask);
+    L.active = static_cast<uint32_t>(lane) < rows;
+    L.n = drone_of(static_cast<uint32_t>(lane));
+    L.d = MULTI ? static_cast<int>(L.n % static_cast<uint32_t>(D)) : 0;
+    L.base = MULTI ? wave0 + (lane < W ? (lane / D) * D : 0) : tid;
     L.env = MULTI ? L.n / static_cast<uint32_t>(D) : L.n;
 
     __shared__ __attribute__((aligned(16))) float sh_rows[kBlock * 12];
@@ -526,15 +542,12 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     __shared__ __attribute__((aligned(16))) float sh_red[MULTI ? 4 * kBlock : 4];   // reward | distance | out-of-bounds per drone
 
     // loop-invariant addressing of this lane's three 16-byte chunks of its wave's 3 KiB row patch
-    const int wave0 = tid & ~63, lane = tid & 63;
-    const uint32_t n0 = bid * static_cast<uint32_t>(kBlock) + wave0;      // first drone of this wave
-    const uint32_t rows = n0 < N ? ((N - n0 < 64u) ? N - n0 : 64u) : 0u;         // lanes of this wave that own a drone
     uint32_t goff[3];
     const char* lsrc = reinterpret_cast<const char*>(sh_rows + wave0 * 12) + lane * 16;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const uint32_t cidx = static_cast<uint32_t>(j * 64 + lane), r = cidx / 3u, part = cidx - 3u * r;
-        goff[j] = (r < rows ? (n0 + r) : block_base + (r & dmask)) * 48u + part * 16u;   // a clone's row goes to the row of its original
+        goff[j] = drone_of(r) * 48u + part * 16u;                     // a clone's row goes to the row of its original
     }
     const uint32_t eoff4 = L.env * 4u;
 
@@ -645,7 +658,20 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
         }
 #undef GPD_STEP_HOT
     } else {
-        const int lanes = multi ? (kBlock / C.drones_per_env) * C.drones_per_env : kBlock;
+        // aviaries of up to 64 drones run gpd_rollout1_kernel with WHOLE aviaries per wave (wave-local exchange, no helper wave, no
+        // workgroup barrier) -- also where the size does not divide 64 and some lanes of every wave stay without a drone: 0.50-0.65 of the
+        // compute-wave + store-wave kernel's time per step at every size from 3 to 63, half-empty waves (33 drones) included
+        // (scratch/exp_r06/ab_wave_local.py, profiles/r06_ab_wave_local_rollout.json).  GPD_ROLLOUT_WAVE_LOCAL=0 (diagnostics, the A/B):
+        // only the powers of two, the rule of rounds 2-5
+        static const char* const wl_env = getenv("GPD_ROLLOUT_WAVE_LOCAL");
+        const int Dm = C.drones_per_env, per_wave = Dm <= 64 ? (64 / Dm) * Dm : 0;
+        const bool pow2 = Dm <= 64 && (Dm & (Dm - 1)) == 0;
+        static const bool store_wave_variant = getenv("GPD_ROLLOUT_STOREWAVE") != nullptr;   // A/B switch, diagnostics only
+        // (terminal observations -- conditional stores -- and the diagnostics switch go to the compute-wave + store-wave kernel, whose
+        // workgroups hold (256 / D) D drones; the two packings agree where D divides 64)
+        const bool shfl = multi && Dm <= 64 && !store_wave_variant && term_obs12 == nullptr &&
+                          (pow2 || S.act_ring != nullptr || !(wl_env != nullptr && wl_env[0] == '0'));   // (gpd_rollout_history: this kernel only)
+        const int lanes = shfl ? 4 * per_wave : (multi ? (kBlock / Dm) * Dm : kBlock);
         const dim3 grid(static_cast<unsigned>((N + lanes - 1) / lanes));
 #define GPD_ROLL1_HOT S.kin, action, S.step_counter, target_pos, init_pose, static_cast<uint32_t>(S.ld), C.num_envs, Tr.num_steps, \
                       (static_cast<uint32_t>(C.auto_reset != 0) | (static_cast<uint32_t>(C.init_per_env != 0) << 1) |      \
@@ -653,10 +679,8 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
         Span Tr = T;
         static const char* const xcd_env = getenv("GPD_ROLLOUT_XCD");          // (diagnostics: 1 = contiguous eighths per XCD, 0 = never)
         Tr.xcd = (grid.x % 8u == 0u && xcd_env != nullptr && xcd_env[0] == '1') ? 1 : 0;
-        const bool shfl = multi && C.drones_per_env <= 64 && (C.drones_per_env & (C.drones_per_env - 1)) == 0;
-        Tr.ring = ((!multi || shfl) && grid.x <= 2u * 256u) ? 4 : 2;   // <= 2 workgroups per CU: LDS is not what limits occupancy
+        Tr.ring = ((!multi || pow2) && grid.x <= 2u * 256u) ? 4 : 2;   // <= 2 workgroups per CU: LDS is not what limits occupancy
         const size_t lds = static_cast<size_t>(Tr.ring) * kSlotBytes;
-        static const bool store_wave_variant = getenv("GPD_ROLLOUT_STOREWAVE") != nullptr;   // A/B switch, diagnostics only
         if (S.act_ring && !store_wave_variant && term_obs12 == nullptr && (shfl || !multi)) {   // gpd_rollout_history (it checked the shape)
             if (shfl)
                 hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false, true, true, true>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
@@ -665,7 +689,7 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
             else
                 hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false, false, true, true>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
         } else
-        if (shfl && !store_wave_variant && term_obs12 == nullptr) {   // aviaries of 2..64 (power of two) drones: no helper wave either
+        if (shfl) {   // aviaries of 2 .. 64 drones, whole aviaries per wave: no helper wave either
             hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false, true>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
         } else if (multi) {
             hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, true, AW>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
@@ -829,8 +853,8 @@ int gpd_rollout_history(const GpdParams* params, const GpdState* state, const Gp
         return fail(GPD_EINVAL, "gpd_rollout_history: strides must be non-negative");
     if (!state || !state->act_ring || !state->ring_pos || state->hist_len <= 0)
         return fail(GPD_EINVAL, "gpd_rollout_history: state has no action ring (act_ring / ring_pos / hist_len)");
-    if (cfg && cfg->drones_per_env > 1 && (cfg->drones_per_env > 64 || (cfg->drones_per_env & (cfg->drones_per_env - 1)) != 0))
-        return fail(GPD_ENOTSUP, "gpd_rollout_history: aviaries of 1, 2, 4 .. 64 drones (use gpd_rollout + gpd_full_obs otherwise)");
+    if (cfg && cfg->drones_per_env > 64)
+        return fail(GPD_ENOTSUP, "gpd_rollout_history: aviaries of up to 64 drones (use gpd_rollout + gpd_full_obs otherwise)");
     if (getenv("GPD_ROLLOUT_STOREWAVE")) return fail(GPD_ENOTSUP, "gpd_rollout_history: not with the GPD_ROLLOUT_STOREWAVE diagnostic");
     const Span T{num_steps, action_step_stride, obs_step_stride, env_step_stride, 2};
     return step_impl("gpd_rollout_history", params, state, cfg, T, actions, target_pos, init_pose, obs12, reward, terminated,

@@ -783,7 +783,7 @@ __global__ __launch_bounds__(kBlock) void gpd_swarm_step_kernel(float* __restric
     L.tid = threadIdx.x;
     L.active = n_raw < N;
     L.n = L.active ? n_raw : 0u;
-    L.le = L.tid; L.d = 0; L.env = L.n; L.shfl = false;
+    L.le = L.tid; L.base = L.tid; L.d = 0; L.env = L.n; L.shfl = false;
     const uint32_t flags = C.physics_flags;
     Carry c;
     float tgx, tgy, tgz, ip[7];

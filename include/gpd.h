@@ -296,7 +296,7 @@ int gpd_rollout(const GpdParams* params, const GpdState* state, const GpdStepCfg
  * way gpd_step does: for a consumer that keeps the history as the zero-copy view (envs/BaseRLAviary.py:65-67, 153-154, 187) and
  * needs no materialised rows -- the K actions never take the detour through a second kernel (gpd_full_obs with obs_full =
  * NULL does the same after a plain gpd_rollout, re-reading them: 1.72 vs 1.29 us per step at 65 536 drones).  No terminal
- * observations; aviaries of 1, 2, 4 .. 64 drones (GPD_ENOTSUP otherwise: use gpd_rollout + gpd_full_obs).
+ * observations; aviaries of up to 64 drones (GPD_ENOTSUP otherwise: use gpd_rollout + gpd_full_obs).
  */
 int gpd_rollout_history(const GpdParams* params, const GpdState* state, const GpdStepCfg* cfg, int32_t num_steps,
                         const float* actions, int64_t action_step_stride, const float* target_pos, const float* init_pose,

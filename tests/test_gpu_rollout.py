@@ -200,12 +200,14 @@ def test_full_observation_rows_step_vs_rollout(gpu_device, act, D, ctrl):
 
 
 @pytest.mark.parametrize("act,D,ctrl,E,K,fused", [("rpm", 1, 240, 1000, 7, True), ("rpm", 1, 30, 333, 40, True), ("pid", 1, 48, 300, 30, True),
-                                                  ("one_d_rpm", 2, 30, 257, 20, True), ("vel", 4, 240, 130, 9, True), ("rpm", 3, 48, 100, 12, False)])
+                                                  ("one_d_rpm", 2, 30, 257, 20, True), ("vel", 4, 240, 130, 9, True), ("rpm", 3, 48, 100, 12, True),
+                                                  ("pid", 7, 48, 41, 12, True), ("rpm", 70, 48, 5, 12, False)])
 def test_rollout_with_lazy_history_pushes_the_ring_inside_the_kernel(gpu_device, act, D, ctrl, E, K, fused):
     """`gpd_rollout_history` (VectorAviary(full_obs="lazy").rollout): every step's action goes into the action ring inside the
     rollout kernel.  Same observations, same ring (the zero-copy history view, the ring positions), same continuation as K
-    single steps -- for rollouts shorter and longer than the history, ragged batches, aviaries of 2 and 4 drones; an aviary of
-    3 drones has no fused variant and takes the post-pass (`pushed_history` False), with the same result."""
+    single steps -- for rollouts shorter and longer than the history, ragged batches, aviaries of 2, 3, 4 and 7 drones (whole
+    aviaries per wave: 63 of a wave's lanes hold a drone for 3 and 7); an aviary of 70 drones has no fused variant and takes the
+    post-pass (`pushed_history` False), with the same result."""
     from gym_pybullet_drones_amd.envs import VectorAviary
     from gym_pybullet_drones_amd.utils.enums import ActionType
     rng = np.random.default_rng(K)
