@@ -282,8 +282,7 @@ def measure(mode, args, env, actions, gather, device, world):
 
 
 def attach_counters(roof, key, m, core, clock_ghz):
-    """Offline-measured per-kernel figures (separate rocprofv3 passes, profiles/*.json) next to the live numbers: HBM traffic from the
-    FETCH_SIZE / WRITE_SIZE counters, scaled to this launch's step count, and the instruction counts behind the VALU-issue roofline."""
+    """Offline rocprofv3 figures (profiles/*.json) beside the live ones: FETCH_SIZE / WRITE_SIZE traffic scaled to this launch's step count, the trace's kernel average, the instruction counts behind the VALU-issue roofline."""
     issue = None
     tfile = os.path.join(REPO, "profiles", "hbm_traffic.json")
     if os.path.exists(tfile):
@@ -300,6 +299,8 @@ def attach_counters(roof, key, m, core, clock_ghz):
                 roof["traffic_note"] = (f"counters of the {prof_steps}-step profile launch scaled by the algorithmic bytes to this "
                                         f"launch's {spl:g} steps (profiles/hbm_traffic.json)")
             roof["rocprof_kernel_avg_us"], roof["rocprof_note"] = (rec.get("rocprof_kernel_avg_ns", 0) / 1e3 if spl == prof_steps else None), rec.get("rocprof_note")
+            own = rocprof_record(f"{key.split(':')[0]}:rollout{spl:g}") if spl != prof_steps else {}     # the committed trace of THIS step count (the driver's: 20)
+            roof.update({k: v for k, v in own.items() if own.get("rocprof_kernel_avg_us") and v is not None})
     cfile = os.path.join(REPO, "profiles", "kernel_counters.json")
     if os.path.exists(cfile):
         rec = json.load(open(cfile)).get(key)
@@ -679,8 +680,7 @@ def rocprof_record(key):
     for name in ("r06_hbm_reconcile.json", "r05_hbm_reconcile.json"):
         try:
             rec = json.load(open(os.path.join(REPO, "profiles", name)))["keys"][key]
-            return {"rocprof_kernel_avg_us": rec["rocprof_kernel_avg_us"], "rocprof_frac": rec["rocprof_frac"],
-                    "rocprof_note": rec.get("note"), "rocprof_file": "profiles/" + name}
+            return {"rocprof_kernel_avg_us": rec["rocprof_kernel_avg_us"], "rocprof_frac": rec.get("rocprof_frac"), "rocprof_note": rec.get("note"), "rocprof_file": "profiles/" + name}
         except Exception:           # noqa: BLE001
             continue
     return {"rocprof_kernel_avg_us": None, "rocprof_note": "no committed reconciliation"}
