@@ -487,7 +487,13 @@ struct RollOut {
 // they are unconditional -- a compile-time variant, not a run-time test).
 // (the argument list starts with the fourteen dwords the launch's first loads need -- kernarg preload, as for gpd_step_kernel: the state,
 // the first action rows, the counter, the target and the reset pose are requested without first waiting for the argument block)
-template <bool PID, bool EXT, int AW, int ACT, bool S1, bool MULTI, bool NT_OBS = true, bool RING = false>
+// DC: the aviary size as a compile-time constant (0: C.drones_per_env) -- BASELINE's two multi-drone shapes, pairs (config 5) and stacks of
+// eight (config 3 ii), at one sub-step per step: the size tests, the mates loops of the downwash and of the task sums and the sub-step loop
+// fold away, the LDS reads of all mates are issued together and no loop branch is taken (a taken branch costs ~60 cycles at one wave per
+// SIMD).  Same operations in the same order: bit for bit the generic kernel (scratch/exp_r06/ab_unroll.py).
+// FL: the physics flags as a compile-time constant too (-1: C.physics_flags) -- the reference's two multi-drone add-on sets, PYB_DW (4) and
+// PYB_GND_DRAG_DW (7): the flag tests of every sub-step (uniform branches: ~11 cycles not taken, 25-60 taken) fold away.
+template <bool PID, bool EXT, int AW, int ACT, bool S1, bool MULTI, bool NT_OBS = true, bool RING = false, int DC = 0, int FL = -1>
 __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     float* __restrict__ hot_kin, const float* __restrict__ action, int32_t* __restrict__ hot_counter, const float* __restrict__ target_pos,
     const float* __restrict__ init_pose, const uint32_t hot_ld, const int32_t hot_num_envs, const int32_t hot_num_steps, const uint32_t hot_bits,
@@ -505,10 +511,10 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     // workgroup -- at 65 536 drones that changed nothing (0.816 vs 0.813-0.821 us per step, round-2 A/B)
     uint32_t bid = blockIdx.x;
     if (T.xcd) { const uint32_t per = gridDim.x >> 3; bid = (blockIdx.x & 7u) * per + (blockIdx.x >> 3); }
-    const int D = MULTI ? C.drones_per_env : 1;
+    const int D = MULTI ? (DC ? DC : C.drones_per_env) : 1;
     const uint32_t N = static_cast<uint32_t>(C.num_envs) * static_cast<uint32_t>(D);
     const int K = T.num_steps;
-    const uint32_t flags = EXT ? C.physics_flags : 0u;
+    const uint32_t flags = EXT ? (FL >= 0 ? static_cast<uint32_t>(FL) : C.physics_flags) : 0u;
     // lane -> drone.  A wave holds W = (64 / D) D drones: WHOLE aviaries, so that an aviary's exchange never leaves its wave (64 when D
     // divides 64 -- every lane has a drone; 63 for D = 3, 60 for D = 12 ...: the last 64 - W < D lanes of the wave are "pad" lanes).  A lane
     // without a drone -- a pad lane, or a lane past the end of the batch -- is an exact CLONE: same state, same action rows, same
@@ -690,7 +696,26 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
                 hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false, false, true, true>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
         } else
         if (shfl) {   // aviaries of 2 .. 64 drones, whole aviaries per wave: no helper wave either
-            hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false, true>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
+            static const bool sized = getenv("GPD_ROLLOUT_SIZED") == nullptr || getenv("GPD_ROLLOUT_SIZED")[0] != '0';   // (0: diagnostics, the A/B)
+#define GPD_ROLL1(S1_, DC_, FL_) hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, S1_, true, true, false, DC_, FL_>), grid, dim3(kBlock), 0, st, \
+                                                    GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12)
+            const bool s1 = C.substeps == 1;
+            bool done = false;
+            if constexpr (EXT) {      // pairs with PYB_DW, stacks of eight with PYB_GND_DRAG_DW: BASELINE configs 5 and 3 (ii)
+                if (sized && s1 && Dm == 8 && C.physics_flags == 7u) { GPD_ROLL1(true, 8, 7); done = true; }
+                else if (sized && s1 && Dm == 2 && C.physics_flags == 4u) { GPD_ROLL1(true, 2, 4); done = true; }
+            }
+            if constexpr (EXT) {      // any aviary size with every add-on at one sub-step per step
+                if (!done && sized && s1 && C.physics_flags == 7u) { GPD_ROLL1(true, 0, 7); done = true; }
+            }
+            if (done) {}
+            else if (sized && s1 && Dm == 8) GPD_ROLL1(true, 8, -1);
+            else if (sized && s1 && Dm == 2) GPD_ROLL1(true, 2, -1);
+            else if (sized && Dm == 8) GPD_ROLL1(false, 8, -1);
+            else if (sized && Dm == 2) GPD_ROLL1(false, 2, -1);       // (MultiHoverAviary's defaults: pairs, 30 Hz control)
+            else if (sized && s1) GPD_ROLL1(true, 0, -1);
+            else GPD_ROLL1(false, 0, -1);
+#undef GPD_ROLL1
         } else if (multi) {
             hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, true, AW>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
                                action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
@@ -706,9 +731,18 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
             const bool plain_obs = obs_stores != nullptr && obs_stores[0] == 'p';
             if (C.substeps == 1 && !PID && !EXT && ACT == GPD_ACT_RPM && (plain_obs || (N <= (1 << 17) && T.num_steps >= 48)))
                 hipLaunchKernelGGL((gpd_rollout1_kernel<false, false, 4, GPD_ACT_RPM, true, false, false>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
-            else if (C.substeps == 1)
-                hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, true, false>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
-            else
+            else if (C.substeps == 1) {
+                static const bool sized = getenv("GPD_ROLLOUT_SIZED") == nullptr || getenv("GPD_ROLLOUT_SIZED")[0] != '0';
+                bool done = false;
+                if constexpr (EXT) {  // single drones with PYB_GND_DRAG_DW's flags (BASELINE config 3 i): the flag tests fold away
+                    if (sized && C.physics_flags == 7u) {
+                        hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, true, false, true, false, 0, 7>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
+                        done = true;
+                    }
+                }
+                if (!done)
+                    hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, true, false>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
+            } else
                 hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false, false>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
         } else {
             hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, false, AW>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
