@@ -16,7 +16,9 @@ namespace {
 // issued without first waiting for a scalar load of the argument block -- one memory round trip off the launch's critical path; the
 // by-value structs follow and are fetched while the vector loads are in flight).  Hot: copies of S.kin, S.step_counter, S.ld, the slot
 // source (S.ring_pos, or the step counters when there is no ring), C.num_envs, C.lanes_per_wave, C.target_per_env.
-template <bool PID, bool EXT, bool MULTI, int AW, int ACT, bool S1>
+// DC / FL: the aviary size and the physics flags as compile-time constants for BASELINE's multi-term shapes (0 / -1: from the argument
+// block), as in gpd_rollout1_kernel below -- the uniform branches on them fold away, S1 then also applies to multi-drone aviaries.
+template <bool PID, bool EXT, bool MULTI, int AW, int ACT, bool S1, int DC = 0, int FL = -1>
 __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     float* __restrict__ hot_kin, const float* __restrict__ action, int32_t* __restrict__ hot_counter,
     const float* __restrict__ target_pos, const int32_t* __restrict__ hot_slot, const uint32_t hot_ld, const int32_t hot_num_envs,
@@ -31,7 +33,7 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     const GpdStepCfg C{hot_num_envs, C_.drones_per_env, C_.act_type, C_.substeps, C_.physics_flags, C_.pyb_dt, C_.ctrl_dt, C_.inv_ctrl_dt,
                        hot_lanes_per_wave, C_.task, C_.xy_bound, C_.z_bound, C_.tilt_bound, C_.term_dist, C_.trunc_counter, hot_target_per_env,
                        C_.init_per_env, C_.auto_reset};
-    const int D = MULTI ? C.drones_per_env : 1;
+    const int D = MULTI ? (DC ? DC : C.drones_per_env) : 1;
     const int tid = threadIdx.x;
     const uint32_t N = static_cast<uint32_t>(C.num_envs) * static_cast<uint32_t>(D);
     // MULTI: whole aviaries per workgroup, one lane per drone.  Single-drone aviaries: LW = lanes_per_wave
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     __shared__ __attribute__((aligned(16))) float sh_red[MULTI ? 4 * kBlock : 4];   // reward | distance | out-of-bounds per drone
     __shared__ __attribute__((aligned(16))) float sh_rows[kBlock * 12];   // obs rows, for the coalesced store of large batches
 
-    const uint32_t flags = EXT ? C.physics_flags : 0u;
+    const uint32_t flags = EXT ? (FL >= 0 ? static_cast<uint32_t>(FL) : C.physics_flags) : 0u;
     Carry c;
     float tgx, tgy, tgz;
     const float4 act = load_action<AW>(action, L.n);
@@ -652,7 +654,20 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
         if (done != nullptr) done->used = done_flag != nullptr;
 #define GPD_STEP_HOT S.kin, action, S.step_counter, target_pos, static_cast<const int32_t*>(S.act_ring ? S.ring_pos : S.step_counter), \
                      static_cast<uint32_t>(S.ld), C.num_envs, C.lanes_per_wave, C.target_per_env
-        if (multi) {
+        static const bool sized = getenv("GPD_ROLLOUT_SIZED") == nullptr || getenv("GPD_ROLLOUT_SIZED")[0] != '0';   // (0: the generic kernels, the A/B)
+        bool launched = false;
+        if constexpr (EXT) {      // BASELINE configs 3 (ii), 5, 3 (i) at one sub-step per step (see gpd_rollout1_kernel)
+#define GPD_STEP1(MULTI_, DC_, FL_) hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, MULTI_, AW, ACT, true, DC_, FL_>), grid, dim3(kBlock), 0, st, GPD_STEP_HOT, P, S, C, \
+                                                       init_pose, obs12, reward, terminated, truncated, term_obs12, done_flag, done_seq)
+            if (sized && C.substeps == 1) {
+                if (multi && C.drones_per_env == 8 && C.physics_flags == 7u) { GPD_STEP1(true, 8, 7); launched = true; }
+                else if (multi && C.drones_per_env == 2 && C.physics_flags == 4u) { GPD_STEP1(true, 2, 4); launched = true; }
+                else if (!multi && C.physics_flags == 7u) { GPD_STEP1(false, 0, 7); launched = true; }
+            }
+#undef GPD_STEP1
+        }
+        if (launched) {
+        } else if (multi) {
             hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, true, AW, ACT, false>), grid, dim3(kBlock), 0, st, GPD_STEP_HOT, P, S, C,
                                init_pose, obs12, reward, terminated, truncated, term_obs12, done_flag, done_seq);
         } else if (C.substeps == 1) {

@@ -77,7 +77,7 @@ WORK = [("stack8x8192_ext_240hz", ["--steps", "64", "--warmup", "64"]), ("stack8
 for rnd in range(2):
     for wl, extra in WORK:
         for mode in ("rollout", "graph"):
-            if mode == "graph" and (rnd or wl != "stack8x8192_ext_240hz" or extra[1] != "64"):
+            if mode == "graph" and (extra[1] != "64" or "pid" in wl or wl == "hover65536_240hz"):      # (the single-step kernel's variants)
                 continue
             for v, lib in LIBS.items():
                 cmd = [sys.executable, os.path.join(R, "bench.py"), "--workload", wl, "--mode", mode, "--no-cpu-baseline", "--no-hbm-leg", "--no-parity", "--no-second-leg",
