@@ -20,12 +20,12 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 res = {}
 for rnd in range(rounds):
     for wl, extra in WORK:
-        if rnd and wl != "hover65536_240hz":
+        if rnd and wl != "hover65536_240hz" and not os.environ.get("GPD_AB_MODE"):
             continue
         for v, lib in LIBS.items():
             e = dict(os.environ, GPD_LIB=os.path.join(R, lib))
             cmd = [sys.executable, os.path.join(R, "bench.py"), "--workload", wl, "--no-cpu-baseline", "--no-hbm-leg", "--no-parity", "--no-second-leg", "--no-dropin-leg",
-                   "--min-time", "0.5"] + extra
+                   "--min-time", "0.5"] + extra + (["--mode", os.environ["GPD_AB_MODE"]] if os.environ.get("GPD_AB_MODE") else [])   # (graph: the single-step kernel)
             p = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=300)
             line = next((l for l in reversed(p.stdout.splitlines()) if l.startswith("{")), None)
             if not line:
