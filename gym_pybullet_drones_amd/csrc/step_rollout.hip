@@ -640,6 +640,10 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     if constexpr (RING) { if (L.active && L.d == 0) S.ring_pos[L.env] = ring_q; }
 }
 
+// the kernels compiled for one aviary size / flag set exist for BaseRLAviary's five action types (not for the raw-RPM rows of CtrlAviary
+// and of subclasses with their own _preprocessAction: every variant is another pair of large kernels to compile)
+template <int ACT> constexpr bool kSizedAct = ACT != GPD_ACT_RAW_RPM && ACT != GPD_ACT_DIRECT_RPM;
+
 template <bool PID, bool EXT, int AW, int ACT>
 hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const GpdState& S, const GpdStepCfg& C,
                        const Span& T, const float* action, const float* target_pos, const float* init_pose,
@@ -656,7 +660,7 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
                      static_cast<uint32_t>(S.ld), C.num_envs, C.lanes_per_wave, C.target_per_env
         static const bool sized = getenv("GPD_ROLLOUT_SIZED") == nullptr || getenv("GPD_ROLLOUT_SIZED")[0] != '0';   // (0: the generic kernels, the A/B)
         bool launched = false;
-        if constexpr (EXT) {      // BASELINE configs 3 (ii), 5, 3 (i) at one sub-step per step (see gpd_rollout1_kernel)
+        if constexpr (EXT && kSizedAct<ACT>) {      // BASELINE configs 3 (ii), 5, 3 (i) at one sub-step per step (see gpd_rollout1_kernel)
 #define GPD_STEP1(MULTI_, DC_, FL_) hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, MULTI_, AW, ACT, true, DC_, FL_>), grid, dim3(kBlock), 0, st, GPD_STEP_HOT, P, S, C, \
                                                        init_pose, obs12, reward, terminated, truncated, term_obs12, done_flag, done_seq)
             if (sized && C.substeps == 1) {
@@ -716,20 +720,20 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
                                                     GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12)
             const bool s1 = C.substeps == 1;
             bool done = false;
-            if constexpr (EXT) {      // pairs with PYB_DW, stacks of eight with PYB_GND_DRAG_DW: BASELINE configs 5 and 3 (ii)
+            if constexpr (EXT && kSizedAct<ACT>) {
+                // pairs with PYB_DW, stacks of eight with PYB_GND_DRAG_DW (BASELINE configs 5 and 3 ii); any size with every add-on
                 if (sized && s1 && Dm == 8 && C.physics_flags == 7u) { GPD_ROLL1(true, 8, 7); done = true; }
                 else if (sized && s1 && Dm == 2 && C.physics_flags == 4u) { GPD_ROLL1(true, 2, 4); done = true; }
+                else if (sized && s1 && C.physics_flags == 7u) { GPD_ROLL1(true, 0, 7); done = true; }
             }
-            if constexpr (EXT) {      // any aviary size with every add-on at one sub-step per step
-                if (!done && sized && s1 && C.physics_flags == 7u) { GPD_ROLL1(true, 0, 7); done = true; }
+            if constexpr (kSizedAct<ACT>) {
+                // pairs with any flag set (MultiHoverAviary's defaults: two drones, 30 Hz control, no add-on force); any size at 240 Hz
+                if (done) {}
+                else if (sized && s1 && Dm == 2) { GPD_ROLL1(true, 2, -1); done = true; }
+                else if (sized && Dm == 2) { GPD_ROLL1(false, 2, -1); done = true; }
+                else if (sized && s1) { GPD_ROLL1(true, 0, -1); done = true; }
             }
-            if (done) {}
-            else if (sized && s1 && Dm == 8) GPD_ROLL1(true, 8, -1);
-            else if (sized && s1 && Dm == 2) GPD_ROLL1(true, 2, -1);
-            else if (sized && Dm == 8) GPD_ROLL1(false, 8, -1);
-            else if (sized && Dm == 2) GPD_ROLL1(false, 2, -1);       // (MultiHoverAviary's defaults: pairs, 30 Hz control)
-            else if (sized && s1) GPD_ROLL1(true, 0, -1);
-            else GPD_ROLL1(false, 0, -1);
+            if (!done) GPD_ROLL1(false, 0, -1);
 #undef GPD_ROLL1
         } else if (multi) {
             hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, true, AW>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
@@ -749,7 +753,7 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
             else if (C.substeps == 1) {
                 static const bool sized = getenv("GPD_ROLLOUT_SIZED") == nullptr || getenv("GPD_ROLLOUT_SIZED")[0] != '0';
                 bool done = false;
-                if constexpr (EXT) {  // single drones with PYB_GND_DRAG_DW's flags (BASELINE config 3 i): the flag tests fold away
+                if constexpr (EXT && kSizedAct<ACT>) {  // single drones with PYB_GND_DRAG_DW's flags (BASELINE config 3 i): the flag tests fold away
                     if (sized && C.physics_flags == 7u) {
                         hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, true, false, true, false, 0, 7>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
                         done = true;
