@@ -1,0 +1,47 @@
+"""Prints one JSON line of digests: rollouts and single steps of the shapes `gpd_rollout1_kernel` / `gpd_step_kernel` have compile-time
+variants for (csrc/step_rollout.hip: aviary size, physics flags, one sub-step per step as template parameters), plus shapes that take
+the generic kernels.  tests/test_gpu_rollout.py runs it twice -- with GPD_ROLLOUT_SIZED=0 (generic kernels only) and without -- and
+compares: the variants are the generic kernel bit for bit."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from gym_pybullet_drones_amd.envs import VectorAviary          # noqa: E402
+from gym_pybullet_drones_amd.utils.enums import ActionType     # noqa: E402
+
+dev = torch.device("cuda", 0)
+out = {}
+# (drones per aviary, physics flags, action type, sub-steps): sized <8,7>, <2,4>, <1 drone,7>, <any,7>, <2,-1> at 1 and 8 sub-steps,
+# <any size, one sub-step>; and generic shapes (3 drones at 30 Hz, 12 drones with the drag term only)
+SHAPES = [(8, 7, "rpm", 1), (8, 7, "pid", 1), (2, 4, "rpm", 1), (2, 4, "vel", 1), (1, 7, "one_d_rpm", 1), (1, 7, "pid", 1), (5, 7, "rpm", 1),
+          (2, 0, "rpm", 1), (2, 0, "one_d_pid", 8), (2, 7, "rpm", 8), (3, 4, "rpm", 1), (3, 7, "rpm", 8), (12, 2, "pid", 1)]
+for D, phys, act, S in SHAPES:
+    E = 777 if D == 1 else 300
+    rng = np.random.default_rng(100 * D + phys)
+    xyz = np.zeros((E, D, 3))
+    xyz[..., :2] = rng.uniform(-0.3, 0.3, size=(E, D, 2))
+    xyz[..., 2] = 0.4 + 0.3 * np.arange(D) + rng.uniform(-0.02, 0.02, size=(E, D))
+    rpy = rng.uniform(-0.1, 0.1, size=(E, D, 3))
+    env = VectorAviary(E, D, initial_xyzs=xyz, initial_rpys=rpy, physics=phys, pyb_freq=240, ctrl_freq=240 // S, act=ActionType(act),
+                       task="hover" if D == 1 else "multihover", auto_reset=True, track_rpm=True, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    a = torch.rand((20, E, D, env.ACT_DIM), generator=g, device=dev) * 2 - 1
+    if act in ("pid", "one_d_pid"):
+        a = a * 0.3
+        a[..., -1] += 1.0
+    if act == "vel":
+        a[..., 3] = a[..., 3].abs()
+    h = hashlib.sha256()
+    for t in (*env.core.rollout(a.contiguous(), update_latest=False), env.core.kin_store):
+        h.update(t.cpu().numpy().tobytes())
+    for k in range(5):
+        for t in env.core.step(a[k].contiguous()):
+            h.update(t.cpu().numpy().tobytes())
+    out[f"D{D}_flags{phys}_{act}_S{S}"] = h.hexdigest()[:20]
+print(json.dumps(out))

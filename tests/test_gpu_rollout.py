@@ -282,3 +282,24 @@ def test_rollout_arena_places_the_blocks_and_changes_no_bit(gpu_device):
     arena2, rep2 = place_rollout(b.core, K, target=0.0, max_arenas=2, max_probes=4)       # a target every layout reaches: one confirmed probe
     assert rep2["probes"] == 1 and rep2["arenas_tried"] == 1 and rep2["reached_target"] and "confirmed_frac" in rep2["all_probes"][0]
     assert b.core._rollout_cache[K][0].data_ptr() >= arena2.slab.data_ptr()
+
+
+def test_kernels_compiled_for_one_aviary_size_and_flag_set_are_the_generic_kernels_bit_for_bit():
+    """`gpd_rollout1_kernel` / `gpd_step_kernel` have variants with the aviary size, the physics flags and "one sub-step per step" as
+    template parameters (BASELINE configs 3 (i), 3 (ii), 5 run 12 / 26 / 28 % faster with them).  Same operations,
+    same order: rollouts and single steps of thirteen shapes -- every variant, and shapes that fall through to the generic kernels --
+    digest identically with GPD_ROLLOUT_SIZED=0 (generic kernels only; the switch is read once per process, hence the two children)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    got = {}
+    for label, extra in (("generic", {"GPD_ROLLOUT_SIZED": "0"}), ("sized", {})):
+        env = {k: v for k, v in os.environ.items() if k != "GPD_ROLLOUT_SIZED"}
+        res = subprocess.run([sys.executable, os.path.join(here, "helpers", "sized_digests.py")], env=dict(env, **extra), capture_output=True,
+                             text=True, timeout=600)
+        line = next((l for l in res.stdout.splitlines() if l.startswith("{")), None)
+        assert res.returncode == 0 and line, res.stderr[-1500:]
+        got[label] = json.loads(line)
+    assert len(got["generic"]) == 13 and got["generic"] == got["sized"], {k: (v, got["sized"].get(k)) for k, v in got["generic"].items() if got["sized"].get(k) != v}
