@@ -643,6 +643,11 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
 // the kernels compiled for one aviary size / flag set exist for BaseRLAviary's five action types (not for the raw-RPM rows of CtrlAviary
 // and of subclasses with their own _preprocessAction: every variant is another pair of large kernels to compile)
 template <int ACT> constexpr bool kSizedAct = ACT != GPD_ACT_RAW_RPM && ACT != GPD_ACT_DIRECT_RPM;
+// GPD_ROLLOUT_SIZED=0 (diagnostics, the A/B; read once per process): the generic kernels only
+inline bool sized_variants() {
+    static const bool on = [] { const char* e = getenv("GPD_ROLLOUT_SIZED"); return e == nullptr || e[0] != '0'; }();
+    return on;
+}
 
 template <bool PID, bool EXT, int AW, int ACT>
 hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const GpdState& S, const GpdStepCfg& C,
@@ -658,7 +663,7 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
         if (done != nullptr) done->used = done_flag != nullptr;
 #define GPD_STEP_HOT S.kin, action, S.step_counter, target_pos, static_cast<const int32_t*>(S.act_ring ? S.ring_pos : S.step_counter), \
                      static_cast<uint32_t>(S.ld), C.num_envs, C.lanes_per_wave, C.target_per_env
-        static const bool sized = getenv("GPD_ROLLOUT_SIZED") == nullptr || getenv("GPD_ROLLOUT_SIZED")[0] != '0';   // (0: the generic kernels, the A/B)
+        const bool sized = sized_variants();
         bool launched = false;
         if constexpr (EXT && kSizedAct<ACT>) {      // BASELINE configs 3 (ii), 5, 3 (i) at one sub-step per step (see gpd_rollout1_kernel)
 #define GPD_STEP1(MULTI_, DC_, FL_) hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, MULTI_, AW, ACT, true, DC_, FL_>), grid, dim3(kBlock), 0, st, GPD_STEP_HOT, P, S, C, \
@@ -715,7 +720,7 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
                 hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false, false, true, true>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
         } else
         if (shfl) {   // aviaries of 2 .. 64 drones, whole aviaries per wave: no helper wave either
-            static const bool sized = getenv("GPD_ROLLOUT_SIZED") == nullptr || getenv("GPD_ROLLOUT_SIZED")[0] != '0';   // (0: diagnostics, the A/B)
+            const bool sized = sized_variants();
 #define GPD_ROLL1(S1_, DC_, FL_) hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, S1_, true, true, false, DC_, FL_>), grid, dim3(kBlock), 0, st, \
                                                     GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12)
             const bool s1 = C.substeps == 1;
@@ -751,7 +756,7 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
             if (C.substeps == 1 && !PID && !EXT && ACT == GPD_ACT_RPM && (plain_obs || (N <= (1 << 17) && T.num_steps >= 48)))
                 hipLaunchKernelGGL((gpd_rollout1_kernel<false, false, 4, GPD_ACT_RPM, true, false, false>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
             else if (C.substeps == 1) {
-                static const bool sized = getenv("GPD_ROLLOUT_SIZED") == nullptr || getenv("GPD_ROLLOUT_SIZED")[0] != '0';
+                const bool sized = sized_variants();
                 bool done = false;
                 if constexpr (EXT && kSizedAct<ACT>) {  // single drones with PYB_GND_DRAG_DW's flags (BASELINE config 3 i): the flag tests fold away
                     if (sized && C.physics_flags == 7u) {
