@@ -35,30 +35,44 @@ def _asm(unit, extra):
         return open(out).read().split("\n")
 
 
+_UNIT_ASM = {}
+
+
+def _unit_asm(index):
+    """The assembly of unit `index`; the first request compiles all four units side by side (the largest takes ~2 min on its own)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from gym_pybullet_drones_amd import _native
+    if not _UNIT_ASM:
+        if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+            pytest.skip("no hipcc")
+        with ThreadPoolExecutor(len(_native.UNITS)) as pool:
+            for i, lines in enumerate(pool.map(lambda u: _asm(*u), _native.UNITS)):
+                _UNIT_ASM[i] = lines
+    return _UNIT_ASM[index]
+
+
 @pytest.fixture(scope="module")
 def gpd_asm():
-    from gym_pybullet_drones_amd import _native
-    return _asm(*_native.UNITS[0])
+    return _unit_asm(0)
 
 
 @pytest.fixture(scope="module")
 def policy_asm():
-    from gym_pybullet_drones_amd import _native
-    return _asm(*_native.UNITS[1])
+    return _unit_asm(1)
 
 
 @pytest.fixture(scope="module")
 def swarm_asm():
     from gym_pybullet_drones_amd import _native
     assert _native.UNITS[2][0] == "swarm.hip"
-    return _asm(*_native.UNITS[2])
+    return _unit_asm(2)
 
 
 @pytest.fixture(scope="module")
 def abi_asm():
     from gym_pybullet_drones_amd import _native
     assert _native.UNITS[3][0] == "abi.hip"
-    return _asm(*_native.UNITS[3])
+    return _unit_asm(3)
 
 
 def _kernel(lines, name):
