@@ -18,7 +18,9 @@ namespace {
 // source (S.ring_pos, or the step counters when there is no ring), C.num_envs, C.lanes_per_wave, C.target_per_env.
 // DC / FL: the aviary size and the physics flags as compile-time constants for BASELINE's multi-term shapes (0 / -1: from the argument
 // block), as in gpd_rollout1_kernel below -- the uniform branches on them fold away, S1 then also applies to multi-drone aviaries.
-template <bool PID, bool EXT, bool MULTI, int AW, int ACT, bool S1, int DC = 0, int FL = -1>
+// HI: with FL, whether the bits above the three add-on models (GPD_PHYS_GROUND, GPD_PHYS_DAMP: what a `Physics.PYB_*` member adds by default)
+// are taken from the argument block (true) or known to be clear (false).
+template <bool PID, bool EXT, bool MULTI, int AW, int ACT, bool S1, int DC = 0, int FL = -1, bool HI = false>
 __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     float* __restrict__ hot_kin, const float* __restrict__ action, int32_t* __restrict__ hot_counter,
     const float* __restrict__ target_pos, const int32_t* __restrict__ hot_slot, const uint32_t hot_ld, const int32_t hot_num_envs,
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
     __shared__ __attribute__((aligned(16))) float sh_red[MULTI ? 4 * kBlock : 4];   // reward | distance | out-of-bounds per drone
     __shared__ __attribute__((aligned(16))) float sh_rows[kBlock * 12];   // obs rows, for the coalesced store of large batches
 
-    const uint32_t flags = EXT ? (FL >= 0 ? static_cast<uint32_t>(FL) : C.physics_flags) : 0u;
+    const uint32_t flags = EXT ? (FL >= 0 ? (static_cast<uint32_t>(FL) | (HI ? C.physics_flags & ~7u : 0u)) : C.physics_flags) : 0u;
     Carry c;
     float tgx, tgy, tgz;
     const float4 act = load_action<AW>(action, L.n);
@@ -495,7 +497,9 @@ struct RollOut {
 // SIMD).  Same operations in the same order: bit for bit the generic kernel (scratch/exp_r06/ab_unroll.py).
 // FL: the physics flags as a compile-time constant too (-1: C.physics_flags) -- the reference's two multi-drone add-on sets, PYB_DW (4) and
 // PYB_GND_DRAG_DW (7): the flag tests of every sub-step (uniform branches: ~11 cycles not taken, 25-60 taken) fold away.
-template <bool PID, bool EXT, int AW, int ACT, bool S1, bool MULTI, bool NT_OBS = true, bool RING = false, int DC = 0, int FL = -1>
+// HI: with FL, the bits above the add-on models (the ground plane and Bullet's damping, which `Physics.PYB_*` members add by default) come
+// from the argument block (true) or are known to be clear (false: exactly the reference's explicit integrator + the add-on models).
+template <bool PID, bool EXT, int AW, int ACT, bool S1, bool MULTI, bool NT_OBS = true, bool RING = false, int DC = 0, int FL = -1, bool HI = false>
 __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     float* __restrict__ hot_kin, const float* __restrict__ action, int32_t* __restrict__ hot_counter, const float* __restrict__ target_pos,
     const float* __restrict__ init_pose, const uint32_t hot_ld, const int32_t hot_num_envs, const int32_t hot_num_steps, const uint32_t hot_bits,
@@ -516,7 +520,7 @@ __global__ __launch_bounds__(kBlock) void gpd_rollout1_kernel(
     const int D = MULTI ? (DC ? DC : C.drones_per_env) : 1;
     const uint32_t N = static_cast<uint32_t>(C.num_envs) * static_cast<uint32_t>(D);
     const int K = T.num_steps;
-    const uint32_t flags = EXT ? (FL >= 0 ? static_cast<uint32_t>(FL) : C.physics_flags) : 0u;
+    const uint32_t flags = EXT ? (FL >= 0 ? (static_cast<uint32_t>(FL) | (HI ? C.physics_flags & ~7u : 0u)) : C.physics_flags) : 0u;
     // lane -> drone.  A wave holds W = (64 / D) D drones: WHOLE aviaries, so that an aviary's exchange never leaves its wave (64 when D
     // divides 64 -- every lane has a drone; 63 for D = 3, 60 for D = 12 ...: the last 64 - W < D lanes of the wave are "pad" lanes).  A lane
     // without a drone -- a pad lane, or a lane past the end of the batch -- is an exact CLONE: same state, same action rows, same
@@ -666,12 +670,20 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
         const bool sized = sized_variants();
         bool launched = false;
         if constexpr (EXT && kSizedAct<ACT>) {      // BASELINE configs 3 (ii), 5, 3 (i) at one sub-step per step (see gpd_rollout1_kernel)
-#define GPD_STEP1(MULTI_, DC_, FL_) hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, MULTI_, AW, ACT, true, DC_, FL_>), grid, dim3(kBlock), 0, st, GPD_STEP_HOT, P, S, C, \
-                                                       init_pose, obs12, reward, terminated, truncated, term_obs12, done_flag, done_seq)
+#define GPD_STEP1(MULTI_, DC_, FL_)                                                                                                                       \
+    do {                                                                                                                                                 \
+        if (hi) hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, MULTI_, AW, ACT, true, DC_, FL_, true>), grid, dim3(kBlock), 0, st, GPD_STEP_HOT, P, S, C,   \
+                                   init_pose, obs12, reward, terminated, truncated, term_obs12, done_flag, done_seq);                                   \
+        else hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, MULTI_, AW, ACT, true, DC_, FL_, false>), grid, dim3(kBlock), 0, st, GPD_STEP_HOT, P, S, C,     \
+                                init_pose, obs12, reward, terminated, truncated, term_obs12, done_flag, done_seq);                                      \
+        launched = true;                                                                                                                                 \
+    } while (0)
+            const uint32_t low = C.physics_flags & 7u;          // the add-on models; above them: the ground plane, Bullet's damping
+            const bool hi = (C.physics_flags & ~7u) != 0u;
             if (sized && C.substeps == 1) {
-                if (multi && C.drones_per_env == 8 && C.physics_flags == 7u) { GPD_STEP1(true, 8, 7); launched = true; }
-                else if (multi && C.drones_per_env == 2 && C.physics_flags == 4u) { GPD_STEP1(true, 2, 4); launched = true; }
-                else if (!multi && C.physics_flags == 7u) { GPD_STEP1(false, 0, 7); launched = true; }
+                if (multi && C.drones_per_env == 8 && low == 7u) GPD_STEP1(true, 8, 7);
+                else if (multi && C.drones_per_env == 2 && low == 4u) GPD_STEP1(true, 2, 4);
+                else if (!multi && low == 7u) GPD_STEP1(false, 0, 7);
             }
 #undef GPD_STEP1
         }
@@ -721,15 +733,19 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
         } else
         if (shfl) {   // aviaries of 2 .. 64 drones, whole aviaries per wave: no helper wave either
             const bool sized = sized_variants();
-#define GPD_ROLL1(S1_, DC_, FL_) hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, S1_, true, true, false, DC_, FL_>), grid, dim3(kBlock), 0, st, \
-                                                    GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12)
+#define GPD_ROLL1H(S1_, DC_, FL_, HI_) hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, S1_, true, true, false, DC_, FL_, HI_>), grid, dim3(kBlock), 0, st, \
+                                                          GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12)
+#define GPD_ROLL1(S1_, DC_, FL_) GPD_ROLL1H(S1_, DC_, FL_, false)
             const bool s1 = C.substeps == 1;
             bool done = false;
             if constexpr (EXT && kSizedAct<ACT>) {
-                // pairs with PYB_DW, stacks of eight with PYB_GND_DRAG_DW (BASELINE configs 5 and 3 ii); any size with every add-on
-                if (sized && s1 && Dm == 8 && C.physics_flags == 7u) { GPD_ROLL1(true, 8, 7); done = true; }
-                else if (sized && s1 && Dm == 2 && C.physics_flags == 4u) { GPD_ROLL1(true, 2, 4); done = true; }
-                else if (sized && s1 && C.physics_flags == 7u) { GPD_ROLL1(true, 0, 7); done = true; }
+                // pairs with PYB_DW, stacks of eight with PYB_GND_DRAG_DW (BASELINE configs 5 and 3 ii); any size with every add-on; each with
+                // the ground plane / damping bits clear (the explicit integrator + add-ons, as BASELINE words it) or from the argument block
+                const uint32_t low = C.physics_flags & 7u;
+                const bool hi = (C.physics_flags & ~7u) != 0u;
+                if (sized && s1 && Dm == 8 && low == 7u) { if (hi) GPD_ROLL1H(true, 8, 7, true); else GPD_ROLL1H(true, 8, 7, false); done = true; }
+                else if (sized && s1 && Dm == 2 && low == 4u) { if (hi) GPD_ROLL1H(true, 2, 4, true); else GPD_ROLL1H(true, 2, 4, false); done = true; }
+                else if (sized && s1 && low == 7u) { if (hi) GPD_ROLL1H(true, 0, 7, true); else GPD_ROLL1H(true, 0, 7, false); done = true; }
             }
             if constexpr (kSizedAct<ACT>) {
                 // pairs with any flag set (MultiHoverAviary's defaults: two drones, 30 Hz control, no add-on force); any size at 240 Hz
@@ -740,6 +756,7 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
             }
             if (!done) GPD_ROLL1(false, 0, -1);
 #undef GPD_ROLL1
+#undef GPD_ROLL1H
         } else if (multi) {
             hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, true, AW>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
                                action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
@@ -758,9 +775,12 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
             else if (C.substeps == 1) {
                 const bool sized = sized_variants();
                 bool done = false;
-                if constexpr (EXT && kSizedAct<ACT>) {  // single drones with PYB_GND_DRAG_DW's flags (BASELINE config 3 i): the flag tests fold away
-                    if (sized && C.physics_flags == 7u) {
-                        hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, true, false, true, false, 0, 7>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
+                if constexpr (EXT && kSizedAct<ACT>) {  // single drones with PYB_GND_DRAG_DW's add-on models (BASELINE config 3 i): the flag tests fold away
+                    if (sized && (C.physics_flags & 7u) == 7u) {
+                        if (C.physics_flags & ~7u)
+                            hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, true, false, true, false, 0, 7, true>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
+                        else
+                            hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, true, false, true, false, 0, 7, false>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
                         done = true;
                     }
                 }

@@ -9,7 +9,9 @@ import sys
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # (drones per aviary, physics flags, ctrl_freq, act): the variant each one takes is in the comment of step_rollout.hip's dispatch
 SHAPES = [(2, 0, 30, "rpm"), (2, 0, 240, "rpm"), (2, 4, 30, "rpm"), (2, 7, 240, "rpm"), (3, 0, 240, "rpm"), (3, 4, 240, "rpm"), (4, 7, 240, "rpm"),
-          (5, 0, 240, "pid"), (8, 0, 240, "rpm"), (8, 4, 240, "rpm"), (16, 7, 240, "rpm"), (1, 7, 240, "one_d_rpm"), (1, 1, 240, "rpm")]
+          (5, 0, 240, "pid"), (8, 0, 240, "rpm"), (8, 4, 240, "rpm"), (16, 7, 240, "rpm"), (1, 7, 240, "one_d_rpm"), (1, 1, 240, "rpm"),
+          # with the ground plane (8) / Bullet's damping (16) bits a `Physics.PYB_*` member adds by default: the HI variants
+          (8, 15, 240, "rpm"), (2, 12, 240, "rpm"), (1, 15, 240, "rpm"), (4, 15, 240, "rpm"), (8, 31, 240, "pid")]
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, R)
     import numpy as np

@@ -19,13 +19,15 @@ out = {}
 # (drones per aviary, physics flags, action type, sub-steps): sized <8,7>, <2,4>, <1 drone,7>, <any,7>, <2,-1> at 1 and 8 sub-steps,
 # <any size, one sub-step>; and generic shapes (3 drones at 30 Hz, 12 drones with the drag term only)
 SHAPES = [(8, 7, "rpm", 1), (8, 7, "pid", 1), (2, 4, "rpm", 1), (2, 4, "vel", 1), (1, 7, "one_d_rpm", 1), (1, 7, "pid", 1), (5, 7, "rpm", 1),
-          (2, 0, "rpm", 1), (2, 0, "one_d_pid", 8), (2, 7, "rpm", 8), (3, 4, "rpm", 1), (3, 7, "rpm", 8), (12, 2, "pid", 1)]
+          (2, 0, "rpm", 1), (2, 0, "one_d_pid", 8), (2, 7, "rpm", 8), (3, 4, "rpm", 1), (3, 7, "rpm", 8), (12, 2, "pid", 1),
+          # ... and with the ground plane (8) / damping (16) bits that `Physics.PYB_*` members add by default (the HI variants)
+          (8, 15, "rpm", 1), (2, 12, "vel", 1), (1, 15, "one_d_rpm", 1), (3, 31, "pid", 1)]
 for D, phys, act, S in SHAPES:
     E = 777 if D == 1 else 300
     rng = np.random.default_rng(100 * D + phys)
     xyz = np.zeros((E, D, 3))
     xyz[..., :2] = rng.uniform(-0.3, 0.3, size=(E, D, 2))
-    xyz[..., 2] = 0.4 + 0.3 * np.arange(D) + rng.uniform(-0.02, 0.02, size=(E, D))
+    xyz[..., 2] = (0.05 if phys & 8 else 0.4) + 0.3 * np.arange(D) + rng.uniform(-0.02, 0.02, size=(E, D))    # (near the plane when it acts)
     rpy = rng.uniform(-0.1, 0.1, size=(E, D, 3))
     env = VectorAviary(E, D, initial_xyzs=xyz, initial_rpys=rpy, physics=phys, pyb_freq=240, ctrl_freq=240 // S, act=ActionType(act),
                        task="hover" if D == 1 else "multihover", auto_reset=True, track_rpm=True, device=dev)

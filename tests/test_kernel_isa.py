@@ -15,7 +15,7 @@ import pytest
 
 from conftest import REPO
 
-HEADLINE = "gpd_rollout1_kernelILb0ELb0ELi4ELi0ELb1ELb0ELb0ELb0ELi0ELin1EE"  # <PID=0, EXT=0, AW=4, ACT=RPM, S1=1, MULTI=0, NT_OBS=0, RING=0, DC=0, FL=-1>
+HEADLINE = "gpd_rollout1_kernelILb0ELb0ELi4ELi0ELb1ELb0ELb0ELb0ELi0ELin1ELb0EE"  # <PID=0, EXT=0, AW=4, ACT=RPM, S1=1, MULTI=0, NT_OBS=0, RING=0, DC=0, FL=-1, HI=0>
 
 
 POLICY = "gpd_rollout_policy_kernelILb0ELi4ELi0ELi5ELb0E"  # <PID=0, AW=4, ACT=RPM, NK1=5 (72-float rows), tanh>
@@ -298,11 +298,11 @@ def test_history_rows_are_streamed_out_in_16_byte_pieces(abi_asm):
 def test_two_drone_aviaries_exchange_through_dpp(gpd_asm):
     """MULTI rollout kernel, RPM, all force terms (BASELINE config 5's kernel): the mate's position (3 values) and its reward /
     distance / out-of-bounds terms (3) arrive by `quad_perm:[1,0,3,2]` moves -- in each of the three copies of the step."""
-    body, _ = _kernel(gpd_asm, "gpd_rollout1_kernelILb0ELb1ELi4ELi0ELb0ELb1ELb1ELb0ELi0ELin1E")      # any aviary size, any flags
+    body, _ = _kernel(gpd_asm, "gpd_rollout1_kernelILb0ELb1ELi4ELi0ELb0ELb1ELb1ELb0ELi0ELin1ELb0E")      # any aviary size, any flags
     assert sum("quad_perm:[1,0,3,2]" in l for l in body) == 18
     # compiled for pairs, PYB_DW's flags, one sub-step per step (what BASELINE config 5 at 240 Hz runs): the same moves, and nothing of the other sizes
     # is left -- no LDS exchange of positions (the only LDS traffic is the observation patch: 3 writes + 3 reads per step copy)
-    body, meta = _kernel(gpd_asm, "gpd_rollout1_kernelILb0ELb1ELi4ELi0ELb1ELb1ELb1ELb0ELi2ELi4E")
+    body, meta = _kernel(gpd_asm, "gpd_rollout1_kernelILb0ELb1ELi4ELi0ELb1ELb1ELb1ELb0ELi2ELi4ELb0E")
     assert sum("quad_perm:[1,0,3,2]" in l for l in body) == 18 and re.search(r"ScratchSize: 0\b", meta)
     assert sum(op.startswith("ds_") for op, _ in _ops(body)) == 18
 
@@ -311,7 +311,7 @@ def test_stacks_of_eight_run_their_exchange_straight_line(gpd_asm):
     """gpd_rollout1_kernel compiled for aviaries of eight (BASELINE config 3 ii, RPM, all force terms, one sub-step per step): in each
     of the three step copies the six 16-byte reads of the mates' positions stand in ONE run (issued together: the second group's LDS
     latency passes under the first group's arithmetic); no scratch."""
-    body, meta = _kernel(gpd_asm, "gpd_rollout1_kernelILb0ELb1ELi4ELi0ELb1ELb1ELb1ELb0ELi8ELi7E")
+    body, meta = _kernel(gpd_asm, "gpd_rollout1_kernelILb0ELb1ELi4ELi0ELb1ELb1ELb1ELb0ELi8ELi7ELb0E")
     assert re.search(r"ScratchSize: 0\b", meta)
     ops = [op for op, _ in _ops(body) if op.startswith("ds_") or op.startswith(("s_cbranch", "s_branch"))]
     runs, cur = [], 0
