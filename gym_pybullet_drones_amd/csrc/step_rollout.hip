@@ -746,6 +746,8 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
                 if (sized && s1 && Dm == 8 && low == 7u) { if (hi) GPD_ROLL1H(true, 8, 7, true); else GPD_ROLL1H(true, 8, 7, false); done = true; }
                 else if (sized && s1 && Dm == 2 && low == 4u) { if (hi) GPD_ROLL1H(true, 2, 4, true); else GPD_ROLL1H(true, 2, 4, false); done = true; }
                 else if (sized && s1 && low == 7u) { if (hi) GPD_ROLL1H(true, 0, 7, true); else GPD_ROLL1H(true, 0, 7, false); done = true; }
+                // pairs with no add-on model and the ground plane / damping bits alone: MultiHoverAviary's defaults (Physics.PYB, 30 Hz control)
+                else if (sized && Dm == 2 && low == 0u && hi) { if (s1) GPD_ROLL1H(true, 2, 0, true); else GPD_ROLL1H(false, 2, 0, true); done = true; }
             }
             if constexpr (kSizedAct<ACT>) {
                 // pairs with any flag set (MultiHoverAviary's defaults: two drones, 30 Hz control, no add-on force); any size at 240 Hz
@@ -772,22 +774,24 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
             const bool plain_obs = obs_stores != nullptr && obs_stores[0] == 'p';
             if (C.substeps == 1 && !PID && !EXT && ACT == GPD_ACT_RPM && (plain_obs || (N <= (1 << 17) && T.num_steps >= 48)))
                 hipLaunchKernelGGL((gpd_rollout1_kernel<false, false, 4, GPD_ACT_RPM, true, false, false>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
-            else if (C.substeps == 1) {
-                const bool sized = sized_variants();
+            else {
+#define GPD_ROLL1S(S1_, FL_, HI_) hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, S1_, false, true, false, 0, FL_, HI_>), grid, dim3(kBlock), 0, st, \
+                                                     GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12)
+                const bool s1 = C.substeps == 1, sized = sized_variants();
                 bool done = false;
-                if constexpr (EXT && kSizedAct<ACT>) {  // single drones with PYB_GND_DRAG_DW's add-on models (BASELINE config 3 i): the flag tests fold away
-                    if (sized && (C.physics_flags & 7u) == 7u) {
-                        if (C.physics_flags & ~7u)
-                            hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, true, false, true, false, 0, 7, true>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
-                        else
-                            hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, true, false, true, false, 0, 7, false>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
-                        done = true;
-                    }
+                if constexpr (EXT && kSizedAct<ACT>) {
+                    // single drones with every add-on model (BASELINE config 3 i), or with none and the ground plane / damping bits alone (what
+                    // `Physics.PYB` resolves to by default): the tests on the three add-on flags fold away
+                    const uint32_t low = C.physics_flags & 7u;
+                    const bool hi = (C.physics_flags & ~7u) != 0u;
+                    if (sized && s1 && low == 7u) { if (hi) GPD_ROLL1S(true, 7, true); else GPD_ROLL1S(true, 7, false); done = true; }
+                    else if (sized && low == 0u && hi) { if (s1) GPD_ROLL1S(true, 0, true); else GPD_ROLL1S(false, 0, true); done = true; }
                 }
-                if (!done)
-                    hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, true, false>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
-            } else
-                hipLaunchKernelGGL((gpd_rollout1_kernel<PID, EXT, AW, ACT, false, false>), grid, dim3(kBlock), 0, st, GPD_ROLL1_HOT, P, S, C, Tr, obs12, reward, terminated, truncated, term_obs12);
+                if (done) {}
+                else if (s1) GPD_ROLL1S(true, -1, false);
+                else GPD_ROLL1S(false, -1, false);
+#undef GPD_ROLL1S
+            }
         } else {
             hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, false, AW>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
                                action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
