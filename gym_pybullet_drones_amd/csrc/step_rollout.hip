@@ -670,22 +670,24 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
         const bool sized = sized_variants();
         bool launched = false;
         if constexpr (EXT && kSizedAct<ACT>) {      // BASELINE configs 3 (ii), 5, 3 (i) at one sub-step per step (see gpd_rollout1_kernel)
-#define GPD_STEP1(MULTI_, DC_, FL_)                                                                                                                       \
+#define GPD_STEP1H(MULTI_, S1_, DC_, FL_, HI_)                                                                                                              \
     do {                                                                                                                                                 \
-        if (hi) hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, MULTI_, AW, ACT, true, DC_, FL_, true>), grid, dim3(kBlock), 0, st, GPD_STEP_HOT, P, S, C,   \
-                                   init_pose, obs12, reward, terminated, truncated, term_obs12, done_flag, done_seq);                                   \
-        else hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, MULTI_, AW, ACT, true, DC_, FL_, false>), grid, dim3(kBlock), 0, st, GPD_STEP_HOT, P, S, C,     \
-                                init_pose, obs12, reward, terminated, truncated, term_obs12, done_flag, done_seq);                                      \
+        hipLaunchKernelGGL((gpd_step_kernel<PID, EXT, MULTI_, AW, ACT, S1_, DC_, FL_, HI_>), grid, dim3(kBlock), 0, st, GPD_STEP_HOT, P, S, C,               \
+                           init_pose, obs12, reward, terminated, truncated, term_obs12, done_flag, done_seq);                                           \
         launched = true;                                                                                                                                 \
     } while (0)
+#define GPD_STEP1(MULTI_, DC_, FL_) do { if (hi) GPD_STEP1H(MULTI_, true, DC_, FL_, true); else GPD_STEP1H(MULTI_, true, DC_, FL_, false); } while (0)
             const uint32_t low = C.physics_flags & 7u;          // the add-on models; above them: the ground plane, Bullet's damping
-            const bool hi = (C.physics_flags & ~7u) != 0u;
-            if (sized && C.substeps == 1) {
-                if (multi && C.drones_per_env == 8 && low == 7u) GPD_STEP1(true, 8, 7);
-                else if (multi && C.drones_per_env == 2 && low == 4u) GPD_STEP1(true, 2, 4);
-                else if (!multi && low == 7u) GPD_STEP1(false, 0, 7);
-            }
+            const bool hi = (C.physics_flags & ~7u) != 0u, s1 = C.substeps == 1;
+            if (sized && s1 && multi && C.drones_per_env == 8 && low == 7u) GPD_STEP1(true, 8, 7);
+            else if (sized && s1 && multi && C.drones_per_env == 2 && low == 4u) GPD_STEP1(true, 2, 4);
+            else if (sized && s1 && !multi && low == 7u) GPD_STEP1(false, 0, 7);
+            // no add-on model, the ground plane / damping bits alone: what `Physics.PYB` -- the default of HoverAviary() and MultiHoverAviary(), whose
+            // step() is this kernel -- resolves to; single drones and pairs, one sub-step or the loop
+            else if (sized && low == 0u && hi && !multi) { if (s1) GPD_STEP1H(false, true, 0, 0, true); else GPD_STEP1H(false, false, 0, 0, true); }
+            else if (sized && low == 0u && hi && multi && C.drones_per_env == 2) { if (s1) GPD_STEP1H(true, true, 2, 0, true); else GPD_STEP1H(true, false, 2, 0, true); }
 #undef GPD_STEP1
+#undef GPD_STEP1H
         }
         if (launched) {
         } else if (multi) {
