@@ -682,6 +682,10 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
             if (sized && s1 && multi && C.drones_per_env == 8 && low == 7u) GPD_STEP1(true, 8, 7);
             else if (sized && s1 && multi && C.drones_per_env == 2 && low == 4u) GPD_STEP1(true, 2, 4);
             else if (sized && s1 && !multi && low == 7u) GPD_STEP1(false, 0, 7);
+            // the two multi-drone add-on sets under the sub-step loop (30 Hz control of 240 Hz physics is the reference's default): one variant each,
+            // the bits above the add-on models read at run time whatever they are (single drones gain 3-5 % there: no variant)
+            else if (sized && multi && C.drones_per_env == 8 && low == 7u) GPD_STEP1H(true, false, 8, 7, true);
+            else if (sized && multi && C.drones_per_env == 2 && low == 4u) GPD_STEP1H(true, false, 2, 4, true);
             // no add-on model, the ground plane / damping bits alone: what `Physics.PYB` -- the default of HoverAviary() and MultiHoverAviary(), whose
             // step() is this kernel -- resolves to; single drones and pairs, one sub-step or the loop
             else if (sized && low == 0u && hi && !multi) { if (s1) GPD_STEP1H(false, true, 0, 0, true); else GPD_STEP1H(false, false, 0, 0, true); }
@@ -748,6 +752,10 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
                 if (sized && s1 && Dm == 8 && low == 7u) { if (hi) GPD_ROLL1H(true, 8, 7, true); else GPD_ROLL1H(true, 8, 7, false); done = true; }
                 else if (sized && s1 && Dm == 2 && low == 4u) { if (hi) GPD_ROLL1H(true, 2, 4, true); else GPD_ROLL1H(true, 2, 4, false); done = true; }
                 else if (sized && s1 && low == 7u) { if (hi) GPD_ROLL1H(true, 0, 7, true); else GPD_ROLL1H(true, 0, 7, false); done = true; }
+                // the same under the sub-step loop (30 Hz control is the reference's default): one variant each, upper bits read at run time
+                else if (sized && Dm == 8 && low == 7u) { GPD_ROLL1H(false, 8, 7, true); done = true; }
+                else if (sized && Dm == 2 && low == 4u) { GPD_ROLL1H(false, 2, 4, true); done = true; }
+                else if (sized && low == 7u) { GPD_ROLL1H(false, 0, 7, true); done = true; }
                 // pairs with no add-on model and the ground plane / damping bits alone: MultiHoverAviary's defaults (Physics.PYB, 30 Hz control)
                 else if (sized && Dm == 2 && low == 0u && hi) { if (s1) GPD_ROLL1H(true, 2, 0, true); else GPD_ROLL1H(false, 2, 0, true); done = true; }
             }

@@ -13,7 +13,9 @@ SHAPES = [(2, 0, 30, "rpm"), (2, 0, 240, "rpm"), (2, 4, 30, "rpm"), (2, 7, 240, 
           # with the ground plane (8) / Bullet's damping (16) bits a `Physics.PYB_*` member adds by default: the HI variants
           (8, 15, 240, "rpm"), (2, 12, 240, "rpm"), (1, 15, 240, "rpm"), (4, 15, 240, "rpm"), (8, 31, 240, "pid"),
           # single drones with the ground plane alone (`Physics.PYB`'s default mask), at 240 and at 30 Hz control
-          (1, 8, 240, "rpm"), (1, 8, 30, "one_d_rpm"), (1, 24, 30, "pid"), (2, 8, 30, "rpm"), (2, 8, 240, "rpm")]
+          (1, 8, 240, "rpm"), (1, 8, 30, "one_d_rpm"), (1, 24, 30, "pid"), (2, 8, 30, "rpm"), (2, 8, 240, "rpm"),
+          # the add-on sets at the reference's default 30 Hz control
+          (1, 15, 30, "rpm"), (1, 7, 30, "pid"), (2, 12, 30, "rpm"), (8, 15, 30, "rpm"), (4, 7, 30, "rpm")]
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, R)
     import numpy as np

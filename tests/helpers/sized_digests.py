@@ -22,7 +22,9 @@ SHAPES = [(8, 7, "rpm", 1), (8, 7, "pid", 1), (2, 4, "rpm", 1), (2, 4, "vel", 1)
           (2, 0, "rpm", 1), (2, 0, "one_d_pid", 8), (2, 7, "rpm", 8), (3, 4, "rpm", 1), (3, 7, "rpm", 8), (12, 2, "pid", 1),
           # ... and with the ground plane (8) / damping (16) bits that `Physics.PYB_*` members add by default (the HI variants)
           (8, 15, "rpm", 1), (2, 12, "vel", 1), (1, 15, "one_d_rpm", 1), (3, 31, "pid", 1), (1, 8, "rpm", 1), (1, 8, "one_d_rpm", 8), (1, 24, "pid", 5),
-          (2, 8, "rpm", 8), (2, 24, "one_d_pid", 1)]
+          (2, 8, "rpm", 8), (2, 24, "one_d_pid", 1),
+          # the add-on sets under the sub-step loop
+          (1, 15, "rpm", 8), (1, 7, "pid", 5), (2, 12, "rpm", 8), (8, 7, "one_d_rpm", 4), (4, 23, "vel", 8)]
 for D, phys, act, S in SHAPES:
     E = 777 if D == 1 else 300
     rng = np.random.default_rng(100 * D + phys)
