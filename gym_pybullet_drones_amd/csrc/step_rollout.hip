@@ -760,10 +760,9 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
                 else if (sized && Dm == 2 && low == 0u && hi) { if (s1) GPD_ROLL1H(true, 2, 0, true); else GPD_ROLL1H(false, 2, 0, true); done = true; }
             }
             if constexpr (kSizedAct<ACT>) {
-                // pairs with any flag set (MultiHoverAviary's defaults: two drones, 30 Hz control, no add-on force); any size at 240 Hz
+                // pairs with any other flag set, and any size, at one sub-step per step (under the sub-step loop the size alone buys nothing)
                 if (done) {}
                 else if (sized && s1 && Dm == 2) { GPD_ROLL1(true, 2, -1); done = true; }
-                else if (sized && Dm == 2) { GPD_ROLL1(false, 2, -1); done = true; }
                 else if (sized && s1) { GPD_ROLL1(true, 0, -1); done = true; }
             }
             if (!done) GPD_ROLL1(false, 0, -1);
