@@ -185,7 +185,9 @@ __device__ __forceinline__ void lds_poke(int* p, int v) {
 
 
 
-template <bool PID, bool EXT, bool MULTI, int AW>
+// ACT / S1: the action type and "one sub-step per step" as compile-time constants, as in the other two kernels (ACT = -1: the run-time
+// ladder, which multi-drone aviaries keep -- their steps are dominated by the exchange and the barriers)
+template <bool PID, bool EXT, bool MULTI, int AW, int ACT = -1, bool S1 = false>
 __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
     const GpdParams P, const GpdState S, const GpdStepCfg C, const Span T, const float* __restrict__ action,
     const float* __restrict__ target_pos, const float* __restrict__ init_pose, float* __restrict__ obs12,
@@ -341,8 +343,8 @@ __global__ __launch_bounds__(kRollThreads) void gpd_rollout_kernel(
     int drained_seen = 0;                                            // last value of sh_drained this wave has read
     auto do_step = [&](const int t, const float4 act) {
         StepOut out;
-        env_step<PID, EXT, MULTI, AW>(P, C, flags, D, L, act, tgx, tgy, tgz, true, ipose, ip[0], ip[1], ip[2], ip[3], ip[4],
-                                      ip[5], ip[6], sh_pos, sh_red, c, out);
+        env_step<PID, EXT, MULTI, AW, ACT, S1>(P, C, flags, D, L, act, tgx, tgy, tgz, true, ipose, ip[0], ip[1], ip[2], ip[3], ip[4],
+                                               ip[5], ip[6], sh_pos, sh_red, c, out);
         const int b = t & (ring - 1);
         if (use_flags && t - ring + 1 > drained_seen) {              // slot b may still hold step t-ring: has it been drained?
             // (the flag is re-read only when the last value seen does not already clear this step: the store wave
@@ -802,8 +804,16 @@ hipError_t launch_step(bool multi, hipStream_t st, const GpdParams& P, const Gpd
 #undef GPD_ROLL1S
             }
         } else {
-            hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, false, AW>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
-                               action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+            // single drones with terminal observations kept (what a VecEnv-style caller asks for): action type and sub-step count folded
+            if (sized_variants() && C.substeps == 1)
+                hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, false, AW, ACT, true>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
+                                   action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+            else if (sized_variants())
+                hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, false, AW, ACT, false>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
+                                   action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
+            else
+                hipLaunchKernelGGL((gpd_rollout_kernel<PID, EXT, false, AW>), grid, dim3(kRollThreads), lds, st, P, S, C, Tr,
+                                   action, target_pos, init_pose, obs12, reward, terminated, truncated, term_obs12);
         }
     }
     return hipGetLastError();

@@ -49,4 +49,21 @@ for D, phys, act, S in SHAPES:
         for t in env.core.step(a[k].contiguous()):
             h.update(t.cpu().numpy().tobytes())
     out[f"D{D}_flags{phys}_{act}_S{S}"] = h.hexdigest()[:20]
+# the compute-wave + store-wave kernel (rollouts that keep terminal observations): its action type / sub-step count variants
+for act, S, phys in (("rpm", 1, 0), ("pid", 1, 7), ("one_d_rpm", 8, 8), ("vel", 2, 0)):
+    E = 777
+    env = VectorAviary(E, 1, physics=phys, pyb_freq=240, ctrl_freq=240 // S, act=ActionType(act), task="hover", auto_reset=True, track_rpm=True,
+                       keep_terminal_obs=True, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    a = torch.rand((20, E, 1, env.ACT_DIM), generator=g, device=dev) * 2 - 1
+    if act == "pid":
+        a = a * 0.3
+        a[..., -1] += 1.0
+    if act == "vel":
+        a[..., 3] = a[..., 3].abs()
+    h = hashlib.sha256()
+    for t in (*env.core.rollout(a.contiguous(), update_latest=True), env.core.kin_store, env.core.term_obs12):
+        h.update(t.cpu().numpy().tobytes())
+    out[f"termobs_flags{phys}_{act}_S{S}"] = h.hexdigest()[:20]
 print(json.dumps(out))

@@ -287,7 +287,7 @@ def test_rollout_arena_places_the_blocks_and_changes_no_bit(gpu_device):
 def test_kernels_compiled_for_one_aviary_size_and_flag_set_are_the_generic_kernels_bit_for_bit():
     """`gpd_rollout1_kernel` / `gpd_step_kernel` have variants with the aviary size, the physics flags and "one sub-step per step" as
     template parameters (BASELINE configs 3 (i), 3 (ii), 5 run 12 / 26 / 28 % faster with them).  Same operations,
-    same order: rollouts and single steps of twenty-seven shapes -- every variant, and shapes that fall through to the generic kernels --
+    same order: rollouts and single steps of twenty-seven shapes, and four rollouts that keep terminal observations (the third kernel's variants) -- every variant, and shapes that fall through to the generic kernels --
     digest identically with GPD_ROLLOUT_SIZED=0 (generic kernels only; the switch is read once per process, hence the two children)."""
     import json
     import os
@@ -302,4 +302,4 @@ def test_kernels_compiled_for_one_aviary_size_and_flag_set_are_the_generic_kerne
         line = next((l for l in res.stdout.splitlines() if l.startswith("{")), None)
         assert res.returncode == 0 and line, res.stderr[-1500:]
         got[label] = json.loads(line)
-    assert len(got["generic"]) == 27 and got["generic"] == got["sized"], {k: (v, got["sized"].get(k)) for k, v in got["generic"].items() if got["sized"].get(k) != v}
+    assert len(got["generic"]) == 31 and got["generic"] == got["sized"], {k: (v, got["sized"].get(k)) for k, v in got["generic"].items() if got["sized"].get(k) != v}
