@@ -101,12 +101,22 @@ __global__ __launch_bounds__(kBlock) void gpd_step_kernel(
             char* dst = reinterpret_cast<char*>(obs12) + static_cast<size_t>(n0) * 48u;
             const uint32_t off = static_cast<uint32_t>(tid & 63) * 16u;
             __builtin_amdgcn_wave_barrier();                          // same wave: the LDS executes its instructions in order
+            if (rows == 64u) {
+                // a full wave (every wave but a ragged batch's last): the three reads in one run, one wait, three unconditional stores --
+                // the masked form below reads, waits and stores three times over (three LDS round trips on the tail of the kernel)
+                const float4 v0 = *reinterpret_cast<const float4*>(src + off), v1 = *reinterpret_cast<const float4*>(src + off + 1024),
+                             v2 = *reinterpret_cast<const float4*>(src + off + 2048);
+                __builtin_nontemporal_store(f4v{v0.x, v0.y, v0.z, v0.w}, reinterpret_cast<f4v*>(dst + off));
+                __builtin_nontemporal_store(f4v{v1.x, v1.y, v1.z, v1.w}, reinterpret_cast<f4v*>(dst + off + 1024));
+                __builtin_nontemporal_store(f4v{v2.x, v2.y, v2.z, v2.w}, reinterpret_cast<f4v*>(dst + off + 2048));
+            } else {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const float4 v = *reinterpret_cast<const float4*>(src + off + j * 1024);
-                if (off + j * 1024 < rows * 48u) {                    // streamed out, not read again by this path: non-temporal
-                    f4v w = {v.x, v.y, v.z, v.w};
-                    __builtin_nontemporal_store(w, reinterpret_cast<f4v*>(dst + off + j * 1024));
+                for (int j = 0; j < 3; ++j) {
+                    const float4 v = *reinterpret_cast<const float4*>(src + off + j * 1024);
+                    if (off + j * 1024 < rows * 48u) {                // streamed out, not read again by this path: non-temporal
+                        f4v w = {v.x, v.y, v.z, v.w};
+                        __builtin_nontemporal_store(w, reinterpret_cast<f4v*>(dst + off + j * 1024));
+                    }
                 }
             }
         }
